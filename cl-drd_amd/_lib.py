@@ -1,0 +1,68 @@
+"""ctypes binding of libcldrd_hip.so (C ABI: include/cldrd_hip.h).  No CPU fallback: if the library is missing
+or a launch is rejected, the call raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcldrd_hip.so")
+
+_lib = None
+
+vp, ci, cf, cull, csz = C.c_void_p, C.c_int, C.c_float, C.c_ulonglong, C.c_size_t
+
+SIGNATURES = {
+    "cldrd_last_error": (C.c_char_p, []),
+    "cldrd_version": (ci, []),
+    "cldrd_device_ok": (ci, []),
+    "cldrd_gemm_nt_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, vp]),
+    "cldrd_wgrad_splits": (ci, [ci, ci, ci]),
+    "cldrd_wgrad_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, vp, csz, ci, vp]),
+    "cldrd_attention_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
+    "cldrd_attention_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
+    "cldrd_ln_partial_blocks": (ci, [ci]),
+    "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp]),
+    "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp]),
+    "cldrd_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, ci, vp]),
+    "cldrd_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cull, ci, vp]),
+    "cldrd_colsum_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    "cldrd_scatter_cls_grad": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "cldrd_score_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
+    "cldrd_score_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
+    "cldrd_loss_fwd_bwd": (ci, [ci, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci, vp]),
+    "cldrd_sqnorm_blocks": (ci, []),
+    "cldrd_grad_clip_coef": (ci, [vp, csz, cf, vp, vp, vp]),
+    "cldrd_adamw_step": (ci, [vp, vp, vp, vp, vp, vp, csz, cf, cf, cf, cf, cf, ci, vp, vp]),
+    "cldrd_cast_bf16": (ci, [vp, vp, csz, vp]),
+    "cldrd_transpose_cast_batched": (ci, [vp, vp, vp, vp, ci, ci, vp]),
+}
+
+
+class CldrdError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the library (once).  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CldrdError(f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
+                         "cldrd_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args):
+    """Invoke an int-returning entry point; raise with cldrd_last_error() on rejection."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise CldrdError(f"{name}: {lib.cldrd_last_error().decode()}")

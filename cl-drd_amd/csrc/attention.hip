@@ -1,0 +1,356 @@
+// Fused multi-head self-attention for the BERT/DistilBERT encoder, forward and backward.
+//
+// Reference call site: HF DistilBertSelfAttention / BertSelfAttention reached from
+// models/nway_dual_encoder.py:52,56,64: softmax(Q K^T / sqrt(dh) + key mask) -> dropout -> . V,
+// dh = 64, sequences <= 256 tokens.  One workgroup owns one (sequence, head): Q, K, V (and dO) live in LDS
+// for the whole kernel, so the L x L score matrix never touches HBM and no cross-workgroup reduction exists.
+//
+// MFMA 32x32x16 bf16 throughout.  Forward computes S^T = K Q^T so that a lane owns one query column: the
+// row softmax is a register-local reduction plus one cross-half shuffle, and the S^T accumulator tile is
+// reused directly as the A operand of P.V (cdna_hip_programming.md section 3, "accumulator tile as the next MFMA's
+// operand"); V is consumed through ds_read_b64_tr_b16 transposing reads.  Backward recomputes P from the
+// saved log-sum-exp in two sweeps: key-on-lane (dK, dV accumulate in registers over all query blocks) and
+// query-on-lane (dQ accumulates over all key blocks).  Probabilities and dS are rounded to bf16 only as
+// MFMA operands; softmax statistics, LSE and delta are fp32.
+#include "common.h"
+
+namespace {
+
+constexpr int RSB = 144;                 // LDS row stride in bytes (64 bf16 + 8 pad): b128 row reads conflict-free
+constexpr float NEG_BIG = -1.0e30f;
+
+__device__ __forceinline__ int rowmap(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
+
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int row, int s, int h) {
+    return *(const bf16x8*)(tile + row * RSB + (2 * s + h) * 16);
+}
+// 8 elements k = {row0 + 0..3, row0 + 8 + 0..3} of column (col0 + (lane & 31)) -- the k order of an accumulator tile
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row0, int col0, int lane) {
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const char* p = tile + (row0 + qq) * RSB + (col0 + 16 * (g & 1) + 4 * pp) * 2;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(p + 8 * RSB));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ __forceinline__ bf16x8 pack8(const float* v) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)f2bf(v[j]);
+    return r;
+}
+
+// copy a [L, 64] bf16 head slice (row stride ld elements) into an LDS tile of Lp rows, zero-filling rows >= L
+__device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld, int L, int Lp) {
+    for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
+        const int row = idx >> 3, ch = idx & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < L) v = *(const uint4*)(src + (size_t)row * ld + ch * 8);
+        *(uint4*)(tile + row * RSB + ch * 16) = v;
+    }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                        bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
+                                                        float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Lp = 32 * NKB;
+    char* sQ = smem;
+    char* sK = sQ + Lp * RSB;
+    char* sV = sK + Lp * RSB;
+    float* sBias = (float*)(sV + Lp * RSB);
+    const int seq = blockIdx.x / H, hd = blockIdx.x % H;
+    const int dm = H * 64, ld = 3 * dm;
+    const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
+    load_tile(sQ, base, ld, L, Lp);
+    load_tile(sK, base + dm, ld, L, Lp);
+    load_tile(sV, base + 2 * dm, ld, L, Lp);
+    for (int k = threadIdx.x; k < Lp; k += blockDim.x)
+        sBias[k] = (k < L && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    for (int qb = wid; qb < NKB; qb += 4) {
+        bf16x8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = row_frag(sQ, qb * 32 + r, s, h);
+        f32x16 S[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            S[kb] = (f32x16){0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], S[kb], 0, 0, 0);
+        }
+        // S[kb][t] = <K[key], Q[q]> with key = 32 kb + rowmap(t, h), q = 32 qb + r
+        float mx = NEG_BIG * 4.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float v = S[kb][t] * scale + sBias[kb * 32 + rowmap(t, h)];
+                S[kb][t] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float e = __expf(S[kb][t] - mx);
+                S[kb][t] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const int q = qb * 32 + r;
+        if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = mx + __logf(sum);
+        const float inv = 1.0f / sum;
+        f32x16 O[2] = {(f32x16){0.f}, (f32x16){0.f}};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            float pv[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                float pr = S[kb][t] * inv;
+                if (drop_thresh) {
+                    const uint64_t e = (((uint64_t)seq * H + hd) * L + q) * L + (kb * 32 + rowmap(t, h));
+                    pr = dropout_keep(seed, e, drop_thresh) ? pr * drop_scale : 0.f;
+                }
+                pv[t] = pr;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pa = pack8(pv + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), O[dt], 0, 0, 0);
+            }
+        }
+        // O[dt][t] = ctx[q = 32 qb + rowmap(t, h)][d = 32 dt + r]
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int qq = qb * 32 + rowmap(t, h);
+                if (qq < L) ctx[((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r] = f2bf(O[dt][t]);
+            }
+    }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                        const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
+                                                        const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
+                                                        float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Lp = 32 * NKB;
+    char* sQ = smem;
+    char* sK = sQ + Lp * RSB;
+    char* sV = sK + Lp * RSB;
+    char* sdO = sV + Lp * RSB;
+    float* sBias = (float*)(sdO + Lp * RSB);
+    float* sLse = sBias + Lp;
+    float* sDelta = sLse + Lp;
+    const int seq = blockIdx.x / H, hd = blockIdx.x % H;
+    const int dm = H * 64, ld = 3 * dm;
+    const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
+    load_tile(sQ, base, ld, L, Lp);
+    load_tile(sK, base + dm, ld, L, Lp);
+    load_tile(sV, base + 2 * dm, ld, L, Lp);
+    {   // dO tile + delta[q] = sum_d dO[q][d] * O[q][d]
+        const bf16_t* dob = dctx + (size_t)seq * L * dm + hd * 64;
+        const bf16_t* ob = ctx + (size_t)seq * L * dm + hd * 64;
+        for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
+            const int row = idx >> 3, ch = idx & 7;
+            uint4 v = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
+            if (row < L) {
+                v = *(const uint4*)(dob + (size_t)row * dm + ch * 8);
+                o = *(const uint4*)(ob + (size_t)row * dm + ch * 8);
+            }
+            *(uint4*)(sdO + row * RSB + ch * 16) = v;
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, oo[4] = {o.x, o.y, o.z, o.w};
+            float dsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dsum += __uint_as_float(vv[j] << 16) * __uint_as_float(oo[j] << 16) +
+                        __uint_as_float(vv[j] & 0xFFFF0000u) * __uint_as_float(oo[j] & 0xFFFF0000u);
+            dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64);
+            if (ch == 0) sDelta[row] = dsum;
+        }
+    }
+    for (int k = threadIdx.x; k < Lp; k += blockDim.x) {
+        sBias[k] = (k < L && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
+        sLse[k] = k < L ? lse[((size_t)seq * H + hd) * L + k] : 1.0e30f;      // rows >= L: P = exp(-inf) = 0
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const uint64_t dbase = ((uint64_t)seq * H + hd) * L;
+
+    // ---------------- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks ----------------
+    for (int kb = wid; kb < NKB; kb += 4) {
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { kf[s] = row_frag(sK, kb * 32 + r, s, h); vf[s] = row_frag(sV, kb * 32 + r, s, h); }
+        const int key = kb * 32 + r;
+        const float bias_k = sBias[key];
+        f32x16 dK[2] = {(f32x16){0.f}, (f32x16){0.f}}, dV[2] = {(f32x16){0.f}, (f32x16){0.f}};
+        for (int qb = 0; qb < NKB; ++qb) {
+            f32x16 S = (f32x16){0.f}, dP = (f32x16){0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, qb * 32 + r, s, h), kf[s], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sdO, qb * 32 + r, s, h), vf[s], dP, 0, 0, 0);
+            }
+            // S[t], dP[t]: query q = 32 qb + rowmap(t, h), key = 32 kb + r
+            float pd[16], ds[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int q = qb * 32 + rowmap(t, h);
+                const float p = __expf(S[t] * scale + bias_k - sLse[q]);
+                float pdv = p, dp = dP[t];
+                if (drop_thresh) {
+                    const bool keep = dropout_keep(seed, (dbase + q) * L + key, drop_thresh);
+                    pdv = keep ? p * drop_scale : 0.f;
+                    dp = keep ? dp * drop_scale : 0.f;
+                }
+                pd[t] = pdv;
+                ds[t] = p * (dp - sDelta[q]);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = pack8(pd + 8 * s2), sb = pack8(ds + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sdO, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, dV[dt], 0, 0, 0);
+                    dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sb, dK[dt], 0, 0, 0);
+                }
+            }
+        }
+        // dV[dt][t] = dV[key][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
+        if (key < L) {
+            bf16_t* ok = dqkv + ((size_t)seq * L + key) * ld + dm + hd * 64;
+            bf16_t* ov = ok + dm;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int d0 = dt * 32 + 8 * u + 4 * h;
+                    uint2 a, b;
+                    a.x = pack2bf(dK[dt][4 * u] * scale, dK[dt][4 * u + 1] * scale);
+                    a.y = pack2bf(dK[dt][4 * u + 2] * scale, dK[dt][4 * u + 3] * scale);
+                    b.x = pack2bf(dV[dt][4 * u], dV[dt][4 * u + 1]);
+                    b.y = pack2bf(dV[dt][4 * u + 2], dV[dt][4 * u + 3]);
+                    *(uint2*)(ok + d0) = a;
+                    *(uint2*)(ov + d0) = b;
+                }
+        }
+    }
+
+    // ---------------- sweep B: query on lane; dQ for 32 queries accumulates over all key blocks ----------------
+    for (int qb = wid; qb < NKB; qb += 4) {
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { qf[s] = row_frag(sQ, qb * 32 + r, s, h); dof[s] = row_frag(sdO, qb * 32 + r, s, h); }
+        const int q = qb * 32 + r;
+        const float lse_q = sLse[q], delta_q = sDelta[q];
+        f32x16 dQ[2] = {(f32x16){0.f}, (f32x16){0.f}};
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 ST = (f32x16){0.f}, dPT = (f32x16){0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                ST = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], ST, 0, 0, 0);
+                dPT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, kb * 32 + r, s, h), dof[s], dPT, 0, 0, 0);
+            }
+            float ds[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int key = kb * 32 + rowmap(t, h);
+                const float p = __expf(ST[t] * scale + sBias[key] - lse_q);
+                float dp = dPT[t];
+                if (drop_thresh) dp = dropout_keep(seed, (dbase + q) * L + key, drop_thresh) ? dp * drop_scale : 0.f;
+                ds[t] = p * (dp - delta_q);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 sa = pack8(ds + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa, tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), dQ[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int qq = qb * 32 + rowmap(t, h);
+                if (qq < L) dqkv[((size_t)seq * L + qq) * ld + hd * 64 + dt * 32 + r] = f2bf(dQ[dt][t] * scale);
+            }
+    }
+}
+
+template <int NKB>
+int launch_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
+               unsigned long long seed, hipStream_t st) {
+    const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_fwd_kernel<NKB>, dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                       (bf16_t*)ctx, lse, L, H, scale, p > 0.f ? dropout_thresh24(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+template <int NKB>
+int launch_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
+               int L, int H, float scale, float p, unsigned long long seed, hipStream_t st) {
+    const size_t lds = 4 * 32 * NKB * RSB + 3 * 32 * NKB * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_bwd_kernel<NKB>, dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                       (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
+                       p > 0.f ? dropout_thresh24(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// qkv: bf16 [nseq*L, 3*H*64] (Q | K | V, heads contiguous inside each); mask: int64 [nseq, L] (0 = padded key) or null;
+// ctx: bf16 [nseq*L, H*64]; lse: fp32 [nseq, H, L] (may be null for inference).
+extern "C" int cldrd_attention_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
+                                   float dropout_p, unsigned long long seed, void* stream) {
+    CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_fwd: need 0 < L <= 256");
+    const float scale = 0.125f;   // 1 / sqrt(64)
+    const int nkb = (L + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    switch (nkb) {
+        case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+        case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+        case 3: return launch_fwd<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+        case 4: return launch_fwd<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+        case 5: return launch_fwd<5>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+        case 6: return launch_fwd<6>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+        case 7: return launch_fwd<7>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+        default: return launch_fwd<8>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+    }
+}
+
+extern "C" int cldrd_attention_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
+                                   void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream) {
+    CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_bwd: need 0 < L <= 256");
+    CLDRD_CHECK(lse != nullptr, "attention_bwd: lse is required");
+    const float scale = 0.125f;
+    const int nkb = (L + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+    switch (nkb) {
+        case 1: return launch_bwd<1>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
+        case 2: return launch_bwd<2>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
+        case 3: return launch_bwd<3>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
+        case 4: return launch_bwd<4>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
+        case 5: return launch_bwd<5>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
+        case 6: return launch_bwd<6>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
+        case 7: return launch_bwd<7>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
+        default: return launch_bwd<8>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
+    }
+}

@@ -1,0 +1,70 @@
+// Shared device helpers for the cldrd gfx950 (CDNA4 / MI355X) kernels.  gfx950 only: 64-lane
+// wavefronts, MFMA 16x16x32 / 32x32x16 bf16, LDS-DMA (global_load_lds), ds_read_b64_tr_b16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;    // MFMA A/B fragment (8 bf16 = 4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define CLDRD_WAVE 64
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even f32 -> bf16 via the hardware cast (keeps NaN a NaN, MI355X_MICROARCH correctness table)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// erf-GELU and its derivative (HF GELUActivation == F.gelu)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// Counter-based dropout: keep(element) is a pure function of (seed, 64-bit element index), so the backward
+// regenerates the mask instead of storing it.  splitmix64 finaliser; keep iff top 24 bits >= p * 2^24.
+__device__ __forceinline__ uint32_t hash_u24(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 40);
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh24) {
+    return hash_u24(seed, idx) >= thresh24;
+}
+static inline uint32_t dropout_thresh24(float p) { return (uint32_t)(p * 16777216.0f); }
+
+// XCD-aware bijective block remap (cdna_hip_programming.md section 5, T1): blocks b and b+8 share an XCD, so
+// give each XCD a contiguous range of logical tiles (neighbouring tiles share operand panels in that XCD's L2).
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+int cldrd_set_error(const char* msg);
+#define CLDRD_CHECK(cond, msg) do { if (!(cond)) return cldrd_set_error(msg); } while (0)
+#define CLDRD_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return cldrd_set_error(hipGetErrorString(e_)); } while (0)

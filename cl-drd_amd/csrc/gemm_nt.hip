@@ -1,0 +1,200 @@
+// C[M,N] = epilogue( alpha * A[M,K] . B[N,K]^T )   bf16 operands, fp32 accumulate on MFMA.
+//
+// This is the Linear layer of the encoder (reference call sites models/nway_dual_encoder.py:52,56,64 ->
+// HF q_lin/k_lin/v_lin/out_lin/ffn.lin1/ffn.lin2) in "NT" form: both operands are
+// K-contiguous (activations [tokens, in], weights [out, in]).  The same kernel serves the data-gradient
+// GEMMs with the transposed bf16 weight shadow as B.
+//
+// Structure (v1): 128x128x64 tiles, 256 threads = 2x2 waves of 64x64, MFMA 16x16x32 bf16.  Operands go
+// HBM -> LDS by LDS-DMA (global_load_lds, 16 B/lane, no VGPR round trip) into two 32 KiB stages; the
+// LDS image is lane-linear per 1 KiB piece (8 rows x 128 B), XOR-swizzled on the SOURCE address
+// (chunk ^= row & 7) and on the ds_read_b128 address, which makes the fragment reads bank-conflict free.
+// One barrier per K tile: loads of tile t+1 are issued right after the barrier and fly under the MFMAs
+// of tile t.  Fused epilogue: bias, erf-GELU (optionally saving the pre-activation), GELU' multiply
+// (data gradient through the activation), dropout, residual add; bf16 or fp32 store.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
+
+struct GemmNtArgs {
+    const bf16_t* A; const bf16_t* B; void* C;
+    int M, N, K, lda, ldb, ldc;
+    const float* bias;            // [N] or null
+    const bf16_t* residual;       // [M, ldr] or null, added last
+    int ldr;
+    bf16_t* preact;               // [M, ldc] or null: (alpha*acc + bias) before the activation
+    const bf16_t* gelu_pre;       // [M, ldc] or null: multiply by gelu'(gelu_pre)
+    int act;                      // 0 none, 1 erf-GELU
+    float alpha;
+    uint32_t drop_thresh;         // 0 = no dropout
+    float drop_scale;
+    uint64_t seed;
+    int out_f32;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntn = (p.N + BN - 1) / BN;
+    const int nwg = gridDim.x;
+    const int tile = xcd_remap(blockIdx.x, nwg);
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // ---- LDS-DMA staging: wave w owns pieces 4w..4w+3 of each operand tile (piece = 8 rows x 128 B) ----
+    const int prow = lane >> 3;                       // row inside the piece == (row & 7)
+    const int chunk = (lane & 7) ^ prow;              // source chunk for LDS slot (lane & 7): swizzle on the source
+    const bf16_t* ga[4];
+    const bf16_t* gb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wid * 4 + i) * 8 + prow;
+        const int ra = min(m0 + r, p.M - 1), rb = min(n0 + r, p.N - 1);
+        ga[i] = p.A + (size_t)ra * p.lda + chunk * 8;
+        gb[i] = p.B + (size_t)rb * p.ldb + chunk * 8;
+    }
+    auto stage = [&](int s, int k0) {
+        char* base = smem + s * STAGE_BYTES + wid * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga[i] + k0), LDS_PTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb[i] + k0), LDS_PTR(base + TILE_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment addressing: lane reads row (lane & 15) of a 16-row tile, 16-B chunk 4*s + (lane >> 4) ----
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int slot = (4 * s + fq) ^ (frow & 7);
+        a_off[s] = (wm * 64 + frow) * 128 + slot * 16;
+        b_off[s] = TILE_BYTES + (wn * 64 + frow) * 128 + slot * 16;
+    }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+        const char* sb = smem + (kt & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *(const bf16x8*)(sb + a_off[s] + t * 16 * 128);
+                bfr[t] = *(const bf16x8*)(sb + b_off[s] + t * 16 * 128);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    // operands swapped on purpose: D'[n][m], so a lane's 4 accumulators are 4 consecutive n
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane holds C[m = .. + (lane & 15)][n = .. + 4*(lane >> 4) + j], j = 0..3 ----
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wm * 64 + mt * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wn * 64 + nt * 16 + fq * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] * p.alpha;
+            const bool full = (n + 3 < p.N);
+            if (p.bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += p.bias[n + j];
+            }
+            const size_t crow = (size_t)m * p.ldc + n;
+            if (p.preact) {
+                if (full) {
+                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                    *(uint2*)(p.preact + crow) = o;
+                } else {
+                    for (int j = 0; j < 4; ++j) if (n + j < p.N) p.preact[crow + j] = f2bf(v[j]);
+                }
+            }
+            if (p.act == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+            }
+            if (p.gelu_pre) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] *= gelu_grad_f(bf2f(p.gelu_pre[crow + j]));
+            }
+            if (p.drop_thresh) {
+                const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = dropout_keep(p.seed, e + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+            }
+            if (p.residual) {
+                const size_t rrow = (size_t)m * p.ldr + n;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += bf2f(p.residual[rrow + j]);
+            }
+            if (p.out_f32) {
+                float* C = (float*)p.C;
+                if (full) *(float4*)(C + crow) = make_float4(v[0], v[1], v[2], v[3]);
+                else for (int j = 0; j < 4; ++j) if (n + j < p.N) C[crow + j] = v[j];
+            } else {
+                bf16_t* C = (bf16_t*)p.C;
+                if (full) {
+                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                    *(uint2*)(C + crow) = o;
+                } else {
+                    for (int j = 0; j < 4; ++j) if (n + j < p.N) C[crow + j] = f2bf(v[j]);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                  const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
+                                  int act, float alpha, float dropout_p, unsigned long long seed, int out_f32,
+                                  void* stream) {
+    CLDRD_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
+    CLDRD_CHECK(K % BK == 0, "gemm_nt: K must be a multiple of 64");
+    CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_nt: lda/ldb must be multiples of 8, ldc of 4");
+    CLDRD_CHECK(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "gemm_nt: operands must be 16-byte aligned");
+    CLDRD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, "gemm_nt: dropout_p out of range");
+    GemmNtArgs a;
+    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
+    a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.bias = bias; a.residual = (const bf16_t*)residual; a.ldr = ldr;
+    a.preact = (bf16_t*)preact; a.gelu_pre = (const bf16_t*)gelu_pre;
+    a.act = act; a.alpha = alpha;
+    a.drop_thresh = dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u;
+    a.drop_scale = 1.0f / (1.0f - dropout_p);
+    a.seed = seed; a.out_f32 = out_f32;
+    const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(nblk), dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, a);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,410 @@
+// Row kernels of the encoder: embedding + LayerNorm, residual LayerNorm (forward / backward), the
+// parameter-gradient reductions that go with them, and column sums for bias gradients.
+//
+// Reference call sites: HF Embeddings.forward (word + position (+ token type) -> LayerNorm(eps 1e-12) ->
+// dropout) and the two post-LN LayerNorms of every transformer block.  All of these
+// are HBM-bound: one wavefront owns one token row (d <= 1024), 8-byte bf16 loads per lane, two-pass
+// mean/variance in registers, wave-level shuffles for the reductions; LN statistics and all parameter
+// gradients are fp32.  Parameter gradients are reduced deterministically: per-block partial rows, then
+// one column-sum pass (no float atomics) - except the embedding-table scatter, which uses fp32 atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_IT = 4;          // d <= 4 * 256
+
+struct RowF { float v[MAX_IT][4]; };
+
+__device__ __forceinline__ void load_row_bf16(const bf16_t* row, int d, int lane, RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            const uint2 u = *(const uint2*)(row + c);
+            r.v[it][0] = __uint_as_float(u.x << 16); r.v[it][1] = __uint_as_float(u.x & 0xFFFF0000u);
+            r.v[it][2] = __uint_as_float(u.y << 16); r.v[it][3] = __uint_as_float(u.y & 0xFFFF0000u);
+        } else {
+            r.v[it][0] = r.v[it][1] = r.v[it][2] = r.v[it][3] = 0.f;
+        }
+    }
+}
+__device__ __forceinline__ void load_row_f32(const float* row, int d, int lane, RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            const float4 u = *(const float4*)(row + c);
+            r.v[it][0] = u.x; r.v[it][1] = u.y; r.v[it][2] = u.z; r.v[it][3] = u.w;
+        } else {
+            r.v[it][0] = r.v[it][1] = r.v[it][2] = r.v[it][3] = 0.f;
+        }
+    }
+}
+__device__ __forceinline__ void store_row_bf16(bf16_t* row, int d, int lane, const RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            uint2 u; u.x = pack2bf(r.v[it][0], r.v[it][1]); u.y = pack2bf(r.v[it][2], r.v[it][3]);
+            *(uint2*)(row + c) = u;
+        }
+    }
+}
+__device__ __forceinline__ void row_stats(const RowF& r, int d, int lane, float eps, float& mean, float& rstd) {
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) s += (r.v[it][0] + r.v[it][1]) + (r.v[it][2] + r.v[it][3]);
+    mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float t = r.v[it][j] - mean; q += t * t; }
+        }
+    }
+    rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+}
+
+// out = LN(x) * gamma + beta;   optional fp32 copy of rows r with r % cls_stride == 0 (the CLS pooling of
+// reference models/nway_dual_encoder.py:52,56,64 folded into the last LayerNorm).
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ out,
+                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int T, int d,
+                                                      float eps, float* __restrict__ cls_out, int cls_stride) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    RowF r;
+    load_row_bf16(x + (size_t)row * d, d, lane, r);
+    float mean, rstd;
+    row_stats(r, d, lane, eps, mean, rstd);
+    const bool cls = cls_out && (row % cls_stride == 0);
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+            r.v[it][0] = (r.v[it][0] - mean) * rstd * g.x + b.x; r.v[it][1] = (r.v[it][1] - mean) * rstd * g.y + b.y;
+            r.v[it][2] = (r.v[it][2] - mean) * rstd * g.z + b.z; r.v[it][3] = (r.v[it][3] - mean) * rstd * g.w + b.w;
+            if (cls) *(float4*)(cls_out + (size_t)(row / cls_stride) * d + c) = make_float4(r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
+        }
+    }
+    store_row_bf16(out + (size_t)row * d, d, lane, r);
+    if (lane == 0) { if (mean_o) mean_o[row] = mean; if (rstd_o) rstd_o[row] = rstd; }
+}
+
+// word + position (+ type) embedding -> LN -> dropout.  Tables are the fp32 master weights (HF keeps the
+// embedding lookup and LayerNorm in fp32 under autocast).
+__global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
+                                                            const float* __restrict__ pos, const float* __restrict__ type0,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            bf16_t* __restrict__ out, float* __restrict__ mean_o,
+                                                            float* __restrict__ rstd_o, int T, int L, int d, int vocab, float eps,
+                                                            uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= T) return;
+    int64_t id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    RowF r, p;
+    load_row_f32(word + (size_t)id * d, d, lane, r);
+    load_row_f32(pos + (size_t)(row % L) * d, d, lane, p);
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.v[it][j] += p.v[it][j];
+    if (type0) {
+        load_row_f32(type0, d, lane, p);
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r.v[it][j] += p.v[it][j];
+    }
+    float mean, rstd;
+    row_stats(r, d, lane, eps, mean, rstd);
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
+            const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y = (r.v[it][j] - mean) * rstd * gg[j] + bb[j];
+                if (drop_thresh) y = dropout_keep(seed, (uint64_t)row * d + c + j, drop_thresh) ? y * drop_scale : 0.f;
+                r.v[it][j] = y;
+            }
+        }
+    }
+    store_row_bf16(out + (size_t)row * d, d, lane, r);
+    if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+}
+
+// Accumulate three per-column partial sums of a block into partial[blockIdx.x][3][d] through LDS.
+__device__ __forceinline__ void block_partials(float* smem, const RowF& a, const RowF& b, const RowF& c3, int d, int lane,
+                                               float* __restrict__ partial) {
+    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) smem[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(&smem[c + j], a.v[it][j]);
+                atomicAdd(&smem[d + c + j], b.v[it][j]);
+                atomicAdd(&smem[2 * d + c + j], c3.v[it][j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) partial[(size_t)blockIdx.x * 3 * d + i] = smem[i];
+}
+
+// LayerNorm backward.  x = the LN input (pre-LN residual sum), dy = gradient of the LN output.
+//   dx  = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))                       -> dx (residual path)
+//   dx2 = dropout-masked dx (the branch that went through dropout before the residual add), or null
+//   partial[blk] = { sum dy*xhat (dgamma), sum dy (dbeta), sum dx2-or-dx (bias grad of the preceding Linear) }
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                      const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                      const float* __restrict__ gamma, bf16_t* __restrict__ dx,
+                                                      bf16_t* __restrict__ dx2, float* __restrict__ partial, int T, int d,
+                                                      uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    const int lane = threadIdx.x & 63;
+    RowF dg, db, dbias;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dg.v[it][j] = db.v[it][j] = dbias.v[it][j] = 0.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += gridDim.x * 4) {
+        RowF g, xr;
+        load_row_bf16(dy + (size_t)row * d, d, lane, g);
+        load_row_bf16(x + (size_t)row * d, d, lane, xr);
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+                const float4 gm = *(const float4*)(gamma + c);
+                const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (xr.v[it][j] - mean) * rstd;
+                    const float dyv = g.v[it][j];
+                    dg.v[it][j] += dyv * xh; db.v[it][j] += dyv;
+                    const float t = dyv * gg[j];
+                    s1 += t; s2 += t * xh;
+                    xr.v[it][j] = xh; g.v[it][j] = t;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
+        RowF o2;
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            const int c = it * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = (c < d) ? rstd * (g.v[it][j] - s1 - xr.v[it][j] * s2) : 0.f;
+                g.v[it][j] = v;
+                if (drop_thresh && c < d) v = dropout_keep(seed, (uint64_t)row * d + c + j, drop_thresh) ? v * drop_scale : 0.f;
+                o2.v[it][j] = v;
+                dbias.v[it][j] += v;
+            }
+        }
+        store_row_bf16(dx + (size_t)row * d, d, lane, g);
+        if (dx2) store_row_bf16(dx2 + (size_t)row * d, d, lane, o2);
+    }
+    block_partials(lsm, dg, db, dbias, d, lane, partial);
+}
+
+// Embedding backward: dy -> (dropout) -> LN backward (statistics saved, input recomputed from the tables)
+// -> scatter-add into the word / position tables (fp32 atomics); LN-parameter and token-type gradients go
+// through per-block partials {dgamma, dbeta, dtype}.
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restrict__ dy, const int64_t* __restrict__ ids,
+                                                            const float* __restrict__ word, const float* __restrict__ pos,
+                                                            const float* __restrict__ type0, const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
+                                                            float* __restrict__ dword, float* __restrict__ dpos,
+                                                            float* __restrict__ partial, int T, int L, int d, int vocab,
+                                                            uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) float lsm[];
+    const int lane = threadIdx.x & 63;
+    RowF dg, db, dt;
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dg.v[it][j] = db.v[it][j] = dt.v[it][j] = 0.f;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += gridDim.x * 4) {
+        int64_t id = ids[row];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const int l = row % L;
+        RowF g, xr, p;
+        load_row_bf16(dy + (size_t)row * d, d, lane, g);
+        load_row_f32(word + (size_t)id * d, d, lane, xr);
+        load_row_f32(pos + (size_t)l * d, d, lane, p);
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xr.v[it][j] += p.v[it][j];
+        if (type0) {
+            load_row_f32(type0, d, lane, p);
+#pragma unroll
+            for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xr.v[it][j] += p.v[it][j];
+        }
+        const float mean = mean_i[row], rstd = rstd_i[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+                const float4 gm = *(const float4*)(gamma + c);
+                const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float dyv = g.v[it][j];
+                    if (drop_thresh) dyv = dropout_keep(seed, (uint64_t)row * d + c + j, drop_thresh) ? dyv * drop_scale : 0.f;
+                    const float xh = (xr.v[it][j] - mean) * rstd;
+                    dg.v[it][j] += dyv * xh; db.v[it][j] += dyv;
+                    const float t = dyv * gg[j];
+                    s1 += t; s2 += t * xh;
+                    xr.v[it][j] = xh; g.v[it][j] = t;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = rstd * (g.v[it][j] - s1 - xr.v[it][j] * s2);
+                    dt.v[it][j] += v;
+                    atomicAdd(dword + (size_t)id * d + c + j, v);
+                    atomicAdd(dpos + (size_t)l * d + c + j, v);
+                }
+            }
+        }
+    }
+    block_partials(lsm, dg, db, dt, d, lane, partial);
+}
+
+// out[c] (+)= sum_b partial[b][c]
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ out0,
+                                       float* __restrict__ out1, float* __restrict__ out2, int seg, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * n + c];
+    float* out = c < seg ? out0 : (c < 2 * seg ? out1 : out2);
+    if (!out) return;
+    const int i = c % seg;
+    out[i] = accumulate ? out[i] + s : s;
+}
+
+// column sums of a bf16 [T, N] matrix: partial[chunk][N]; thread owns 4 columns, block owns 1024 columns x rows_per_blk rows
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, float* __restrict__ partial, int T, int N,
+                                                      int ld, int rows_per_blk) {
+    const int c = blockIdx.x * 1024 + threadIdx.x * 4;
+    if (c >= N) return;
+    const int r0 = blockIdx.y * rows_per_blk, r1 = min(T, r0 + rows_per_blk);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const uint2 u = *(const uint2*)(x + (size_t)r * ld + c);
+        s0 += __uint_as_float(u.x << 16); s1 += __uint_as_float(u.x & 0xFFFF0000u);
+        s2 += __uint_as_float(u.y << 16); s3 += __uint_as_float(u.y & 0xFFFF0000u);
+    }
+    *(float4*)(partial + (size_t)blockIdx.y * N + c) = make_float4(s0, s1, s2, s3);
+}
+
+// g[T, d] = 0 except rows r*stride <- dcls[r] (gradient of the CLS pooling)
+__global__ void scatter_cls_kernel(const float* __restrict__ dcls, bf16_t* __restrict__ g, int R, int d, int stride) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) g[(size_t)r * stride * d + c] = f2bf(dcls[(size_t)r * d + c]);
+}
+
+}  // namespace
+
+static inline int ln_bwd_blocks(int T) { int b = (T + 3) / 4; return b < 1024 ? b : 1024; }
+
+extern "C" int cldrd_ln_partial_blocks(int T) { return ln_bwd_blocks(T); }
+
+extern "C" int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
+                                   int T, int d, float eps, float* cls_out, int cls_stride, void* stream) {
+    CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_fwd: need 0 < d <= 1024, d % 4 == 0");
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
+                       (bf16_t*)out, mean, rstd, T, d, eps, cls_out, cls_stride > 0 ? cls_stride : 1);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
+                                  const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
+                                  int d, int vocab, float eps, float dropout_p, unsigned long long seed, void* stream) {
+    CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_fwd: bad shape");
+    hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, word, pos,
+                       type0, gamma, beta, (bf16_t*)out, mean, rstd, T, L, d, vocab, eps,
+                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_reduce(const float* partial, int nblk, int d, float* o0, float* o1, float* o2, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 255) / 256), dim3(256), 0, st, partial, nblk, 3 * d, o0, o1, o2, d, accumulate);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+// partial must hold cldrd_ln_partial_blocks(T) * 3 * d floats.  dgamma/dbeta/dbias are accumulated (+=) when accumulate != 0.
+extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                   void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
+                                   int d, float dropout_p, unsigned long long seed, int accumulate, void* stream) {
+    CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_bwd: need 0 < d <= 1024, d % 4 == 0");
+    const int nb = ln_bwd_blocks(T);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 3 * d * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
+                       (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d,
+                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    CLDRD_LAUNCH_CHECK();
+    return launch_reduce(partial, nb, d, dgamma, dbeta, dbias, accumulate, (hipStream_t)stream);
+}
+
+extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,
+                                  const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
+                                  float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,
+                                  float dropout_p, unsigned long long seed, int accumulate, void* stream) {
+    CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_bwd: bad shape");
+    const int nb = ln_bwd_blocks(T);
+    hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(nb), dim3(256), 3 * d * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
+                       (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial, T, L, d, vocab,
+                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    CLDRD_LAUNCH_CHECK();
+    return launch_reduce(partial, nb, d, dgamma, dbeta, dtype0, accumulate, (hipStream_t)stream);
+}
+
+// bias gradient: out[N] (+)= column sums of x[T, N].  partial must hold ceil(T/128) * N floats.
+extern "C" int cldrd_colsum_bf16(const void* x, float* out, float* partial, int T, int N, int ld, int accumulate, void* stream) {
+    CLDRD_CHECK(T > 0 && N > 0 && N % 4 == 0 && ld % 4 == 0, "colsum: N and ld must be multiples of 4");
+    const int rows = 128;
+    const int ny = (T + rows - 1) / rows;
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 1023) / 1024, ny), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial, T, N, ld, rows);
+    CLDRD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)partial, ny, N,
+                       out, (float*)nullptr, (float*)nullptr, N, accumulate);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_scatter_cls_grad(const float* dcls, void* g, int R, int d, int stride, int T, void* stream) {
+    CLDRD_CHECK(R > 0 && d > 0 && stride > 0 && (long long)R * stride <= (long long)T + stride - 1, "scatter_cls_grad: bad shape");
+    if (hipMemsetAsync(g, 0, (size_t)T * d * sizeof(bf16_t), (hipStream_t)stream) != hipSuccess) return cldrd_set_error("scatter_cls_grad: memset failed");
+    hipLaunchKernelGGL(scatter_cls_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, (bf16_t*)g, R, d, stride);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,168 @@
+// Optimizer step of the trainer over ONE flat fp32 parameter buffer (both towers), fused:
+//   pass 1: global gradient square-norm (deterministic two-stage reduction) -> clip coefficient on device
+//   pass 2: clip + legacy-HF AdamW + linear-schedule lr + bf16 shadow weights, one read/write of (p, g, m, v)
+//
+// Reference: trainer/multistep-curriculum/nway_listwise_1.py:353-367 (unscale_, clip_grad_norm_(1.0), AdamW step,
+// scheduler.step) and :258-266 (two param groups: no weight decay for names containing "bias"/"LayerNorm.weight").
+// the reference spends ~4 extra passes over 0.5 GB x (p, g, m, v); this is HBM-bound at
+// 28 B/param (+2 B/param for the bf16 shadow the MFMA GEMMs consume).  No host synchronisation: the clip
+// coefficient stays in device memory.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n4, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 v = ((const float4*)g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)), out[2] = 1 if the norm is not finite
+__global__ void clip_coef_kernel(const float* __restrict__ partial, int nblk, float max_norm, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(red[0]);
+        out[0] = norm;
+        const float c = max_norm / (norm + 1e-6f);
+        out[1] = (max_norm > 0.f) ? (c < 1.f ? c : 1.f) : 1.f;
+        out[2] = (norm == norm && norm < 3.0e38f) ? 0.f : 1.f;
+    }
+}
+
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; const uint8_t* decay; bf16_t* shadow;
+    size_t n4; float lr, beta1, beta2, eps, wd, step_size; const float* coef;
+};
+
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    const float coef = a.coef ? a.coef[1] : 1.0f;
+    const bool skip = a.coef && a.coef[2] != 0.f;        // non-finite gradient norm: leave the weights untouched
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += stride) {
+        float4 p = ((float4*)a.p)[i];
+        if (!skip) {
+            const float4 g = ((const float4*)a.g)[i];
+            float4 m = ((float4*)a.m)[i], v = ((float4*)a.v)[i];
+            const bool dec = a.decay[i >> 4] != 0;         // flag per 64 elements
+            const float gg[4] = {g.x * coef, g.y * coef, g.z * coef, g.w * coef};
+            float pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mm[j] = a.beta1 * mm[j] + (1.f - a.beta1) * gg[j];
+                vv[j] = a.beta2 * vv[j] + (1.f - a.beta2) * gg[j] * gg[j];
+                pp[j] -= a.step_size * mm[j] / (sqrtf(vv[j]) + a.eps);
+                if (dec) pp[j] -= a.lr * a.wd * pp[j];
+            }
+            p = make_float4(pp[0], pp[1], pp[2], pp[3]);
+            ((float4*)a.p)[i] = p;
+            ((float4*)a.m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            ((float4*)a.v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+        if (a.shadow) {
+            uint2 o; o.x = pack2bf(p.x, p.y); o.y = pack2bf(p.z, p.w);
+            ((uint2*)a.shadow)[i] = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 p = ((const float4*)src)[i];
+        uint2 o; o.x = pack2bf(p.x, p.y); o.y = pack2bf(p.z, p.w);
+        ((uint2*)dst)[i] = o;
+    }
+}
+
+// Batched fp32 [rows, cols] -> bf16 [cols, rows] transposes (the K-contiguous weight shadows of the data-gradient
+// GEMMs).  desc[i] = {src offset, dst offset, rows, cols} in elements; tile_prefix[i] = first 32x32 tile of matrix i.
+__global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              const long long* __restrict__ desc, const int* __restrict__ tile_prefix,
+                                                              int ndesc) {
+    __shared__ float tile[32][33];
+    int i = 0;
+    while (i + 1 < ndesc && (int)blockIdx.x >= tile_prefix[i + 1]) ++i;
+    const long long so = desc[4 * i], dof = desc[4 * i + 1];
+    const int rows = (int)desc[4 * i + 2], cols = (int)desc[4 * i + 3];
+    const int t = blockIdx.x - tile_prefix[i];
+    const int tcols = (cols + 31) / 32;
+    const int r0 = (t / tcols) * 32, c0 = (t % tcols) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < rows && c < cols) ? src[so + (long long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < cols && r < rows) dst[dof + (long long)c * rows + r] = f2bf(tile[tx][k]);
+    }
+}
+
+}  // namespace
+
+static inline int stream_blocks(size_t n4) {
+    size_t b = (n4 + 255) / 256;
+    return (int)(b < 2048 ? (b ? b : 1) : 2048);
+}
+
+extern "C" int cldrd_sqnorm_blocks(void) { return 2048; }
+
+// out: device float[3] = {norm, clip coefficient, non-finite flag}; partial: device float[cldrd_sqnorm_blocks()].
+extern "C" int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, float* partial, float* out, void* stream) {
+    CLDRD_CHECK(n > 0 && n % 4 == 0 && ((uintptr_t)g % 16 == 0), "grad_clip_coef: n must be a multiple of 4, g 16-byte aligned");
+    const int nb = stream_blocks(n / 4);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, n / 4, partial);
+    CLDRD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, nb, max_norm, out);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+// Legacy transformers.AdamW (correct_bias=True), step is 1-based.  decay_flags: one byte per 64 parameters.
+// clip: device float[3] from cldrd_grad_clip_coef or null.  shadow: bf16 copy of the updated parameters or null.
+extern "C" int cldrd_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,
+                                size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                const float* clip, void* stream) {
+    CLDRD_CHECK(n > 0 && n % 64 == 0, "adamw_step: n must be a multiple of 64");
+    CLDRD_CHECK(step >= 1, "adamw_step: step is 1-based");
+    AdamArgs a;
+    a.p = p; a.g = g; a.m = m; a.v = v; a.decay = decay_flags; a.shadow = (bf16_t*)shadow; a.n4 = n / 4;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.coef = clip;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.step_size = (float)((double)lr * sqrt(bc2) / bc1);
+    hipLaunchKernelGGL(adamw_kernel, dim3(stream_blocks(a.n4)), dim3(256), 0, (hipStream_t)stream, a);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_cast_bf16(const float* src, void* dst, size_t n, void* stream) {
+    CLDRD_CHECK(n > 0 && n % 4 == 0, "cast_bf16: n must be a multiple of 4");
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_transpose_cast_batched(const float* src, void* dst, const long long* desc, const int* tile_prefix, int ndesc,
+                                            int total_tiles, void* stream) {
+    CLDRD_CHECK(ndesc > 0 && total_tiles > 0, "transpose_cast_batched: empty");
+    hipLaunchKernelGGL(transpose_cast_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, desc, tile_prefix, ndesc);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}

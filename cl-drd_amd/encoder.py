@@ -1,0 +1,584 @@
+"""The BERT / DistilBERT encoder tower on MI355X: flat parameter store + explicit forward / backward over the
+C-ABI kernels (include/cldrd_hip.h).
+
+Stands in for ``transformers.AutoModel.from_pretrained(...)`` as used by the reference
+(``models/nway_dual_encoder.py:14-19,52,56,64``): same parameter names (state-dict compatible with HF
+DistilBertModel / BertModel checkpoints), same maths (post-LN transformer, erf-GELU, additive key mask,
+LayerNorm eps 1e-12, dropout 0.1), CLS pooling folded into the last LayerNorm.
+
+MI355X-first layout decisions
+  * all parameters of a tower live in ONE fp32 buffer (``flat_p``; gradients in ``flat_g`` with the same layout),
+    each ``nn.Parameter`` is a view -> the optimizer / gradient-norm / RCCL all-reduce run over flat ranges
+    (one bucket per transformer layer, reverse order) instead of 100 small tensors;
+  * q/k/v weights are adjacent, so the fused [3d, d] QKV projection is a view, not a copy;
+  * the MFMA GEMMs read bf16 shadows (``flat_h``) plus K-contiguous transposed shadows of the four big matrices
+    of each layer (for the data-gradient GEMMs), refreshed by the fused optimizer kernel;
+  * activations are bf16, LayerNorm statistics / softmax log-sum-exp / CLS output fp32; the backward is written
+    by hand (no autograd graph inside the tower), dropout masks are regenerated from a counter-based hash.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import asdict, dataclass
+
+import torch
+import torch.nn as nn
+
+from . import hip_ops as ops
+
+_KNOWN = {
+    "distilbert-base-uncased": dict(arch="distilbert", vocab_size=30522, dim=768, n_heads=12, hidden_dim=3072, n_layers=6,
+                                    max_position_embeddings=512),
+    "sebastian-hofstaetter/distilbert-dot-tas_b-b256-msmarco": dict(arch="distilbert", vocab_size=30522, dim=768, n_heads=12,
+                                                                    hidden_dim=3072, n_layers=6, max_position_embeddings=512),
+    "bert-base-uncased": dict(arch="bert", vocab_size=30522, dim=768, n_heads=12, hidden_dim=3072, n_layers=12,
+                              max_position_embeddings=512),
+}
+
+
+@dataclass
+class EncoderConfig:
+    arch: str = "distilbert"            # "distilbert" | "bert"
+    vocab_size: int = 30522
+    dim: int = 768
+    n_heads: int = 12
+    hidden_dim: int = 3072
+    n_layers: int = 6
+    max_position_embeddings: int = 512
+    type_vocab_size: int = 2
+    eps: float = 1e-12
+    dropout: float = 0.1                # hidden / embedding dropout
+    attention_dropout: float = 0.1
+    initializer_range: float = 0.02
+
+    def validate(self):
+        if self.arch not in ("distilbert", "bert"):
+            raise ValueError(f"unsupported arch {self.arch}")
+        if self.dim != self.n_heads * 64:
+            raise ValueError("the attention kernel needs head dim 64 (dim == 64 * n_heads)")
+        if self.dim % 128 or self.hidden_dim % 128 or self.dim > 1024:
+            raise ValueError("dim and hidden_dim must be multiples of 128, dim <= 1024")
+
+    @classmethod
+    def from_hf_dict(cls, c: dict) -> "EncoderConfig":
+        mt = c.get("model_type", "distilbert")
+        if mt == "distilbert":
+            return cls(arch="distilbert", vocab_size=c["vocab_size"], dim=c["dim"], n_heads=c["n_heads"],
+                       hidden_dim=c["hidden_dim"], n_layers=c["n_layers"],
+                       max_position_embeddings=c["max_position_embeddings"], dropout=c.get("dropout", 0.1),
+                       attention_dropout=c.get("attention_dropout", 0.1), initializer_range=c.get("initializer_range", 0.02))
+        if mt == "bert":
+            return cls(arch="bert", vocab_size=c["vocab_size"], dim=c["hidden_size"], n_heads=c["num_attention_heads"],
+                       hidden_dim=c["intermediate_size"], n_layers=c["num_hidden_layers"],
+                       max_position_embeddings=c["max_position_embeddings"], type_vocab_size=c.get("type_vocab_size", 2),
+                       eps=c.get("layer_norm_eps", 1e-12), dropout=c.get("hidden_dropout_prob", 0.1),
+                       attention_dropout=c.get("attention_probs_dropout_prob", 0.1),
+                       initializer_range=c.get("initializer_range", 0.02))
+        raise ValueError(f"unsupported model_type {mt}")
+
+    def to_hf_dict(self) -> dict:
+        if self.arch == "distilbert":
+            return dict(model_type="distilbert", vocab_size=self.vocab_size, dim=self.dim, n_heads=self.n_heads,
+                        hidden_dim=self.hidden_dim, n_layers=self.n_layers,
+                        max_position_embeddings=self.max_position_embeddings, dropout=self.dropout,
+                        attention_dropout=self.attention_dropout, activation="gelu", initializer_range=self.initializer_range)
+        return dict(model_type="bert", vocab_size=self.vocab_size, hidden_size=self.dim, num_attention_heads=self.n_heads,
+                    intermediate_size=self.hidden_dim, num_hidden_layers=self.n_layers,
+                    max_position_embeddings=self.max_position_embeddings, type_vocab_size=self.type_vocab_size,
+                    layer_norm_eps=self.eps, hidden_dropout_prob=self.dropout,
+                    attention_probs_dropout_prob=self.attention_dropout, hidden_act="gelu",
+                    initializer_range=self.initializer_range)
+
+
+def layer_param_names(cfg: EncoderConfig, i: int):
+    """HF names of one layer in flat-buffer order: q, k, v (weights), q, k, v (biases), out, ln1, ffn1, ffn2, ln2."""
+    if cfg.arch == "distilbert":
+        p = f"transformer.layer.{i}."
+        q, k, v, o = p + "attention.q_lin", p + "attention.k_lin", p + "attention.v_lin", p + "attention.out_lin"
+        ln1, f1, f2, ln2 = p + "sa_layer_norm", p + "ffn.lin1", p + "ffn.lin2", p + "output_layer_norm"
+    else:
+        p = f"encoder.layer.{i}."
+        q, k, v = p + "attention.self.query", p + "attention.self.key", p + "attention.self.value"
+        o, ln1 = p + "attention.output.dense", p + "attention.output.LayerNorm"
+        f1, f2, ln2 = p + "intermediate.dense", p + "output.dense", p + "output.LayerNorm"
+    return dict(q=q, k=k, v=v, o=o, ln1=ln1, f1=f1, f2=f2, ln2=ln2)
+
+
+def param_table(cfg: EncoderConfig):
+    """[(hf_name, shape)] in flat-buffer order."""
+    d, f = cfg.dim, cfg.hidden_dim
+    t = [("embeddings.word_embeddings.weight", (cfg.vocab_size, d)),
+         ("embeddings.position_embeddings.weight", (cfg.max_position_embeddings, d))]
+    if cfg.arch == "bert":
+        t.append(("embeddings.token_type_embeddings.weight", (cfg.type_vocab_size, d)))
+    t += [("embeddings.LayerNorm.weight", (d,)), ("embeddings.LayerNorm.bias", (d,))]
+    for i in range(cfg.n_layers):
+        n = layer_param_names(cfg, i)
+        t += [(n["q"] + ".weight", (d, d)), (n["k"] + ".weight", (d, d)), (n["v"] + ".weight", (d, d)),
+              (n["q"] + ".bias", (d,)), (n["k"] + ".bias", (d,)), (n["v"] + ".bias", (d,)),
+              (n["o"] + ".weight", (d, d)), (n["o"] + ".bias", (d,)),
+              (n["ln1"] + ".weight", (d,)), (n["ln1"] + ".bias", (d,)),
+              (n["f1"] + ".weight", (f, d)), (n["f1"] + ".bias", (f,)),
+              (n["f2"] + ".weight", (d, f)), (n["f2"] + ".bias", (d,)),
+              (n["ln2"] + ".weight", (d,)), (n["ln2"] + ".bias", (d,))]
+    return t
+
+
+def _numel(shape):
+    n = 1
+    for s in shape:
+        n *= s
+    return n
+
+
+class FlatLayout:
+    """Offsets of every parameter inside the flat buffer (each start aligned to 64 elements)."""
+
+    def __init__(self, cfg: EncoderConfig):
+        self.cfg = cfg
+        self.entries = {}          # name -> (offset, shape)
+        self.order = []
+        off = 0
+        self.layer_range = []      # (start, end) of each transformer layer
+        self.embed_range = None
+        first_layer_name = layer_param_names(cfg, 0)["q"] + ".weight" if cfg.n_layers else None
+        cur_layer_start = None
+        for name, shape in param_table(cfg):
+            if name == first_layer_name:
+                self.embed_range = (0, off)
+            for i in range(cfg.n_layers):
+                if name == layer_param_names(cfg, i)["q"] + ".weight":
+                    if cur_layer_start is not None:
+                        self.layer_range.append((cur_layer_start, off))
+                    cur_layer_start = off
+            self.entries[name] = (off, tuple(shape))
+            self.order.append(name)
+            off += (_numel(shape) + 63) // 64 * 64
+        if cur_layer_start is not None:
+            self.layer_range.append((cur_layer_start, off))
+        if self.embed_range is None:
+            self.embed_range = (0, off)
+        self.total = off
+        # transposed bf16 shadows: per layer WqkvT [d,3d], WoT [d,d], W1T [d,f], W2T [f,d]
+        d, f = cfg.dim, cfg.hidden_dim
+        self.t_entries = []        # per layer dict name -> (offset, (rows, cols) of the transposed matrix)
+        toff = 0
+        for i in range(cfg.n_layers):
+            e = {}
+            for key, shp in (("qkv", (d, 3 * d)), ("o", (d, d)), ("f1", (d, f)), ("f2", (f, d))):
+                e[key] = (toff, shp)
+                toff += shp[0] * shp[1]
+            self.t_entries.append(e)
+        self.t_total = toff
+
+
+def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    mod = root
+    parts = dotted.split(".")
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, nn.Module())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], param)
+
+
+class _Tape:
+    """Activations saved by one training forward of one tower."""
+    __slots__ = ("M", "L", "T", "ids", "mask", "seed", "mean0", "rstd0", "layers", "p_embed")
+
+
+class HipEncoder(nn.Module):
+    """One encoder tower.  ``encode(ids, mask)`` -> CLS embeddings fp32 [M, d]."""
+
+    def __init__(self, cfg: EncoderConfig, seed: int | None = None):
+        super().__init__()
+        cfg.validate()
+        self.cfg = cfg
+        self.layout = FlatLayout(cfg)
+        self.flat_p = torch.zeros(self.layout.total, dtype=torch.float32)
+        self.flat_g = None
+        self.flat_h = None          # bf16 shadow (same layout)
+        self.flat_t = None          # transposed bf16 shadows
+        self._t_desc = None
+        self._shadow_version = -1
+        self._names = list(self.layout.order)
+        for name in self._names:
+            off, shape = self.layout.entries[name]
+            _attach(self, name, nn.Parameter(self.flat_p[off:off + _numel(shape)].view(shape)))
+        self.reset_parameters(seed)
+        self.step_seed = 0
+
+    # ------------------------------------------------------------------ parameters
+    def named_flat(self):
+        d = dict(self.named_parameters())
+        return [(n, d[n]) for n in self._names]
+
+    def reset_parameters(self, seed: int | None = None):
+        """HF init: N(0, initializer_range) for Linear / Embedding weights, LN gamma 1, biases and LN beta 0."""
+        g = torch.Generator().manual_seed(0 if seed is None else seed)
+        with torch.no_grad():
+            for name, p in self.named_flat():
+                if "LayerNorm.weight" in name or "layer_norm.weight" in name:
+                    p.fill_(1.0)
+                elif name.endswith(".bias"):
+                    p.zero_()
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * self.cfg.initializer_range)
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self._reflatten()
+        return self
+
+    def _reflatten(self):
+        """Re-establish the flat aliasing after .to()/.cuda() moved the parameters one by one."""
+        params = dict(self.named_parameters())
+        dev = params[self._names[0]].device
+        if self.flat_p.device != dev or any(
+                params[n].data_ptr() != self.flat_p.data_ptr() + 4 * self.layout.entries[n][0] for n in self._names[:3]):
+            flat = torch.zeros(self.layout.total, dtype=torch.float32, device=dev)
+            for n in self._names:
+                off, shape = self.layout.entries[n]
+                flat[off:off + _numel(shape)].view(shape).copy_(params[n].data.to(torch.float32))
+                params[n].data = flat[off:off + _numel(shape)].view(shape)
+            self.flat_p = flat
+            self.flat_g = None
+            self.flat_h = self.flat_t = self._t_desc = None
+            self._shadow_version = -1
+
+    def adopt_flat(self, flat_p: torch.Tensor, flat_g: torch.Tensor | None = None):
+        """Move this tower's parameters into a slice of a model-level flat buffer (same device)."""
+        assert flat_p.numel() == self.layout.total and flat_p.dtype == torch.float32
+        flat_p.copy_(self.flat_p.to(flat_p.device))
+        params = dict(self.named_parameters())
+        for n in self._names:
+            off, shape = self.layout.entries[n]
+            params[n].data = flat_p[off:off + _numel(shape)].view(shape)
+        self.flat_p = flat_p
+        self.flat_g = flat_g
+        if flat_g is not None:
+            self._bind_grads()
+        self._shadow_version = -1
+
+    def _bind_grads(self):
+        params = dict(self.named_parameters())
+        for n in self._names:
+            off, shape = self.layout.entries[n]
+            params[n].grad = self.flat_g[off:off + _numel(shape)].view(shape)
+
+    def ensure_grads(self):
+        if self.flat_g is None or self.flat_g.device != self.flat_p.device:
+            self.flat_g = torch.zeros_like(self.flat_p)
+        p0 = next(self.parameters())
+        if p0.grad is None or p0.grad.data_ptr() != self.flat_g.data_ptr():
+            self._bind_grads()
+
+    def g(self, name):
+        off, shape = self.layout.entries[name]
+        return self.flat_g[off:off + _numel(shape)].view(shape)
+
+    def w(self, name):
+        off, shape = self.layout.entries[name]
+        return self.flat_p[off:off + _numel(shape)].view(shape)
+
+    def h(self, name):
+        off, shape = self.layout.entries[name]
+        return self.flat_h[off:off + _numel(shape)].view(shape)
+
+    # ------------------------------------------------------------------ bf16 shadows
+    def _build_t_desc(self):
+        cfg, lay = self.cfg, self.layout
+        desc, prefix, tiles = [], [0], 0
+        for i in range(cfg.n_layers):
+            n = layer_param_names(cfg, i)
+            te = lay.t_entries[i]
+            for key, src_name, rows, cols in (("qkv", n["q"] + ".weight", 3 * cfg.dim, cfg.dim),
+                                              ("o", n["o"] + ".weight", cfg.dim, cfg.dim),
+                                              ("f1", n["f1"] + ".weight", cfg.hidden_dim, cfg.dim),
+                                              ("f2", n["f2"] + ".weight", cfg.dim, cfg.hidden_dim)):
+                desc += [lay.entries[src_name][0], te[key][0], rows, cols]
+                tiles += ((rows + 31) // 32) * ((cols + 31) // 32)
+                prefix.append(tiles)
+        dev = self.flat_p.device
+        self._t_desc = (torch.tensor(desc, dtype=torch.int64, device=dev), torch.tensor(prefix, dtype=torch.int32, device=dev),
+                        len(desc) // 4, tiles)
+
+    def refresh_shadows(self, need_transposed: bool = True, cast: bool = True):
+        """bf16 copies of the weights for the MFMA GEMMs (+ transposed copies for the data-gradient GEMMs)."""
+        if not self.flat_p.is_cuda:
+            raise RuntimeError("HipEncoder runs on the GPU only: move the model with .cuda() first (no CPU path)")
+        if self.flat_h is None:
+            self.flat_h = torch.empty(self.layout.total, dtype=torch.bfloat16, device=self.flat_p.device)
+        if cast:
+            ops.cast_bf16(self.flat_p, self.flat_h)
+        if need_transposed and self.cfg.n_layers:
+            if self.flat_t is None:
+                self.flat_t = torch.empty(self.layout.t_total, dtype=torch.bfloat16, device=self.flat_p.device)
+            if self._t_desc is None:
+                self._build_t_desc()
+            desc, prefix, nd, tiles = self._t_desc
+            ops.transpose_cast_batched(self.flat_p, self.flat_t, desc, prefix, nd, tiles)
+            self._t_fresh = True
+        else:
+            self._t_fresh = False
+        self._shadow_version = self.flat_p._version
+
+    def _shadows_ok(self, need_t):
+        return (self.flat_h is not None and self._shadow_version == self.flat_p._version and
+                (not need_t or (self.flat_t is not None and getattr(self, "_t_fresh", False))))
+
+    def ht(self, layer, key):
+        off, shp = self.layout.t_entries[layer][key]
+        return self.flat_t[off:off + shp[0] * shp[1]].view(shp)
+
+    # ------------------------------------------------------------------ forward
+    def _layer_weights(self, i):
+        cfg, n = self.cfg, layer_param_names(self.cfg, i)
+        d = cfg.dim
+        oq = self.layout.entries[n["q"] + ".weight"][0]
+        ob = self.layout.entries[n["q"] + ".bias"][0]
+        return dict(Wqkv=self.flat_h[oq:oq + 3 * d * d].view(3 * d, d), bqkv=self.flat_p[ob:ob + 3 * d],
+                    Wo=self.h(n["o"] + ".weight"), bo=self.w(n["o"] + ".bias"),
+                    g1=self.w(n["ln1"] + ".weight"), b1=self.w(n["ln1"] + ".bias"),
+                    W1=self.h(n["f1"] + ".weight"), bf1=self.w(n["f1"] + ".bias"),
+                    W2=self.h(n["f2"] + ".weight"), bf2=self.w(n["f2"] + ".bias"),
+                    g2=self.w(n["ln2"] + ".weight"), b2=self.w(n["ln2"] + ".bias"))
+
+    def _layer_grads(self, i):
+        cfg, n = self.cfg, layer_param_names(self.cfg, i)
+        d = cfg.dim
+        oq = self.layout.entries[n["q"] + ".weight"][0]
+        ob = self.layout.entries[n["q"] + ".bias"][0]
+        return dict(Wqkv=self.flat_g[oq:oq + 3 * d * d].view(3 * d, d), bqkv=self.flat_g[ob:ob + 3 * d],
+                    Wo=self.g(n["o"] + ".weight"), bo=self.g(n["o"] + ".bias"),
+                    g1=self.g(n["ln1"] + ".weight"), b1=self.g(n["ln1"] + ".bias"),
+                    W1=self.g(n["f1"] + ".weight"), bf1=self.g(n["f1"] + ".bias"),
+                    W2=self.g(n["f2"] + ".weight"), bf2=self.g(n["f2"] + ".bias"),
+                    g2=self.g(n["ln2"] + ".weight"), b2=self.g(n["ln2"] + ".bias"))
+
+    @staticmethod
+    def _buf(rows, cols, dev, dtype=torch.bfloat16):
+        rp = ops.pad_rows(rows)
+        if rp == rows:
+            return torch.empty(rp, cols, dtype=dtype, device=dev)
+        return torch.zeros(rp, cols, dtype=dtype, device=dev)      # zero tail: contract of cldrd_wgrad_bf16
+
+    def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None, *, train: bool | None = None,
+               save: bool = False, seed: int | None = None):
+        """CLS embeddings fp32 [M, d] (== HF ``model(**enc)[0][:, 0, :]``).  With ``save`` also returns the tape."""
+        cfg = self.cfg
+        train = self.training if train is None else train
+        if input_ids.dim() != 2:
+            raise ValueError("input_ids must be [M, L]")
+        M, L = input_ids.shape
+        if L > 256 or L > cfg.max_position_embeddings:
+            raise ValueError("sequence length must be <= 256 (and <= max_position_embeddings)")
+        dev = self.flat_p.device
+        if not self._shadows_ok(save):
+            self.refresh_shadows(need_transposed=save)
+        ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
+        mask = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
+        T, d, f, H = M * L, cfg.dim, cfg.hidden_dim, cfg.n_heads
+        p_h = cfg.dropout if train else 0.0
+        p_a = cfg.attention_dropout if train else 0.0
+        if seed is None:
+            self.step_seed += 1
+            seed = (self.step_seed * 0x9E3779B1) & 0x7FFFFFFFFFFF
+        tape = None
+        if save:
+            tape = _Tape()
+            tape.M, tape.L, tape.T, tape.ids, tape.mask, tape.seed, tape.layers = M, L, T, ids, mask, seed, []
+            tape.p_embed = p_h
+        f32 = dict(dtype=torch.float32, device=dev)
+        x = self._buf(T, d, dev)
+        mean0, rstd0 = torch.empty(T, **f32), torch.empty(T, **f32)
+        type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
+        ops.embed_ln_fwd(ids.view(-1), self.w("embeddings.word_embeddings.weight"),
+                         self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
+                         self.w("embeddings.LayerNorm.bias"), x, mean0, rstd0, T, L, cfg.eps, p_h, seed)
+        if save:
+            tape.mean0, tape.rstd0 = mean0, rstd0
+        cls = torch.empty(M, d, **f32)
+        p_out = p_h if cfg.arch == "bert" else 0.0          # DistilBERT has no dropout after out_lin
+        for i in range(cfg.n_layers):
+            W = self._layer_weights(i)
+            s_l = seed + 7919 * (i + 1)
+            qkv = self._buf(T, 3 * d, dev)
+            ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
+            ctx = self._buf(T, d, dev)
+            lse = torch.empty(M, H, L, **f32) if save else None
+            ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1)
+            s1 = self._buf(T, d, dev)
+            ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x, dropout_p=p_out, seed=s_l + 2)
+            x1 = self._buf(T, d, dev)
+            mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if save else (None, None)
+            ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps)
+            hbuf = self._buf(T, f, dev)
+            pre = self._buf(T, f, dev) if save else None
+            ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=1)
+            s2 = self._buf(T, d, dev)
+            ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=x1, dropout_p=p_h, seed=s_l + 3)
+            xo = self._buf(T, d, dev)
+            mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if save else (None, None)
+            last = i == cfg.n_layers - 1
+            ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, T, cfg.eps, cls if last else None, L)
+            if save:
+                tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
+                                        h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h, p_a=p_a, p_out=p_out))
+            x = xo
+        if cfg.n_layers == 0:
+            cls.copy_(x.view(ops.pad_rows(T), d)[:T].view(M, L, d)[:, 0].float())
+        return (cls, tape) if save else cls
+
+    # ------------------------------------------------------------------ backward
+    def backward_from_cls(self, tape: _Tape, dcls: torch.Tensor, after_layer=None):
+        """Accumulate parameter gradients of this tower into ``flat_g`` given dL/dCLS (fp32 [M, d]).
+
+        ``after_layer(i)`` (optional) is called when the gradients of transformer layer i are complete (and with
+        -1 after the embedding gradients): the hook the trainer uses to launch that bucket's all-reduce."""
+        cfg = self.cfg
+        self.ensure_grads()
+        M, L, T = tape.M, tape.L, tape.T
+        d, f, H = cfg.dim, cfg.hidden_dim, cfg.n_heads
+        dev = self.flat_p.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        partial = torch.empty(max(ops.ln_partial_elems(T, d), ((T + 127) // 128) * max(3 * d, f)), **f32)
+        ws = torch.empty(max(ops.wgrad_workspace_elems(T, 3 * d, d), ops.wgrad_workspace_elems(T, d, d),
+                             ops.wgrad_workspace_elems(T, f, d), ops.wgrad_workspace_elems(T, d, f)), **f32)
+        g = self._buf(T, d, dev)
+        ops.scatter_cls_grad(dcls.contiguous(), g, M, L, T)
+        for i in reversed(range(cfg.n_layers)):
+            W, G, a = self._layer_weights(i), self._layer_grads(i), tape.layers[i]
+            s_l, p_h, p_a, p_out = a["seed"], a["p_h"], a["p_a"], a["p_out"]
+            # --- output LayerNorm + FFN ---
+            ds2 = self._buf(T, d, dev)
+            ds2m = self._buf(T, d, dev) if p_h > 0 else None
+            ops.layernorm_bwd(g, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], partial, T,
+                              p_h, s_l + 3)
+            dF = ds2m if ds2m is not None else ds2
+            ops.wgrad(dF, a["h"], G["W2"], T, ws, accumulate=True)
+            dpre = self._buf(T, f, dev)
+            ops.gemm_nt(dF, self.ht(i, "f2"), dpre, T, gelu_pre=a["pre"])
+            ops.colsum(dpre, G["bf1"], partial, T)
+            ops.wgrad(dpre, a["x1"], G["W1"], T, ws, accumulate=True)
+            dx1 = self._buf(T, d, dev)
+            ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T, residual=ds2)
+            # --- attention-output LayerNorm + attention ---
+            ds1 = self._buf(T, d, dev)
+            ds1m = self._buf(T, d, dev) if p_out > 0 else None
+            ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], partial, T,
+                              p_out, s_l + 2)
+            dA = ds1m if ds1m is not None else ds1
+            ops.wgrad(dA, a["ctx"], G["Wo"], T, ws, accumulate=True)
+            dctx = self._buf(T, d, dev)
+            ops.gemm_nt(dA, self.ht(i, "o"), dctx, T)
+            dqkv = self._buf(T, 3 * d, dev)
+            ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1)
+            ops.colsum(dqkv, G["bqkv"], partial, T)
+            ops.wgrad(dqkv, a["x_in"], G["Wqkv"], T, ws, accumulate=True)
+            g = self._buf(T, d, dev)
+            ops.gemm_nt(dqkv, self.ht(i, "qkv"), g, T, residual=ds1)
+            tape.layers[i] = None        # free this layer's activations
+            if after_layer is not None:
+                after_layer(i)
+        type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
+        dtype0 = self.g("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
+        ops.embed_ln_bwd(g, tape.ids.view(-1), self.w("embeddings.word_embeddings.weight"),
+                         self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
+                         tape.mean0, tape.rstd0, self.g("embeddings.word_embeddings.weight"),
+                         self.g("embeddings.position_embeddings.weight"), dtype0, self.g("embeddings.LayerNorm.weight"),
+                         self.g("embeddings.LayerNorm.bias"), partial, T, L, tape.p_embed, tape.seed)
+        if after_layer is not None:
+            after_layer(-1)
+
+    # ------------------------------------------------------------------ HF-style call surface
+    def forward(self, input_ids=None, attention_mask=None, **_):
+        """``encoder(**enc)[0][:, 0, :]`` compatibility: returns a 1-tuple whose element supports ``[:, 0, :]``."""
+        return (_ClsOnly(encode_autograd(self, input_ids, attention_mask)),)
+
+    # ------------------------------------------------------------------ (de)serialisation
+    def save_pretrained(self, path: str):
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as fh:
+            json.dump(self.cfg.to_hf_dict(), fh, indent=1)
+        torch.save({k: v.detach().cpu().clone() for k, v in self.state_dict().items()}, os.path.join(path, "pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, name_or_path, seed: int | None = None) -> "HipEncoder":
+        if isinstance(name_or_path, EncoderConfig):
+            return cls(name_or_path, seed=seed)
+        if os.path.isdir(str(name_or_path)):
+            with open(os.path.join(name_or_path, "config.json")) as fh:
+                cfg = EncoderConfig.from_hf_dict(json.load(fh))
+            enc = cls(cfg, seed=seed)
+            st = os.path.join(name_or_path, "model.safetensors")
+            if os.path.exists(st):
+                from safetensors.torch import load_file
+                sd = load_file(st)
+            else:
+                sd = torch.load(os.path.join(name_or_path, "pytorch_model.bin"), map_location="cpu")
+            enc.load_hf_state_dict(sd)
+            return enc
+        if str(name_or_path) in _KNOWN:
+            # no network in this environment: architecture of the named checkpoint, seeded random weights
+            import warnings
+            warnings.warn(f"{name_or_path}: pretrained weights are not available offline; using seeded random init")
+            return cls(EncoderConfig(**_KNOWN[str(name_or_path)]), seed=seed)
+        raise FileNotFoundError(f"{name_or_path}: not a local model directory and not a known architecture name")
+
+    def load_hf_state_dict(self, sd: dict):
+        """Accepts HF DistilBertModel / BertModel keys (optional ``distilbert.`` / ``bert.`` prefix; pooler ignored)."""
+        own = dict(self.named_parameters())
+        seen = set()
+        with torch.no_grad():
+            for k, v in sd.items():
+                kk = k
+                for pre in ("distilbert.", "bert."):
+                    if kk.startswith(pre):
+                        kk = kk[len(pre):]
+                if kk in own:
+                    own[kk].copy_(v.to(torch.float32))
+                    seen.add(kk)
+        missing = [n for n in self._names if n not in seen]
+        if missing:
+            raise KeyError(f"missing keys in checkpoint: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+
+
+class _ClsOnly:
+    """What ``encoder(**enc)[0]`` returns: only the CLS row is materialised; ``[:, 0, :]`` / ``[:, 0]``
+    give the fp32 CLS embeddings, anything else is refused loudly."""
+
+    def __init__(self, cls):
+        self.cls = cls
+
+    def __getitem__(self, idx):
+        if isinstance(idx, tuple) and len(idx) >= 2 and idx[0] == slice(None) and idx[1] == 0 and \
+                all(i == slice(None) for i in idx[2:]):
+            return self.cls
+        raise NotImplementedError("HipEncoder only materialises the CLS token: use last_hidden_state[:, 0, :]")
+
+
+class _EncodeFn(torch.autograd.Function):
+    """Autograd bridge for the reference-style loop (``loss.backward()``): the tower's hand-written backward runs
+    when the CLS gradient arrives; parameter gradients are accumulated straight into ``flat_g`` / ``param.grad``."""
+
+    @staticmethod
+    def forward(ctx, anchor, enc, ids, mask):
+        cls, tape = enc.encode(ids, mask, save=True)
+        ctx.enc, ctx.tape = enc, tape
+        return cls
+
+    @staticmethod
+    def backward(ctx, dcls):
+        ctx.enc.backward_from_cls(ctx.tape, dcls.contiguous().float())
+        ctx.tape = None
+        return None, None, None, None
+
+
+def encode_autograd(enc: HipEncoder, ids, mask):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in enc.parameters()):
+        if getattr(enc, "_anchor", None) is None or enc._anchor.device != enc.flat_p.device:
+            enc._anchor = torch.zeros(1, device=enc.flat_p.device, requires_grad=True)
+        return _EncodeFn.apply(enc._anchor, enc, ids, mask)
+    return enc.encode(ids, mask, save=False)

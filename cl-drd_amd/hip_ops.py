@@ -1,0 +1,212 @@
+"""Typed Python wrappers over the C ABI (include/cldrd_hip.h): torch tensors in, device pointers out.
+
+PyTorch is only plumbing here (device memory + the current HIP stream); every wrapper checks dtype / layout /
+device on the host (the reference raises Python exceptions before launch) and then calls
+the kernel.  There is no fallback: tensors must live on a GPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import call
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name, dim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor must be on the GPU (cldrd_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if dim is not None and t.dim() != dim:
+        raise ValueError(f"{name}: expected {dim} dims, got {t.dim()}")
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dim must be contiguous")
+    return t
+
+
+def pad_rows(rows: int) -> int:
+    """Activation / gradient buffers feeding cldrd_wgrad_bf16 are allocated with rows rounded up to 64 (zero tail)."""
+    return (rows + 63) // 64 * 64
+
+
+def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pre=None, act=0, alpha=1.0,
+            dropout_p=0.0, seed=0):
+    """out[M,N] = epilogue(alpha * A[M,K] @ B[N,K]^T); A, B bf16; out bf16 or fp32."""
+    _chk(A, BF16, "A", 2), _chk(B, BF16, "B", 2)
+    M = A.shape[0] if M is None else M
+    N, K = B.shape
+    if A.shape[1] != K or out.shape[1] != N or out.shape[0] < M or A.shape[0] < M:
+        raise ValueError(f"gemm_nt: shape mismatch A{tuple(A.shape)} B{tuple(B.shape)} out{tuple(out.shape)} M={M}")
+    out_f32 = 1 if out.dtype == F32 else 0
+    if not out_f32:
+        _chk(out, BF16, "out", 2)
+    if bias is not None:
+        _chk(bias, F32, "bias", 1)
+    for t, n in ((residual, "residual"), (preact, "preact"), (gelu_pre, "gelu_pre")):
+        if t is not None:
+            _chk(t, BF16, n, 2)
+    call("cldrd_gemm_nt_bf16", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
+         _p(residual), residual.stride(0) if residual is not None else 0, _p(preact), _p(gelu_pre), act, alpha,
+         dropout_p, seed, out_f32, _stream())
+    return out
+
+
+def wgrad_workspace_elems(M, N1, N2) -> int:
+    return _lib.load().cldrd_wgrad_splits(M, N1, N2) * N1 * N2
+
+
+def wgrad(dY, X, dW, M, workspace, accumulate=False):
+    """dW[N1,N2] (+)= dY[:M]^T @ X[:M]; dY, X bf16 with >= pad_rows(M) rows (zero tail); dW fp32."""
+    _chk(dY, BF16, "dY", 2), _chk(X, BF16, "X", 2), _chk(dW, F32, "dW", 2), _chk(workspace, F32, "workspace")
+    N1, N2 = dW.shape
+    if dY.shape[1] != N1 or X.shape[1] != N2 or not dW.is_contiguous():
+        raise ValueError("wgrad: shape mismatch")
+    if dY.shape[0] < pad_rows(M) or X.shape[0] < pad_rows(M):
+        raise ValueError("wgrad: operands need ceil(M/64)*64 rows allocated")
+    call("cldrd_wgrad_bf16", _p(dY), _p(X), _p(dW), M, N1, N2, dY.stride(0), X.stride(0), _p(workspace),
+         workspace.numel() * 4, 1 if accumulate else 0, _stream())
+    return dW
+
+
+def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0):
+    _chk(qkv, BF16, "qkv", 2), _chk(ctx, BF16, "ctx", 2)
+    if mask is not None:
+        _chk(mask, torch.int64, "mask", 2)
+        if not mask.is_contiguous() or tuple(mask.shape) != (nseq, L):
+            raise ValueError("attention: mask must be contiguous int64 [nseq, L]")
+    if qkv.shape[1] != 3 * H * 64 or ctx.shape[1] != H * 64 or not qkv.is_contiguous() or not ctx.is_contiguous():
+        raise ValueError("attention: qkv must be [T, 3*H*64], ctx [T, H*64], contiguous")
+    if lse is not None:
+        _chk(lse, F32, "lse")
+    call("cldrd_attention_fwd", _p(qkv), _p(mask), _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, _stream())
+    return ctx
+
+
+def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, seed=0):
+    for t, n in ((qkv, "qkv"), (ctx, "ctx"), (dctx, "dctx"), (dqkv, "dqkv")):
+        _chk(t, BF16, n, 2)
+        if not t.is_contiguous():
+            raise ValueError(f"attention_bwd: {n} must be contiguous")
+    _chk(lse, F32, "lse")
+    call("cldrd_attention_bwd", _p(qkv), _p(mask), _p(ctx), _p(dctx), _p(lse), _p(dqkv), nseq, L, H, dropout_p, seed,
+         _stream())
+    return dqkv
+
+
+def ln_partial_elems(T, d) -> int:
+    return _lib.load().cldrd_ln_partial_blocks(T) * 3 * d
+
+
+def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps, dropout_p=0.0, seed=0):
+    _chk(ids, torch.int64, "ids")
+    d = word.shape[1]
+    call("cldrd_embed_ln_fwd", _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd),
+         T, L, d, word.shape[0], eps, dropout_p, seed, _stream())
+    return out
+
+
+def embed_ln_bwd(dy, ids, word, pos, type0, gamma, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, partial, T, L,
+                 dropout_p=0.0, seed=0, accumulate=True):
+    d = word.shape[1]
+    call("cldrd_embed_ln_bwd", _p(dy), _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(mean), _p(rstd), _p(dword),
+         _p(dpos), _p(dtype0), _p(dgamma), _p(dbeta), _p(partial), T, L, d, word.shape[0], dropout_p, seed,
+         1 if accumulate else 0, _stream())
+
+
+def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_stride=0):
+    _chk(x, BF16, "x", 2), _chk(out, BF16, "out", 2), _chk(gamma, F32, "gamma", 1), _chk(beta, F32, "beta", 1)
+    d = x.shape[1]
+    call("cldrd_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), T, d, eps, _p(cls_out),
+         cls_stride, _stream())
+    return out
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_dropped, dgamma, dbeta, dbias, partial, T, dropout_p=0.0, seed=0,
+                  accumulate=True):
+    _chk(dy, BF16, "dy", 2), _chk(x, BF16, "x", 2), _chk(dx, BF16, "dx", 2)
+    d = x.shape[1]
+    call("cldrd_layernorm_bwd", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dx_dropped), _p(dgamma),
+         _p(dbeta), _p(dbias), _p(partial), T, d, dropout_p, seed, 1 if accumulate else 0, _stream())
+
+
+def colsum(x, out, partial, T, accumulate=True):
+    _chk(x, BF16, "x", 2), _chk(out, F32, "out", 1)
+    call("cldrd_colsum_bf16", _p(x), _p(out), _p(partial), T, x.shape[1], x.stride(0), 1 if accumulate else 0, _stream())
+
+
+def scatter_cls_grad(dcls, g, R, stride, T):
+    _chk(dcls, F32, "dcls", 2), _chk(g, BF16, "g", 2)
+    call("cldrd_scatter_cls_grad", _p(dcls), _p(g), R, dcls.shape[1], stride, T, _stream())
+
+
+def score_fwd(q, p, logits, B, N, mode=0):
+    _chk(q, F32, "q", 2), _chk(p, F32, "p", 2), _chk(logits, F32, "logits", 2)
+    call("cldrd_score_fwd", _p(q), _p(p), _p(logits), B, N, q.shape[1], mode, _stream())
+    return logits
+
+
+def score_bwd(dlogits, q, p, dq, dp, B, N, mode=0):
+    for t, n in ((dlogits, "dlogits"), (q, "q"), (p, "p"), (dq, "dq"), (dp, "dp")):
+        _chk(t, F32, n, 2)
+    call("cldrd_score_bwd", _p(dlogits), _p(q), _p(p), _p(dq), _p(dp), B, N, q.shape[1], mode, _stream())
+
+
+LOSS_KINDS = {"kl_div": 0, "margin_mse": 1, "ranknet": 2, "lambda_mrr": 3}
+
+
+def loss_fwd_bwd(kind, y_pred, y_true, *, batch_weight=None, T=1.0, pad_indicator=-1.0, reduction="mean"):
+    """Returns (loss_out float[2] on device = {loss, pair count}, grad [B,N])."""
+    if reduction not in ("mean", "sum"):
+        raise ValueError("Reduction method can be either sum or mean")
+    _chk(y_pred, F32, "y_pred", 2), _chk(y_true, F32, "y_true", 2)
+    if y_pred.shape != y_true.shape:
+        raise ValueError("loss: y_pred and y_true must have the same shape")
+    y_pred, y_true = y_pred.contiguous(), y_true.contiguous()
+    B, N = y_pred.shape
+    out = torch.empty(2, dtype=F32, device=y_pred.device)
+    grad = torch.empty_like(y_pred)
+    ws = torch.empty(2 * B, dtype=F32, device=y_pred.device)
+    if batch_weight is not None:
+        _chk(batch_weight, F32, "batch_weight", 1)
+    call("cldrd_loss_fwd_bwd", LOSS_KINDS[kind], _p(y_pred), _p(y_true), _p(batch_weight), _p(out), _p(grad), _p(ws), B, N,
+         float(T), float(pad_indicator), 1 if reduction == "mean" else 0, _stream())
+    return out, grad
+
+
+def sqnorm_blocks() -> int:
+    return _lib.load().cldrd_sqnorm_blocks()
+
+
+def grad_clip_coef(g, max_norm, partial, out):
+    _chk(g, F32, "g", 1)
+    call("cldrd_grad_clip_coef", _p(g), g.numel(), float(max_norm), _p(partial), _p(out), _stream())
+    return out
+
+
+def adamw_step(p, g, m, v, decay_flags, shadow, *, lr, beta1, beta2, eps, weight_decay, step, clip=None):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, F32, n, 1)
+    call("cldrd_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(decay_flags), _p(shadow), p.numel(), float(lr), float(beta1),
+         float(beta2), float(eps), float(weight_decay), int(step), _p(clip), _stream())
+
+
+def cast_bf16(src, dst):
+    _chk(src, F32, "src", 1), _chk(dst, BF16, "dst", 1)
+    call("cldrd_cast_bf16", _p(src), _p(dst), src.numel(), _stream())
+
+
+def transpose_cast_batched(src, dst, desc, tile_prefix, ndesc, total_tiles):
+    call("cldrd_transpose_cast_batched", _p(src), _p(dst), _p(desc), _p(tile_prefix), ndesc, total_tiles, _stream())

@@ -1,0 +1,65 @@
+"""``__graft_entry__.smoke()``: one tiny N-way training step of the hot path on cuda:0, checked against the CPU
+oracle (test infrastructure under ``oracle/``; imported here only as the checker)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def tiny_config():
+    from .encoder import EncoderConfig
+    return EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=2,
+                         max_position_embeddings=64, dropout=0.0, attention_dropout=0.0)
+
+
+def build_tiny_model(cfg=None, share_weights=False, seed=3, std=0.1):
+    from . import synthetic as syn
+    from .models import NwayDualEncoder
+    cfg = cfg or tiny_config()
+    model = NwayDualEncoder(cfg, share_weights=share_weights)
+    with torch.no_grad():
+        for ti, tower in enumerate(model.towers()):
+            for name, p in tower.named_flat():
+                p.copy_(syn.init_param(seed + ti, name, tuple(p.shape), std=std, perturb=True))
+    return model
+
+
+def oracle_params(model):
+    """fp32 CPU copies of both towers' parameters keyed by HF names, for oracle.encoder_ref."""
+    q = {k: v.detach().float().cpu().clone() for k, v in model.query_encoder.named_flat()}
+    p = q if model.share_weights else {k: v.detach().float().cpu().clone() for k, v in model.passage_encoder.named_flat()}
+    return q, p
+
+
+def oracle_cfg(cfg):
+    from oracle.encoder_ref import RefConfig
+    return RefConfig(arch=cfg.arch, vocab_size=cfg.vocab_size, dim=cfg.dim, n_heads=cfg.n_heads, hidden_dim=cfg.hidden_dim,
+                     n_layers=cfg.n_layers, max_position_embeddings=cfg.max_position_embeddings,
+                     type_vocab_size=cfg.type_vocab_size, eps=cfg.eps)
+
+
+def smoke():
+    from oracle import encoder_ref as E
+    from oracle import losses_ref as LR
+    from . import synthetic as syn
+    from .trainer import NwayTrainer
+
+    torch.cuda.set_device(0)
+    cfg = tiny_config()
+    model = build_tiny_model(cfg).cuda()
+    model.train()
+    batch = syn.nway_batch(4680, 2, 4, 8, 32, vocab=cfg.vocab_size, ragged=True)
+    qp, pp = oracle_params(model)
+    tr = NwayTrainer(model, loss="margin_mse", learning_rate=1e-3, warmup_steps=0, total_steps=10)
+    loss_out, logits = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    ref_logits = E.nway_forward(qp, pp, oracle_cfg(cfg), batch["query"], batch["nway_passages"]).detach().numpy()
+    ref_loss, _ = LR.margin_mse(ref_logits, batch["labels"].numpy())
+    got = logits.cpu().numpy()
+    err = np.abs(got - ref_logits).max() / (np.abs(ref_logits).max() + 1e-6)
+    assert err < 3e-2, f"smoke: logits differ from the oracle (rel err {err:.3e})"
+    assert abs(loss_out[0].item() - ref_loss) <= 5e-2 * abs(ref_loss) + 1e-3, (loss_out[0].item(), ref_loss)
+    tr.optimizer_step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.flat_p).all()
+    print(f"smoke: logits rel err {err:.2e}, loss {loss_out[0].item():.5f} (oracle {ref_loss:.5f})")

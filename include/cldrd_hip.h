@@ -1,0 +1,108 @@
+/* cldrd_hip.h - C ABI of libcldrd_hip.so: the MI355X (gfx950) kernels behind the CL-DRD hot path.
+ *
+ * The reference (HansiZeng/CL-DRD) is pure Python and has no FFI: its hot path bottoms out in PyTorch /
+ * HuggingFace / faiss calls.  Each entry point below replaces one of those call sites; the Python host code in
+ * cl-drd_amd/ (a mirror of the reference's models / losses / retriever modules) binds them with ctypes, and
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless stated; the caller owns all memory;
+ *   - bf16 tensors are passed as void* (raw bfloat16 bits), fp32 as float*, token ids / masks as int64;
+ *   - matrices are row-major; `ld*` are row strides in ELEMENTS;
+ *   - `stream` is a hipStream_t (NULL = default stream); all calls are asynchronous and graph-capturable
+ *     (no allocation, no host synchronisation inside);
+ *   - return value 0 = launched; non-zero = rejected, cldrd_last_error() gives the reason (thread local).
+ *     Nothing is computed on the CPU: without a gfx950 device the launches fail.
+ *   - dropout: keep-mask = hash(seed, element index) (counter based); the backward entry points regenerate the
+ *     mask from the same (p, seed), nothing is stored.  p = 0 disables it.
+ */
+#ifndef CLDRD_HIP_H
+#define CLDRD_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* cldrd_last_error(void);
+int cldrd_version(void);
+int cldrd_device_ok(void);            /* 1 if device 0 is a gfx950 */
+
+/* ---- encoder Linear layers -------------------------------------------------------------------------------
+ * Replaces torch.nn.Linear inside the HF encoder (reference models/nway_dual_encoder.py:52,56,64 ->
+ * transformers DistilBERT q_lin/k_lin/v_lin/out_lin/ffn.lin1/ffn.lin2, BERT query/key/value/dense).
+ *   C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T)
+ *   epilogue order: + bias[N] -> (store preact) -> act (1 = erf-GELU) -> * gelu'(gelu_pre) -> dropout -> + residual
+ *   K % 64 == 0; A/B/C 16-byte aligned; out_f32 != 0 stores fp32 instead of bf16. */
+int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                       const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
+                       int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, void* stream);
+
+/* Weight gradient dW[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (A = dY, B = layer input; autograd's Linear backward).
+ * N1, N2 multiples of 128.  A and B must have ceil(M/64)*64 rows allocated with rows >= M zero.
+ * workspace: >= cldrd_wgrad_splits(M,N1,N2) * N1 * N2 floats. */
+int cldrd_wgrad_splits(int M, int N1, int N2);
+int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, int M, int N1, int N2, int lda, int ldb,
+                     float* workspace, size_t workspace_bytes, int accumulate, void* stream);
+
+/* ---- attention (HF DistilBertSelfAttention / BertSelfAttention, head dim 64, L <= 256) --------------------
+ * qkv: bf16 [nseq*L, 3*H*64] = Q | K | V;  mask: int64 [nseq, L], 0 = padded key, or NULL;
+ * ctx: bf16 [nseq*L, H*64];  lse: fp32 [nseq, H, L] (NULL allowed in forward-only use). */
+int cldrd_attention_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
+                        float dropout_p, unsigned long long seed, void* stream);
+int cldrd_attention_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
+                        void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
+
+/* ---- embeddings + LayerNorm (HF Embeddings.forward, sa_layer_norm / output_layer_norm) --------------------
+ * d <= 1024, d % 4 == 0.  `partial` scratch: cldrd_ln_partial_blocks(T) * 3 * d floats. */
+int cldrd_ln_partial_blocks(int T);
+int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
+                       const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
+                       int d, int vocab, float eps, float dropout_p, unsigned long long seed, void* stream);
+int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,
+                       const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
+                       float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,
+                       float dropout_p, unsigned long long seed, int accumulate, void* stream);
+/* out = LN(x)*gamma+beta (bf16); cls_out (fp32 [T/cls_stride, d], optional) receives rows r % cls_stride == 0:
+ * the `[0][:, 0, :]` CLS pooling of models/nway_dual_encoder.py:52,56,64. */
+int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
+                        int T, int d, float eps, float* cls_out, int cls_stride, void* stream);
+/* dx = LN backward of dy; dx_dropped (optional) = dropout-masked dx for the branch that passed through dropout;
+ * dgamma/dbeta/dbias (each optional) receive sum(dy*xhat), sum(dy), sum(dx_dropped or dx). */
+int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                        void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
+                        int d, float dropout_p, unsigned long long seed, int accumulate, void* stream);
+/* out[N] (+)= column sums of bf16 x[T,N] (bias gradients).  partial: ceil(T/128) * N floats. */
+int cldrd_colsum_bf16(const void* x, float* out, float* partial, int T, int N, int ld, int accumulate, void* stream);
+/* g = zeros(bf16 [T,d]); g[r*stride] = dcls[r]  (gradient of the CLS pooling). */
+int cldrd_scatter_cls_grad(const float* dcls, void* g, int R, int d, int stride, int T, void* stream);
+
+/* ---- N-way scoring (models/nway_dual_encoder.py:30-47) ----------------------------------------------------
+ * mode 0: logits[B,N]; 1: in-batch, all negatives [B,B*N]; 2: in-batch, next sample's N [B,2N]. fp32. */
+int cldrd_score_fwd(const float* q, const float* p, float* logits, int B, int N, int d, int mode, void* stream);
+int cldrd_score_bwd(const float* dlogits, const float* q, const float* p, float* dq, float* dp, int B, int N, int d,
+                    int mode, void* stream);
+
+/* ---- losses (losses/kl_div.py, margin_mse.py, ranknet.py, lambda_rank.py) ---------------------------------
+ * kind 0 KLDiv(T) | 1 MarginMSE | 2 ranknet_loss | 3 lambda_mrr_loss (batch_weight != NULL: bweight_lambda_mrr_loss).
+ * loss_out: float[2] = {loss, valid pair count}; grad [B,N] = dloss/dy_pred; workspace float[2*B]. */
+int cldrd_loss_fwd_bwd(int kind, const float* y_pred, const float* y_true, const float* batch_weight, float* loss_out,
+                       float* grad, float* workspace, int B, int N, float T, float pad_indicator, int mean_reduction,
+                       void* stream);
+
+/* ---- optimizer step (trainer/multistep-curriculum/nway_listwise_1.py:353-367) ------------------------------
+ * One flat fp32 buffer for all parameters.  clip out: float[3] = {grad L2 norm, clip coefficient, non-finite flag}. */
+int cldrd_sqnorm_blocks(void);
+int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, float* partial, float* out, void* stream);
+int cldrd_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,
+                     size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                     const float* clip, void* stream);
+int cldrd_cast_bf16(const float* src, void* dst, size_t n, void* stream);
+int cldrd_transpose_cast_batched(const float* src, void* dst, const long long* desc, const int* tile_prefix, int ndesc,
+                                 int total_tiles, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,105 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/cldrd_hip.h declares; the Python binding table covers the same set; the product has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "cldrd_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cldrd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from cldrd_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/cldrd_hip.h but not exported"
+
+
+def test_binding_table_matches_header():
+    from cldrd_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_version_and_error_string_without_gpu():
+    from cldrd_amd import _lib
+    lib = _lib.load()
+    assert lib.cldrd_version() >= 100
+    assert isinstance(lib.cldrd_last_error(), bytes)
+
+
+def test_no_cpu_fallback():
+    """Ops refuse CPU tensors instead of silently computing on the host."""
+    from cldrd_amd import hip_ops as ops
+    from cldrd_amd.losses import KLDiv
+    a = torch.zeros(64, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        ops.gemm_nt(a, a, torch.zeros(64, 64, dtype=torch.bfloat16))
+    with pytest.raises(RuntimeError):
+        KLDiv()(torch.zeros(2, 3), torch.zeros(2, 3))
+
+
+def test_state_dict_keys_match_reference_layout():
+    from cldrd_amd.encoder import EncoderConfig
+    from cldrd_amd.models import NwayDualEncoder
+    from oracle.encoder_ref import RefConfig, param_shapes
+    for arch in ("distilbert", "bert"):
+        cfg = EncoderConfig(arch=arch, vocab_size=256, dim=128, n_heads=2, hidden_dim=256, n_layers=2, max_position_embeddings=32)
+        m = NwayDualEncoder(cfg, share_weights=False)
+        ref = param_shapes(RefConfig(arch=arch, vocab_size=256, dim=128, n_heads=2, hidden_dim=256, n_layers=2, max_position_embeddings=32))
+        sd = m.state_dict()
+        assert sorted(sd) == sorted([f"{t}.{k}" for t in ("query_encoder", "passage_encoder") for k in ref])
+        for k, shp in ref.items():
+            assert tuple(sd["query_encoder." + k].shape) == tuple(shp)
+        shared = NwayDualEncoder(cfg, share_weights=True)
+        assert shared.passage_encoder is shared.query_encoder
+        assert len(shared.state_dict()) == 2 * len(ref)       # both prefixes present, as in the reference
+
+
+def test_flat_views_alias_and_load_state_dict():
+    from cldrd_amd.encoder import EncoderConfig, HipEncoder
+    cfg = EncoderConfig(vocab_size=256, dim=128, n_heads=2, hidden_dim=256, n_layers=1, max_position_embeddings=32)
+    a, b = HipEncoder(cfg, seed=1), HipEncoder(cfg, seed=2)
+    b.load_state_dict(a.state_dict())
+    assert torch.equal(a.flat_p, b.flat_p)
+    # DDP-style 'module.' prefix stripping as in reference retriever/index_text.py:63-73
+    sd = {"module." + k: v for k, v in a.state_dict().items()}
+    c = HipEncoder(cfg, seed=3)
+    c.load_state_dict({k[7:]: v for k, v in sd.items()})
+    assert torch.equal(a.flat_p, c.flat_p)
+    # q/k/v weights are adjacent: the fused [3d, d] view is a plain slice
+    off = c.layout.entries["transformer.layer.0.attention.q_lin.weight"][0]
+    fused = c.flat_p[off:off + 3 * 128 * 128].view(384, 128)
+    assert torch.equal(fused[128:256], dict(c.named_parameters())["transformer.layer.0.attention.k_lin.weight"])
+
+
+def test_weight_decay_groups_follow_reference_rule():
+    from cldrd_amd.trainer import no_decay
+    assert no_decay("module.query_encoder.embeddings.LayerNorm.weight")
+    assert no_decay("module.query_encoder.transformer.layer.0.ffn.lin1.bias")
+    assert not no_decay("module.query_encoder.transformer.layer.0.sa_layer_norm.weight")
+
+
+def test_lr_schedule_matches_golden():
+    import numpy as np
+    from cldrd_amd.trainer import linear_schedule_factor
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "lr_schedule.npz"))
+    for name in ("a", "b", "c"):
+        warm, total = int(g[name + "/warmup"]), int(g[name + "/total"])
+        for s, f in zip(g[name + "/steps"], g[name + "/factor"]):
+            assert linear_schedule_factor(int(s), warm, total) == pytest.approx(float(f), abs=1e-12)

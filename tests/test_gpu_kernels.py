@@ -1,0 +1,363 @@
+"""Kernel-level parity on the MI355X (run with -m gpu): every C-ABI entry point against a plain fp32/fp64
+PyTorch-CPU / numpy statement of the same op on the same (bf16-rounded) inputs.  Tolerances are written at
+each check: bf16 outputs carry one 2^-9 relative rounding, fp32 outputs only accumulation-order noise."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cldrd_amd.synthetic as syn
+from cldrd_amd import hip_ops as ops
+
+DEV = "cuda"
+
+
+def rnd(seed, shape, scale=1.0):
+    return torch.from_numpy((syn.normal(seed, int(np.prod(shape))) * scale).astype(np.float32).reshape(shape))
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def close(got, ref, rtol, atol, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = int((err > tol).sum())
+    assert bad == 0, f"{what}: {bad}/{err.numel()} off, max err {err.max().item():.4e} (ref max {ref.abs().max().item():.3e})"
+
+
+# ------------------------------------------------------------------------------------------------ GEMM NT
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 768, 768), (2048, 2304, 768), (240, 768, 3072),
+                                   (4096, 3072, 768), (77, 384, 192)])
+def test_gemm_nt_plain(M, N, K):
+    A, B = bf(rnd(1, (M, K))), bf(rnd(2, (N, K)))
+    ref = A.float() @ B.float().T
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out)
+    # bf16 store: rel 2^-8; fp32 accumulation order: ~1e-6 * sqrt(K) * |a||b|
+    close(out, ref, 1.0 / 128, 1e-3 * math.sqrt(K), f"gemm_nt {M}x{N}x{K}")
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out32)
+    close(out32, ref, 1e-4, 1e-4 * math.sqrt(K), f"gemm_nt f32 {M}x{N}x{K}")
+
+
+def test_gemm_nt_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed C write (cdna_hip_programming.md section 3)."""
+    M = N = K = 128
+    A = torch.eye(M)
+    B = torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 100.0
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(bf(A).to(DEV), bf(B).to(DEV), out)
+    assert torch.equal(out.cpu(), bf(B).float().T.contiguous())
+
+
+def test_gemm_nt_epilogues():
+    M, N, K = 520, 384, 256
+    A, B = bf(rnd(3, (M, K), 0.5)), bf(rnd(4, (N, K), 0.5))
+    bias = rnd(5, (N,))
+    res = bf(rnd(6, (M, N)))
+    base = A.float() @ B.float().T + bias
+    Ad, Bd = A.to(DEV), B.to(DEV)
+    # bias + GELU with the pre-activation saved
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(Ad, Bd, out, bias=bias.to(DEV), preact=pre, act=1)
+    close(pre, base, 1 / 128, 2e-2, "preact")
+    close(out, torch.nn.functional.gelu(base), 1 / 128, 2e-2, "gelu")
+    # bias + residual
+    ops.gemm_nt(Ad, Bd, out, bias=bias.to(DEV), residual=res.to(DEV))
+    close(out, base + res.float(), 1 / 128, 2e-2, "residual")
+    # data gradient through GELU: acc * gelu'(pre) + residual, alpha
+    gp = bf(rnd(7, (M, N)))
+    x = gp.float()
+    gelu_grad = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+    ops.gemm_nt(Ad, Bd, out, gelu_pre=gp.to(DEV), residual=res.to(DEV), alpha=0.5)
+    close(out, 0.5 * (A.float() @ B.float().T) * gelu_grad + res.float(), 1 / 128, 2e-2, "gelu_grad")
+
+
+def test_gemm_nt_dropout_is_deterministic_and_unbiased():
+    M, N, K = 512, 256, 64
+    A, B = bf(torch.ones(M, K)), bf(torch.ones(N, K) / K)
+    out1 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    out2 = torch.empty_like(out1)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out1, dropout_p=0.1, seed=1234)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out2, dropout_p=0.1, seed=1234)
+    assert torch.equal(out1, out2)
+    keep = (out1 != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    kept = out1[out1 != 0]
+    assert torch.allclose(kept, torch.full_like(kept, 1 / 0.9), rtol=1e-5)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out2, dropout_p=0.1, seed=99)
+    assert not torch.equal(out1, out2)
+
+
+# ------------------------------------------------------------------------------------------------ weight gradient
+@pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (200, 128, 256), (1024, 384, 128), (4096, 768, 768), (3000, 256, 768)])
+def test_wgrad(M, N1, N2):
+    Mp = ops.pad_rows(M)
+    dY, X = torch.zeros(Mp, N1), torch.zeros(Mp, N2)
+    dY[:M], X[:M] = rnd(8, (M, N1)), rnd(9, (M, N2))
+    dY, X = bf(dY), bf(X)
+    ref = dY.float().T @ X.float()
+    dW = torch.full((N1, N2), 7.0, dtype=torch.float32, device=DEV)
+    ws = torch.empty(ops.wgrad_workspace_elems(M, N1, N2), dtype=torch.float32, device=DEV)
+    ops.wgrad(dY.to(DEV), X.to(DEV), dW, M, ws, accumulate=False)
+    close(dW, ref, 1e-4, 1e-4 * math.sqrt(M), f"wgrad {M}x{N1}x{N2}")
+    ops.wgrad(dY.to(DEV), X.to(DEV), dW, M, ws, accumulate=True)
+    close(dW, 2 * ref, 1e-4, 2e-4 * math.sqrt(M), "wgrad accumulate")
+
+
+def test_wgrad_asymmetric():
+    M, N1, N2 = 128, 128, 128
+    dY = torch.zeros(M, N1)
+    dY[torch.arange(M), torch.arange(M)] = 1.0            # identity -> dW = X (row i of dW = row i of X)
+    X = (torch.arange(M * N2, dtype=torch.float32).reshape(M, N2) % 127) - 60.0
+    dW = torch.empty(N1, N2, dtype=torch.float32, device=DEV)
+    ws = torch.empty(ops.wgrad_workspace_elems(M, N1, N2), dtype=torch.float32, device=DEV)
+    ops.wgrad(bf(dY).to(DEV), bf(X).to(DEV), dW, M, ws)
+    assert torch.equal(dW.cpu(), bf(X).float())
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, mask, nseq, L, H):
+    d = H * 64
+    x = qkv.double().view(nseq, L, 3, H, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    s = q @ k.transpose(2, 3) * 0.125
+    if mask is not None:
+        s = s.masked_fill(mask[:, None, None, :] == 0, -1e30)
+    p = torch.softmax(s, -1)
+    lse = torch.logsumexp(s, -1)
+    return (p @ v).transpose(1, 2).reshape(nseq * L, d), lse
+
+
+@pytest.mark.parametrize("nseq,L,H,masked", [(3, 32, 2, False), (2, 30, 2, True), (4, 128, 2, True), (2, 100, 3, True),
+                                              (2, 64, 12, False), (2, 256, 2, True), (1, 160, 1, True), (5, 8, 1, True)])
+def test_attention_fwd_bwd(nseq, L, H, masked):
+    d = H * 64
+    T = nseq * L
+    qkv = bf(rnd(10, (T, 3 * d), 1.0))
+    mask = None
+    if masked:
+        lens = np.clip(syn.msmarco_lengths(11, nseq, L), 2, L)
+        lens[0] = L
+        mask = torch.from_numpy((np.arange(L)[None, :] < lens[:, None]).astype(np.int64))
+    qv = qkv.double().requires_grad_(True)
+    ref, ref_lse = attn_ref(qv, mask, nseq, L, H)
+    dctx = bf(rnd(12, (T, d)))
+    ref.backward(dctx.double())
+    ctx = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(nseq, H, L, dtype=torch.float32, device=DEV)
+    md = None if mask is None else mask.to(DEV)
+    ops.attention_fwd(qkv.to(DEV), md, ctx, lse, nseq, L, H)
+    # P is rounded to bf16 before P.V (rel 2^-9 per term) and ctx is stored in bf16
+    close(ctx, ref, 1 / 64, 2e-2, f"attention fwd L={L}")
+    close(lse, ref_lse, 1e-4, 1e-3, "lse")
+    dqkv = torch.zeros(T, 3 * d, dtype=torch.bfloat16, device=DEV)
+    ops.attention_bwd(qkv.to(DEV), md, ctx, dctx.to(DEV), lse, dqkv, nseq, L, H)
+    g = qv.grad.float()
+    if mask is not None:      # gradients of padded query rows are not defined by the contract (they never reach the loss)
+        valid = mask.bool().reshape(-1)
+        # padded rows still receive dK/dV = 0 in the reference; the kernel writes them as 0 too
+    scale = g.abs().max().item()
+    close(dqkv, g, 1 / 32, 2e-2 * scale, f"attention bwd L={L}")
+
+
+def test_attention_dropout_statistics():
+    nseq, L, H = 2, 64, 2
+    T, d = nseq * L, H * 64
+    qkv = torch.zeros(T, 3 * d)
+    qkv[:, 2 * d:] = 1.0                                  # V = 1 -> ctx = sum_k P_drop = kept mass / (1 - p)
+    ctx = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    ops.attention_fwd(bf(qkv).to(DEV), None, ctx, None, nseq, L, H, dropout_p=0.5, seed=7)
+    m = ctx.float().mean().item()
+    assert abs(m - 1.0) < 0.05
+    ctx2 = torch.empty_like(ctx)
+    ops.attention_fwd(bf(qkv).to(DEV), None, ctx2, None, nseq, L, H, dropout_p=0.5, seed=7)
+    assert torch.equal(ctx, ctx2)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm / embeddings
+@pytest.mark.parametrize("T,d", [(7, 128), (1000, 768), (130, 1024), (64, 256)])
+def test_layernorm_fwd_bwd(T, d):
+    x = bf(rnd(13, (T, d), 2.0) + 0.5)
+    gamma, beta = 1 + rnd(14, (d,), 0.1), rnd(15, (d,), 0.1)
+    dy = bf(rnd(16, (T, d)))
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    y = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-12)
+    y.backward(dy.double())
+    out = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(T, device=DEV), torch.empty(T, device=DEV)
+    L = 4 if T % 4 == 0 else 1
+    cls = torch.empty((T + L - 1) // L, d, dtype=torch.float32, device=DEV)
+    ops.layernorm_fwd(x.to(DEV), gamma.to(DEV), beta.to(DEV), out, mean, rstd, T, 1e-12, cls, L)
+    close(out, y, 1 / 128, 1e-2, "ln fwd")
+    close(cls[: T // L if T % L == 0 else T], y[::L], 1e-5, 1e-5, "ln cls fp32")
+    dx = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    dg, db, dbias = (torch.zeros(d, device=DEV) for _ in range(3))
+    partial = torch.empty(ops.ln_partial_elems(T, d), device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), dx, None, dg, db, dbias, partial, T, accumulate=False)
+    close(dx, xr.grad, 1 / 64, 1e-2 * xr.grad.abs().max().item(), "ln dx")
+    close(dg, gr.grad, 1e-3, 1e-3 * gr.grad.abs().max().item(), "ln dgamma")
+    close(db, br.grad, 1e-3, 1e-3 * br.grad.abs().max().item(), "ln dbeta")
+    close(dbias, dx.float().sum(0), 2e-2, 2e-2 * dx.float().sum(0).abs().max().item() + 1e-2, "ln dbias")
+
+
+def test_embed_ln_fwd_bwd():
+    V, P, d, M, L = 300, 40, 256, 6, 20
+    T = M * L
+    word, pos, typ = rnd(20, (V, d)), rnd(21, (P, d)), rnd(22, (2, d))
+    gamma, beta = 1 + rnd(23, (d,), 0.1), rnd(24, (d,), 0.1)
+    ids = torch.from_numpy(syn.randint(25, 0, V, T))
+    dy = bf(rnd(26, (T, d)))
+    w, p_, t_ = (a.double().requires_grad_(True) for a in (word, pos, typ))
+    g_, b_ = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    e = w[ids] + p_[torch.arange(T) % L] + t_[0]
+    y = torch.nn.functional.layer_norm(e, (d,), g_, b_, 1e-12)
+    y.backward(dy.double())
+    out = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(T, device=DEV), torch.empty(T, device=DEV)
+    wd, pd, td, gd, bd = (a.to(DEV) for a in (word, pos, typ, gamma, beta))
+    ops.embed_ln_fwd(ids.to(DEV), wd, pd, td[0], gd, bd, out, mean, rstd, T, L, 1e-12)
+    close(out, y, 1 / 128, 1e-2, "embed fwd")
+    dword, dpos, dtyp = torch.zeros_like(wd), torch.zeros_like(pd), torch.zeros_like(td)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    partial = torch.empty(ops.ln_partial_elems(T, d), device=DEV)
+    ops.embed_ln_bwd(dy.to(DEV), ids.to(DEV), wd, pd, td[0], gd, mean, rstd, dword, dpos, dtyp[0], dg, db, partial, T, L)
+    for got, ref, name in ((dword, w.grad, "dword"), (dpos, p_.grad, "dpos"), (dtyp, t_.grad, "dtype"), (dg, g_.grad, "dgamma"),
+                           (db, b_.grad, "dbeta")):
+        close(got, ref, 1e-3, 1e-3 * ref.abs().max().item(), name)
+
+
+def test_colsum_and_scatter():
+    T, N = 1000, 2304
+    x = bf(rnd(27, (T, N)))
+    out = torch.zeros(N, device=DEV)
+    partial = torch.empty(((T + 127) // 128) * N, device=DEV)
+    ops.colsum(x.to(DEV), out, partial, T, accumulate=False)
+    close(out, x.double().sum(0), 1e-4, 1e-3, "colsum")
+    R, d, L = 5, 128, 16
+    dcls = rnd(28, (R, d))
+    g = torch.full((ops.pad_rows(R * L), d), 3.0, dtype=torch.bfloat16, device=DEV)
+    ops.scatter_cls_grad(dcls.to(DEV), g, R, L, R * L)
+    ref = torch.zeros(R * L, d)
+    ref[::L] = dcls
+    close(g[: R * L], ref, 1 / 256, 0, "scatter_cls")
+
+
+# ------------------------------------------------------------------------------------------------ scoring / losses
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_score_fwd_bwd(mode):
+    from oracle.encoder_ref import in_batch_index
+    B, N, d = 4, 6, 128
+    q, p = rnd(30, (B, d)), rnd(31, (B * N, d))
+    idx = torch.arange(B)[:, None] * N + torch.arange(N)[None] if mode == 0 else in_batch_index(B, N, mode == 1)
+    qr, pr = q.double().requires_grad_(True), p.double().requires_grad_(True)
+    ref = (qr[:, None, :] * pr[idx]).sum(-1)
+    dl = rnd(32, tuple(ref.shape))
+    ref.backward(dl.double())
+    logits = torch.empty(tuple(ref.shape), dtype=torch.float32, device=DEV)
+    ops.score_fwd(q.to(DEV), p.to(DEV), logits, B, N, mode)
+    close(logits, ref, 1e-5, 1e-4, "score fwd")
+    dq, dp = torch.empty(B, d, device=DEV), torch.empty(B * N, d, device=DEV)
+    ops.score_bwd(dl.to(DEV), q.to(DEV), p.to(DEV), dq, dp, B, N, mode)
+    close(dq, qr.grad, 1e-5, 1e-4, "score dq")
+    close(dp, pr.grad, 1e-5, 1e-4, "score dp")
+
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "losses.npz"))
+
+
+@pytest.mark.parametrize("name", [str(n) for n in G["names"]])
+def test_losses_match_reference_goldens(name):
+    """HIP loss kernels against the vectors captured from the reference losses/*.py (value and gradient)."""
+    from cldrd_amd import losses as Lh
+    kind = str(G[name + "/kind"])
+    yp = torch.tensor(G[name + "/y_pred"], device=DEV, requires_grad=True)
+    yt = torch.tensor(G[name + "/y_true"], device=DEV)
+    kw = {k.split("/kw_")[1]: G[k] for k in G.files if k.startswith(name + "/kw_")}
+    red = str(kw["reduction"]) if "reduction" in kw else "mean"
+    if kind == "kl":
+        loss = Lh.KLDiv(float(kw["T"]))(yp, yt)
+    elif kind == "mse":
+        loss = Lh.MarginMSE()(yp, yt)
+    elif kind == "ranknet":
+        loss = Lh.ranknet_loss(yp, yt, reduction=red)
+    elif kind == "lambda":
+        loss = Lh.lambda_mrr_loss(yp, yt, reduction=red)
+    else:
+        loss = Lh.bweight_lambda_mrr_loss(yp, yt, torch.tensor(kw["batch_weight"], device=DEV), reduction=red)
+    loss.backward()
+    ref_v, ref_g = float(G[name + "/value"]), G[name + "/grad"]
+    assert loss.item() == pytest.approx(ref_v, rel=3e-5, abs=1e-6)          # both sides fp32
+    scale = float(np.abs(ref_g).max())
+    assert np.allclose(yp.grad.cpu().numpy(), ref_g, rtol=5e-4, atol=3e-5 * scale + 1e-9)
+
+
+def test_loss_error_behaviour():
+    from cldrd_amd import losses as Lh
+    yp = torch.zeros(2, 3, device=DEV)
+    yt = torch.tensor([[1.0, 0.5, -1.0], [1.0, 0.5, 0.0]], device=DEV)
+    with pytest.raises(ValueError):
+        Lh.lambda_mrr_loss(yp, yt, reduction="max")
+    with pytest.raises(AssertionError):
+        Lh.ranknet_loss(yp, yt)                                               # -1 labels asserted absent (ranknet.py:16)
+    with pytest.raises(AssertionError):
+        Lh.KLDiv()(torch.zeros(3, device=DEV), torch.zeros(3, device=DEV))   # inputs must be 2-D (kl_div.py:17)
+    before = yp.clone()
+    Lh.lambda_mrr_loss(yp, yt)
+    assert torch.equal(yp, before)                                            # inputs are not mutated
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_clip_and_adamw_match_oracle():
+    from oracle import optim_ref as O
+    n = 64 * 1000
+    p, g = rnd(40, (n,)), rnd(41, (n,), 0.01)
+    m, v = rnd(42, (n,), 0.001), rnd(43, (n,), 0.001).abs() * 1e-3
+    flags = torch.zeros(n // 64, dtype=torch.uint8)
+    flags[::2] = 1
+    pd, gd, md, vd = (a.to(DEV).clone() for a in (p, g, m, v))
+    clip = torch.zeros(3, device=DEV)
+    partial = torch.empty(ops.sqnorm_blocks(), device=DEV)
+    ops.grad_clip_coef(gd, 1.0, partial, clip)
+    total, coef = O.clip_coef([g.numpy()], 1.0)
+    assert clip[0].item() == pytest.approx(total, rel=1e-5) and clip[1].item() == pytest.approx(coef, rel=1e-5)
+    assert clip[2].item() == 0.0
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    ops.adamw_step(pd, gd, md, vd, flags.to(DEV), shadow, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=3,
+                   clip=clip)
+    dec = flags.repeat_interleave(64).bool().numpy()
+    gn = g.double().numpy() * coef
+    p1, m1, v1 = O.adamw_step(p.numpy(), gn, m.numpy(), v.numpy(), lr=1e-3, step=3, weight_decay=0.0)
+    p2, _, _ = O.adamw_step(p.numpy(), gn, m.numpy(), v.numpy(), lr=1e-3, step=3, weight_decay=0.01)
+    ref_p = np.where(dec, p2, p1)
+    assert np.allclose(pd.cpu().numpy(), ref_p, rtol=1e-5, atol=1e-6)
+    assert np.allclose(md.cpu().numpy(), m1, rtol=1e-5, atol=1e-8)
+    assert np.allclose(vd.cpu().numpy(), v1, rtol=1e-5, atol=1e-10)
+    assert torch.equal(shadow.cpu(), pd.cpu().to(torch.bfloat16))
+    # non-finite gradients leave the weights untouched
+    gd[5] = float("inf")
+    ops.grad_clip_coef(gd, 1.0, partial, clip)
+    before = pd.clone()
+    ops.adamw_step(pd, gd, md, vd, flags.to(DEV), None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=4, clip=clip)
+    assert clip[2].item() == 1.0 and torch.equal(pd, before)
+
+
+def test_transpose_cast_batched():
+    src = rnd(44, (128 * 96 + 64 * 200,))
+    desc = torch.tensor([0, 0, 128, 96, 128 * 96, 128 * 96, 64, 200], dtype=torch.int64, device=DEV)
+    t0, t1 = 4 * 3, 2 * 7
+    prefix = torch.tensor([0, t0, t0 + t1], dtype=torch.int32, device=DEV)
+    dst = torch.zeros(src.numel(), dtype=torch.bfloat16, device=DEV)
+    ops.transpose_cast_batched(src.to(DEV), dst, desc, prefix, 2, t0 + t1)
+    a = src[: 128 * 96].view(128, 96).T.contiguous().to(torch.bfloat16)
+    b = src[128 * 96:].view(64, 200).T.contiguous().to(torch.bfloat16)
+    assert torch.equal(dst[: 128 * 96].cpu().view(96, 128), a) and torch.equal(dst[128 * 96:].cpu().view(200, 64), b)

@@ -1,0 +1,207 @@
+"""End-to-end parity of the hot path on the MI355X (run with -m gpu): NwayDualEncoder forward / backward and the
+fused trainer step against the CPU oracle (oracle/, itself pinned to the reference by tests/golden/*.npz), plus
+the full-size golden of BASELINE.json configs[0].
+
+Tolerances: GPU bf16 vs fp32 oracle -> logits <= 5e-3 of the logit scale at full size
+(looser on the tiny models, whose weights are 10x larger than the HF init), loss <= 1e-2 rel, gradient cosine >= 0.999."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cldrd_amd.synthetic as syn
+from cldrd_amd import selftest
+from cldrd_amd.encoder import EncoderConfig
+from cldrd_amd.models import NwayDualEncoder
+from cldrd_amd.trainer import NwayTrainer
+from oracle import encoder_ref as E
+from oracle import losses_ref as LR
+from oracle import optim_ref as O
+
+from conftest import GOLDEN
+
+
+def cos(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+def small_cfg(arch="distilbert", layers=2):
+    return EncoderConfig(arch=arch, vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=layers,
+                         max_position_embeddings=64, dropout=0.0, attention_dropout=0.0)
+
+
+def oracle_run(model, cfg, batch, loss_kind, in_batch=False, all_neg=True, T=1.0):
+    qp, pp = selftest.oracle_params(model)
+    for p in set(list(qp.values()) + list(pp.values())):
+        p.requires_grad_(True)
+    logits = E.nway_forward(qp, pp, selftest.oracle_cfg(cfg), batch["query"], batch["nway_passages"], in_batch, all_neg)
+    labels = batch["labels"].numpy()
+    if in_batch:
+        labels = np.concatenate([labels, np.full((labels.shape[0], logits.shape[1] - labels.shape[1]), -0.5, np.float32)], 1)
+    fn = {"margin_mse": LR.margin_mse, "kl_div": lambda a, b: LR.kl_div(a, b, T), "lambda_mrr": LR.lambda_mrr,
+          "ranknet": LR.ranknet}[loss_kind]
+    val, dl = fn(logits.detach().numpy(), labels)
+    logits.backward(torch.from_numpy(dl).float())
+    return logits.detach().numpy(), val, qp, pp
+
+
+@pytest.mark.parametrize("arch,loss_kind,share", [("distilbert", "margin_mse", False), ("bert", "lambda_mrr", False),
+                                                   ("distilbert", "kl_div", True)])
+def test_small_model_forward_backward_vs_oracle(arch, loss_kind, share):
+    cfg = small_cfg(arch)
+    model = selftest.build_tiny_model(cfg, share_weights=share).cuda()
+    model.train()
+    label_kind = "teacher" if loss_kind in ("margin_mse", "kl_div") else "mode9"
+    batch = syn.nway_batch(4680, 3, 5, 10, 40, vocab=cfg.vocab_size, ragged=True, label_kind=label_kind)
+    ref_logits, ref_loss, qp, pp = oracle_run(model, cfg, batch, loss_kind)
+    tr = NwayTrainer(model, loss=loss_kind, learning_rate=1e-3, warmup_steps=0, total_steps=100)
+    loss_out, logits = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    got = logits.cpu().numpy()
+    scale = np.abs(ref_logits).max()
+    assert np.abs(got - ref_logits).max() <= 2e-2 * scale, f"logits off: {np.abs(got - ref_logits).max() / scale:.3e}"
+    assert loss_out[0].item() == pytest.approx(ref_loss, rel=5e-2, abs=1e-3)
+    towers = [("query_encoder", model.query_encoder, qp)]
+    if not share:
+        towers.append(("passage_encoder", model.passage_encoder, pp))
+    for tname, tower, ref_params in towers:
+        tower.ensure_grads()
+        all_g, all_r = [], []
+        for name, p in tower.named_flat():
+            gg, rr = p.grad.detach().cpu().numpy(), ref_params[name].grad.numpy()
+            all_g.append(gg.ravel()), all_r.append(rr.ravel())
+            if np.linalg.norm(rr) > 1e-3 * max(1.0, ref_loss):          # skip analytically-zero grads (k bias)
+                assert cos(gg, rr) > 0.995, f"{tname}.{name}: cosine {cos(gg, rr):.5f}"
+                assert np.linalg.norm(gg) == pytest.approx(np.linalg.norm(rr), rel=5e-2), f"{tname}.{name}"
+        assert cos(np.concatenate(all_g), np.concatenate(all_r)) > 0.999
+
+
+@pytest.mark.parametrize("all_neg", [True, False])
+def test_in_batch_negatives_vs_oracle(all_neg):
+    cfg = small_cfg()
+    model = selftest.build_tiny_model(cfg).cuda()
+    model.in_batch_loss, model.all_in_batch_neg = True, all_neg
+    model.train()
+    batch = syn.nway_batch(4680, 3, 4, 8, 24, vocab=cfg.vocab_size, ragged=True, label_kind="mode9")
+    ref_logits, ref_loss, qp, pp = oracle_run(model, cfg, batch, "lambda_mrr", True, all_neg)
+    tr = NwayTrainer(model, loss="lambda_mrr")
+    loss_out, logits = tr.forward_backward(batch)
+    got = logits.cpu().numpy()
+    assert got.shape == ref_logits.shape
+    assert np.abs(got - ref_logits).max() <= 2e-2 * np.abs(ref_logits).max()
+    g = np.concatenate([p.grad.cpu().numpy().ravel() for _, p in model.passage_encoder.named_flat()])
+    r = np.concatenate([pp[n].grad.numpy().ravel() for n, _ in model.passage_encoder.named_flat()])
+    assert cos(g, r) > 0.995
+
+
+def test_autograd_bridge_matches_fused_path():
+    """The reference-style loop (model(...) -> loss -> loss.backward()) and the fused trainer give the same gradients."""
+    from cldrd_amd.losses import MarginMSE
+    cfg = small_cfg()
+    model = selftest.build_tiny_model(cfg).cuda()
+    model.train()
+    batch = syn.nway_batch(4680, 2, 3, 8, 32, vocab=cfg.vocab_size, ragged=True)
+    dev_batch = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in batch.items()}
+    tr = NwayTrainer(model, loss="margin_mse")
+    loss_out, logits = tr.forward_backward(batch)
+    fused = tr.flat_g.clone()
+    tr.flat_g.zero_()
+    logits2 = model(dev_batch["query"], dev_batch["nway_passages"])
+    loss = MarginMSE()(logits2, dev_batch["labels"])
+    loss.backward()
+    assert torch.allclose(logits2, logits, rtol=0, atol=0)
+    assert loss.item() == pytest.approx(loss_out[0].item(), rel=1e-6)
+    # embedding scatter uses float atomics (order-dependent in the last bits); everything else is bit-reproducible
+    assert torch.allclose(tr.flat_g, fused, rtol=1e-4, atol=1e-6 * fused.abs().max().item())
+    # eval-mode calls of the reference surface
+    model.eval()
+    with torch.no_grad():
+        q = model.query_embs(dev_batch["query"])
+        p = model.nway_passage_embs(dev_batch["nway_passages"])
+        assert q.shape == (2, cfg.dim) and p.shape == (2, 3, cfg.dim) and q.dtype == torch.float32
+        out = model.query_encoder(**dev_batch["query"])[0][:, 0, :]
+        assert torch.equal(out, q)
+
+
+def test_trainer_step_matches_oracle_update():
+    """clip_grad_norm_ + legacy AdamW + linear schedule on the GPU vs the oracle restatement, from the GPU's own gradients."""
+    cfg = small_cfg(layers=1)
+    model = selftest.build_tiny_model(cfg).cuda()
+    model.train()
+    batch = syn.nway_batch(4680, 2, 3, 8, 16, vocab=cfg.vocab_size)
+    tr = NwayTrainer(model, loss="margin_mse", learning_rate=1e-3, warmup_steps=2, total_steps=10, weight_decay=0.01)
+    tr.global_step = 1          # lr factor 0.5 in effect
+    p0 = tr.flat_p.clone()
+    tr.forward_backward(batch)
+    g = tr.flat_g.clone()
+    lr = tr.optimizer_step()
+    assert lr == pytest.approx(1e-3 * 0.5)
+    total, coef = O.clip_coef([g.cpu().numpy()], 1.0)
+    assert tr.clip[0].item() == pytest.approx(total, rel=1e-4)
+    dec = tr.decay_flags.repeat_interleave(64).bool().cpu().numpy()
+    gn = g.double().cpu().numpy() * coef
+    z = np.zeros_like(gn)
+    p1, _, _ = O.adamw_step(p0.cpu().numpy(), gn, z, z, lr=lr, step=2, weight_decay=0.0)
+    p2, _, _ = O.adamw_step(p0.cpu().numpy(), gn, z, z, lr=lr, step=2, weight_decay=0.01)
+    ref = np.where(dec, p2, p1)
+    assert np.allclose(tr.flat_p.cpu().numpy(), ref, rtol=2e-5, atol=2e-6)
+    # decay flags follow the reference's name rule
+    off, shape = model.query_encoder.layout.entries["transformer.layer.0.sa_layer_norm.weight"]
+    assert dec[off]                       # decayed (does not match 'LayerNorm.weight')
+    off, _ = model.query_encoder.layout.entries["embeddings.LayerNorm.weight"]
+    assert not dec[off]
+    off, _ = model.query_encoder.layout.entries["transformer.layer.0.ffn.lin1.bias"]
+    assert not dec[off]
+    # shadows follow the update
+    t = model.query_encoder
+    assert torch.equal(t.flat_h.float(), t.flat_p.to(torch.bfloat16).float())
+    w2 = t.w("transformer.layer.0.ffn.lin2.weight")
+    assert torch.equal(t.ht(0, "f2").float(), w2.T.contiguous().to(torch.bfloat16).float())
+
+
+def test_loss_decreases_over_steps_with_dropout():
+    cfg = small_cfg()
+    cfg.dropout = cfg.attention_dropout = 0.1
+    model = selftest.build_tiny_model(cfg, std=0.05).cuda()
+    model.train()
+    batch = syn.nway_batch(4680, 4, 6, 8, 32, vocab=cfg.vocab_size, ragged=True)
+    tr = NwayTrainer(model, loss="kl_div", learning_rate=2e-3, warmup_steps=1, total_steps=1000, max_grad_norm=1.0)
+    losses = [tr.train_step(batch)[0].item() for _ in range(40)]
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[1:6]), losses
+
+
+def test_full_size_cfg1_matches_reference_golden():
+    """BASELINE.json configs[0] (DistilBERT, N=8, batch=4, margin_mse, L=128) on the GPU against the logits/loss the
+    REFERENCE produced for the same seeded weights and batch (tests/golden/full_distilbert_cfg1.npz)."""
+    path = os.path.join(GOLDEN, "full_distilbert_cfg1.npz")
+    g = np.load(path)
+    cfg = EncoderConfig(arch="distilbert", dropout=0.0, attention_dropout=0.0)
+    model = NwayDualEncoder(cfg, share_weights=False)
+    with torch.no_grad():
+        for seed, tower in ((11, model.query_encoder), (12, model.passage_encoder)):
+            for name, p in tower.named_flat():
+                p.copy_(syn.init_param(seed, name, tuple(p.shape), std=0.02, perturb=True))
+    model.cuda().train()
+    batch = syn.nway_batch(4680, int(g["B"]), int(g["N"]), int(g["Lq"]), int(g["Lp"]), ragged=True)
+    tr = NwayTrainer(model, loss="margin_mse")
+    loss_out, logits = tr.forward_backward(batch)
+    ref = g["logits"]
+    err = np.abs(logits.cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err <= 5e-3, f"logits rel err {err:.3e}"
+    assert loss_out[0].item() == pytest.approx(float(g["loss"]), rel=1e-2)
+    # per-tensor gradient norms from the reference's backward
+    names, vals = [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]
+    params = {f"query_encoder.{n}": p for n, p in model.query_encoder.named_flat()}
+    params.update({f"passage_encoder.{n}": p for n, p in model.passage_encoder.named_flat()})
+    big = vals.max()
+    checked = 0
+    for n, v in zip(names, vals):
+        if v > 1e-3 * big:
+            assert params[n].grad.norm().item() == pytest.approx(v, rel=3e-2), n
+            checked += 1
+    assert checked > 100
