@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py - headline benchmark of the CL-DRD hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full training step of BASELINE.json configs[1] on one batch of synthetic MSMARCO-shaped input
+already resident in HBM: DistilBERT-6L dual encoder (two unshared towers, random init), N=32 passages per query,
+per-GPU batch B=8, seq_len 128 (queries 30), kl_div loss, bf16 MFMA compute with fp32 master weights, dropout 0.1
+active, forward + loss + backward + RCCL gradient all-reduce (N>1) + clip_grad_norm + AdamW.  Rank 0 prints ONE JSON
+line: whole-job samples/s, the roofline of the dominant kernel (the NT MFMA GEMM, timed live with HIP events on the
+launch stream), index-encode passages/s, and the CPU oracle timed on the host cores (N=1 only; a reported baseline,
+not the target).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
+D, DFF, NL = 768, 3072, 6
+
+
+def flops_seq_fwd(L):
+    """Forward FLOPs of one DistilBERT sequence, SURVEY.md section 8d: nl*(8 L d^2 + 4 L d dff + 4 L^2 d)."""
+    return NL * (8 * L * D * D + 4 * L * D * DFF + 4 * L * L * D)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (queries)")
+    ap.add_argument("--nway", type=int, default=32)
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--q-len", type=int, default=30)
+    ap.add_argument("--loss", default="kl_div")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-index", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import cldrd_amd.synthetic as syn
+    from cldrd_amd import hip_ops as ops
+    from cldrd_amd.encoder import EncoderConfig
+    from cldrd_amd.models import NwayDualEncoder
+    from cldrd_amd.trainer import NwayTrainer
+
+    B, N, L, Lq = args.batch, args.nway, args.seq_len, args.q_len
+    cfg = EncoderConfig(arch="distilbert")                  # DistilBERT-6L, dropout 0.1 (HF defaults)
+    torch.manual_seed(0)
+    model = NwayDualEncoder(cfg, share_weights=False).to(dev)
+    model.train()
+    trainer = NwayTrainer(model, loss=args.loss, T=1.0, learning_rate=7e-6, warmup_steps=4000, total_steps=100000)
+    batch = syn.nway_batch(4680 + 1000 * rank, B, N, Lq, L, ragged=False, label_kind="teacher")
+    batch = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in batch.items()}
+
+    # ---- live per-launch timing of the dominant kernel (HIP events on the launch stream) ----
+    gemm_events = []
+    if not args.no_kernel_events:
+        raw_gemm = ops.gemm_nt
+
+        def timed_gemm(A, Bm, out, M=None, **kw):
+            m = A.shape[0] if M is None else M
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = raw_gemm(A, Bm, out, M, **kw)
+            e1.record()
+            if timed_gemm.on:
+                gemm_events.append((e0, e1, 2.0 * m * Bm.shape[0] * Bm.shape[1]))
+            return r
+        timed_gemm.on = False
+        ops.gemm_nt = timed_gemm
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(batch)
+    sync_all()
+    if not args.no_kernel_events:
+        timed_gemm.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss_out = trainer.train_step(batch)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if not args.no_kernel_events:
+        timed_gemm.on = False
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    samples_per_s = world * B * args.steps / dt
+    final_loss = float(loss_out[0].item())
+
+    roofline = None
+    if gemm_events and rank == 0:
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_events)
+        tot_fl = sum(f for _, _, f in gemm_events)
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        roofline = {"kernel": "gemm_nt_kernel (bf16 MFMA, all forward + data-gradient Linear GEMMs)", "bound": "mfma",
+                    "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "launches": len(gemm_events), "avg_launch_us": round(1e3 * tot_ms / len(gemm_events), 2),
+                    "gflop_per_launch": round(tot_fl / len(gemm_events) / 1e9, 2),
+                    "time_share_of_step": round(tot_ms * 1e-3 / dt, 3)}
+
+    # ---- index path: encode passages/s (retriever/index_text.py: bs = 512) ----
+    index = None
+    if not args.no_index:
+        model.eval()
+        ib = syn.seq_batch(99 + rank, 512, L)["seq"]
+        ids, mask = ib["input_ids"].to(dev), ib["attention_mask"].to(dev)
+        with torch.no_grad():
+            for _ in range(2):
+                model.passage_embs({"input_ids": ids, "attention_mask": mask})
+            sync_all()
+            t1 = time.perf_counter()
+            it = 10
+            for _ in range(it):
+                emb = model.passage_embs({"input_ids": ids, "attention_mask": mask})
+            sync_all()
+            di = time.perf_counter() - t1
+        ti = torch.tensor([di], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(ti, op=dist.ReduceOp.MAX)
+        pps = world * 512 * it / float(ti.item())
+        index = {"value": round(pps, 1), "unit": "passages/s", "batch": 512, "seq_len": L,
+                 "mfma_frac": round(pps * flops_seq_fwd(L) / (world * PEAK_BF16_TFLOPS * 1e12), 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(N, L, Lq)
+
+    if rank == 0:
+        flops_per_sample = 3.0 * (N * flops_seq_fwd(L) + flops_seq_fwd(Lq))
+        out = {
+            "metric": "train (q,N-psg) samples/sec + index passages/sec, DistilBERT N=32 at 1/8 GPUs",
+            "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"cfg2: DistilBERT-6L dual encoder (2 unshared towers), N={N}, {args.loss}, seq_len={L}, q_len={Lq}, "
+                                   f"per-GPU batch {B}, dropout 0.1, fwd+loss+bwd+allreduce+clip+AdamW",
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "model_tflop_per_sample": round(flops_per_sample / 1e12, 4),
+            "step_mfma_frac": round(samples_per_s * flops_per_sample / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "final_loss": final_loss,
+            "index": index, "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(N, L, Lq):
+    """The CPU oracle (oracle/, a port of the reference path pinned to it by tests/golden) timed on this box's host cores:
+    one fp32 training step (forward + loss + backward + clip + AdamW) of the same workload at B=2."""
+    import numpy as np
+    import torch
+    from oracle import encoder_ref as E
+    from oracle import losses_ref as LR
+    import cldrd_amd.synthetic as syn
+    cores = min(len(os.sched_getaffinity(0)), 32)      # more threads than this only adds contention in torch-CPU
+    torch.set_num_threads(cores)
+    Bc = 1
+    cfg = E.RefConfig()
+    shapes = E.param_shapes(cfg)
+    g = torch.Generator().manual_seed(0)
+    qp = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in shapes.items()}
+    pp = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in shapes.items()}
+    batch = syn.nway_batch(1, Bc, N, Lq, L)
+    warm = syn.nway_batch(2, 1, 2, 8, 16)
+    E.nway_forward(qp, pp, cfg, warm["query"], warm["nway_passages"]).sum().backward()
+    params = list(qp.values()) + list(pp.values())
+    for p in params:
+        p.grad = None
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    t0 = time.perf_counter()
+    logits = E.nway_forward(qp, pp, cfg, batch["query"], batch["nway_passages"])
+    _, dl = LR.kl_div(logits.detach().numpy(), batch["labels"].numpy())
+    logits.backward(torch.from_numpy(dl).float())
+    with torch.no_grad():
+        total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)).item()
+        coef = min(1.0, 1.0 / (total + 1e-6))
+        for p, mm, vv in zip(params, m, v):
+            gq = p.grad * coef
+            mm.mul_(0.9).add_(gq, alpha=0.1)
+            vv.mul_(0.999).addcmul_(gq, gq, value=0.001)
+            p.addcdiv_(mm, vv.sqrt().add_(1e-8), value=-7e-6 * (1 - 0.999) ** 0.5 / (1 - 0.9))
+            p.mul_(1 - 7e-6 * 0.01)
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 fp32 step (fwd+loss+bwd+clip+AdamW) of the same workload at B={Bc} (N={N}, L={L}), oracle/encoder_ref.py on torch-CPU, {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -48,6 +48,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it brings its own HIP runtime (libamdhip64); loading ours before it would put a second runtime
+    # in the process and the launches would see no device
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise CldrdError(f"{LIB_PATH} not found: build it first (python -c 'import __graft_entry__ as g; g.build()'). "
                          "cldrd_amd has no CPU fallback.")

@@ -176,6 +176,10 @@ def make_model_golden(NwayDualEncoder, ref_losses, out, arch, cfgd, B, N, Lq, Lp
         loss.backward()
         blob["logits"] = logits.detach().numpy()
         blob["loss"] = np.float64(loss.item())
+        # the reference's own mixed-precision path (it trains under autocast, nway_listwise_1.py:334); CPU autocast
+        # only offers bf16, which is also the build's compute type: this is the drift the reference itself accepts
+        with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+            blob["logits_autocast_bf16"] = model(batch["query"], batch["nway_passages"]).float().numpy()
         with torch.no_grad():
             blob["q_cls"] = model.query_embs(batch["query"]).numpy()
             blob["p_cls"] = model.nway_passage_embs(batch["nway_passages"]).numpy()
