@@ -13,28 +13,14 @@
 // of tile t.  Fused epilogue: bias, erf-GELU (optionally saving the pre-activation), GELU' multiply
 // (data gradient through the activation), dropout, residual add; bf16 or fp32 store.
 #include "common.h"
+#include "gemm_epilogue.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
-
-struct GemmNtArgs {
-    const bf16_t* A; const bf16_t* B; void* C;
-    int M, N, K, lda, ldb, ldc;
-    const float* bias;            // [N] or null
-    const bf16_t* residual;       // [M, ldr] or null, added last
-    int ldr;
-    bf16_t* preact;               // [M, ldc] or null: (alpha*acc + bias) before the activation
-    const bf16_t* gelu_pre;       // [M, ldc] or null: multiply by gelu'(gelu_pre)
-    int act;                      // 0 none, 1 erf-GELU
-    float alpha;
-    uint32_t drop_thresh;         // 0 = no dropout
-    float drop_scale;
-    uint64_t seed;
-    int out_f32;
-};
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -107,68 +93,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
         }
     }
 
-    // ---- epilogue: lane holds C[m = .. + (lane & 15)][n = .. + 4*(lane >> 4) + j], j = 0..3 ----
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int m = m0 + wm * 64 + mt * 16 + frow;
-        if (m >= p.M) continue;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wn * 64 + nt * 16 + fq * 4;
-            if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][j] * p.alpha;
-            const bool full = (n + 3 < p.N);
-            if (p.bias) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += p.bias[n + j];
-            }
-            const size_t crow = (size_t)m * p.ldc + n;
-            if (p.preact) {
-                if (full) {
-                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                    *(uint2*)(p.preact + crow) = o;
-                } else {
-                    for (int j = 0; j < 4; ++j) if (n + j < p.N) p.preact[crow + j] = f2bf(v[j]);
-                }
-            }
-            if (p.act == 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
-            }
-            if (p.gelu_pre) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] *= gelu_grad_f(bf2f(p.gelu_pre[crow + j]));
-            }
-            if (p.drop_thresh) {
-                const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = dropout_keep(p.seed, e + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
-            }
-            if (p.residual) {
-                const size_t rrow = (size_t)m * p.ldr + n;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += bf2f(p.residual[rrow + j]);
-            }
-            if (p.out_f32) {
-                float* C = (float*)p.C;
-                if (full) *(float4*)(C + crow) = make_float4(v[0], v[1], v[2], v[3]);
-                else for (int j = 0; j < 4; ++j) if (n + j < p.N) C[crow + j] = v[j];
-            } else {
-                bf16_t* C = (bf16_t*)p.C;
-                if (full) {
-                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                    *(uint2*)(C + crow) = o;
-                } else {
-                    for (int j = 0; j < 4; ++j) if (n + j < p.N) C[crow + j] = f2bf(v[j]);
-                }
-            }
-        }
-    }
+    gemm_nt_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 }  // namespace
+
+int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a, int force_bn, hipStream_t st);   // gemm_nt_ring.hip
 
 extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
@@ -188,6 +118,13 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
     a.drop_thresh = dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u;
     a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.seed = seed; a.out_f32 = out_f32;
+    // large-M shapes go to the 256-row ring kernel; CLDRD_GEMM_TILE=128|192|256 forces a variant (experiments)
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("CLDRD_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    if (force != 128) {
+        const int rc = cldrd_gemm_nt_ring_dispatch(a, force, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     static bool attr_set = false;
     if (!attr_set) {

@@ -296,13 +296,21 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
     block_partials(lsm, dg, db, dt, d, lane, partial);
 }
 
-// out[c] (+)= sum_b partial[b][c]
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ out0,
-                                       float* __restrict__ out1, float* __restrict__ out2, int seg, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * n + c];
+// out[c] (+)= sum_b partial[b][c].  Block = 64 columns x 4 row groups (coalesced 256-B row reads), LDS combine.
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ out0,
+                                                               float* __restrict__ out1, float* __restrict__ out2, int seg, int accumulate) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < n) {
+        int b = rg;
+        for (; b + 4 < nblk; b += 8) { s0 += partial[(size_t)b * n + c]; s1 += partial[(size_t)(b + 4) * n + c]; }
+        if (b < nblk) s0 += partial[(size_t)b * n + c];
+    }
+    red[rg][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (rg != 0 || c >= n) return;
+    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
     float* out = c < seg ? out0 : (c < 2 * seg ? out1 : out2);
     if (!out) return;
     const int i = c % seg;
@@ -332,7 +340,7 @@ __global__ void scatter_cls_kernel(const float* __restrict__ dcls, bf16_t* __res
 
 }  // namespace
 
-static inline int ln_bwd_blocks(int T) { int b = (T + 3) / 4; return b < 1024 ? b : 1024; }
+static inline int ln_bwd_blocks(int T) { int b = (T + 3) / 4; return b < 512 ? b : 512; }
 
 extern "C" int cldrd_ln_partial_blocks(int T) { return ln_bwd_blocks(T); }
 
@@ -357,7 +365,7 @@ extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const
 }
 
 static int launch_reduce(const float* partial, int nblk, int d, float* o0, float* o1, float* o2, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 255) / 256), dim3(256), 0, st, partial, nblk, 3 * d, o0, o1, o2, d, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 63) / 64), dim3(256), 0, st, partial, nblk, 3 * d, o0, o1, o2, d, accumulate);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -395,7 +403,7 @@ extern "C" int cldrd_colsum_bf16(const void* x, float* out, float* partial, int 
     const int ny = (T + rows - 1) / rows;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 1023) / 1024, ny), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial, T, N, ld, rows);
     CLDRD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)partial, ny, N,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)partial, ny, N,
                        out, (float*)nullptr, (float*)nullptr, N, accumulate);
     CLDRD_LAUNCH_CHECK();
     return 0;

@@ -34,7 +34,9 @@ def close(got, ref, rtol, atol, what=""):
 
 # ------------------------------------------------------------------------------------------------ GEMM NT
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 768, 768), (2048, 2304, 768), (240, 768, 3072),
-                                   (4096, 3072, 768), (77, 384, 192)])
+                                   (4096, 3072, 768), (77, 384, 192),
+                                   # large-M ring kernel: BN=192 / BN=256 variants, M tails, 1..4 K slices, K=3072
+                                   (1100, 384, 96), (1030, 512, 64), (1024, 1024, 32), (2000, 768, 3072), (1500, 256, 128)])
 def test_gemm_nt_plain(M, N, K):
     A, B = bf(rnd(1, (M, K))), bf(rnd(2, (N, K)))
     ref = A.float() @ B.float().T
@@ -57,8 +59,8 @@ def test_gemm_nt_asymmetric_identity():
     assert torch.equal(out.cpu(), bf(B).float().T.contiguous())
 
 
-def test_gemm_nt_epilogues():
-    M, N, K = 520, 384, 256
+@pytest.mark.parametrize("M,N,K", [(520, 384, 256), (1300, 384, 256), (1300, 512, 256)])
+def test_gemm_nt_epilogues(M, N, K):
     A, B = bf(rnd(3, (M, K), 0.5)), bf(rnd(4, (N, K), 0.5))
     bias = rnd(5, (N,))
     res = bf(rnd(6, (M, N)))
