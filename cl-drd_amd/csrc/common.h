@@ -38,11 +38,20 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// erf-GELU and its derivative (HF GELUActivation == F.gelu)
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+// erf-GELU and its derivative (HF GELUActivation == F.gelu).  erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the bf16 output rounding): one v_rcp + one v_exp + 6 FMAs instead of libm's erff
+// (~40 VALU ops), which made the GELU epilogues VALU-bound (100 M activations per FFN GEMM).  exp(-x^2/2) is shared
+// between erf(x / sqrt 2) and the Gaussian density of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    e = __expf(-z * z);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
 }
+__device__ __forceinline__ float gelu_f(float x) { float c, e; gelu_parts(x, c, e); return x * c; }
+__device__ __forceinline__ float gelu_grad_f(float x) { float c, e; gelu_parts(x, c, e); return fmaf(x * 0.39894228040143268f, e, c); }
 
 // Counter-based dropout: keep(element) is a pure function of (seed, 64-bit element index), so the backward
 // regenerates the mask instead of storing it.  splitmix64 finaliser; keep iff top 24 bits >= p * 2^24.

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
         }
     }
 
-    gemm_nt_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    __syncthreads();      // all fragment reads of the last K tile are done: the staging buffers become epilogue scratch
+    gemm_nt_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, (float*)smem + wid * (32 * 68));
 }
 
 }  // namespace
@@ -105,7 +106,7 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
                                   int act, float alpha, float dropout_p, unsigned long long seed, int out_f32,
                                   void* stream) {
     CLDRD_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
-    CLDRD_CHECK(K % BK == 0, "gemm_nt: K must be a multiple of 64");
+    CLDRD_CHECK(K % 32 == 0, "gemm_nt: K must be a multiple of 32");
     CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_nt: lda/ldb must be multiples of 8, ldc of 4");
     CLDRD_CHECK(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "gemm_nt: operands must be 16-byte aligned");
     CLDRD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, "gemm_nt: dropout_p out of range");
@@ -119,12 +120,13 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
     a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.seed = seed; a.out_f32 = out_f32;
     // large-M shapes go to the 256-row ring kernel; CLDRD_GEMM_TILE=128|192|256 forces a variant (experiments)
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("CLDRD_GEMM_TILE"); force = e ? atoi(e) : 0; }
+    const char* env_tile = getenv("CLDRD_GEMM_TILE");
+    const int force = env_tile ? atoi(env_tile) : 0;
     if (force != 128) {
         const int rc = cldrd_gemm_nt_ring_dispatch(a, force, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
+    CLDRD_CHECK(K % BK == 0, "gemm_nt: K must be a multiple of 64 for M < 1024 or N not a multiple of 192/256");
     const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     static bool attr_set = false;
     if (!attr_set) {

@@ -110,7 +110,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     }
-    gemm_nt_epilogue<8, NT>(p, acc, m0 + wm * 128, n0 + wn * WN, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();     // last slice fully consumed by every wave: the ring becomes epilogue scratch
+    asm volatile("" ::: "memory");
+    gemm_nt_epilogue<8, NT>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
 }
 
 template <int BN>

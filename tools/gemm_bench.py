@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the NT GEMM variants on the encoder shapes (interleaved rounds in one process)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cldrd_amd import hip_ops as ops
+
+def main():
+    dev = "cuda"
+    T = int(os.environ.get("T", 32768))
+    shapes = [("qkv", T, 2304, 768, {}), ("out", T, 768, 768, {"res": 1}), ("ffn1", T, 3072, 768, {"pre": 1, "act": 1}),
+              ("ffn2", T, 768, 3072, {"res": 1}), ("dgrad_ffn2", T, 3072, 768, {"gp": 1}), ("dgrad_qkv", T, 768, 2304, {"res": 1})]
+    torch.manual_seed(0)
+    for name, M, N, K, ep in shapes:
+        A = torch.randn(M, K, device=dev).bfloat16()
+        B = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        bias = torch.randn(N, device=dev)
+        kw = dict(bias=bias)
+        if ep.get("res"): kw["residual"] = torch.randn(M, N, device=dev).bfloat16()
+        if ep.get("pre"): kw["preact"] = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        if ep.get("act"): kw["act"] = 1
+        if ep.get("gp"): kw["gelu_pre"] = torch.randn(M, N, device=dev).bfloat16()
+        res = {}
+        for rnd in range(3):
+            for tile in ("128", "192", "256"):
+                if tile == "256" and N % 256: continue
+                os.environ["CLDRD_GEMM_TILE"] = tile
+                for _ in range(2): ops.gemm_nt(A, B, out, **kw)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10): ops.gemm_nt(A, B, out, **kw)
+                e1.record(); torch.cuda.synchronize()
+                res.setdefault(tile, []).append(e0.elapsed_time(e1) / 10)
+        fl = 2.0 * M * N * K
+        # plain (no epilogue extras) for the best tile
+        line = f"{name:11s} M={M} N={N} K={K}: "
+        for tile, ts in res.items():
+            t = min(ts)
+            line += f" tile{tile}: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF/s |"
+        print(line, flush=True)
+    os.environ.pop("CLDRD_GEMM_TILE", None)
+
+if __name__ == "__main__":
+    main()
