@@ -18,89 +18,128 @@ struct GemmNtArgs {
     int out_f32;
 };
 
+// compile-time epilogue flavours (each GEMM kernel is instantiated per flavour so the 16x-unrolled epilogue carries
+// only the code it needs); EPI_GENERIC reads every switch from GemmNtArgs at run time.
+enum : int {
+    EPI_BIAS = 1, EPI_PREACT = 2, EPI_GELU = 4, EPI_GELUGRAD = 8, EPI_DROPOUT = 16, EPI_RESIDUAL = 32, EPI_F32 = 64,
+    EPI_GENERIC = 1 << 20
+};
 
-// Fused epilogue for 4 consecutive output columns (m, n..n+3), values v[] = raw accumulators.
+template <int EPI> struct EpiFlags {
+    const bool bias, preact, gelu, gelugrad, dropout, residual, f32;
+    __device__ __forceinline__ explicit EpiFlags(const GemmNtArgs& p)
+        : bias(EPI == EPI_GENERIC ? p.bias != nullptr : (EPI & EPI_BIAS) != 0),
+          preact(EPI == EPI_GENERIC ? p.preact != nullptr : (EPI & EPI_PREACT) != 0),
+          gelu(EPI == EPI_GENERIC ? p.act == 1 : (EPI & EPI_GELU) != 0),
+          gelugrad(EPI == EPI_GENERIC ? p.gelu_pre != nullptr : (EPI & EPI_GELUGRAD) != 0),
+          dropout(EPI == EPI_GENERIC ? p.drop_thresh != 0 : (EPI & EPI_DROPOUT) != 0),
+          residual(EPI == EPI_GENERIC ? p.residual != nullptr : (EPI & EPI_RESIDUAL) != 0),
+          f32(EPI == EPI_GENERIC ? p.out_f32 != 0 : (EPI & EPI_F32) != 0) {}
+};
+
+static inline int epi_flavour(const GemmNtArgs& a) {
+    return (a.bias ? EPI_BIAS : 0) | (a.preact ? EPI_PREACT : 0) | (a.act == 1 ? EPI_GELU : 0) | (a.gelu_pre ? EPI_GELUGRAD : 0) |
+           (a.drop_thresh ? EPI_DROPOUT : 0) | (a.residual ? EPI_RESIDUAL : 0) | (a.out_f32 ? EPI_F32 : 0);
+}
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    uint4 o;
+    o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+    return o;
+}
+
+// Fused epilogue for 8 consecutive output columns (m, n..n+7); v[] = raw accumulators, bias8/res/gp already loaded.
 // order: alpha*acc + bias -> (store preact) -> GELU -> * gelu'(gelu_pre) -> dropout -> + residual -> store
-__device__ __forceinline__ void gemm_nt_apply4(const GemmNtArgs& p, float (&v)[4], int m, int n) {
+template <int EPI>
+__device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFlags<EPI>& fl, float (&v)[8], int m, int n,
+                                               const float (&bias8)[8], const uint4& res, const uint4& gp) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] *= p.alpha;
-    const bool full = (n + 3 < p.N);
-    if (p.bias) {
-        if (full) {
-            const float4 b = *(const float4*)(p.bias + n);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        } else {
-            for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += p.bias[n + j];
-        }
+    for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+    if (fl.bias) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bias8[j];
     }
     const size_t crow = (size_t)m * p.ldc + n;
-    if (p.preact) {
-        if (full) {
-            uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-            *(uint2*)(p.preact + crow) = o;
-        } else {
-            for (int j = 0; j < 4; ++j) if (n + j < p.N) p.preact[crow + j] = f2bf(v[j]);
-        }
-    }
-    if (p.act == 1) {
+    if (fl.preact) *(uint4*)(p.preact + crow) = pack8(v);
+    if (fl.gelu) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = gelu_f(v[j]);
+        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
     }
-    if (p.gelu_pre) {
-        if (full) {
-            const uint2 g = *(const uint2*)(p.gelu_pre + crow);
-            v[0] *= gelu_grad_f(__uint_as_float(g.x << 16)); v[1] *= gelu_grad_f(__uint_as_float(g.x & 0xFFFF0000u));
-            v[2] *= gelu_grad_f(__uint_as_float(g.y << 16)); v[3] *= gelu_grad_f(__uint_as_float(g.y & 0xFFFF0000u));
-        } else {
-            for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] *= gelu_grad_f(bf2f(p.gelu_pre[crow + j]));
-        }
+    if (fl.gelugrad) {
+        float g[8];
+        unpack8(gp, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(g[j]);
     }
-    if (p.drop_thresh) {
+    if (fl.dropout) {
         const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = dropout_keep(p.seed, e + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = dropout_keep(p.seed, e + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
     }
-    if (p.residual) {
-        const size_t rrow = (size_t)m * p.ldr + n;
-        if (full) {
-            const uint2 r = *(const uint2*)(p.residual + rrow);
-            v[0] += __uint_as_float(r.x << 16); v[1] += __uint_as_float(r.x & 0xFFFF0000u);
-            v[2] += __uint_as_float(r.y << 16); v[3] += __uint_as_float(r.y & 0xFFFF0000u);
-        } else {
-            for (int j = 0; j < 4; ++j) if (n + j < p.N) v[j] += bf2f(p.residual[rrow + j]);
-        }
+    if (fl.residual) {
+        float r[8];
+        unpack8(res, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
-    if (p.out_f32) {
-        float* C = (float*)p.C;
-        if (full) *(float4*)(C + crow) = make_float4(v[0], v[1], v[2], v[3]);
-        else for (int j = 0; j < 4; ++j) if (n + j < p.N) C[crow + j] = v[j];
+    if (fl.f32) {
+        float* C = (float*)p.C + crow;
+        *(float4*)C = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        bf16_t* C = (bf16_t*)p.C;
-        if (full) {
-            uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-            *(uint2*)(C + crow) = o;
-        } else {
-            for (int j = 0; j < 4; ++j) if (n + j < p.N) C[crow + j] = f2bf(v[j]);
-        }
+        *(uint4*)((bf16_t*)p.C + crow) = pack8(v);
     }
 }
 
 // Epilogue for a wave that owns MT x NT MFMA-16x16 tiles computed with SWAPPED operands (D'[n][m]): lane holds
 // C[m = row0 + mt*16 + (lane & 15)][n = col0 + nt*16 + 4*(lane >> 4) + j], j = 0..3.
 //
-// The accumulator layout would store 32-B row fragments (16 rows per instruction): the store tail ran at ~1.5 TB/s
-// and cost more than the K loop on the K = 768 shapes.  So the fp32 accumulators take one trip through a
-// wave-private LDS patch (32 rows at a time, row stride padded by 4 floats: conflict-free ds_write_b128) and come
-// back row-major, 4 columns per lane: every global access of the epilogue (stores, residual / gelu_pre loads)
-// is then a full 128-B (NT=4) or 96-B (NT=3) row segment per 16 / 12 lanes.
+// Stores in the accumulator layout are 32-B row fragments and every residual / gelu_pre load would be a dependent
+// 8-B access: that tail ran at ~1.5 TB/s and cost more than the K loop on the K = 768 shapes.  So the fp32
+// accumulators take one trip through a wave-private LDS patch, 32 rows at a time (row stride padded by 4 floats:
+// conflict-free ds_write_b128), and come back row-major, 8 columns per lane: every global access of the epilogue is
+// a 16-B-per-lane access of full row segments.  The residual / gelu_pre operands of chunk c+1 are requested before
+// chunk c is processed, so their latency hides under the LDS trip and the math of the previous chunk.
 // `patch` = this wave's LDS scratch, 32 * (NT*16 + 4) floats; the caller has already synchronised the workgroup
 // after the last fragment read of the K loop (the patch aliases the staging buffers).
-template <int MT, int NT>
+template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane,
                                                  float* patch) {
-    constexpr int WCOLS = NT * 16, RS = WCOLS + 4, LPR = WCOLS / 4, RPP = 64 / LPR;
+    constexpr int WCOLS = NT * 16, RS = WCOLS + 4, LPR = WCOLS / 8, RPP = 64 / LPR, NPASS = (32 + RPP - 1) / RPP;
+    const EpiFlags<EPI> fl(p);
     const int frow = lane & 15, fq = lane >> 4;
-    const int rr = lane / LPR, rc = (lane % LPR) * 4;
+    const int rr = lane / LPR, rc = (lane % LPR) * 8;
+    const int n = col0 + rc;
+    const bool lane_ok = rr < RPP && n < p.N;       // N % 8 == 0 (checked by the launcher): a started group is complete
+    float bias8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
+    if (fl.bias && lane_ok) {
+        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
+        bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+    uint4 res[NPASS], gp[NPASS];
+    auto prefetch = [&](int mh) {
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int r = pass * RPP + rr;
+            const int m = row0 + mh * 32 + r;
+            res[pass] = make_uint4(0, 0, 0, 0);
+            gp[pass] = make_uint4(0, 0, 0, 0);
+            if (lane_ok && r < 32 && m < p.M) {
+                if (fl.residual) res[pass] = *(const uint4*)(p.residual + (size_t)m * p.ldr + n);
+                if (fl.gelugrad) gp[pass] = *(const uint4*)(p.gelu_pre + (size_t)m * p.ldc + n);
+            }
+        }
+    };
+    if (fl.residual || fl.gelugrad) prefetch(0);
 #pragma unroll
     for (int mh = 0; mh < MT / 2; ++mh) {
 #pragma unroll
@@ -108,17 +147,26 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 *(f32x4*)(patch + (t * 16 + frow) * RS + nt * 16 + fq * 4) = acc[2 * mh + t][nt];
+        uint4 cres[NPASS], cgp[NPASS];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) { cres[pass] = res[pass]; cgp[pass] = gp[pass]; }
+        if ((fl.residual || fl.gelugrad) && mh + 1 < MT / 2) prefetch(mh + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll 1
-        for (int pass = 0; pass < (32 + RPP - 1) / RPP; ++pass) {
+        float v[NPASS][8];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
             const int r = pass * RPP + rr;
-            const int m = row0 + mh * 32 + r, n = col0 + rc;
-            if (rr < RPP && r < 32 && m < p.M && n < p.N) {
-                const f32x4 t4 = *(const f32x4*)(patch + r * RS + rc);
-                float v[4] = {t4[0], t4[1], t4[2], t4[3]};
-                gemm_nt_apply4(p, v, m, n);
-            }
+            const float* src = patch + (r < 32 ? r : 0) * RS + rc;
+            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+            v[pass][0] = lo[0]; v[pass][1] = lo[1]; v[pass][2] = lo[2]; v[pass][3] = lo[3];
+            v[pass][4] = hi[0]; v[pass][5] = hi[1]; v[pass][6] = hi[2]; v[pass][7] = hi[3];
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // patch may be overwritten by the next chunk from here on
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int r = pass * RPP + rr;
+            const int m = row0 + mh * 32 + r;
+            if (lane_ok && r < 32 && m < p.M) gemm_nt_apply8<EPI>(p, fl, v[pass], m, n, bias8, cres[pass], cgp[pass]);
+        }
     }
 }

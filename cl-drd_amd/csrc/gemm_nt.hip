@@ -22,6 +22,7 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;        // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;    // A + B
 
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -94,7 +95,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
     }
 
     __syncthreads();      // all fragment reads of the last K tile are done: the staging buffers become epilogue scratch
-    gemm_nt_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, (float*)smem + wid * (32 * 68));
+    gemm_nt_epilogue<4, 4, EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, (float*)smem + wid * (32 * 68));
+}
+
+template <int EPI>
+int launch_nt(const GemmNtArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        attr_set = true;
+    }
+    const int nblk = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI>), dim3(nblk), dim3(256), 2 * STAGE_BYTES, st, a);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
@@ -107,7 +121,8 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
                                   void* stream) {
     CLDRD_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
     CLDRD_CHECK(K % 32 == 0, "gemm_nt: K must be a multiple of 32");
-    CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0, "gemm_nt: lda/ldb must be multiples of 8, ldc of 4");
+    CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && N % 8 == 0 && (residual == nullptr || ldr % 8 == 0),
+                "gemm_nt: N, lda, ldb, ldc, ldr must be multiples of 8");
     CLDRD_CHECK(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "gemm_nt: operands must be 16-byte aligned");
     CLDRD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, "gemm_nt: dropout_p out of range");
     GemmNtArgs a;
@@ -127,13 +142,16 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
         if (rc >= 0) return rc;
     }
     CLDRD_CHECK(K % BK == 0, "gemm_nt: K must be a multiple of 64 for M < 1024 or N not a multiple of 192/256");
-    const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
-        attr_set = true;
+    switch (epi_flavour(a)) {
+        case 0: return launch_nt<0>(a, (hipStream_t)stream);
+        case EPI_BIAS: return launch_nt<EPI_BIAS>(a, (hipStream_t)stream);
+        case EPI_BIAS | EPI_PREACT | EPI_GELU: return launch_nt<EPI_BIAS | EPI_PREACT | EPI_GELU>(a, (hipStream_t)stream);
+        case EPI_BIAS | EPI_RESIDUAL: return launch_nt<EPI_BIAS | EPI_RESIDUAL>(a, (hipStream_t)stream);
+        case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL: return launch_nt<EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL>(a, (hipStream_t)stream);
+        case EPI_GELUGRAD: return launch_nt<EPI_GELUGRAD>(a, (hipStream_t)stream);
+        case EPI_RESIDUAL: return launch_nt<EPI_RESIDUAL>(a, (hipStream_t)stream);
+        case EPI_F32: return launch_nt<EPI_F32>(a, (hipStream_t)stream);
+        default: return launch_nt<EPI_GENERIC>(a, (hipStream_t)stream);
     }
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(nblk), dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, a);
-    CLDRD_LAUNCH_CHECK();
-    return 0;
 }
+
