@@ -460,8 +460,7 @@ class HipEncoder(nn.Module):
             ops.wgrad(dF, a["h"], G["W2"], T, ws, accumulate=True)
             dpre = self._buf(T, f, dev)
             ops.gemm_nt(dF, self.ht(i, "f2"), dpre, T, gelu_pre=a["pre"])
-            ops.colsum(dpre, G["bf1"], partial, T)
-            ops.wgrad(dpre, a["x1"], G["W1"], T, ws, accumulate=True)
+            ops.wgrad(dpre, a["x1"], G["W1"], T, ws, accumulate=True, dbias=G["bf1"])
             dx1 = self._buf(T, d, dev)
             ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T, residual=ds2)
             # --- attention-output LayerNorm + attention ---
@@ -475,8 +474,7 @@ class HipEncoder(nn.Module):
             ops.gemm_nt(dA, self.ht(i, "o"), dctx, T)
             dqkv = self._buf(T, 3 * d, dev)
             ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1)
-            ops.colsum(dqkv, G["bqkv"], partial, T)
-            ops.wgrad(dqkv, a["x_in"], G["Wqkv"], T, ws, accumulate=True)
+            ops.wgrad(dqkv, a["x_in"], G["Wqkv"], T, ws, accumulate=True, dbias=G["bqkv"])
             g = self._buf(T, d, dev)
             ops.gemm_nt(dqkv, self.ht(i, "qkv"), g, T, residual=ds1)
             tape.layers[i] = None        # free this layer's activations

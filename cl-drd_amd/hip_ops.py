@@ -65,18 +65,21 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
 
 
 def wgrad_workspace_elems(M, N1, N2) -> int:
-    return _lib.load().cldrd_wgrad_splits(M, N1, N2) * N1 * N2
+    return _lib.load().cldrd_wgrad_splits(M, N1, N2) * (N1 * N2 + N1)
 
 
-def wgrad(dY, X, dW, M, workspace, accumulate=False):
-    """dW[N1,N2] (+)= dY[:M]^T @ X[:M]; dY, X bf16 with >= pad_rows(M) rows (zero tail); dW fp32."""
+def wgrad(dY, X, dW, M, workspace, accumulate=False, dbias=None):
+    """dW[N1,N2] (+)= dY[:M]^T @ X[:M] (and dbias[N1] (+)= column sums of dY[:M]); dY, X bf16 with >= pad_rows(M)
+    rows (zero tail); dW, dbias fp32."""
     _chk(dY, BF16, "dY", 2), _chk(X, BF16, "X", 2), _chk(dW, F32, "dW", 2), _chk(workspace, F32, "workspace")
     N1, N2 = dW.shape
     if dY.shape[1] != N1 or X.shape[1] != N2 or not dW.is_contiguous():
         raise ValueError("wgrad: shape mismatch")
     if dY.shape[0] < pad_rows(M) or X.shape[0] < pad_rows(M):
         raise ValueError("wgrad: operands need ceil(M/64)*64 rows allocated")
-    call("cldrd_wgrad_bf16", _p(dY), _p(X), _p(dW), M, N1, N2, dY.stride(0), X.stride(0), _p(workspace),
+    if dbias is not None:
+        _chk(dbias, F32, "dbias", 1)
+    call("cldrd_wgrad_bf16", _p(dY), _p(X), _p(dW), _p(dbias), M, N1, N2, dY.stride(0), X.stride(0), _p(workspace),
          workspace.numel() * 4, 1 if accumulate else 0, _stream())
     return dW
 

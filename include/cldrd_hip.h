@@ -39,11 +39,12 @@ int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int 
                        const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                        int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, void* stream);
 
-/* Weight gradient dW[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (A = dY, B = layer input; autograd's Linear backward).
+/* Weight gradient dW[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (A = dY, B = layer input; autograd's Linear backward), and,
+ * when dbias != NULL, the bias gradient dbias[N1] (+)= column sums of A in the same pass.
  * N1, N2 multiples of 128.  A and B must have ceil(M/64)*64 rows allocated with rows >= M zero.
- * workspace: >= cldrd_wgrad_splits(M,N1,N2) * N1 * N2 floats. */
+ * workspace: >= cldrd_wgrad_splits(M,N1,N2) * (N1 * N2 + N1) floats. */
 int cldrd_wgrad_splits(int M, int N1, int N2);
-int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, int M, int N1, int N2, int lda, int ldb,
+int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, float* dbias, int M, int N1, int N2, int lda, int ldb,
                      float* workspace, size_t workspace_bytes, int accumulate, void* stream);
 
 /* ---- attention (HF DistilBertSelfAttention / BertSelfAttention, head dim 64, L <= 256) --------------------

@@ -100,7 +100,8 @@ def test_gemm_nt_dropout_is_deterministic_and_unbiased():
 
 
 # ------------------------------------------------------------------------------------------------ weight gradient
-@pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (200, 128, 256), (1024, 384, 128), (4096, 768, 768), (3000, 256, 768)])
+@pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (200, 128, 256), (1024, 384, 128), (4096, 768, 768), (3000, 256, 768),
+                                     (8192, 2304, 768), (2048, 768, 3072), (130, 512, 128)])
 def test_wgrad(M, N1, N2):
     Mp = ops.pad_rows(M)
     dY, X = torch.zeros(Mp, N1), torch.zeros(Mp, N2)
@@ -111,8 +112,10 @@ def test_wgrad(M, N1, N2):
     ws = torch.empty(ops.wgrad_workspace_elems(M, N1, N2), dtype=torch.float32, device=DEV)
     ops.wgrad(dY.to(DEV), X.to(DEV), dW, M, ws, accumulate=False)
     close(dW, ref, 1e-4, 1e-4 * math.sqrt(M), f"wgrad {M}x{N1}x{N2}")
-    ops.wgrad(dY.to(DEV), X.to(DEV), dW, M, ws, accumulate=True)
+    db = torch.full((N1,), 3.0, dtype=torch.float32, device=DEV)
+    ops.wgrad(dY.to(DEV), X.to(DEV), dW, M, ws, accumulate=True, dbias=db)
     close(dW, 2 * ref, 1e-4, 2e-4 * math.sqrt(M), "wgrad accumulate")
+    close(db, 3.0 + dY.double().sum(0), 1e-4, 1e-4 * math.sqrt(M), "wgrad fused bias gradient")
 
 
 def test_wgrad_asymmetric():

