@@ -205,7 +205,7 @@ extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
     const int tiles = (N1 / wgrad_t1(N1)) * (N2 / T2);
     const int ktotal = (M + BK - 1) / BK;
     if (tiles <= 0) return 1;
-    int splits = (256 + tiles - 1) / tiles;          // one workgroup per CU
+    int splits = 256 / tiles;                        // at most one workgroup per CU: a second partial round would double the time
     if (splits > ktotal) splits = ktotal;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;

@@ -167,7 +167,7 @@ __device__ __forceinline__ void block_partials(float* smem, const RowF& a, const
 //   dx  = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))                       -> dx (residual path)
 //   dx2 = dropout-masked dx (the branch that went through dropout before the residual add), or null
 //   partial[blk] = { sum dy*xhat (dgamma), sum dy (dbeta), sum dx2-or-dx (bias grad of the preceding Linear) }
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                       const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                       const float* __restrict__ gamma, bf16_t* __restrict__ dx,
                                                       bf16_t* __restrict__ dx2, float* __restrict__ partial, int T, int d,
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dg.v[it][j] = db.v[it][j] = dbias.v[it][j] = 0.f;
-    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += gridDim.x * 4) {
+    const int wpb = blockDim.x >> 6;      // waves per block: 8 -> 16 waves per CU keep enough loads in flight
+    for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < T; row += gridDim.x * wpb) {
         RowF g, xr;
         load_row_bf16(dy + (size_t)row * d, d, lane, g);
         load_row_bf16(x + (size_t)row * d, d, lane, xr);
@@ -340,7 +341,7 @@ __global__ void scatter_cls_kernel(const float* __restrict__ dcls, bf16_t* __res
 
 }  // namespace
 
-static inline int ln_bwd_blocks(int T) { int b = (T + 3) / 4; return b < 512 ? b : 512; }
+static inline int ln_bwd_blocks(int T) { int b = (T + 7) / 8; return b < 512 ? (b ? b : 1) : 512; }
 
 extern "C" int cldrd_ln_partial_blocks(int T) { return ln_bwd_blocks(T); }
 
@@ -376,7 +377,7 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
                                    int d, float dropout_p, unsigned long long seed, int accumulate, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_bwd: need 0 < d <= 1024, d % 4 == 0");
     const int nb = ln_bwd_blocks(T);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 3 * d * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(512), 3 * d * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d,
                        dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();

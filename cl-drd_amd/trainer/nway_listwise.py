@@ -77,6 +77,7 @@ class NwayTrainer:
         self.clip = torch.zeros(3, dtype=torch.float32, device=dev)
         self.norm_partial = torch.empty(ops.sqnorm_blocks(), dtype=torch.float32, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.distributed else None
+        self.q_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = []
         if self.distributed:
             # DDP constructor semantics (reference :250-255): rank 0's parameters win
@@ -116,9 +117,19 @@ class NwayTrainer:
         q, nw = batch["query"], batch["nway_passages"]
         bz, nway, L = nw["input_ids"].shape
         self.flat_g.zero_()
-        q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True)
+        main = torch.cuda.current_stream()
+        # The query tower is ~1 % of the FLOPs but dozens of small, latency-bound launches: it runs on its own stream
+        # next to the passage tower (forward and backward) instead of in front of it.
+        side = self.q_stream if not model.share_weights else main
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True)
         p_cls, p_tape = pe.encode(nw["input_ids"].reshape(bz * nway, L), nw["attention_mask"].reshape(bz * nway, L),
                                   train=True, save=True)
+        if side is not main:
+            main.wait_stream(side)
+            q_cls.record_stream(main)
         mode = score_mode(model.in_batch_loss, model.all_in_batch_neg)
         Np = nway if mode == 0 else (bz * nway if mode == 1 else 2 * nway)
         logits = torch.empty(bz, Np, dtype=torch.float32, device=q_cls.device)
@@ -138,10 +149,14 @@ class NwayTrainer:
             if self.distributed:
                 dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
         else:
+            side.wait_stream(main)
+            dq.record_stream(side)
+            with torch.cuda.stream(side):
+                qe.backward_from_cls(q_tape, dq, after_layer=self._bucket_hook(0))
             pe.backward_from_cls(p_tape, dp, after_layer=self._bucket_hook(1))
-            qe.backward_from_cls(q_tape, dq, after_layer=self._bucket_hook(0))
+            main.wait_stream(side)
             if self.distributed:
-                torch.cuda.current_stream().wait_stream(self.comm_stream)
+                main.wait_stream(self.comm_stream)
         return loss_out, logits
 
     def optimizer_step(self):
