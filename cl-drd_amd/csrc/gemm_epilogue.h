@@ -16,12 +16,14 @@ struct GemmNtArgs {
     float drop_scale;
     uint64_t seed;
     int out_f32;
+    // EPI_FILTER (top-k scan): keep C[m][n] >= thr[m] as candidate (n, score) of query m
+    const float* thr; int* counts; int* cand_rows; float* cand_scores; int cap;
 };
 
 // compile-time epilogue flavours (each GEMM kernel is instantiated per flavour so the 16x-unrolled epilogue carries
 // only the code it needs); EPI_GENERIC reads every switch from GemmNtArgs at run time.
 enum : int {
-    EPI_BIAS = 1, EPI_PREACT = 2, EPI_GELU = 4, EPI_GELUGRAD = 8, EPI_DROPOUT = 16, EPI_RESIDUAL = 32, EPI_F32 = 64,
+    EPI_BIAS = 1, EPI_PREACT = 2, EPI_GELU = 4, EPI_GELUGRAD = 8, EPI_DROPOUT = 16, EPI_RESIDUAL = 32, EPI_F32 = 64, EPI_FILTER = 128,
     EPI_GENERIC = 1 << 20
 };
 
@@ -167,6 +169,34 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
             const int r = pass * RPP + rr;
             const int m = row0 + mh * 32 + r;
             if (lane_ok && r < 32 && m < p.M) gemm_nt_apply8<EPI>(p, fl, v[pass], m, n, bias8, cres[pass], cgp[pass]);
+        }
+    }
+}
+
+// Top-k scan epilogue (no store of C): lane holds C[m = query][n = 4 consecutive index rows]; anything at or above the
+// query's threshold is appended to that query's candidate list.  Hits are ~0.1 % of the elements, so the atomics are rare.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_nt_filter_epilogue(const GemmNtArgs& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = row0 + mt * 16 + frow;
+        if (m >= p.M) continue;
+        const float t = p.thr[m];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = col0 + nt * 16 + fq * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[mt][nt][j] * p.alpha;
+                if (n + j < p.N && v >= t) {
+                    const int pos = atomicAdd(p.counts + m, 1);
+                    if (pos < p.cap) {
+                        p.cand_rows[(size_t)m * p.cap + pos] = n + j;
+                        p.cand_scores[(size_t)m * p.cap + pos] = v;
+                    }
+                }
+            }
         }
     }
 }

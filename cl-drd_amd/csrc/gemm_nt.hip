@@ -94,8 +94,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
         }
     }
 
-    __syncthreads();      // all fragment reads of the last K tile are done: the staging buffers become epilogue scratch
-    gemm_nt_epilogue<4, 4, EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, (float*)smem + wid * (32 * 68));
+    if constexpr (EPI == EPI_FILTER) {
+        gemm_nt_filter_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+    } else {
+        __syncthreads();      // all fragment reads of the last K tile are done: the staging buffers become epilogue scratch
+        gemm_nt_epilogue<4, 4, EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, (float*)smem + wid * (32 * 68));
+    }
 }
 
 template <int EPI>
@@ -134,6 +138,7 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
     a.drop_thresh = dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u;
     a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.seed = seed; a.out_f32 = out_f32;
+    a.thr = nullptr; a.counts = nullptr; a.cand_rows = nullptr; a.cand_scores = nullptr; a.cap = 0;
     // large-M shapes go to the 256-row ring kernel; CLDRD_GEMM_TILE=128|192|256 forces a variant (experiments)
     const char* env_tile = getenv("CLDRD_GEMM_TILE");
     const int force = env_tile ? atoi(env_tile) : 0;
@@ -155,3 +160,18 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
     }
 }
 
+
+// Top-k scan over one index shard: scores = Q[nq,d] . P[rows,d]^T on bf16 MFMA; every (query, row) with score >= thr[query]
+// is appended to the query's candidate list (counts must be zeroed by the caller; counts[q] may exceed cap = overflow).
+extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
+                                      int* cand_rows, float* cand_scores, int cap, void* stream) {
+    CLDRD_CHECK(nq > 0 && rows > 0 && rows < 2147483647LL && d % BK == 0 && cap > 0, "topk_scan_filter: bad arguments");
+    CLDRD_CHECK(((uintptr_t)Q % 16 == 0) && ((uintptr_t)P % 16 == 0), "topk_scan_filter: operands must be 16-byte aligned");
+    GemmNtArgs a;
+    a.A = (const bf16_t*)Q; a.B = (const bf16_t*)P; a.C = nullptr;
+    a.M = nq; a.N = (int)rows; a.K = d; a.lda = d; a.ldb = d; a.ldc = 0;
+    a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.preact = nullptr; a.gelu_pre = nullptr; a.act = 0; a.alpha = 1.0f;
+    a.drop_thresh = 0; a.drop_scale = 1.0f; a.seed = 0; a.out_f32 = 0;
+    a.thr = thr; a.counts = counts; a.cand_rows = cand_rows; a.cand_scores = cand_scores; a.cap = cap;
+    return launch_nt<EPI_FILTER>(a, (hipStream_t)stream);
+}

@@ -213,3 +213,43 @@ def cast_bf16(src, dst):
 
 def transpose_cast_batched(src, dst, desc, tile_prefix, ndesc, total_tiles):
     call("cldrd_transpose_cast_batched", _p(src), _p(dst), _p(desc), _p(tile_prefix), ndesc, total_tiles, _stream())
+
+
+# ---------------------------------------------------------------------------------------------------- top-k search
+def topk_scan_filter(Qb, Pb, thr, counts, cand_rows, cand_scores):
+    _chk(Qb, BF16, "Qb", 2), _chk(Pb, BF16, "Pb", 2), _chk(thr, F32, "thr", 1)
+    _chk(counts, torch.int32, "counts", 1), _chk(cand_rows, torch.int32, "cand_rows", 2), _chk(cand_scores, F32, "cand_scores", 2)
+    nq, d = Qb.shape
+    if Pb.shape[1] != d or not Qb.is_contiguous() or not Pb.is_contiguous():
+        raise ValueError("topk_scan_filter: shape mismatch")
+    call("cldrd_topk_scan_filter", _p(Qb), _p(Pb), nq, Pb.shape[0], d, _p(thr), _p(counts), _p(cand_rows), _p(cand_scores),
+         cand_rows.shape[1], _stream())
+
+
+def topk_kth_largest(scores, S, kth, thr):
+    _chk(scores, F32, "scores", 2), _chk(thr, F32, "thr", 1)
+    call("cldrd_topk_kth_largest", _p(scores), scores.stride(0), scores.shape[0], S, int(kth), _p(thr), _stream())
+
+
+def topk_rescore(q32, P32, counts, cand_rows, cand_scores):
+    _chk(q32, F32, "q32", 2), _chk(P32, F32, "P32", 2)
+    call("cldrd_topk_rescore", _p(q32), _p(P32), q32.shape[1], _p(counts), _p(cand_rows), _p(cand_scores), q32.shape[0],
+         cand_rows.shape[1], _stream())
+
+
+def topk_sort(counts, cand_rows, cand_scores, k, D, I):
+    _chk(D, F32, "D", 2), _chk(I, torch.int32, "I", 2)
+    call("cldrd_topk_sort", _p(counts), _p(cand_rows), _p(cand_scores), cand_rows.shape[0], cand_rows.shape[1], int(k), _p(D),
+         _p(I), _stream())
+
+
+def row_sqnorm_max(P32) -> float:
+    _chk(P32, F32, "P32", 2)
+    out = torch.zeros(1, dtype=torch.int32, device=P32.device)
+    call("cldrd_row_sqnorm_max", _p(P32), P32.shape[0], P32.shape[1], _p(out), _stream())
+    return float(out.view(torch.float32).item())
+
+
+def gather_cast_rows(src32, dst_bf16, n_out, stride):
+    _chk(src32, F32, "src32", 2), _chk(dst_bf16, BF16, "dst_bf16", 2)
+    call("cldrd_gather_cast_rows", _p(src32), _p(dst_bf16), n_out, stride, src32.shape[1], _stream())

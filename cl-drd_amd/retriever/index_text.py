@@ -1,0 +1,90 @@
+"""``retriever/index_text.py`` of the reference (:30-109) on MI355X: load a checkpoint (``module.`` prefix stripped), encode
+the collection with the passage tower, build the flat inner-product index with ids, write it plus ``meta.pkl``.
+
+Same flags; extra: ``--synthetic_rows N`` (encode N synthetic MSMARCO-shaped passages instead of ``--passages_path``) and
+``--rank/--world`` style sharding through torch.distributed env vars: rank r encodes and stores the contiguous shard r
+(independent units, no collective)."""
+from __future__ import annotations
+
+import argparse
+import os
+import pickle
+from collections import OrderedDict
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from ..dataset import SequenceDataset, SyntheticSequenceDataset
+from ..models.nway_dual_encoder import NwayDualEncoder
+from .retrieval_utils import ShardedFlatIPIndex, construct_flatindex_from_embeddings, get_embeddings_from_scratch, write_index
+
+
+def get_args(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--resume", default="")
+    parser.add_argument("--model_name_or_path", default="distilbert-base-uncased")
+    parser.add_argument("--tokenizer_name_or_path", default="distilbert-base-uncased")
+    parser.add_argument("--passages_path", default="")
+    parser.add_argument("--max_length", default=256)
+    parser.add_argument("--index_dir", default="")
+    parser.add_argument("--is_query", default=False)
+    parser.add_argument("--is_parallel", default=True)
+    parser.add_argument("--share_weights", action="store_true", default=False)
+    parser.add_argument("--synthetic_rows", type=int, default=0)
+    args = parser.parse_args(argv)
+    args.max_length = int(args.max_length)      # the reference leaves it a str when passed on the command line
+    if not os.path.exists(args.index_dir):
+        os.makedirs(args.index_dir, exist_ok=True)
+    return args
+
+
+def load_checkpoint_into(model, path, is_parallel=True):
+    checkpoint = torch.load(path, map_location="cpu")
+    state_dict = checkpoint["state_dict"]
+    if is_parallel:
+        new_state_dict = OrderedDict()
+        for k, v in state_dict.items():
+            new_state_dict[k[7:] if k.startswith("module.") else k] = v     # remove `module.`
+        state_dict = new_state_dict
+    model.load_state_dict(state_dict)
+
+
+def main(args):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    model = NwayDualEncoder(args.model_name_or_path, share_weights=args.share_weights)
+    print("************************* share weights = {} *************************".format(args.share_weights))
+    if args.resume:
+        print(f"load model from ==> {args.resume}")
+        load_checkpoint_into(model, args.resume, args.is_parallel)
+    model.cuda()
+
+    if args.synthetic_rows:
+        lo, hi = ShardedFlatIPIndex.shard_bounds(args.synthetic_rows, world, rank)
+        dataset = SyntheticSequenceDataset(hi - lo, args.max_length, first_id=lo)
+        text_loader = dataset.loader()
+    else:
+        from transformers import AutoTokenizer
+        tokenizer = AutoTokenizer.from_pretrained(args.tokenizer_name_or_path)
+        dataset = SequenceDataset.create_from_seqs_file(args.passages_path, tokenizer, args.max_length, is_query=args.is_query)
+        lo, hi = ShardedFlatIPIndex.shard_bounds(len(dataset), world, rank)
+        dataset.ids, dataset.seqs = dataset.ids[lo:hi], dataset.seqs[lo:hi]
+        text_loader = torch.utils.data.DataLoader(dataset, batch_size=512, shuffle=False, num_workers=4, collate_fn=dataset.collate_fn)
+
+    text_embs, text_ids = get_embeddings_from_scratch(model, text_loader, use_fp16=True, is_query=args.is_query, show_progress_bar=True)
+    text_id_to_idx = {tid: idx for idx, tid in enumerate(text_ids)}
+    print("embs dtype: ", text_embs.dtype)
+    index = construct_flatindex_from_embeddings(text_embs, np.array(text_ids))
+    stem = Path(args.resume).stem.split(".")[0] if args.resume else "random_init"
+    index_path = os.path.join(args.index_dir, stem + (f".shard{rank}of{world}" if world > 1 else "") + ".index")
+    write_index(index, index_path)
+    with open(os.path.join(args.index_dir, "meta.pkl" if world == 1 else f"meta.shard{rank}.pkl"), "wb") as f:
+        pickle.dump({"text_ids": np.array(text_ids), "text_id_to_idx": text_id_to_idx}, f)
+    return index_path
+
+
+if __name__ == "__main__":
+    main(get_args())

@@ -38,6 +38,21 @@ def linear_schedule_factor(step: int, warmup_steps: int, total_steps: int) -> fl
     return max(0.0, float(total_steps - step) / float(max(1, total_steps - warmup_steps)))
 
 
+def allreduce_buckets(flat_g: torch.Tensor, buckets, world: int, group=None):
+    """SUM all-reduce of every (tower, layer, start, end) bucket of the flat gradient buffer (blocking form; the trainer
+    issues the same calls per bucket from the backward hooks on a side stream).  The division by world_size is folded
+    into dlogits, so the reduced buffer already holds the mean gradient."""
+    if world <= 1:
+        return
+    for _, _, a, b in buckets:
+        dist.all_reduce(flat_g[a:b], op=dist.ReduceOp.SUM, group=group)
+
+
+def owns_example(line_idx: int, rank: int, nranks: int) -> bool:
+    """Data sharding rule of the reference (dataset/nway_dataset.py:305): example line i belongs to rank i % nranks."""
+    return line_idx % nranks == rank
+
+
 class NwayTrainer:
     def __init__(self, model: NwayDualEncoder, *, loss: str = "lambda_mrr", T: float = 1.0, learning_rate: float = 7e-6,
                  weight_decay: float = 0.01, adam_epsilon: float = 1e-8, max_grad_norm: float = 1.0, warmup_steps: int = 4000,
