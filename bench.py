@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-index", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-retrieve", action="store_true")
+    ap.add_argument("--retrieve-rows", type=int, default=1105228, help="index rows per GPU (8 841 823 / 8)")
     args = ap.parse_args()
 
     import torch
@@ -151,6 +153,37 @@ def main():
         index = {"value": round(pps, 1), "unit": "passages/s", "batch": 512, "seq_len": L,
                  "mfma_frac": round(pps * flops_seq_fwd(L) / (world * PEAK_BF16_TFLOPS * 1e12), 4)}
 
+    # ---- retrieve path: cfg5 shard (8 841 823 / 8 rows x 768), 128-query batches, k = 1000 ----
+    retrieve = None
+    if not args.no_retrieve:
+        from cldrd_amd.retriever.retrieval_utils import FlatIPIndex
+        del trainer, model
+        torch.cuda.empty_cache()
+        rows = args.retrieve_rows
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        P = torch.randn(rows, D, device=dev, generator=gen)
+        P *= ((9.0 + 3.0 * torch.rand(rows, 1, device=dev, generator=gen)) / P.norm(dim=1, keepdim=True))
+        flat_index = FlatIPIndex.from_device_rows(P, id_offset=rank * rows)
+        flat_index.profile = True
+        qn = torch.randn(3 * 128, D, device=dev, generator=gen)
+        qn *= (10.0 / qn.norm(dim=1, keepdim=True))
+        qh = qn.cpu().numpy()
+        flat_index.search(qh[:128], 1000)                  # warm-up
+        sync_all()
+        t2 = time.perf_counter()
+        Dq, Iq = flat_index.search(qh, 1000)
+        sync_all()
+        dr = time.perf_counter() - t2
+        st = flat_index.last_stats
+        scan_ms = sum(st["scan_ms"]) / len(st["scan_ms"])
+        scan_bytes = rows * D * 2 + 128 * D * 2
+        retrieve = {"queries_per_s": round(world * qh.shape[0] / dr, 1), "rows_per_shard": rows, "k": 1000, "batch": 128,
+                    "scans": st["scans"], "rescans": st["rescans"], "candidates_per_query": round(st["candidates"] / qh.shape[0], 1),
+                    "scan_kernel_ms": round(scan_ms, 3), "scan_hbm_gb_s": round(scan_bytes / scan_ms / 1e6, 1),
+                    "scan_hbm_frac": round(scan_bytes / scan_ms / 1e6 / 8000.0, 4),
+                    "scan_tflops": round(2.0 * 128 * rows * D / scan_ms / 1e9, 1)}
+        del flat_index, P
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(N, L, Lq)
@@ -168,7 +201,7 @@ def main():
             "model_tflop_per_sample": round(flops_per_sample / 1e12, 4),
             "step_mfma_frac": round(samples_per_s * flops_per_sample / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "final_loss": final_loss,
-            "index": index, "roofline": roofline, "cpu_baseline": cpu,
+            "index": index, "retrieve": retrieve, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -186,7 +219,7 @@ def cpu_baseline(N, L, Lq):
     import cldrd_amd.synthetic as syn
     cores = min(len(os.sched_getaffinity(0)), 32)      # more threads than this only adds contention in torch-CPU
     torch.set_num_threads(cores)
-    Bc = 1
+    Bc = 4
     cfg = E.RefConfig()
     shapes = E.param_shapes(cfg)
     g = torch.Generator().manual_seed(0)

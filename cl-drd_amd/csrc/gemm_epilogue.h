@@ -200,3 +200,36 @@ __device__ __forceinline__ void gemm_nt_filter_epilogue(const GemmNtArgs& p, f32
         }
     }
 }
+
+// Same filter with the roles swapped (ring kernel: rows m = index rows, columns n = queries): thr / counts are per column.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_nt_filter_epilogue_cols(const GemmNtArgs& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+    float t[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = col0 + nt * 16 + fq * 4 + j;
+            t[nt][j] = n < p.N ? p.thr[n] : __builtin_inff();
+        }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = row0 + mt * 16 + frow;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = acc[mt][nt][j] * p.alpha;
+                if (v >= t[nt][j]) {
+                    const int n = col0 + nt * 16 + fq * 4 + j;
+                    const int pos = atomicAdd(p.counts + n, 1);
+                    if (pos < p.cap) {
+                        p.cand_rows[(size_t)n * p.cap + pos] = m;
+                        p.cand_scores[(size_t)n * p.cap + pos] = v;
+                    }
+                }
+            }
+    }
+}

@@ -118,6 +118,7 @@ int launch_nt(const GemmNtArgs& a, hipStream_t st) {
 }  // namespace
 
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a, int force_bn, hipStream_t st);   // gemm_nt_ring.hip
+int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st);                     // gemm_nt_ring.hip
 
 extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
@@ -173,5 +174,11 @@ extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long
     a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.preact = nullptr; a.gelu_pre = nullptr; a.act = 0; a.alpha = 1.0f;
     a.drop_thresh = 0; a.drop_scale = 1.0f; a.seed = 0; a.out_f32 = 0;
     a.thr = thr; a.counts = counts; a.cand_rows = cand_rows; a.cand_scores = cand_scores; a.cap = cap;
+    const char* env_tile = getenv("CLDRD_GEMM_TILE");
+    if (rows >= 4096 && nq <= 128 && !(env_tile && atoi(env_tile) == 128) && (double)rows * d * 2.0 < 4.0e9) {
+        // large shard: index rows are the M dimension of the 256-row ring kernel, the (<= 128) queries its N tile
+        a.A = (const bf16_t*)P; a.B = (const bf16_t*)Q; a.M = (int)rows; a.N = nq;
+        return cldrd_gemm_nt_ring_scan(a, (hipStream_t)stream);
+    }
     return launch_nt<EPI_FILTER>(a, (hipStream_t)stream);
 }

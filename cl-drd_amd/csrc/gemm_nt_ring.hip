@@ -30,7 +30,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     constexpr int BPW = BN / 64;             // 1-KiB B pieces per wave (8 rows x 128 B each): BN/8 pieces over 8 waves
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ntn = p.N / BN;
+    const int ntn = (p.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
     const int wm = wid >> 2, wn = wid & 3;
@@ -140,10 +140,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
         klast(b1);
     }
 
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();     // last K tile fully consumed by every wave: the slots become epilogue scratch
-    asm volatile("" ::: "memory");
-    gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
+    if constexpr (EPI == EPI_FILTER) {
+        gemm_nt_filter_epilogue_cols<8, NT>(p, acc, m0 + wm * 128, n0 + wn * WN, lane);
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // last K tile fully consumed by every wave: the slots become epilogue scratch
+        asm volatile("" ::: "memory");
+        gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
+    }
 }
 
 template <int BN, int EPI>
@@ -154,7 +158,7 @@ int launch_ring_epi(const GemmNtArgs& a, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const int nblk = ((a.M + BM - 1) / BM) * (a.N / BN);
+    const int nblk = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, EPI>), dim3(nblk), dim3(512), lds, st, a);
     CLDRD_LAUNCH_CHECK();
     return 0;
@@ -176,6 +180,9 @@ int launch_ring(const GemmNtArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+
+// Top-k scan with the index rows as M (256-row tiles) and up to 128 queries as N.
+int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st) { return launch_ring_epi<128, EPI_FILTER>(a, st); }
 
 // Returns -1 if this variant does not apply (caller falls back to the 128x128 kernel), else the launch status.
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a, int force_bn, hipStream_t st) {

@@ -93,6 +93,7 @@ class FlatIPIndex:
         self.device = None
         self._p32 = self._pbf = self._sample = None
         self.last_stats = {}
+        self.profile = False          # bench.py: time the scan kernel with HIP events
 
     # -- construction -----------------------------------------------------------------------------------------
     def add_with_ids(self, embeddings, ids):
@@ -113,14 +114,28 @@ class FlatIPIndex:
     def add(self, embeddings):
         self.add_with_ids(embeddings, None)
 
+    @classmethod
+    def from_device_rows(cls, rows32: torch.Tensor, id_offset: int = 0) -> "FlatIPIndex":
+        """Index over fp32 rows that already live in HBM (e.g. an encode shard that never left the GPU)."""
+        idx = cls(rows32.shape[1])
+        idx.ntotal, idx.id_offset = rows32.shape[0], id_offset
+        idx._attach(rows32.contiguous())
+        return idx
+
     def to_gpu(self, device):
         """Make the shard resident in HBM: fp32 rows (exact re-score), bf16 shadow (scan), bf16 row sample (threshold)."""
         device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("FlatIPIndex.search runs on the GPU only (no CPU path)")
+        with torch.cuda.device(device):
+            self._attach(torch.from_numpy(np.ascontiguousarray(self.embeddings)).to(device))
+        return self
+
+    def _attach(self, p32: torch.Tensor):
+        device = p32.device
         self.device = device
         with torch.cuda.device(device):
-            self._p32 = torch.from_numpy(self.embeddings).to(device)
+            self._p32 = p32
             n, d = self._p32.shape
             self._pbf = torch.empty(n, d, dtype=torch.bfloat16, device=device)
             ops.cast_bf16(self._p32.view(-1), self._pbf.view(-1))
@@ -130,7 +145,6 @@ class FlatIPIndex:
             self._sample = torch.zeros((self._s_rows + 7) // 8 * 8, d, dtype=torch.bfloat16, device=device)
             ops.gather_cast_rows(self._p32, self._sample, self._s_rows, self._s_stride)
             self._max_norm = math.sqrt(ops.row_sqnorm_max(self._p32))
-        return self
 
     # -- search -------------------------------------------------------------------------------------------------
     def search(self, queries, k: int):
@@ -156,6 +170,9 @@ class FlatIPIndex:
                 else:
                     glob = np.where(valid, self.ids[np.maximum(rows, 0)], -1)
                 I[lo:lo + QUERY_TILE, :kk] = glob
+        if "scan_events" in stats:
+            torch.cuda.synchronize()
+            stats["scan_ms"] = [a.elapsed_time(b) for a, b in stats.pop("scan_events")]
         self.last_stats = stats
         return D, I
 
@@ -173,7 +190,9 @@ class FlatIPIndex:
         samp = torch.empty(nq, self._sample.shape[0], dtype=torch.float32, device=dev)
         ops.gemm_nt(qb, self._sample, samp, nq)
         lam = kk * S / n
-        kth = int(min(S, math.ceil(lam + 3.0 * math.sqrt(lam) + 1.0))) if S < n else kk
+        # lam = expected number of sample rows inside the global top-kk; +4.5 sigma makes a too-high estimate (-> rescan)
+        # a ~1e-5 event per query at the price of ~25 % more candidates
+        kth = int(min(S, math.ceil(lam + 4.5 * math.sqrt(lam) + 1.0))) if S < n else kk
         thr_dev = torch.empty(nq, dtype=torch.float32, device=dev)
         ops.topk_kth_largest(samp, S, kth, thr_dev)
         thr = thr_dev.cpu().numpy().astype(np.float64) - eps
@@ -188,7 +207,13 @@ class FlatIPIndex:
         for attempt in range(12):
             thr_dev.copy_(torch.from_numpy(thr.astype(np.float32)))
             counts.zero_()
+            if self.profile:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             ops.topk_scan_filter(qb, self._pbf, thr_dev, counts, cand_rows, cand_scores)      # 2. scan
+            if self.profile:
+                e1.record()
+                stats.setdefault("scan_events", []).append((e0, e1))
             ops.topk_rescore(q32, self._p32, counts, cand_rows, cand_scores)                    # 3. exact re-score
             ops.topk_sort(counts, cand_rows, cand_scores, kk, D, I)                             # 4. sort + cut
             stats["scans"] += 1
