@@ -21,6 +21,9 @@ SIGNATURES = {
     "cldrd_wgrad_bf16": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, csz, ci, vp]),
     "cldrd_attention_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
     "cldrd_attention_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
+    "cldrd_attention_cls_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
+    "cldrd_attention_cls_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
+    "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, vp]),
     "cldrd_ln_partial_blocks": (ci, [ci]),
     "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp]),
     "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp]),

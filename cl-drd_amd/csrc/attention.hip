@@ -354,3 +354,167 @@ extern "C" int cldrd_attention_bwd(const void* qkv, const long long* mask, const
         default: return launch_bwd<8>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
     }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// CLS-only attention for the LAST encoder layer.  The reference pools `last_hidden_state[:, 0, :]`
+// (models/nway_dual_encoder.py:52,56,64), so in the last layer only the query of token 0 matters:
+// K and V are still needed for every token, but the score matrix shrinks to one row per (sequence, head) and
+// everything after attention runs on one row per sequence.  One wavefront per (sequence, head).
+namespace {
+
+__global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
+                                                           const int64_t* __restrict__ mask, bf16_t* __restrict__ ctx,
+                                                           float* __restrict__ probs, int L, int H, float scale,
+                                                           uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    __shared__ float sp[256];
+    __shared__ float sq[64];
+    const int seq = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x;
+    const int dm = H * 64;
+    sq[lane] = bf2f(qc[(size_t)seq * dm + hd * 64 + lane]);
+    __syncthreads();
+    const bf16_t* kb = kv + (size_t)seq * L * 2 * dm + hd * 64;
+    const bf16_t* vb = kb + dm;
+    float sc[4];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = lane + 64 * i;
+        float s = -1.0e30f;
+        if (key < L && (!mask || mask[(size_t)seq * L + key] != 0)) {
+            const bf16_t* kr = kb + (size_t)key * 2 * dm;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint4 u = *(const uint4*)(kr + c * 8);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    a += __uint_as_float(w[j] << 16) * sq[c * 8 + 2 * j] + __uint_as_float(w[j] & 0xFFFF0000u) * sq[c * 8 + 2 * j + 1];
+            }
+            s = a * scale;
+        }
+        sc[i] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sc[i] = __expf(sc[i] - mx); sum += (lane + 64 * i < L) ? sc[i] : 0.f; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = lane + 64 * i;
+        if (key < L) {
+            const float p = sc[i] * inv;
+            probs[((size_t)seq * H + hd) * L + key] = p;
+            float pd = p;
+            if (drop_thresh) pd = dropout_keep(seed, (((uint64_t)seq * H + hd) * L + 0) * L + key, drop_thresh) ? p * drop_scale : 0.f;
+            sp[key] = pd;
+        }
+    }
+    __syncthreads();
+    float o = 0.f;
+    for (int key = 0; key < L; ++key) o += sp[key] * bf2f(vb[(size_t)key * 2 * dm + lane]);
+    ctx[(size_t)seq * dm + hd * 64 + lane] = f2bf(o);
+}
+
+__global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
+                                                           const float* __restrict__ probs, const bf16_t* __restrict__ dctx,
+                                                           bf16_t* __restrict__ dqc, bf16_t* __restrict__ dkv, int L, int H,
+                                                           float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    __shared__ float sds[256], spd[256], sdo[64];
+    const int seq = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x;
+    const int dm = H * 64;
+    sdo[lane] = bf2f(dctx[(size_t)seq * dm + hd * 64 + lane]);
+    const float qd = bf2f(qc[(size_t)seq * dm + hd * 64 + lane]);
+    __syncthreads();
+    const bf16_t* kb = kv + (size_t)seq * L * 2 * dm + hd * 64;
+    const bf16_t* vb = kb + dm;
+    float p[4], dp[4], dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = lane + 64 * i;
+        p[i] = dp[i] = 0.f;
+        if (key < L) {
+            p[i] = probs[((size_t)seq * H + hd) * L + key];
+            const bf16_t* vr = vb + (size_t)key * 2 * dm;
+            float a = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint4 u = *(const uint4*)(vr + c * 8);
+                const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    a += __uint_as_float(w[j] << 16) * sdo[c * 8 + 2 * j] + __uint_as_float(w[j] & 0xFFFF0000u) * sdo[c * 8 + 2 * j + 1];
+            }
+            float pdv = p[i];
+            if (drop_thresh) {
+                const bool keep = dropout_keep(seed, (((uint64_t)seq * H + hd) * L + 0) * L + key, drop_thresh);
+                pdv = keep ? p[i] * drop_scale : 0.f;
+                a = keep ? a * drop_scale : 0.f;
+            }
+            dp[i] = a;
+            spd[key] = pdv;
+            dot += p[i] * a;
+        }
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int key = lane + 64 * i;
+        if (key < L) sds[key] = p[i] * (dp[i] - dot) * scale;
+    }
+    __syncthreads();
+    // lane = feature: dq = sum_key ds[key] K[key]; dK[key] = ds[key] q; dV[key] = p_drop[key] dO
+    bf16_t* dkb = dkv + (size_t)seq * L * 2 * dm + hd * 64;
+    float dq = 0.f;
+    for (int key = 0; key < L; ++key) {
+        const float ds = sds[key];
+        dq += ds * bf2f(kb[(size_t)key * 2 * dm + lane]);
+        dkb[(size_t)key * 2 * dm + lane] = f2bf(ds * qd);
+        dkb[(size_t)key * 2 * dm + dm + lane] = f2bf(spd[key] * sdo[lane]);
+    }
+    dqc[(size_t)seq * dm + hd * 64 + lane] = f2bf(dq);
+}
+
+// dst[m * stride_rows] += src[m]  (bf16 rows of d elements)
+__global__ __launch_bounds__(256) void add_rows_strided_kernel(bf16_t* __restrict__ dst, const bf16_t* __restrict__ src, int M, int d,
+                                                                int stride_rows) {
+    const int m = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const size_t o = (size_t)m * stride_rows * d + c;
+        dst[o] = f2bf(bf2f(dst[o]) + bf2f(src[(size_t)m * d + c]));
+    }
+}
+
+}  // namespace
+
+// qc: bf16 [nseq, H*64] (CLS queries); kv: bf16 [nseq*L, 2*H*64] = K | V; ctx: bf16 [nseq, H*64]; probs: fp32 [nseq, H, L]
+extern "C" int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L,
+                                       int H, float dropout_p, unsigned long long seed, void* stream) {
+    CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0 && probs != nullptr, "attention_cls_fwd: need 0 < L <= 256 and a probs buffer");
+    hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
+                       (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u,
+                       1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+// dqc: bf16 [nseq, H*64]; dkv: bf16 [nseq*L, 2*H*64] (every row written)
+extern "C" int cldrd_attention_cls_bwd(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
+                                       int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream) {
+    CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_cls_bwd: need 0 < L <= 256");
+    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv, probs,
+                       (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f,
+                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, void* stream) {
+    CLDRD_CHECK(M > 0 && d > 0 && stride_rows > 0, "add_rows_strided: bad arguments");
+    hipLaunchKernelGGL(add_rows_strided_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst, (const bf16_t*)src, M, d, stride_rows);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}

@@ -208,6 +208,8 @@ class HipEncoder(nn.Module):
             _attach(self, name, nn.Parameter(self.flat_p[off:off + _numel(shape)].view(shape)))
         self.reset_parameters(seed)
         self.step_seed = 0
+        # last layer: compute only the CLS row after the K/V projection (CLDRD_CLS_ONLY=0 restores the full layer)
+        self.cls_only_last = os.environ.get("CLDRD_CLS_ONLY", "1") != "0"
 
     # ------------------------------------------------------------------ parameters
     def named_flat(self):
@@ -404,6 +406,9 @@ class HipEncoder(nn.Module):
         for i in range(cfg.n_layers):
             W = self._layer_weights(i)
             s_l = seed + 7919 * (i + 1)
+            if i == cfg.n_layers - 1 and self.cls_only_last:
+                self._last_layer_cls_fwd(x, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls)
+                break
             qkv = self._buf(T, 3 * d, dev)
             ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
             ctx = self._buf(T, d, dev)
@@ -431,6 +436,82 @@ class HipEncoder(nn.Module):
             cls.copy_(x.view(ops.pad_rows(T), d)[:T].view(M, L, d)[:, 0].float())
         return (cls, tape) if save else cls
 
+    # ------------------------------------------------------------------ last layer, CLS row only
+    def _last_layer_cls_fwd(self, x, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls):
+        """Only ``last_hidden_state[:, 0, :]`` is consumed (reference models/nway_dual_encoder.py:52,56,64), so the last
+        layer projects K and V for every token but Q, attention, out-proj, FFN and both LayerNorms for token 0 only:
+        identical CLS output, ~1/6 of the layer's FLOPs."""
+        cfg = self.cfg
+        d, f, H = cfg.dim, cfg.hidden_dim, cfg.n_heads
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        kv = self._buf(T, 2 * d, dev)
+        ops.gemm_nt(x, W["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
+        xc = self._buf(M, d, dev)
+        xc[:M].copy_(x[:T].view(M, L, d)[:, 0, :])                 # gather the CLS rows (a copy, no arithmetic)
+        qc = self._buf(M, d, dev)
+        ops.gemm_nt(xc, W["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
+        ctxc = self._buf(M, d, dev)
+        probs = torch.empty(M, H, L, **f32)
+        ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1)
+        s1 = self._buf(M, d, dev)
+        ops.gemm_nt(ctxc, W["Wo"], s1, M, bias=W["bo"], residual=xc, dropout_p=p_out, seed=s_l + 2)
+        x1 = self._buf(M, d, dev)
+        mean1, rstd1 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
+        ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, M, cfg.eps)
+        hbuf = self._buf(M, f, dev)
+        pre = self._buf(M, f, dev) if save else None
+        ops.gemm_nt(x1, W["W1"], hbuf, M, bias=W["bf1"], preact=pre, act=1)
+        s2 = self._buf(M, d, dev)
+        ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1, dropout_p=p_h, seed=s_l + 3)
+        xo = self._buf(M, d, dev)
+        mean2, rstd2 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
+        ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, M, cfg.eps, cls, 1)
+        if save:
+            tape.layers.append(dict(cls_only=True, x_in=x, kv=kv, xc=xc, qc=qc, ctx=ctxc, probs=probs, s1=s1, mean1=mean1,
+                                    rstd1=rstd1, x1=x1, pre=pre, h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h,
+                                    p_a=p_a, p_out=p_out))
+
+    def _last_layer_cls_bwd(self, i, a, tape, dcls, partial, ws):
+        """Backward of :meth:`_last_layer_cls_fwd`; returns dL/d(layer input) as a full [T, d] bf16 tensor."""
+        cfg = self.cfg
+        d, f, H = cfg.dim, cfg.hidden_dim, cfg.n_heads
+        M, L, T = tape.M, tape.L, tape.T
+        dev = self.flat_p.device
+        W, G = self._layer_weights(i), self._layer_grads(i)
+        s_l, p_h, p_a, p_out = a["seed"], a["p_h"], a["p_a"], a["p_out"]
+        gc = self._buf(M, d, dev)
+        ops.scatter_cls_grad(dcls.contiguous(), gc, M, 1, M)
+        ds2 = self._buf(M, d, dev)
+        ds2m = self._buf(M, d, dev) if p_h > 0 else None
+        ops.layernorm_bwd(gc, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], partial, M, p_h, s_l + 3)
+        dF = ds2m if ds2m is not None else ds2
+        ops.wgrad(dF, a["h"], G["W2"], M, ws, accumulate=True)
+        dpre = self._buf(M, f, dev)
+        ops.gemm_nt(dF, self.ht(i, "f2"), dpre, M, gelu_pre=a["pre"])
+        ops.wgrad(dpre, a["x1"], G["W1"], M, ws, accumulate=True, dbias=G["bf1"])
+        dx1 = self._buf(M, d, dev)
+        ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, M, residual=ds2)
+        ds1 = self._buf(M, d, dev)
+        ds1m = self._buf(M, d, dev) if p_out > 0 else None
+        ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], partial, M, p_out, s_l + 2)
+        dA = ds1m if ds1m is not None else ds1
+        ops.wgrad(dA, a["ctx"], G["Wo"], M, ws, accumulate=True)
+        dctx = self._buf(M, d, dev)
+        ops.gemm_nt(dA, self.ht(i, "o"), dctx, M)
+        dqc = self._buf(M, d, dev)
+        dkv = self._buf(T, 2 * d, dev)
+        ops.attention_cls_bwd(a["qc"], a["kv"], a["probs"], dctx, dqc, dkv, M, L, H, p_a, s_l + 1)
+        ops.wgrad(dqc, a["xc"], G["Wqkv"][:d], M, ws, accumulate=True, dbias=G["bqkv"][:d])
+        ops.wgrad(dkv, a["x_in"], G["Wqkv"][d:], T, ws, accumulate=True, dbias=G["bqkv"][d:])
+        wt = self.ht(i, "qkv")                                      # [d, 3d] = Wqkv^T
+        g = self._buf(T, d, dev)
+        ops.gemm_nt(dkv, wt[:, d:], g, T)                           # through K and V: every token
+        gq = self._buf(M, d, dev)
+        ops.gemm_nt(dqc, wt[:, :d], gq, M, residual=ds1)            # through Q and the residual: CLS rows only
+        ops.add_rows_strided(g, gq, M, L)
+        return g
+
     # ------------------------------------------------------------------ backward
     def backward_from_cls(self, tape: _Tape, dcls: torch.Tensor, after_layer=None):
         """Accumulate parameter gradients of this tower into ``flat_g`` given dL/dCLS (fp32 [M, d]).
@@ -444,12 +525,20 @@ class HipEncoder(nn.Module):
         dev = self.flat_p.device
         f32 = dict(dtype=torch.float32, device=dev)
         partial = torch.empty(max(ops.ln_partial_elems(T, d), ((T + 127) // 128) * max(3 * d, f)), **f32)
-        ws = torch.empty(max(ops.wgrad_workspace_elems(T, 3 * d, d), ops.wgrad_workspace_elems(T, d, d),
-                             ops.wgrad_workspace_elems(T, f, d), ops.wgrad_workspace_elems(T, d, f)), **f32)
-        g = self._buf(T, d, dev)
-        ops.scatter_cls_grad(dcls.contiguous(), g, M, L, T)
+        ws = torch.empty(max(ops.wgrad_workspace_elems(r, n1, n2) for r in (T, M)
+                             for n1, n2 in ((3 * d, d), (2 * d, d), (d, d), (f, d), (d, f))), **f32)
+        g = None
         for i in reversed(range(cfg.n_layers)):
             W, G, a = self._layer_weights(i), self._layer_grads(i), tape.layers[i]
+            if a.get("cls_only"):
+                g = self._last_layer_cls_bwd(i, a, tape, dcls, partial, ws)
+                tape.layers[i] = None
+                if after_layer is not None:
+                    after_layer(i)
+                continue
+            if g is None:
+                g = self._buf(T, d, dev)
+                ops.scatter_cls_grad(dcls.contiguous(), g, M, L, T)
             s_l, p_h, p_a, p_out = a["seed"], a["p_h"], a["p_a"], a["p_out"]
             # --- output LayerNorm + FFN ---
             ds2 = self._buf(T, d, dev)

@@ -109,6 +109,26 @@ def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, se
     return dqkv
 
 
+def attention_cls_fwd(qc, kv, mask, ctx, probs, nseq, L, H, dropout_p=0.0, seed=0):
+    _chk(qc, BF16, "qc", 2), _chk(kv, BF16, "kv", 2), _chk(ctx, BF16, "ctx", 2), _chk(probs, F32, "probs")
+    if kv.shape[1] != 2 * H * 64 or not kv.is_contiguous() or not qc.is_contiguous() or not ctx.is_contiguous():
+        raise ValueError("attention_cls: kv must be contiguous [T, 2*H*64]")
+    call("cldrd_attention_cls_fwd", _p(qc), _p(kv), _p(mask), _p(ctx), _p(probs), nseq, L, H, dropout_p, seed, _stream())
+
+
+def attention_cls_bwd(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p=0.0, seed=0):
+    for t, n in ((qc, "qc"), (kv, "kv"), (dctx, "dctx"), (dqc, "dqc"), (dkv, "dkv")):
+        _chk(t, BF16, n, 2)
+        if not t.is_contiguous():
+            raise ValueError(f"attention_cls_bwd: {n} must be contiguous")
+    call("cldrd_attention_cls_bwd", _p(qc), _p(kv), _p(probs), _p(dctx), _p(dqc), _p(dkv), nseq, L, H, dropout_p, seed, _stream())
+
+
+def add_rows_strided(dst, src, M, stride_rows):
+    _chk(dst, BF16, "dst", 2), _chk(src, BF16, "src", 2)
+    call("cldrd_add_rows_strided", _p(dst), _p(src), M, src.shape[1], stride_rows, _stream())
+
+
 def ln_partial_elems(T, d) -> int:
     return _lib.load().cldrd_ln_partial_blocks(T) * 3 * d
 

@@ -55,6 +55,16 @@ int cldrd_attention_fwd(const void* qkv, const long long* mask, void* ctx, float
 int cldrd_attention_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                         void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
 
+/* CLS-only attention of the LAST layer (the reference pools last_hidden_state[:, 0, :], models/nway_dual_encoder.py:52,56,64):
+ * qc: bf16 [nseq, H*64] = queries of token 0; kv: bf16 [nseq*L, 2*H*64] = K | V of every token; ctx/dctx/dqc: bf16 [nseq, H*64];
+ * probs: fp32 [nseq, H, L] (softmax row, saved for the backward); dkv: bf16 [nseq*L, 2*H*64] (every row written).
+ * cldrd_add_rows_strided: dst[m * stride_rows] += src[m] for bf16 rows of d elements (puts the CLS-row gradients back). */
+int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L,
+                            int H, float dropout_p, unsigned long long seed, void* stream);
+int cldrd_attention_cls_bwd(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
+                            int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
+int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, void* stream);
+
 /* ---- embeddings + LayerNorm (HF Embeddings.forward, sa_layer_norm / output_layer_norm) --------------------
  * d <= 1024, d % 4 == 0.  `partial` scratch: cldrd_ln_partial_blocks(T) * 3 * d floats. */
 int cldrd_ln_partial_blocks(int T);
