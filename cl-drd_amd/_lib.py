@@ -40,6 +40,7 @@ SIGNATURES = {
     "cldrd_cast_bf16": (ci, [vp, vp, csz, vp]),
     "cldrd_transpose_cast_batched": (ci, [vp, vp, vp, vp, ci, ci, vp]),
     "cldrd_topk_scan_filter": (ci, [vp, vp, ci, C.c_longlong, ci, vp, vp, vp, vp, ci, vp]),
+    "cldrd_topk_scan_filter_tiled": (ci, [vp, vp, ci, C.c_longlong, ci, vp, vp, vp, vp, ci, vp]),
     "cldrd_topk_kth_largest": (ci, [vp, ci, ci, ci, ci, vp, vp]),
     "cldrd_topk_rescore": (ci, [vp, vp, ci, vp, vp, vp, ci, ci, vp]),
     "cldrd_topk_sort": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),

@@ -119,6 +119,8 @@ int launch_nt(const GemmNtArgs& a, hipStream_t st) {
 
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a, int force_bn, hipStream_t st);   // gemm_nt_ring.hip
 int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st);                     // gemm_nt_ring.hip
+int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts, int* cand_rows,
+                           float* cand_scores, int cap, hipStream_t st);            // topk.hip
 
 extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
@@ -164,8 +166,8 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
 
 // Top-k scan over one index shard: scores = Q[nq,d] . P[rows,d]^T on bf16 MFMA; every (query, row) with score >= thr[query]
 // is appended to the query's candidate list (counts must be zeroed by the caller; counts[q] may exceed cap = overflow).
-extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
-                                      int* cand_rows, float* cand_scores, int cap, void* stream) {
+static int scan_filter_impl(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
+                            int* cand_rows, float* cand_scores, int cap, void* stream, bool tiled) {
     CLDRD_CHECK(nq > 0 && rows > 0 && rows < 2147483647LL && d % BK == 0 && cap > 0, "topk_scan_filter: bad arguments");
     CLDRD_CHECK(((uintptr_t)Q % 16 == 0) && ((uintptr_t)P % 16 == 0), "topk_scan_filter: operands must be 16-byte aligned");
     GemmNtArgs a;
@@ -174,6 +176,11 @@ extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long
     a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.preact = nullptr; a.gelu_pre = nullptr; a.act = 0; a.alpha = 1.0f;
     a.drop_thresh = 0; a.drop_scale = 1.0f; a.seed = 0; a.out_f32 = 0;
     a.thr = thr; a.counts = counts; a.cand_rows = cand_rows; a.cand_scores = cand_scores; a.cap = cap;
+    const char* env_scan = getenv("CLDRD_SCAN");          // "gemm" forces the tiled-GEMM scan (A/B experiments)
+    if (!tiled && !(env_scan && env_scan[0] == 'g')) {
+        const int rc = cldrd_topk_scan_stream(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, (hipStream_t)stream);
+        if (rc >= 0) return rc;
+    }
     const char* env_tile = getenv("CLDRD_GEMM_TILE");
     if (rows >= 4096 && nq <= 128 && !(env_tile && atoi(env_tile) == 128) && (double)rows * d * 2.0 < 4.0e9) {
         // large shard: index rows are the M dimension of the 256-row ring kernel, the (<= 128) queries its N tile
@@ -181,4 +188,15 @@ extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long
         return cldrd_gemm_nt_ring_scan(a, (hipStream_t)stream);
     }
     return launch_nt<EPI_FILTER>(a, (hipStream_t)stream);
+}
+
+extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
+                                      int* cand_rows, float* cand_scores, int cap, void* stream) {
+    return scan_filter_impl(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, stream, false);
+}
+
+// Same contract, always through the tiled kernels (hits go straight to the global lists: never sets counts[nq]).
+extern "C" int cldrd_topk_scan_filter_tiled(const void* Q, const void* P, int nq, long long rows, int d, const float* thr,
+                                            int* counts, int* cand_rows, float* cand_scores, int cap, void* stream) {
+    return scan_filter_impl(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, stream, true);
 }

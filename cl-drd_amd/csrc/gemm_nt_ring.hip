@@ -28,6 +28,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     constexpr int NT = BN / 64;              // 16-col MFMA tiles per wave
     constexpr int WN = BN / 4;               // wave tile width
     constexpr int BPW = BN / 64;             // 1-KiB B pieces per wave (8 rows x 128 B each): BN/8 pieces over 8 waves
+    constexpr int NSLOT = (3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2;     // BN = 128: two K tiles in flight
+    constexpr int G = 4 + BPW;               // LDS-DMA instructions per wave per K tile
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntn = (p.N + BN - 1) / BN;
@@ -90,10 +92,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
         mfma_row(1, bc);
         __builtin_amdgcn_sched_barrier(0);
         if (sync) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // K tile kt+1 must have landed; with a third slot K tile kt+2 (issued one tile ago) stays in flight
+            if (NSLOT == 3 && kt + 2 < nk_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 2 < nk_) stage(slot, kt + 2);
+            if (kt + NSLOT < nk_) stage(slot, kt + NSLOT);  // slot of K tile kt: its fragments are in registers everywhere
             __builtin_amdgcn_sched_barrier(0);
         }
         af[0] = *(const bf16x8*)(na);
@@ -119,23 +123,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     };
 
     stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NSLOT == 3 && nk_ > 1) {
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (nk_ > 1) stage(1, 1);
+    if (NSLOT == 3) { if (nk_ > 2) stage(2, 2); } else { if (nk_ > 1) stage(1, 1); }
 #pragma unroll
     for (int t = 0; t < NT; ++t) b0[t] = *(const bf16x8*)(smem + b_off[0] + t * 16 * 128);
 #pragma unroll
     for (int t = 0; t < 8; ++t) af[t] = *(const bf16x8*)(smem + a_off[0] + t * 16 * 128);
 
+    int cs = 0;                                                                 // slot of K tile kt
     for (int kt = 0; kt + 1 < nk_; ++kt) {
-        const char* cur = smem + (kt & 1) * SLOT;
-        const char* nxt = smem + ((kt + 1) & 1) * SLOT;
-        kstep(b0, b1, cur + a_off[1], cur + b_off[1], false, kt & 1, kt);       // k-step 0; prefetch k-step 1 of this slot
-        kstep(b1, b0, nxt + a_off[0], nxt + b_off[0], true, kt & 1, kt);        // k-step 1; prefetch k-step 0 of K tile kt+1
+        const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
+        const char* cur = smem + cs * SLOT;
+        const char* nxt = smem + ns * SLOT;
+        kstep(b0, b1, cur + a_off[1], cur + b_off[1], false, cs, kt);           // k-step 0; prefetch k-step 1 of this slot
+        kstep(b1, b0, nxt + a_off[0], nxt + b_off[0], true, cs, kt);            // k-step 1; prefetch k-step 0 of K tile kt+1
+        cs = ns;
     }
     {   // last K tile: nothing left to recycle
-        const char* cur = smem + ((nk_ - 1) & 1) * SLOT;
+        const char* cur = smem + cs * SLOT;
         kstep(b0, b1, cur + a_off[1], cur + b_off[1], false, 0, nk_);
         klast(b1);
     }
@@ -152,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
 
 template <int BN, int EPI>
 int launch_ring_epi(const GemmNtArgs& a, hipStream_t st) {
-    constexpr int lds = 2 * (A_BYTES + BN * BK * 2);
+    constexpr int lds = ((3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2) * (A_BYTES + BN * BK * 2);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

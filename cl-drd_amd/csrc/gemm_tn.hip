@@ -41,6 +41,8 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
     constexpr int A_BYTES = BK * T1 * 2, SLOT = A_BYTES + B_BYTES;
     constexpr int LPR_A = T1 / 8, RA = 64 / LPR_A;      // lanes per A row, A rows per 1-KiB piece
     constexpr int BPW = 16 / NW;                        // B pieces per wave
+    constexpr int NSLOT = 3;                            // K tiles kt+1 and kt+2 stay in flight while kt is consumed
+    constexpr int G = 4 + BPW;                          // LDS-DMA instructions per wave per K tile
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nt2 = N2 / T2;
@@ -117,10 +119,12 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
         mfma_row(0, bc);
         __builtin_amdgcn_sched_barrier(0);
         if (sync) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // K tile kt+1 must have landed; K tile kt+2 (issued one tile ago) may stay in flight
+            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 2 < nk) stage(slot, kt + 2);
+            if (kt + 3 < nk) stage(slot, kt + 3);          // slot kt % 3: every wave holds tile kt's fragments in registers
             __builtin_amdgcn_sched_barrier(0);
         }
         af[0] = tr_pair(a_addr(nbase, nks, 0, 0), a_addr(nbase, nks, 1, 0));
@@ -144,22 +148,27 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
 
     if (nk > 0) {
         stage(0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (nk > 1) stage(1, 1);
+        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (nk > 1) stage(1, 1);
+        if (nk > 2) stage(2, 2);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             b0[t] = tr_pair(b_addr(smem, 0, 0, t), b_addr(smem, 0, 1, t));
             af[t] = tr_pair(a_addr(smem, 0, 0, t), a_addr(smem, 0, 1, t));
         }
+        int cs = 0;                                        // slot of K tile kt
         for (int kt = 0; kt + 1 < nk; ++kt) {
-            const char* cur = smem + (kt & 1) * SLOT;
-            const char* nxt = smem + ((kt + 1) & 1) * SLOT;
-            kstep(b0, b1, cur, 1, false, kt & 1, kt);
-            kstep(b1, b0, nxt, 0, true, kt & 1, kt);
+            const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
+            const char* cur = smem + cs * SLOT;
+            const char* nxt = smem + ns * SLOT;
+            kstep(b0, b1, cur, 1, false, cs, kt);
+            kstep(b1, b0, nxt, 0, true, cs, kt);
+            cs = ns;
         }
-        const char* cur = smem + ((nk - 1) & 1) * SLOT;
+        const char* cur = smem + cs * SLOT;
         kstep(b0, b1, cur, 1, false, 0, nk);
 #pragma unroll
         for (int t1 = 0; t1 < 4; ++t1) mfma_row(t1, b1);
@@ -215,7 +224,7 @@ extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
 template <int WM, bool BIAS>
 static int launch_tn(const void* A, const void* B, float* ws, int M, int N1, int N2, int lda, int ldb, int splits, int kps,
                      size_t slab_stride, hipStream_t st) {
-    constexpr int lds = 2 * (BK * 64 * WM * 2 + B_BYTES);
+    constexpr int lds = 3 * (BK * 64 * WM * 2 + B_BYTES);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<WM, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -12,6 +12,7 @@
 // Kernels here: per-query k-th largest of the sample scores (threshold estimate, radix select), fp32 re-score,
 // bitonic sort + cut, max row norm.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -144,6 +145,192 @@ __global__ __launch_bounds__(256) void gather_cast_rows_kernel(const float* __re
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Streaming scan: the HBM-bound part of the search.  The 128 queries of a batch stay in REGISTERS (wave w keeps the
+// MFMA B fragments of queries 16w..16w+15 for the whole K range: KS*4 VGPRs), the index streams through a 3-slot LDS
+// ring in tiles of 32 whole rows = 32*d*2 bytes of CONTIGUOUS memory per tile (full-page DRAM bursts; the tiled GEMM
+// fetched 128-B slivers of 256 different rows per step and topped out at ~2.3 TB/s).  Persistent: one workgroup per
+// CU walks tiles b, b+grid, ...; two tiles (96 KiB at d = 768) stay in flight per CU behind a counted vmcnt.
+// Hits (score >= thr[query], ~0.2 % of the scores) go to a small LDS list and are flushed to the per-query candidate
+// lists with global atomics only when the list fills up or at the end, so the DMA queue is never drained in the loop.
+template <int KS, int ablate>     // d = 32 * KS; ablate != 0: timing experiments only (tools/scan_bench.py)
+__global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q, int nq,
+                                                              long long rows, const float* __restrict__ thr,
+                                                              int* __restrict__ counts, int* __restrict__ cand_rows,
+                                                              float* __restrict__ cand_scores, int cap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int R = 32, ROWB = KS * 64, TILEB = R * ROWB, PIECES = TILEB / 1024, NW = 8, PPW = PIECES / NW, NSLOT = 3;
+    constexpr int LCAP = (160 * 1024 - NSLOT * TILEB - 16) / 12 < 4096 ? (160 * 1024 - NSLOT * TILEB - 16) / 12 : 4096;   // LDS hit list
+    int* lcount = (int*)(smem + NSLOT * TILEB);
+    int* lq = lcount + 4;
+    int* lrow = lq + LCAP;
+    float* lscore = (float*)(lrow + LCAP);
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long ntiles = (rows + R - 1) / R;
+
+    // ---- this wave's 16 queries as B fragments for every k-step (registers, loaded once): 4*KS VGPRs
+    const int qn = wid * 16 + (lane & 15);
+    bf16x8 bq[KS];
+    {
+        const bf16_t* qp = Q + (size_t)min(qn, nq - 1) * (KS * 32) + 8 * (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bq[ks] = *(const bf16x8*)(qp + ks * 32);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bq[ks]));      // wait for the loads here, not inside the tile loop
+    }
+    const float thr_lane = qn < nq ? thr[qn] : __builtin_inff();
+    const uint32_t lcount_off = (uint32_t)(uintptr_t)LDS_PTR(lcount), lq_off = (uint32_t)(uintptr_t)LDS_PTR(lq);
+    static_assert(8 * LCAP < 65536, "ds_write offset field");
+    if (threadIdx.x == 0) *lcount = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing but LDS-DMA is in flight from here on
+
+    // ---- DMA addressing: piece p = wid*PPW + j covers LDS bytes [1024 p, 1024 p + 1024) of the tile image
+    uint32_t soff[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int byte = (wid * PPW + j) * 1024 + lane * 16;
+        const int row = byte / ROWB, cl = (byte % ROWB) / 16;
+        soff[j] = (uint32_t)(row * ROWB + ((cl ^ (row & 15)) * 16));      // XOR on the source side, LDS stays linear
+    }
+    const long long last = rows * ROWB - 16;                              // clamp the tail tile inside the allocation
+    auto stage = [&](int slot, long long tile) {
+        char* dst = smem + slot * TILEB + wid * PPW * 1024;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            long long off = tile * (long long)TILEB + soff[j];
+            off = off > last ? last : off;
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR((const char*)P + off), LDS_PTR(dst + j * 1024), 16, 0, 0);
+        }
+    };
+
+    uint32_t rd_off[4];
+#pragma unroll
+    for (int kr = 0; kr < 4; ++kr)
+        rd_off[kr] = (lane & 15) * ROWB + ((((kr << 2) ^ (lane & 12)) | ((lane >> 4) ^ (lane & 3))) * 16);
+    const long long t0 = blockIdx.x, step = gridDim.x;
+    if (t0 < ntiles) stage(0, t0);
+    if (t0 + step < ntiles) stage(1, t0 + step);
+    int cs = 0;
+    for (long long t = t0; t < ntiles; t += step) {
+        // tile t must have landed; tile t+step may stay in flight.  NO global memory operation other than the DMA may appear
+        // inside this loop: hipcc would put s_waitcnt vmcnt(0) next to it and drain the two tiles in flight (measured: ~1 us per hit)
+        if (t + step < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                       // ... for every wave; slot of tile t-step is free
+        asm volatile("" ::: "memory");
+        const int fs = cs == 0 ? NSLOT - 1 : cs - 1;                        // slot of tile t-step
+        const char* sb = smem + cs * TILEB;
+        cs = cs == NSLOT - 1 ? 0 : cs + 1;
+        if (ablate == 1) {                                                  // timing experiments only: DMA stream alone
+            if (t + 2 * step < ntiles) stage(fs, t + 2 * step);
+            continue;
+        }
+        // Two half-row chunks of A fragments are kept in flight ahead of the MFMAs that consume them: with 2 waves per SIMD
+        // nothing else hides the LDS latency (measured: reads alone and MFMAs alone both keep up with the DMA stream,
+        // read -> wait -> MFMA in one chain does not).  sched_barrier pins the order, hipcc still counts the lgkmcnt waits.
+        constexpr int CH = KS % 3 == 0 ? KS / 3 : KS / 2, NCM = KS / CH, NC = 2 * NCM;      // chunk = CH k-steps of one 16-row half
+        bf16x8 ab[2][CH];
+        // chunk position of k-step ks in row r: ((4 ks + (lane >> 4)) ^ (r & 15)) = 16 (ks >> 2) + (((ks & 3) << 2) ^ (r & 12) | (lane >> 4) ^ (r & 3)):
+        // four lane-dependent bases, everything else is an immediate offset of the ds_read
+        const char* pk[4];
+#pragma unroll
+        for (int kr = 0; kr < 4; ++kr) pk[kr] = sb + rd_off[kr];
+        auto fetch = [&](bf16x8(&a)[CH], int c) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int ks = (c % NCM) * CH + i;
+                a[i] = *(const bf16x8*)(pk[ks & 3] + (c / NCM) * 16 * ROWB + (ks >> 2) * 256);
+            }
+        };
+        auto emit = [&](f32x4 acc, int mt) {        // acc[j] = <P[row], Q[qn]> with row = 32 t + 16 mt + 4 (lane >> 4) + j
+            if (ablate == 2) { asm volatile("" ::"v"(acc)); return; }
+            const int row0 = (int)(t * R) + mt * 16 + 4 * (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (acc[j] >= thr_lane && row0 + j < (int)rows) {
+                    // LDS list append, hand-issued: through atomicAdd / plain stores hipcc orders these LDS accesses after
+                    // the LDS-DMA in flight (s_waitcnt vmcnt(0) per hit), which stalls the stream
+                    uint32_t e;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(e) : "v"(lcount_off), "v"(1u) : "memory");
+                    if (e < (uint32_t)LCAP) {
+                        const uint32_t a = lq_off + 4u * e;
+                        asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"
+                                     ::"v"(a), "v"(qn), "v"(row0 + j), "v"(acc[j]), "n"(4 * LCAP), "n"(8 * LCAP) : "memory");
+                    }
+                }
+            }
+        };
+        fetch(ab[0], 0);
+        fetch(ab[1], 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 2 * step < ntiles) stage(fs, t + 2 * step);                 // issued under the latency of the first fragment reads
+        f32x4 acc;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (c % NCM == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[c & 1][i], bq[(c % NCM) * CH + i], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 < NC) fetch(ab[c & 1], c + 2);
+            if (c % NCM == NCM - 1) emit(acc, c / NCM);
+        }
+    }
+    // ---- the only global writes of the kernel: move the hit list to the per-query candidate lists.  One global atomic
+    // per (block, query) reserves the block's range in that query's list (per-hit atomics on 128 addresses serialise in L2).
+    __syncthreads();
+    int* qcnt = (int*)smem;                    // the tile ring is dead: [0,128) per-query hit counts, [128,256) global bases
+    if (threadIdx.x < 256) qcnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int nhits = *lcount;
+    const int n = min(nhits, LCAP);
+    for (int e = threadIdx.x; e < n; e += blockDim.x) lq[e] |= atomicAdd(qcnt + lq[e], 1) << 8;      // rank inside the block
+    __syncthreads();
+    if (threadIdx.x < 128 && qcnt[threadIdx.x] > 0) qcnt[128 + threadIdx.x] = atomicAdd(counts + threadIdx.x, qcnt[threadIdx.x]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const int q = lq[e] & 255;
+        const int pos = qcnt[128 + q] + (lq[e] >> 8);
+        if (pos < cap) { cand_rows[(size_t)q * cap + pos] = lrow[e]; cand_scores[(size_t)q * cap + pos] = lscore[e]; }
+    }
+    if (threadIdx.x == 0 && nhits > LCAP) atomicAdd(counts + nq, nhits - LCAP);      // counts[nq] = hits dropped (host rescans with the tiled kernel)
+}
+
+template <int KS, int ABL>
+int launch_scan_stream_abl(const void* Q, const void* P, int nq, long long rows, const float* thr, int* counts, int* cand_rows,
+                           float* cand_scores, int cap, hipStream_t st) {
+    constexpr int tb = 3 * 32 * KS * 64;
+    constexpr int lcap = (160 * 1024 - tb - 16) / 12 < 4096 ? (160 * 1024 - tb - 16) / 12 : 4096;
+    constexpr int lds = tb + 16 + lcap * 12;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)scan_stream_kernel<KS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const long long ntiles = (rows + 31) / 32;
+    const int grid = (int)(ntiles < 256 ? ntiles : 256);
+    hipLaunchKernelGGL((scan_stream_kernel<KS, ABL>), dim3(grid), dim3(512), lds, st, (const bf16_t*)P, (const bf16_t*)Q, nq, rows, thr,
+                       counts, cand_rows, cand_scores, cap);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KS>
+int launch_scan_stream(const void* Q, const void* P, int nq, long long rows, const float* thr, int* counts, int* cand_rows,
+                       float* cand_scores, int cap, hipStream_t st) {
+    if (KS == 24) {                                    // ablations exist for the d = 768 instance only
+        const char* ab = getenv("CLDRD_SCAN_ABLATE");
+        switch (ab ? atoi(ab) : 0) {
+            case 1: return launch_scan_stream_abl<24, 1>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+            case 2: return launch_scan_stream_abl<24, 2>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+            default: break;
+        }
+    }
+    return launch_scan_stream_abl<KS, 0>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+}
+
 }  // namespace
 
 extern "C" int cldrd_topk_kth_largest(const float* scores, int ld, int nq, int S, int kth, float* thr, void* stream) {
@@ -192,4 +379,16 @@ extern "C" int cldrd_gather_cast_rows(const float* src, void* dst, size_t n_out,
     hipLaunchKernelGGL(gather_cast_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n_out, stride, d);
     CLDRD_LAUNCH_CHECK();
     return 0;
+}
+
+// Streaming form of cldrd_topk_scan_filter for d in {128, 256, 768} and nq <= 128 (returns -1 when it does not apply).
+int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts, int* cand_rows,
+                           float* cand_scores, int cap, hipStream_t st) {
+    if (nq > 128 || rows < 64 || rows >= 2147483647LL / 32) return -1;
+    switch (d) {
+        case 128: return launch_scan_stream<4>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+        case 256: return launch_scan_stream<8>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+        case 768: return launch_scan_stream<24>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+        default: return -1;
+    }
 }

@@ -236,13 +236,13 @@ def transpose_cast_batched(src, dst, desc, tile_prefix, ndesc, total_tiles):
 
 
 # ---------------------------------------------------------------------------------------------------- top-k search
-def topk_scan_filter(Qb, Pb, thr, counts, cand_rows, cand_scores):
+def topk_scan_filter(Qb, Pb, thr, counts, cand_rows, cand_scores, tiled=False):
     _chk(Qb, BF16, "Qb", 2), _chk(Pb, BF16, "Pb", 2), _chk(thr, F32, "thr", 1)
     _chk(counts, torch.int32, "counts", 1), _chk(cand_rows, torch.int32, "cand_rows", 2), _chk(cand_scores, F32, "cand_scores", 2)
     nq, d = Qb.shape
-    if Pb.shape[1] != d or not Qb.is_contiguous() or not Pb.is_contiguous():
-        raise ValueError("topk_scan_filter: shape mismatch")
-    call("cldrd_topk_scan_filter", _p(Qb), _p(Pb), nq, Pb.shape[0], d, _p(thr), _p(counts), _p(cand_rows), _p(cand_scores),
+    if Pb.shape[1] != d or not Qb.is_contiguous() or not Pb.is_contiguous() or counts.numel() < nq + 1:
+        raise ValueError("topk_scan_filter: shape mismatch (counts needs nq + 1 entries)")
+    call("cldrd_topk_scan_filter_tiled" if tiled else "cldrd_topk_scan_filter", _p(Qb), _p(Pb), nq, Pb.shape[0], d, _p(thr), _p(counts), _p(cand_rows), _p(cand_scores),
          cand_rows.shape[1], _stream())
 
 

@@ -196,7 +196,7 @@ class FlatIPIndex:
         thr_dev = torch.empty(nq, dtype=torch.float32, device=dev)
         ops.topk_kth_largest(samp, S, kth, thr_dev)
         thr = thr_dev.cpu().numpy().astype(np.float64) - eps
-        counts = torch.empty(nq, dtype=torch.int32, device=dev)
+        counts = torch.empty(nq + 1, dtype=torch.int32, device=dev)      # [nq]: hits the streaming scan had to drop
         cand_rows = torch.empty(nq, CAND_CAP, dtype=torch.int32, device=dev)
         cand_scores = torch.empty(nq, CAND_CAP, dtype=torch.float32, device=dev)
         D = torch.empty(nq, kk, dtype=torch.float32, device=dev)
@@ -219,6 +219,15 @@ class FlatIPIndex:
             stats["scans"] += 1
             stats["rescans"] += attempt > 0
             c = counts.cpu().numpy()
+            if c[nq] != 0:        # the streaming kernel's on-chip hit list overflowed: redo this scan with the tiled kernel
+                counts.zero_()
+                ops.topk_scan_filter(qb, self._pbf, thr_dev, counts, cand_rows, cand_scores, tiled=True)
+                ops.topk_rescore(q32, self._p32, counts, cand_rows, cand_scores)
+                ops.topk_sort(counts, cand_rows, cand_scores, kk, D, I)
+                stats["scans"] += 1
+                stats["tiled_rescans"] = stats.get("tiled_rescans", 0) + 1
+                c = counts.cpu().numpy()
+            c = c[:nq]
             Dh, Ih = D.cpu().numpy(), I.cpu().numpy().astype(np.int64)
             stats["candidates"] += int(np.minimum(c, CAND_CAP)[todo].sum())
             # 5. proof of exactness per query

@@ -114,12 +114,16 @@ int cldrd_transpose_cast_batched(const float* src, void* dst, const long long* d
                                  int total_tiles, void* stream);
 
 /* ---- exact inner-product top-k over one index shard (retriever/retrieval_utils.py:131-153 -> faiss IndexFlatIP.search) ---
- * scan:    bf16 MFMA GEMM Q[nq,d] . P[rows,d]^T; (query, row) pairs with score >= thr[query] are appended to the query's
- *          candidate list (cand_rows / cand_scores: [nq, cap]; counts[nq] zeroed by the caller, may exceed cap = overflow);
+ * scan:    bf16 MFMA scores Q[nq,d] . P[rows,d]^T; (query, row) pairs with score >= thr[query] are appended to the query's
+ *          candidate list (cand_rows / cand_scores: [nq, cap]).  counts has nq + 1 ints zeroed by the caller:
+ *          counts[q] may exceed cap (= overflow of that list), counts[nq] != 0 means the streaming kernel dropped hits
+ *          (its on-chip list was full): rescan with cldrd_topk_scan_filter_tiled, which has no such list;
  * kth:     thr[q] = kth largest of scores[q][0..S) (threshold estimate from the sample scores);
  * rescore: cand_scores <- exact fp32 <q, P32[row]>;
  * sort:    per query (score desc, row asc), first k -> D[nq,k], I[nq,k] (row index, -1 = missing). */
 int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
+                           int* cand_rows, float* cand_scores, int cap, void* stream);
+int cldrd_topk_scan_filter_tiled(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
                            int* cand_rows, float* cand_scores, int cap, void* stream);
 int cldrd_topk_kth_largest(const float* scores, int ld, int nq, int S, int kth, float* thr, void* stream);
 int cldrd_topk_rescore(const float* q, const float* P, int d, const int* counts, const int* cand_rows, float* cand_scores,

@@ -141,3 +141,52 @@ def test_encode_and_cli_end_to_end(tmp_path):
     ranks = [int(l.split("\t")[2]) for l in lines[:7]]
     scores = [float(l.split("\t")[3]) for l in lines[:7]]
     assert ranks == list(range(1, 8)) and scores == sorted(scores, reverse=True)
+
+
+@pytest.mark.parametrize("nq,rows,d", [(128, 40000, 768), (37, 5003, 768), (16, 9000, 128), (128, 70001, 256)])
+def test_scan_stream_and_tiled_report_the_same_candidates(nq, rows, d):
+    """The streaming scan (hit list on chip) and the tiled scan must report the same (query, row) sets with the same bf16
+    scores; only the order inside a query's list is unspecified."""
+    Q = torch.from_numpy(syn.normal(21, nq * d).reshape(nq, d).astype(np.float32)).to(DEV).bfloat16()
+    P = torch.from_numpy(syn.normal(22, rows * d).reshape(rows, d).astype(np.float32)).to(DEV).bfloat16()
+    S = Q.float() @ P.float().T
+    thr = torch.quantile(S[:, :4096], 1.0 - 40.0 / 4096, dim=1).contiguous()
+    got = []
+    for tiled in (False, True):
+        counts = torch.zeros(nq + 1, dtype=torch.int32, device=DEV)
+        cr = torch.full((nq, 2048), -1, dtype=torch.int32, device=DEV)
+        cs = torch.zeros(nq, 2048, device=DEV)
+        ops.topk_scan_filter(Q, P, thr, counts, cr, cs, tiled=tiled)
+        c = counts.cpu().numpy()
+        assert c[nq] == 0 and (c[:nq] <= 2048).all()
+        crh, csh = cr.cpu().numpy(), cs.cpu().numpy()
+        got.append([dict(zip(crh[q, :c[q]].tolist(), csh[q, :c[q]].tolist())) for q in range(nq)])
+    Sh, th = S.cpu().numpy(), thr.cpu().numpy()
+    for q in range(nq):
+        assert got[0][q].keys() == got[1][q].keys()
+        rows_q = np.fromiter(got[0][q].keys(), dtype=np.int64)
+        assert len(rows_q) == len(set(rows_q.tolist())) and (rows_q >= 0).all() and (rows_q < rows).all()
+        # every clear hit is present, nothing clearly below the threshold is (fp32 accumulation order differs from torch's)
+        tol = 1e-3 * (1.0 + abs(th[q]))
+        assert set(np.where(Sh[q] >= th[q] + tol)[0].tolist()) <= set(rows_q.tolist())
+        assert (Sh[q, rows_q] >= th[q] - tol).all()
+        a = np.array([got[0][q][r] for r in rows_q]); b = np.array([got[1][q][r] for r in rows_q])
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-5) and np.allclose(a, Sh[q, rows_q], rtol=1e-4, atol=1e-3)
+
+
+def test_scan_stream_marks_dropped_hits_and_search_recovers():
+    """A threshold far too low overflows the streaming kernel's on-chip list: counts[nq] must say so (never silent)."""
+    nq, rows, d = 128, 30000, 768
+    Q = torch.from_numpy(syn.normal(23, nq * d).reshape(nq, d).astype(np.float32)).to(DEV).bfloat16()
+    P = torch.from_numpy(syn.normal(24, rows * d).reshape(rows, d).astype(np.float32)).to(DEV).bfloat16()
+    thr = torch.full((nq,), -1e30, device=DEV)
+    counts = torch.zeros(nq + 1, dtype=torch.int32, device=DEV)
+    cr = torch.empty(nq, 64, dtype=torch.int32, device=DEV)
+    cs = torch.empty(nq, 64, device=DEV)
+    ops.topk_scan_filter(Q, P, thr, counts, cr, cs)
+    c = counts.cpu().numpy()
+    assert c[nq] > 0 and int(c[:nq].sum()) + int(c[nq]) == nq * rows
+    counts.zero_()
+    ops.topk_scan_filter(Q, P, thr, counts, cr, cs, tiled=True)
+    c = counts.cpu().numpy()
+    assert c[nq] == 0 and (c[:nq] == rows).all()
