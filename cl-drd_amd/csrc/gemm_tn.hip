@@ -16,6 +16,8 @@
 //
 // Contract: A and B must have ceil(M/64)*64 rows allocated and rows >= M must be zero (the host allocates
 // activation / gradient buffers that way and no kernel writes past row M).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -26,11 +28,17 @@ constexpr int B_BYTES = BK * T2 * 2;   // 16 KiB
 
 __device__ __forceinline__ int swz(int m) { return 2 * ((m & 3) | (((m >> 3) & 1) << 2)); }
 
-__device__ __forceinline__ bf16x8 tr_pair(const char* lo_p, const char* hi_p) {
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)lo_p);
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)hi_p);
-    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+// One MFMA operand = two transposing reads (token rows m and m + 4: same swizzle, fixed byte distance HI).  They are issued
+// by hand: hipcc models the ds_read_tr builtin as an LDS access that may alias the LDS-DMA in flight and puts
+// s_waitcnt vmcnt(0) in front of it, which drains the two K tiles being prefetched on every k-step (the kernel then runs at
+// DMA latency, not at MFMA rate).  The price is that the lgkmcnt waits are ours too, see kstep().
+struct Frag { bf16x4 lo, hi; };
+template <int OFF, int HI>
+__device__ __forceinline__ void tr_issue(Frag& f, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr), "n"(OFF), "n"(OFF + HI) : "memory");
 }
+__device__ __forceinline__ bf16x8 frag8(const Frag& f) { return (bf16x8){f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]}; }
 
 template <int WM, bool BIAS>
 __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
@@ -82,18 +90,17 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
     };
 
     // ---- transposed-read addressing: 16-lane group g reads token rows 8g+q (+4); lane (4q+pp) supplies cols 4pp..4pp+3.
-    // offsets for k-step ks, read r (0: rows 8g+q, 1: +4), column tile 0; column tile t adds 2 slots BEFORE the swizzle.
+    // Token row m = 32 ks + 8 g + 4 r + q: swz(m) depends on q and g only, so one LDS offset per column tile t covers every
+    // k-step (ks: + 32 rows) and both reads (r: + 4 rows) through the instruction's immediate offset.
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-    auto a_addr = [&](const char* slot_base, int ks, int r, int t) {
-        const int m = 32 * ks + 8 * g + 4 * r + q;
-        const int col = wm * 64 + t * 16 + 4 * pp;
-        return slot_base + m * (T1 * 2) + (((col >> 3) ^ swz(m)) * 16) + (col & 7) * 2;
-    };
-    auto b_addr = [&](const char* slot_base, int ks, int r, int t) {
-        const int m = 32 * ks + 8 * g + 4 * r + q;
-        const int col = wn * 64 + t * 16 + 4 * pp;
-        return slot_base + A_BYTES + m * 256 + (((col >> 3) ^ swz(m)) * 16) + (col & 7) * 2;
-    };
+    const int m0 = 8 * g + q;
+    uint32_t ra[4], rb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ca = wm * 64 + t * 16 + 4 * pp, cb = wn * 64 + t * 16 + 4 * pp;
+        ra[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + m0 * (T1 * 2) + (((ca >> 3) ^ swz(m0)) * 16) + (ca & 7) * 2;
+        rb[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + A_BYTES + m0 * 256 + (((cb >> 3) ^ swz(m0)) * 16) + (cb & 7) * 2;
+    }
 
     f32x4 acc[4][4];
     f32x4 accb[4];
@@ -106,16 +113,27 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
     const short one = (short)0x3F80;     // bf16 1.0
     const bf16x8 ones = (bf16x8){one, one, one, one, one, one, one, one};
 
-    bf16x8 af[4], b0[4], b1[4];
-    auto mfma_row = [&](int t1, bf16x8 (&bc)[4]) {
+    Frag af[4], b0[4], b1[4];
+    auto mfma_row = [&](int t1, Frag (&bc)[4]) {
+        const bf16x8 a = frag8(af[t1]);
 #pragma unroll
         for (int t2 = 0; t2 < 4; ++t2)
             // swapped operands: D'[n2][n1] so the lane's 4 accumulators run along n2 (contiguous in dW rows)
-            acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[t2], af[t1], acc[t1][t2], 0, 0, 0);
-        if (do_bias) accb[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[t1], accb[t1], 0, 0, 0);
+            acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(bc[t2]), a, acc[t1][t2], 0, 0, 0);
+        if (do_bias) accb[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a, accb[t1], 0, 0, 0);
     };
-    // one 32-token k-step; next fragments come from (nbase, nks)
-    auto kstep = [&](bf16x8 (&bc)[4], bf16x8 (&bn)[4], const char* nbase, int nks, bool sync, int slot, int kt) {
+    // LDS returns in issue order.  Issue order per k-step: A0, B'0..B'3, A1, A2, A3 (2 reads each; B' = next k-step's B).
+    // Row t1 >= 1 needs A[t1] of the previous k-step: 14 younger reads may stay outstanding; row 0 needs A0 and B: 6.
+    auto wait_row0 = [&](Frag (&bc)[4]) {
+        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo), "+v"(bc[1].hi),
+                     "+v"(bc[2].lo), "+v"(bc[2].hi), "+v"(bc[3].lo), "+v"(bc[3].hi));
+    };
+    // one 32-token k-step over (af, bc); the next fragments come from slot offset noff, k-step NKS of that slot
+    auto kstep = [&](Frag (&bc)[4], Frag (&bn)[4], uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
+        constexpr int NKS = decltype(nks_tag)::value;
+        constexpr int OA = NKS * 32 * T1 * 2, OB = NKS * 32 * 256;
+        wait_row0(bc);
+        __builtin_amdgcn_sched_barrier(0);
         mfma_row(0, bc);
         __builtin_amdgcn_sched_barrier(0);
         if (sync) {
@@ -127,24 +145,22 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
             if (kt + 3 < nk) stage(slot, kt + 3);          // slot kt % 3: every wave holds tile kt's fragments in registers
             __builtin_amdgcn_sched_barrier(0);
         }
-        af[0] = tr_pair(a_addr(nbase, nks, 0, 0), a_addr(nbase, nks, 1, 0));
+        tr_issue<OA, 4 * T1 * 2>(af[0], ra[0] + noff);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) bn[t] = tr_pair(b_addr(nbase, nks, 0, t), b_addr(nbase, nks, 1, t));
+        for (int t = 0; t < 4; ++t) tr_issue<OB, 4 * 256>(bn[t], rb[t] + noff);
 #pragma unroll
         for (int t1 = 1; t1 < 4; ++t1) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(af[t1].lo), "+v"(af[t1].hi));
+            __builtin_amdgcn_sched_barrier(0);
             mfma_row(t1, bc);
-            af[t1] = tr_pair(a_addr(nbase, nks, 0, t1), a_addr(nbase, nks, 1, t1));
-        }
-        if (!do_bias) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
-#pragma unroll
-            for (int t1 = 1; t1 < 4; ++t1) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
+            tr_issue<OA, 4 * T1 * 2>(af[t1], ra[t1] + noff);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    using KS0 = std::integral_constant<int, 0>;
+    using KS1 = std::integral_constant<int, 1>;
 
     if (nk > 0) {
         stage(0, 0);
@@ -154,24 +170,27 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (nk > 2) stage(2, 2);
+        tr_issue<0, 4 * T1 * 2>(af[0], ra[0]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            b0[t] = tr_pair(b_addr(smem, 0, 0, t), b_addr(smem, 0, 1, t));
-            af[t] = tr_pair(a_addr(smem, 0, 0, t), a_addr(smem, 0, 1, t));
-        }
+        for (int t = 0; t < 4; ++t) tr_issue<0, 4 * 256>(b0[t], rb[t]);
+#pragma unroll
+        for (int t = 1; t < 4; ++t) tr_issue<0, 4 * T1 * 2>(af[t], ra[t]);
         int cs = 0;                                        // slot of K tile kt
         for (int kt = 0; kt + 1 < nk; ++kt) {
             const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
-            const char* cur = smem + cs * SLOT;
-            const char* nxt = smem + ns * SLOT;
-            kstep(b0, b1, cur, 1, false, cs, kt);
-            kstep(b1, b0, nxt, 0, true, cs, kt);
+            kstep(b0, b1, (uint32_t)(cs * SLOT), KS1{}, false, cs, kt);
+            kstep(b1, b0, (uint32_t)(ns * SLOT), KS0{}, true, cs, kt);
             cs = ns;
         }
-        const char* cur = smem + cs * SLOT;
-        kstep(b0, b1, cur, 1, false, 0, nk);
+        kstep(b0, b1, (uint32_t)(cs * SLOT), KS1{}, false, 0, nk);
+        wait_row0(b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(0, b1);
 #pragma unroll
-        for (int t1 = 0; t1 < 4; ++t1) mfma_row(t1, b1);
+        for (int t1 = 1; t1 < 4; ++t1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[t1].lo), "+v"(af[t1].hi));
+            mfma_row(t1, b1);
+        }
     }
 
     float* slab = slabs + (size_t)split * slab_stride;

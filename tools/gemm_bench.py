@@ -41,6 +41,24 @@ def main():
             line += f" tile{tile}: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF/s |"
         print(line, flush=True)
     os.environ.pop("CLDRD_GEMM_TILE", None)
+    # weight gradients: dW[N1,N2] = dY[T,N1]^T X[T,N2] (+ bias gradient), split-K slabs + reduction included
+    for name, N1, N2 in [("w_qkv", 2304, 768), ("w_out", 768, 768), ("w_ffn1", 3072, 768), ("w_ffn2", 768, 3072)]:
+        dY = (torch.randn(T, N1, device=dev) * 0.02).bfloat16()
+        X = torch.randn(T, N2, device=dev).bfloat16()
+        dW = torch.empty(N1, N2, device=dev)
+        db = torch.empty(N1, device=dev)
+        ws = torch.empty(ops.wgrad_workspace_elems(T, N1, N2), device=dev)
+        ts = []
+        for rnd in range(3):
+            for _ in range(2): ops.wgrad(dY, X, dW, T, ws, dbias=db)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): ops.wgrad(dY, X, dW, T, ws, dbias=db)
+            e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) / 10)
+        t = min(ts)
+        print(f"{name:11s} T={T} N1={N1} N2={N2}: {t*1e3:7.1f} us {2.0*T*N1*N2/t/1e9:7.1f} TF/s (slab reduction included)", flush=True)
 
 if __name__ == "__main__":
     main()
