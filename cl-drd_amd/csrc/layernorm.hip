@@ -232,20 +232,32 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
                                                             const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                             float* __restrict__ dword, float* __restrict__ dpos,
                                                             float* __restrict__ partial, int T, int L, int d, int vocab,
-                                                            uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+                                                            uint32_t drop_thresh, float drop_scale, uint64_t seed, int pos_uniform) {
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     const int lane = threadIdx.x & 63;
-    RowF dg, db, dt;
+    // pos_uniform: the row stride of a wave (4 * gridDim.x) is a multiple of L, so every row of this wave sits at the same
+    // position: its position-table gradient is summed in registers and leaves with ONE atomic per element (the per-row
+    // atomics of nseq sequences onto the same L x d addresses were the bulk of this kernel's time).
+    RowF dg, db, dt, dp;
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dg.v[it][j] = db.v[it][j] = dt.v[it][j] = 0.f;
+        for (int j = 0; j < 4; ++j) dg.v[it][j] = db.v[it][j] = dt.v[it][j] = dp.v[it][j] = 0.f;
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += gridDim.x * 4) {
         int64_t id = ids[row];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const int l = row % L;
         RowF g, xr, p;
         load_row_bf16(dy + (size_t)row * d, d, lane, g);
+        {   // a row whose incoming gradient is exactly zero (padded positions: nothing attends to them) contributes exactly
+            // zero to every sum below: skip it, and with it the atomics of all pad tokens onto the one [PAD] table row
+            float amax = 0.f;
+#pragma unroll
+            for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(g.v[it][j]));
+            if (wave_max(amax) == 0.f) continue;
+        }
         load_row_f32(word + (size_t)id * d, d, lane, xr);
         load_row_f32(pos + (size_t)l * d, d, lane, p);
 #pragma unroll
@@ -289,8 +301,20 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
                     const float v = rstd * (g.v[it][j] - s1 - xr.v[it][j] * s2);
                     dt.v[it][j] += v;
                     atomicAdd(dword + (size_t)id * d + c + j, v);
-                    atomicAdd(dpos + (size_t)l * d + c + j, v);
+                    if (pos_uniform) dp.v[it][j] += v;
+                    else atomicAdd(dpos + (size_t)l * d + c + j, v);
                 }
+            }
+        }
+    }
+    if (pos_uniform) {
+        const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) % L;
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) atomicAdd(dpos + (size_t)l * d + c + j, dp.v[it][j]);
             }
         }
     }
@@ -389,10 +413,15 @@ extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const fl
                                   float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,
                                   float dropout_p, unsigned long long seed, int accumulate, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_bwd: bad shape");
-    const int nb = ln_bwd_blocks(T);
+    int nb = ln_bwd_blocks(T);                      // the caller sized `partial` for this many blocks; fewer is fine
+    int g4 = 4, r = L;                              // gcd(4, L)
+    while (r) { const int t = g4 % r; g4 = r; r = t; }
+    const int step = L / g4;                        // grids that are multiples of this make the wave row stride 4*nb a multiple of L
+    const int pos_uniform = nb >= step;
+    if (pos_uniform) nb = (nb / step) * step;
     hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(nb), dim3(256), 3 * d * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
                        (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial, T, L, d, vocab,
-                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed, pos_uniform);
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dtype0, accumulate, (hipStream_t)stream);
 }
