@@ -142,25 +142,44 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
-// Accumulate three per-column partial sums of a block into partial[blockIdx.x][3][d] through LDS.
-__device__ __forceinline__ void block_partials(float* smem, const RowF& a, const RowF& b, const RowF& c3, int d, int lane,
-                                               float* __restrict__ partial) {
-    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) smem[i] = 0.f;
-    __syncthreads();
+// Sum three per-column accumulators over the waves of a block and write them to partial[blockIdx.x][3][d].
+// Binary tree over the waves through LDS with plain 16-byte stores / loads (fixed order: bitwise reproducible; LDS float
+// atomics from 8 waves onto the same 3*d addresses cost more than the row streaming itself).
+// LDS: (waves / 2) * 3 * MAX_IT * 64 float4 = 6 KiB per wave pair.
+__device__ __forceinline__ void block_partials(float* smem, RowF& a, RowF& b, RowF& c3, int d, int lane, float* __restrict__ partial) {
+    const int w = threadIdx.x >> 6;
+    float4* s4 = (float4*)smem;
+    RowF* acc[3] = {&a, &b, &c3};
+    for (int half = (int)(blockDim.x >> 7); half >= 1; half >>= 1) {
+        if (w >= half && w < 2 * half) {
 #pragma unroll
-    for (int it = 0; it < MAX_IT; ++it) {
-        const int c = it * 256 + lane * 4;
-        if (c < d) {
+            for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                atomicAdd(&smem[c + j], a.v[it][j]);
-                atomicAdd(&smem[d + c + j], b.v[it][j]);
-                atomicAdd(&smem[2 * d + c + j], c3.v[it][j]);
-            }
+                for (int it = 0; it < MAX_IT; ++it)
+                    s4[(((w - half) * 3 + k) * MAX_IT + it) * 64 + lane] = make_float4(acc[k]->v[it][0], acc[k]->v[it][1], acc[k]->v[it][2], acc[k]->v[it][3]);
         }
+        __syncthreads();
+        if (w < half) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int it = 0; it < MAX_IT; ++it) {
+                    const float4 t = s4[((w * 3 + k) * MAX_IT + it) * 64 + lane];
+                    acc[k]->v[it][0] += t.x; acc[k]->v[it][1] += t.y; acc[k]->v[it][2] += t.z; acc[k]->v[it][3] += t.w;
+                }
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 3 * d; i += blockDim.x) partial[(size_t)blockIdx.x * 3 * d + i] = smem[i];
+    if (w == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int it = 0; it < MAX_IT; ++it) {
+                const int c = it * 256 + lane * 4;
+                if (c < d)
+                    *(float4*)(partial + (size_t)blockIdx.x * 3 * d + k * d + c) = make_float4(acc[k]->v[it][0], acc[k]->v[it][1], acc[k]->v[it][2], acc[k]->v[it][3]);
+            }
+    }
 }
 
 // LayerNorm backward.  x = the LN input (pre-LN residual sum), dy = gradient of the LN output.
@@ -321,21 +340,25 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
     block_partials(lsm, dg, db, dt, d, lane, partial);
 }
 
-// out[c] (+)= sum_b partial[b][c].  Block = 64 columns x 4 row groups (coalesced 256-B row reads), LDS combine.
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ out0,
-                                                               float* __restrict__ out1, float* __restrict__ out2, int seg, int accumulate) {
-    __shared__ float red[4][64];
+// out[c] (+)= sum_b partial[b][c].  Block = 64 columns x 16 row groups (coalesced 256-B row reads, 16 short load chains
+// per column instead of one long one), fixed-order LDS combine.
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const float* __restrict__ partial, int nblk, int n, float* __restrict__ out0,
+                                                                float* __restrict__ out1, float* __restrict__ out2, int seg, int accumulate) {
+    constexpr int RG = 16;
+    __shared__ float red[RG][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     float s0 = 0.f, s1 = 0.f;
     if (c < n) {
         int b = rg;
-        for (; b + 4 < nblk; b += 8) { s0 += partial[(size_t)b * n + c]; s1 += partial[(size_t)(b + 4) * n + c]; }
+        for (; b + RG < nblk; b += 2 * RG) { s0 += partial[(size_t)b * n + c]; s1 += partial[(size_t)(b + RG) * n + c]; }
         if (b < nblk) s0 += partial[(size_t)b * n + c];
     }
     red[rg][threadIdx.x & 63] = s0 + s1;
     __syncthreads();
     if (rg != 0 || c >= n) return;
-    const float s = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RG; i += 4) s += (red[i][threadIdx.x] + red[i + 1][threadIdx.x]) + (red[i + 2][threadIdx.x] + red[i + 3][threadIdx.x]);
     float* out = c < seg ? out0 : (c < 2 * seg ? out1 : out2);
     if (!out) return;
     const int i = c % seg;
@@ -365,7 +388,12 @@ __global__ void scatter_cls_kernel(const float* __restrict__ dcls, bf16_t* __res
 
 }  // namespace
 
-static inline int ln_bwd_blocks(int T) { int b = (T + 7) / 8; return b < 512 ? (b ? b : 1) : 512; }
+static inline int ln_bwd_blocks(int T) {
+    static int cap = 0;
+    if (!cap) { const char* e = getenv("CLDRD_LN_BLOCKS"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 512; }
+    int b = (T + 7) / 8;
+    return b < cap ? (b ? b : 1) : cap;
+}
 
 extern "C" int cldrd_ln_partial_blocks(int T) { return ln_bwd_blocks(T); }
 
@@ -390,7 +418,7 @@ extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const
 }
 
 static int launch_reduce(const float* partial, int nblk, int d, float* o0, float* o1, float* o2, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 63) / 64), dim3(256), 0, st, partial, nblk, 3 * d, o0, o1, o2, d, accumulate);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 63) / 64), dim3(1024), 0, st, partial, nblk, 3 * d, o0, o1, o2, d, accumulate);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -401,7 +429,7 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
                                    int d, float dropout_p, unsigned long long seed, int accumulate, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_bwd: need 0 < d <= 1024, d % 4 == 0");
     const int nb = ln_bwd_blocks(T);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(512), 3 * d * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(512), (512 / 128) * 3 * MAX_IT * 64 * sizeof(float4), (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d,
                        dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();
@@ -419,7 +447,7 @@ extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const fl
     const int step = L / g4;                        // grids that are multiples of this make the wave row stride 4*nb a multiple of L
     const int pos_uniform = nb >= step;
     if (pos_uniform) nb = (nb / step) * step;
-    hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(nb), dim3(256), 3 * d * sizeof(float), (hipStream_t)stream, (const bf16_t*)dy,
+    hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(nb), dim3(256), (256 / 128) * 3 * MAX_IT * 64 * sizeof(float4), (hipStream_t)stream, (const bf16_t*)dy,
                        (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial, T, L, d, vocab,
                        dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed, pos_uniform);
     CLDRD_LAUNCH_CHECK();
@@ -433,7 +461,7 @@ extern "C" int cldrd_colsum_bf16(const void* x, float* out, float* partial, int 
     const int ny = (T + rows - 1) / rows;
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 1023) / 1024, ny), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, partial, T, N, ld, rows);
     CLDRD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)partial, ny, N,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((N + 63) / 64), dim3(1024), 0, (hipStream_t)stream, (const float*)partial, ny, N,
                        out, (float*)nullptr, (float*)nullptr, N, accumulate);
     CLDRD_LAUNCH_CHECK();
     return 0;
