@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--q-len", type=int, default=30)
     ap.add_argument("--loss", default="kl_div")
+    ap.add_argument("--dropout", type=float, default=0.1, help="experiments only: the judged workload is the HF default 0.1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-index", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
@@ -68,7 +69,7 @@ def main():
     from cldrd_amd.trainer import NwayTrainer
 
     B, N, L, Lq = args.batch, args.nway, args.seq_len, args.q_len
-    cfg = EncoderConfig(arch="distilbert")                  # DistilBERT-6L, dropout 0.1 (HF defaults)
+    cfg = EncoderConfig(arch="distilbert", dropout=args.dropout, attention_dropout=args.dropout)   # DistilBERT-6L, HF defaults
     torch.manual_seed(0)
     model = NwayDualEncoder(cfg, share_weights=False).to(dev)
     model.train()
@@ -196,7 +197,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"cfg2: DistilBERT-6L dual encoder (2 unshared towers), N={N}, {args.loss}, seq_len={L}, q_len={Lq}, "
-                                   f"per-GPU batch {B}, dropout 0.1, fwd+loss+bwd+allreduce+clip+AdamW",
+                                   f"per-GPU batch {B}, dropout {args.dropout:g}, fwd+loss+bwd+allreduce+clip+AdamW",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "model_tflop_per_sample": round(flops_per_sample / 1e12, 4),
             "step_mfma_frac": round(samples_per_s * flops_per_sample / (world * PEAK_BF16_TFLOPS * 1e12), 4),

@@ -107,18 +107,21 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         const int q = qb * 32 + r;
         if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = mx + __logf(sum);
         const float inv = 1.0f / sum;
+        // dropout mask element (row, col) = ((seq*H + hd)*L + q, key); keys rowmap(t, h), t even / odd, are a column pair
+        const uint32_t rk = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + q));
         f32x16 O[2] = {(f32x16){0.f}, (f32x16){0.f}};
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             float pv[16];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                float pr = S[kb][t] * inv;
+            for (int t = 0; t < 16; t += 2) {
+                float p0 = S[kb][t] * inv, p1 = S[kb][t + 1] * inv;
                 if (drop_thresh) {
-                    const uint64_t e = (((uint64_t)seq * H + hd) * L + q) * L + (kb * 32 + rowmap(t, h));
-                    pr = dropout_keep(seed, e, drop_thresh) ? pr * drop_scale : 0.f;
+                    const uint32_t hh = drop_pair(rk, (uint32_t)(kb * 32 + rowmap(t, h)));
+                    p0 = drop_keep_lo(hh, drop_thresh) ? p0 * drop_scale : 0.f;
+                    p1 = drop_keep_hi(hh, drop_thresh) ? p1 * drop_scale : 0.f;
                 }
-                pv[t] = pr;
+                pv[t] = p0; pv[t + 1] = p1;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -153,6 +156,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     float* sBias = (float*)(sdO + Lp * RSB);
     float* sLse = sBias + Lp;
     float* sDelta = sLse + Lp;
+    uint32_t* sRk = (uint32_t*)(sDelta + Lp);          // dropout row key of every query row (common.h)
     const int seq = blockIdx.x / H, hd = blockIdx.x % H;
     const int dm = H * 64, ld = 3 * dm;
     const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
@@ -183,12 +187,12 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     for (int k = threadIdx.x; k < Lp; k += blockDim.x) {
         sBias[k] = (k < L && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
         sLse[k] = k < L ? lse[((size_t)seq * H + hd) * L + k] : 1.0e30f;      // rows >= L: P = exp(-inf) = 0
+        sRk[k] = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + k));
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const uint64_t dbase = ((uint64_t)seq * H + hd) * L;
 
     // ---------------- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks ----------------
     for (int kb = wid; kb < NKB; kb += 4) {
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
                 const float p = __expf(S[t] * scale + bias_k - sLse[q]);
                 float pdv = p, dp = dP[t];
                 if (drop_thresh) {
-                    const bool keep = dropout_keep(seed, (dbase + q) * L + key, drop_thresh);
+                    const bool keep = dropout_keep(sRk[q], (uint32_t)key, drop_thresh);
                     pdv = keep ? p * drop_scale : 0.f;
                     dp = keep ? dp * drop_scale : 0.f;
                 }
@@ -257,6 +261,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
         for (int s = 0; s < 4; ++s) { qf[s] = row_frag(sQ, qb * 32 + r, s, h); dof[s] = row_frag(sdO, qb * 32 + r, s, h); }
         const int q = qb * 32 + r;
         const float lse_q = sLse[q], delta_q = sDelta[q];
+        const uint32_t rk_q = sRk[q];
         f32x16 dQ[2] = {(f32x16){0.f}, (f32x16){0.f}};
         for (int kb = 0; kb < NKB; ++kb) {
             f32x16 ST = (f32x16){0.f}, dPT = (f32x16){0.f};
@@ -267,12 +272,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
             }
             float ds[16];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
+            for (int t = 0; t < 16; t += 2) {
                 const int key = kb * 32 + rowmap(t, h);
-                const float p = __expf(ST[t] * scale + sBias[key] - lse_q);
-                float dp = dPT[t];
-                if (drop_thresh) dp = dropout_keep(seed, (dbase + q) * L + key, drop_thresh) ? dp * drop_scale : 0.f;
-                ds[t] = p * (dp - delta_q);
+                const float p0 = __expf(ST[t] * scale + sBias[key] - lse_q), p1 = __expf(ST[t + 1] * scale + sBias[key + 1] - lse_q);
+                float dp0 = dPT[t], dp1 = dPT[t + 1];
+                if (drop_thresh) {
+                    const uint32_t hh = drop_pair(rk_q, (uint32_t)key);
+                    dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 * drop_scale : 0.f;
+                    dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 * drop_scale : 0.f;
+                }
+                ds[t] = p0 * (dp0 - delta_q);
+                ds[t + 1] = p1 * (dp1 - delta_q);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -298,18 +308,18 @@ int launch_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, in
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_fwd_kernel<NKB>, dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                       (bf16_t*)ctx, lse, L, H, scale, p > 0.f ? dropout_thresh24(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+                       (bf16_t*)ctx, lse, L, H, scale, p > 0.f ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 template <int NKB>
 int launch_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
                int L, int H, float scale, float p, unsigned long long seed, hipStream_t st) {
-    const size_t lds = 4 * 32 * NKB * RSB + 3 * 32 * NKB * sizeof(float);
+    const size_t lds = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(attn_bwd_kernel<NKB>, dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                        (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                       p > 0.f ? dropout_thresh24(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+                       p > 0.f ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -409,7 +419,7 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
             const float p = sc[i] * inv;
             probs[((size_t)seq * H + hd) * L + key] = p;
             float pd = p;
-            if (drop_thresh) pd = dropout_keep(seed, (((uint64_t)seq * H + hd) * L + 0) * L + key, drop_thresh) ? p * drop_scale : 0.f;
+            if (drop_thresh) pd = dropout_keep(drop_rowkey(seed, (uint32_t)((seq * H + hd) * L)), (uint32_t)key, drop_thresh) ? p * drop_scale : 0.f;
             sp[key] = pd;
         }
     }
@@ -450,7 +460,7 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
             }
             float pdv = p[i];
             if (drop_thresh) {
-                const bool keep = dropout_keep(seed, (((uint64_t)seq * H + hd) * L + 0) * L + key, drop_thresh);
+                const bool keep = dropout_keep(drop_rowkey(seed, (uint32_t)((seq * H + hd) * L)), (uint32_t)key, drop_thresh);
                 pdv = keep ? p[i] * drop_scale : 0.f;
                 a = keep ? a * drop_scale : 0.f;
             }
@@ -495,7 +505,7 @@ extern "C" int cldrd_attention_cls_fwd(const void* qc, const void* kv, const lon
                                        int H, float dropout_p, unsigned long long seed, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0 && probs != nullptr, "attention_cls_fwd: need 0 < L <= 256 and a probs buffer");
     hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
-                       (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u,
+                       (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u,
                        1.0f / (1.0f - dropout_p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();
     return 0;
@@ -507,7 +517,7 @@ extern "C" int cldrd_attention_cls_bwd(const void* qc, const void* kv, const flo
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_cls_bwd: need 0 < L <= 256");
     hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv, probs,
                        (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f,
-                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

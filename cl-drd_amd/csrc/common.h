@@ -53,19 +53,28 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
 __device__ __forceinline__ float gelu_f(float x) { float c, e; gelu_parts(x, c, e); return x * c; }
 __device__ __forceinline__ float gelu_grad_f(float x) { float c, e; gelu_parts(x, c, e); return fmaf(x * 0.39894228040143268f, e, c); }
 
-// Counter-based dropout: keep(element) is a pure function of (seed, 64-bit element index), so the backward
-// regenerates the mask instead of storing it.  splitmix64 finaliser; keep iff top 24 bits >= p * 2^24.
-__device__ __forceinline__ uint32_t hash_u24(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + (idx + 1) * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 40);
+// Counter-based dropout, regenerated (never stored) wherever a mask is needed: forward, backward, and the numpy mirror in
+// oracle/dropout_ref.py.  An element is addressed by (row, col) of the tensor the mask applies to:
+//     rowkey = mix32(row + (mix32(lo32(seed)) ^ hi32(seed) * 0x9E3779B9))  once per row (the seed part is wave-uniform)
+//     h      = mix32(rowkey ^ (col >> 1))                                   one hash per PAIR of columns
+//     keep   = ((col & 1) ? h >> 16 : h & 0xFFFF) >= thresh16,  thresh16 = round(p * 65536)
+// mix32 is the "lowbias32" finaliser: two 32-bit multiplies.  (The first version hashed a flattened 64-bit index with
+// splitmix64: two 64-bit multiplies per ELEMENT are ~16 quarter-rate v_mul_*_u32; dropout cost 1.1 ms of a 14.5 ms step.)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
 }
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh24) {
-    return hash_u24(seed, idx) >= thresh24;
+__device__ __forceinline__ uint32_t drop_rowkey(uint64_t seed, uint32_t row) {
+    return mix32(row + (mix32((uint32_t)seed) ^ ((uint32_t)(seed >> 32) * 0x9E3779B9u)));
 }
-static inline uint32_t dropout_thresh24(float p) { return (uint32_t)(p * 16777216.0f); }
+__device__ __forceinline__ uint32_t drop_pair(uint32_t rowkey, uint32_t col) { return mix32(rowkey ^ (col >> 1)); }
+__device__ __forceinline__ bool drop_keep_lo(uint32_t h, uint32_t thresh16) { return (h & 0xFFFFu) >= thresh16; }
+__device__ __forceinline__ bool drop_keep_hi(uint32_t h, uint32_t thresh16) { return (h >> 16) >= thresh16; }
+__device__ __forceinline__ bool dropout_keep(uint32_t rowkey, uint32_t col, uint32_t thresh16) {
+    const uint32_t h = drop_pair(rowkey, col);
+    return ((col & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= thresh16;
+}
+static inline uint32_t dropout_thresh16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 
 // XCD-aware bijective block remap (cdna_hip_programming.md section 5, T1): blocks b and b+8 share an XCD, so
 // give each XCD a contiguous range of logical tiles (neighbouring tiles share operand panels in that XCD's L2).

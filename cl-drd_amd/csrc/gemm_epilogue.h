@@ -80,9 +80,13 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(g[j]);
     }
     if (fl.dropout) {
-        const uint64_t e = (uint64_t)m * (uint64_t)p.N + (uint64_t)n;
+        const uint32_t rk = drop_rowkey(p.seed, (uint32_t)m);      // n is a multiple of 8: four column pairs
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = dropout_keep(p.seed, e + j, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+        for (int j = 0; j < 8; j += 2) {
+            const uint32_t h = drop_pair(rk, (uint32_t)(n + j));
+            v[j] = drop_keep_lo(h, p.drop_thresh) ? v[j] * p.drop_scale : 0.f;
+            v[j + 1] = drop_keep_hi(h, p.drop_thresh) ? v[j + 1] * p.drop_scale : 0.f;
+        }
     }
     if (fl.residual) {
         float r[8];

@@ -138,7 +138,7 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
     a.bias = bias; a.residual = (const bf16_t*)residual; a.ldr = ldr;
     a.preact = (bf16_t*)preact; a.gelu_pre = (const bf16_t*)gelu_pre;
     a.act = act; a.alpha = alpha;
-    a.drop_thresh = dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u;
+    a.drop_thresh = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.seed = seed; a.out_f32 = out_f32;
     a.thr = nullptr; a.counts = nullptr; a.cand_rows = nullptr; a.cand_scores = nullptr; a.cap = 0;

@@ -124,16 +124,19 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
     }
     float mean, rstd;
     row_stats(r, d, lane, eps, mean, rstd);
+    const uint32_t rk = drop_rowkey(seed, (uint32_t)row);
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
         const int c = it * 256 + lane * 4;
         if (c < d) {
             const float4 g = *(const float4*)(gamma + c), b = *(const float4*)(beta + c);
             const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {b.x, b.y, b.z, b.w};
+            const uint32_t h0 = drop_pair(rk, c), h1 = drop_pair(rk, c + 2);
+            const bool keep[4] = {drop_keep_lo(h0, drop_thresh), drop_keep_hi(h0, drop_thresh), drop_keep_lo(h1, drop_thresh), drop_keep_hi(h1, drop_thresh)};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float y = (r.v[it][j] - mean) * rstd * gg[j] + bb[j];
-                if (drop_thresh) y = dropout_keep(seed, (uint64_t)row * d + c + j, drop_thresh) ? y * drop_scale : 0.f;
+                if (drop_thresh) y = keep[j] ? y * drop_scale : 0.f;
                 r.v[it][j] = y;
             }
         }
@@ -224,14 +227,17 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ 
         }
         s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
         RowF o2;
+        const uint32_t rk = drop_rowkey(seed, (uint32_t)row);
 #pragma unroll
         for (int it = 0; it < MAX_IT; ++it) {
             const int c = it * 256 + lane * 4;
+            const uint32_t h0 = drop_pair(rk, c), h1 = drop_pair(rk, c + 2);
+            const bool keep[4] = {drop_keep_lo(h0, drop_thresh), drop_keep_hi(h0, drop_thresh), drop_keep_lo(h1, drop_thresh), drop_keep_hi(h1, drop_thresh)};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float v = (c < d) ? rstd * (g.v[it][j] - s1 - xr.v[it][j] * s2) : 0.f;
                 g.v[it][j] = v;
-                if (drop_thresh && c < d) v = dropout_keep(seed, (uint64_t)row * d + c + j, drop_thresh) ? v * drop_scale : 0.f;
+                if (drop_thresh && c < d) v = keep[j] ? v * drop_scale : 0.f;
                 o2.v[it][j] = v;
                 dbias.v[it][j] += v;
             }
@@ -291,6 +297,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
                 for (int j = 0; j < 4; ++j) xr.v[it][j] += p.v[it][j];
         }
         const float mean = mean_i[row], rstd = rstd_i[row];
+        const uint32_t rk = drop_rowkey(seed, (uint32_t)row);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < MAX_IT; ++it) {
@@ -298,10 +305,12 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
             if (c < d) {
                 const float4 gm = *(const float4*)(gamma + c);
                 const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
+                const uint32_t h0 = drop_pair(rk, c), h1 = drop_pair(rk, c + 2);
+                const bool keep[4] = {drop_keep_lo(h0, drop_thresh), drop_keep_hi(h0, drop_thresh), drop_keep_lo(h1, drop_thresh), drop_keep_hi(h1, drop_thresh)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float dyv = g.v[it][j];
-                    if (drop_thresh) dyv = dropout_keep(seed, (uint64_t)row * d + c + j, drop_thresh) ? dyv * drop_scale : 0.f;
+                    if (drop_thresh) dyv = keep[j] ? dyv * drop_scale : 0.f;
                     const float xh = (xr.v[it][j] - mean) * rstd;
                     dg.v[it][j] += dyv * xh; db.v[it][j] += dyv;
                     const float t = dyv * gg[j];
@@ -412,7 +421,7 @@ extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_fwd: bad shape");
     hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, word, pos,
                        type0, gamma, beta, (bf16_t*)out, mean, rstd, T, L, d, vocab, eps,
-                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -431,7 +440,7 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
     const int nb = ln_bwd_blocks(T);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(512), (512 / 128) * 3 * MAX_IT * 64 * sizeof(float4), (hipStream_t)stream, (const bf16_t*)dy,
                        (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d,
-                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dbias, accumulate, (hipStream_t)stream);
 }
@@ -449,7 +458,7 @@ extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const fl
     if (pos_uniform) nb = (nb / step) * step;
     hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(nb), dim3(256), (256 / 128) * 3 * MAX_IT * 64 * sizeof(float4), (hipStream_t)stream, (const bf16_t*)dy,
                        (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial, T, L, d, vocab,
-                       dropout_p > 0.f ? dropout_thresh24(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed, pos_uniform);
+                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed, pos_uniform);
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dtype0, accumulate, (hipStream_t)stream);
 }

@@ -366,3 +366,71 @@ def test_transpose_cast_batched():
     a = src[: 128 * 96].view(128, 96).T.contiguous().to(torch.bfloat16)
     b = src[128 * 96:].view(64, 200).T.contiguous().to(torch.bfloat16)
     assert torch.equal(dst[: 128 * 96].cpu().view(96, 128), a) and torch.equal(dst[128 * 96:].cpu().view(200, 64), b)
+
+
+# ------------------------------------------------------------------------------------------------ dropout masks (exact)
+from oracle import dropout_ref as DR
+
+
+@pytest.mark.parametrize("M,N,K,seed", [(300, 256, 64, 1234), (2048, 768, 128, (7 << 32) | 99), (1100, 384, 64, 5)])
+def test_gemm_dropout_mask_is_the_oracle_mask(M, N, K, seed):
+    """out = dropout(A.B^T) + residual with the mask of oracle/dropout_ref.py at (row, col) = (m, n), scale 1/(1-p)."""
+    p = 0.1
+    A, B = bf(rnd(40, (M, K))), bf(rnd(41, (N, K)))
+    res = bf(rnd(42, (M, N)))
+    plain = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), plain)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out, residual=res.to(DEV), dropout_p=p, seed=seed)
+    keep = torch.from_numpy(DR.keep_mask(seed, p, M, N))
+    ref = torch.where(keep, plain.cpu() / (1 - p), torch.zeros(())) + res.float()
+    close(out, ref, 1e-6, 1e-6, "gemm dropout mask")
+    assert abs(keep.float().mean().item() - (1 - p)) < 0.01
+
+
+@pytest.mark.parametrize("T,d", [(513, 768), (64, 256)])
+def test_layernorm_bwd_dropout_branch_uses_the_oracle_mask(T, d):
+    p, seed = 0.1, 31337
+    x, dy = bf(rnd(43, (T, d), 2.0)), bf(rnd(44, (T, d)))
+    gamma = 1 + rnd(45, (d,), 0.1)
+    mean = x.float().mean(1)
+    rstd = 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-12)
+    dx = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    dx2 = torch.empty_like(dx)
+    dg, db, dbias = (torch.zeros(d, device=DEV) for _ in range(3))
+    partial = torch.empty(ops._lib.load().cldrd_ln_partial_blocks(T) * 3 * d, device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean.to(DEV), rstd.to(DEV), gamma.to(DEV), dx, dx2, dg, db, dbias, partial, T,
+                      dropout_p=p, seed=seed, accumulate=False)
+    keep = torch.from_numpy(DR.keep_mask(seed, p, T, d))
+    # dx2 is computed from the unrounded dx: compare against the fp32 formula, one bf16 rounding
+    xh = (x.float() - mean[:, None]) * rstd[:, None]
+    t = dy.float() * gamma
+    ref = rstd[:, None] * (t - t.mean(1, keepdim=True) - xh * (t * xh).mean(1, keepdim=True))
+    close(dx, ref, 1 / 128, 1e-3, "ln_bwd dx")
+    close(dx2, torch.where(keep, ref / (1 - p), torch.zeros(())), 1 / 128, 1e-3, "ln_bwd dropped dx")
+    assert torch.equal(dx2.cpu() == 0, ~keep | (dx2.cpu() == 0))
+    close(dbias, torch.where(keep, ref / (1 - p), torch.zeros(())).sum(0), 1e-3, 1e-2, "bias gradient of the dropped branch")
+
+
+@pytest.mark.parametrize("nseq,L,H", [(2, 64, 2), (3, 128, 1), (2, 30, 2)])
+def test_attention_dropout_fwd_bwd_against_the_oracle_mask(nseq, L, H):
+    """softmax -> dropout(mask of oracle/dropout_ref.py, scale 1/(1-p)) -> . V, forward and both backward sweeps."""
+    p, seed = 0.25, 4242
+    d, T = H * 64, nseq * L
+    qkv = bf(rnd(46, (T, 3 * d), 1.0))
+    keep = torch.from_numpy(DR.attention_keep_mask(seed, p, nseq, H, L))
+    qv = qkv.double().requires_grad_(True)
+    x = qv.view(nseq, L, 3, H, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    P = torch.softmax(q @ k.transpose(2, 3) * 0.125, -1)
+    ref = ((P * keep / (1 - p)) @ v).transpose(1, 2).reshape(T, d)
+    dctx = bf(rnd(47, (T, d)))
+    ref.backward(dctx.double())
+    ctx = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(nseq, H, L, dtype=torch.float32, device=DEV)
+    ops.attention_fwd(qkv.to(DEV), None, ctx, lse, nseq, L, H, dropout_p=p, seed=seed)
+    close(ctx, ref, 1 / 64, 3e-2, "attention fwd with dropout")
+    dqkv = torch.zeros(T, 3 * d, dtype=torch.bfloat16, device=DEV)
+    ops.attention_bwd(qkv.to(DEV), None, ctx, dctx.to(DEV), lse, dqkv, nseq, L, H, dropout_p=p, seed=seed)
+    g = qv.grad.float()
+    close(dqkv, g, 1 / 32, 2e-2 * g.abs().max().item(), "attention bwd with dropout")
