@@ -22,9 +22,7 @@
 
 namespace {
 
-constexpr int T2 = 128;                // output tile is (64*WM) x 128, WM = 4 (8 waves) or 2 (4 waves, small models)
 constexpr int BK = 64;                 // tokens per LDS slot
-constexpr int B_BYTES = BK * T2 * 2;   // 16 KiB
 
 __device__ __forceinline__ int swz(int m) { return 2 * ((m & 3) | (((m >> 3) & 1) << 2)); }
 
@@ -40,17 +38,19 @@ __device__ __forceinline__ void tr_issue(Frag& f, uint32_t addr) {
 }
 __device__ __forceinline__ bf16x8 frag8(const Frag& f) { return (bf16x8){f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]}; }
 
-template <int WM, bool BIAS>
-__global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                          float* __restrict__ slabs, int M, int N1, int N2, int lda, int ldb,
-                                                          int splits, int ksteps_per_split, size_t slab_stride) {
+template <int T1, int T2, int NW, bool BIAS>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                         float* __restrict__ slabs, int M, int N1, int N2, int lda, int ldb,
+                                                         int splits, int ksteps_per_split, size_t slab_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int T1 = 64 * WM, NW = 2 * WM;
-    constexpr int A_BYTES = BK * T1 * 2, SLOT = A_BYTES + B_BYTES;
+    constexpr int WGN = T2 / 64, WGM = NW / WGN;        // wave grid; a wave owns (16 FA) x 64 of the tile
+    constexpr int FA = T1 / WGM / 16;                   // A fragments (16 n1 columns each) per wave
+    constexpr int A_BYTES = BK * T1 * 2, B_BYTES = BK * T2 * 2, SLOT = A_BYTES + B_BYTES;
     constexpr int LPR_A = T1 / 8, RA = 64 / LPR_A;      // lanes per A row, A rows per 1-KiB piece
-    constexpr int BPW = 16 / NW;                        // B pieces per wave
-    constexpr int NSLOT = 3;                            // K tiles kt+1 and kt+2 stay in flight while kt is consumed
-    constexpr int G = 4 + BPW;                          // LDS-DMA instructions per wave per K tile
+    constexpr int LPR_B = T2 / 8, RB = 64 / LPR_B;
+    constexpr int APW = A_BYTES / 1024 / NW, BPW = B_BYTES / 1024 / NW;     // pieces per wave
+    constexpr int NSLOT = 3 * SLOT <= 160 * 1024 ? 3 : 2;                   // 3: K tiles kt+1 and kt+2 stay in flight
+    constexpr int G = APW + BPW;                        // LDS-DMA instructions per wave per K tile
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nt2 = N2 / T2;
@@ -61,29 +61,28 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
     const int ktotal = (M + BK - 1) / BK;
     const int kbeg = split * ksteps_per_split;
     const int nk = min(ktotal, kbeg + ksteps_per_split) - kbeg;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WGN, wn = wid % WGN;
     const bool do_bias = BIAS && c2 == 0 && wn == 0;
 
-    // ---- LDS-DMA.  A: piece = RA token rows x (T1*2) B, wave w owns pieces 4w..4w+3.
-    //                B: piece = 4 token rows x 256 B, wave w owns pieces BPW*w .. BPW*w + BPW-1.
-    uint32_t oa[4], ob[BPW];
+    // ---- LDS-DMA.  A piece = RA token rows x (T1*2) B, B piece = RB token rows x (T2*2) B; wave w owns pieces APW*w.. / BPW*w..
+    uint32_t oa[APW], ob[BPW];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = RA * (4 * wid + i) + lane / LPR_A;
+    for (int i = 0; i < APW; ++i) {
+        const int r = RA * (APW * wid + i) + lane / LPR_A;
         oa[i] = (uint32_t)r * (uint32_t)(lda * 2) + (uint32_t)(c1 * 2) + (uint32_t)(((lane % LPR_A) ^ swz(r)) * 16);
     }
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
-        const int r = 4 * (BPW * wid + i) + (lane >> 4);
-        ob[i] = (uint32_t)r * (uint32_t)(ldb * 2) + (uint32_t)(c2 * 2) + (uint32_t)(((lane & 15) ^ swz(r)) * 16);
+        const int r = RB * (BPW * wid + i) + lane / LPR_B;
+        ob[i] = (uint32_t)r * (uint32_t)(ldb * 2) + (uint32_t)(c2 * 2) + (uint32_t)(((lane % LPR_B) ^ swz(r)) * 16);
     }
     auto stage = [&](int slot, int kt) {
         char* base = smem + slot * SLOT;
         const char* pa = (const char*)A + (size_t)(kbeg + kt) * BK * lda * 2;
         const char* pb = (const char*)B + (size_t)(kbeg + kt) * BK * ldb * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + oa[i]), LDS_PTR(base + (4 * wid + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < APW; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + oa[i]), LDS_PTR(base + (APW * wid + i) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < BPW; ++i)
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb + ob[i]), LDS_PTR(base + A_BYTES + (BPW * wid + i) * 1024), 16, 0, 0);
@@ -94,64 +93,70 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
     // k-step (ks: + 32 rows) and both reads (r: + 4 rows) through the instruction's immediate offset.
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int m0 = 8 * g + q;
-    uint32_t ra[4], rb[4];
+    uint32_t ra[FA], rb[4];
+#pragma unroll
+    for (int t = 0; t < FA; ++t) {
+        const int ca = wm * (16 * FA) + t * 16 + 4 * pp;
+        ra[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + m0 * (T1 * 2) + (((ca >> 3) ^ swz(m0)) * 16) + (ca & 7) * 2;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int ca = wm * 64 + t * 16 + 4 * pp, cb = wn * 64 + t * 16 + 4 * pp;
-        ra[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + m0 * (T1 * 2) + (((ca >> 3) ^ swz(m0)) * 16) + (ca & 7) * 2;
-        rb[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + A_BYTES + m0 * 256 + (((cb >> 3) ^ swz(m0)) * 16) + (cb & 7) * 2;
+        const int cb = wn * 64 + t * 16 + 4 * pp;
+        rb[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + A_BYTES + m0 * (T2 * 2) + (((cb >> 3) ^ swz(m0)) * 16) + (cb & 7) * 2;
     }
 
-    f32x4 acc[4][4];
-    f32x4 accb[4];
+    f32x4 acc[FA][4];
+    f32x4 accb[BIAS ? FA : 1];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < FA; ++i) {
+        if (BIAS) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const short one = (short)0x3F80;     // bf16 1.0
     const bf16x8 ones = (bf16x8){one, one, one, one, one, one, one, one};
 
-    Frag af[4], b0[4], b1[4];
+    Frag af[FA], b0[4], b1[4];
     auto mfma_row = [&](int t1, Frag (&bc)[4]) {
         const bf16x8 a = frag8(af[t1]);
 #pragma unroll
         for (int t2 = 0; t2 < 4; ++t2)
             // swapped operands: D'[n2][n1] so the lane's 4 accumulators run along n2 (contiguous in dW rows)
             acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(bc[t2]), a, acc[t1][t2], 0, 0, 0);
-        if (do_bias) accb[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a, accb[t1], 0, 0, 0);
+        if (BIAS && do_bias) accb[BIAS ? t1 : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a, accb[BIAS ? t1 : 0], 0, 0, 0);
     };
-    // LDS returns in issue order.  Issue order per k-step: A0, B'0..B'3, A1, A2, A3 (2 reads each; B' = next k-step's B).
-    // Row t1 >= 1 needs A[t1] of the previous k-step: 14 younger reads may stay outstanding; row 0 needs A0 and B: 6.
+    // LDS returns in issue order.  Issue order per k-step: A0, B'0..B'3, A1, .., A(FA-1) (2 reads each; B' = next k-step's B).
+    // Row 0 needs A0 and B, the 2 (FA-1) reads of A1.. are younger.  Row t1 >= 1 needs A[t1] of the previous k-step:
+    // 2 FA + 6 younger reads (the lgkmcnt field stops at 15: for FA = 8 a few older refills are waited for too).
+    constexpr int W0 = 2 * (FA - 1), WR = 2 * FA + 6 < 15 ? 2 * FA + 6 : 15;
     auto wait_row0 = [&](Frag (&bc)[4]) {
-        asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo), "+v"(bc[1].hi),
-                     "+v"(bc[2].lo), "+v"(bc[2].hi), "+v"(bc[3].lo), "+v"(bc[3].hi));
+        asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo), "+v"(bc[1].hi),
+                     "+v"(bc[2].lo), "+v"(bc[2].hi), "+v"(bc[3].lo), "+v"(bc[3].hi) : "n"(W0));
     };
     // one 32-token k-step over (af, bc); the next fragments come from slot offset noff, k-step NKS of that slot
     auto kstep = [&](Frag (&bc)[4], Frag (&bn)[4], uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
         constexpr int NKS = decltype(nks_tag)::value;
-        constexpr int OA = NKS * 32 * T1 * 2, OB = NKS * 32 * 256;
+        constexpr int OA = NKS * 32 * T1 * 2, OB = NKS * 32 * T2 * 2;
         wait_row0(bc);
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(0, bc);
         __builtin_amdgcn_sched_barrier(0);
         if (sync) {
-            // K tile kt+1 must have landed; K tile kt+2 (issued one tile ago) may stay in flight
-            if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+            // K tile kt+1 must have landed; with three slots K tile kt+2 (issued one tile ago) may stay in flight
+            if (NSLOT == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (kt + 3 < nk) stage(slot, kt + 3);          // slot kt % 3: every wave holds tile kt's fragments in registers
+            if (kt + NSLOT < nk) stage(slot, kt + NSLOT);  // slot of K tile kt: every wave holds its fragments in registers
             __builtin_amdgcn_sched_barrier(0);
         }
         tr_issue<OA, 4 * T1 * 2>(af[0], ra[0] + noff);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) tr_issue<OB, 4 * 256>(bn[t], rb[t] + noff);
+        for (int t = 0; t < 4; ++t) tr_issue<OB, 4 * T2 * 2>(bn[t], rb[t] + noff);
 #pragma unroll
-        for (int t1 = 1; t1 < 4; ++t1) {
+        for (int t1 = 1; t1 < FA; ++t1) {
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(af[t1].lo), "+v"(af[t1].hi));
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(af[t1].lo), "+v"(af[t1].hi) : "n"(WR));
             __builtin_amdgcn_sched_barrier(0);
             mfma_row(t1, bc);
             __builtin_amdgcn_sched_barrier(0);
@@ -164,17 +169,20 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
 
     if (nk > 0) {
         stage(0, 0);
-        if (nk > 1) stage(1, 1);
-        if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NSLOT == 3 && nk > 1) {
+            stage(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (nk > 2) stage(2, 2);
+        if (NSLOT == 3) { if (nk > 2) stage(2, 2); } else { if (nk > 1) stage(1, 1); }
         tr_issue<0, 4 * T1 * 2>(af[0], ra[0]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) tr_issue<0, 4 * 256>(b0[t], rb[t]);
+        for (int t = 0; t < 4; ++t) tr_issue<0, 4 * T2 * 2>(b0[t], rb[t]);
 #pragma unroll
-        for (int t = 1; t < 4; ++t) tr_issue<0, 4 * T1 * 2>(af[t], ra[t]);
+        for (int t = 1; t < FA; ++t) tr_issue<0, 4 * T1 * 2>(af[t], ra[t]);
         int cs = 0;                                        // slot of K tile kt
         for (int kt = 0; kt + 1 < nk; ++kt) {
             const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(0, b1);
 #pragma unroll
-        for (int t1 = 1; t1 < 4; ++t1) {
+        for (int t1 = 1; t1 < FA; ++t1) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[t1].lo), "+v"(af[t1].hi));
             mfma_row(t1, b1);
         }
@@ -195,14 +203,14 @@ __global__ __launch_bounds__(128 * WM, 2) void gemm_tn_kernel(const bf16_t* __re
 
     float* slab = slabs + (size_t)split * slab_stride;
 #pragma unroll
-    for (int t1 = 0; t1 < 4; ++t1) {
-        const int n1 = c1 + wm * 64 + t1 * 16 + (lane & 15);
+    for (int t1 = 0; t1 < FA; ++t1) {
+        const int n1 = c1 + wm * (16 * FA) + t1 * 16 + (lane & 15);
 #pragma unroll
         for (int t2 = 0; t2 < 4; ++t2) {
             const int n2 = c2 + wn * 64 + t2 * 16 + 4 * (lane >> 4);
             *(float4*)(slab + (size_t)n1 * N2 + n2) = make_float4(acc[t1][t2][0], acc[t1][t2][1], acc[t1][t2][2], acc[t1][t2][3]);
         }
-        if (do_bias && lane < 16) slab[(size_t)N1 * N2 + n1] = accb[t1][0];       // every n2 row of D' holds the same column sums
+        if (BIAS && do_bias && lane < 16) slab[(size_t)N1 * N2 + n1] = accb[BIAS ? t1 : 0][0];       // every n2 row of D' holds the same column sums
     }
 }
 
@@ -227,30 +235,51 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 
 }  // namespace
 
-static inline int wgrad_t1(int N1) { return N1 % 256 == 0 ? 256 : 128; }
-
-extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
-    const int tiles = (N1 / wgrad_t1(N1)) * (N2 / T2);
-    const int ktotal = (M + BK - 1) / BK;
-    if (tiles <= 0) return 1;
-    int splits = 256 / tiles;                        // at most one workgroup per CU: a second partial round would double the time
-    if (splits > ktotal) splits = ktotal;
-    if (splits < 1) splits = 1;
-    if (splits > 64) splits = 64;
-    return splits;
+// tile choice: 256 x 256 (8 waves of 128 x 64) when both extents allow, else 256 x 128 (8 waves of 64 x 64), else 128 x 128 (4 waves)
+struct WgradTile { int t1, t2; };
+static inline WgradTile wgrad_tile(int N1, int N2) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("CLDRD_WGRAD_TILE"); force = e ? atoi(e) : 0; }
+    // measured (T = 32768): the 256 x 256 tile needs all 256 VGPRs, spills, and has room for two LDS slots only:
+    // 430-480 TF/s against 690-810 TF/s for 256 x 128.  It stays instantiable for experiments (CLDRD_WGRAD_TILE=256).
+    if (N1 % 256 == 0 && N2 % 256 == 0 && force == 256) return {256, 256};
+    if (N1 % 256 == 0) return {256, 128};
+    return {128, 128};
 }
 
-template <int WM, bool BIAS>
+// Token-range splits per output tile.  One workgroup occupies a CU (LDS), so tiles * splits workgroups run in
+// ceil(tiles * splits / 256) rounds of ceil(ktotal / splits) K tiles each, plus a per-workgroup cost (pipeline fill, slab
+// write) of about OVERHEAD K-tile times.  Pick the split count with the smallest modelled time: e.g. 72 tiles -> 7 splits
+// (504 workgroups = 1.97 rounds) beats 3 splits (216 workgroups, 40 idle CUs); 270 workgroups would be the worst case.
+extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
+    const WgradTile t = wgrad_tile(N1, N2);
+    const int tiles = (N1 / t.t1) * (N2 / t.t2);
+    const int ktotal = (M + BK - 1) / BK;
+    if (tiles <= 0) return 1;
+    static int overhead = -1;
+    if (overhead < 0) { const char* e = getenv("CLDRD_WGRAD_OVERHEAD"); overhead = e ? atoi(e) : 6; }
+    int best = 1;
+    long best_cost = -1;
+    for (int sp = 1; sp <= 64 && sp <= ktotal; ++sp) {
+        const long rounds = ((long)tiles * sp + 255) / 256;
+        const long cost = rounds * ((ktotal + sp - 1) / sp + overhead);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sp; }
+    }
+    return best;
+}
+
+template <int T1, int T2, int NW, bool BIAS>
 static int launch_tn(const void* A, const void* B, float* ws, int M, int N1, int N2, int lda, int ldb, int splits, int kps,
                      size_t slab_stride, hipStream_t st) {
-    constexpr int lds = 3 * (BK * 64 * WM * 2 + B_BYTES);
+    constexpr int slot = BK * (T1 + T2) * 2;
+    constexpr int lds = (3 * slot <= 160 * 1024 ? 3 : 2) * slot;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<WM, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T1, T2, NW, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const int tiles = (N1 / (64 * WM)) * (N2 / T2);
-    hipLaunchKernelGGL((gemm_tn_kernel<WM, BIAS>), dim3(tiles * splits), dim3(128 * WM), lds, st, (const bf16_t*)A, (const bf16_t*)B, ws,
+    const int tiles = (N1 / T1) * (N2 / T2);
+    hipLaunchKernelGGL((gemm_tn_kernel<T1, T2, NW, BIAS>), dim3(tiles * splits), dim3(64 * NW), lds, st, (const bf16_t*)A, (const bf16_t*)B, ws,
                        M, N1, N2, lda, ldb, splits, kps, slab_stride);
     CLDRD_LAUNCH_CHECK();
     return 0;
@@ -260,7 +289,7 @@ static int launch_tn(const void* A, const void* B, float* ws, int M, int N1, int
 extern "C" int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, float* dbias, int M, int N1, int N2, int lda, int ldb,
                                 float* workspace, size_t workspace_bytes, int accumulate, void* stream) {
     CLDRD_CHECK(M > 0, "wgrad: empty problem");
-    CLDRD_CHECK(N1 % 128 == 0 && N2 % T2 == 0, "wgrad: N1 and N2 must be multiples of 128");
+    CLDRD_CHECK(N1 % 128 == 0 && N2 % 128 == 0, "wgrad: N1 and N2 must be multiples of 128");
     CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0, "wgrad: lda/ldb must be multiples of 8");
     CLDRD_CHECK(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)dW % 16 == 0) && ((uintptr_t)workspace % 16 == 0),
                 "wgrad: operands must be 16-byte aligned");
@@ -272,13 +301,14 @@ extern "C" int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, float* 
     const int ktotal = (M + BK - 1) / BK;
     const int kps = (ktotal + splits - 1) / splits;
     hipStream_t st = (hipStream_t)stream;
+    const WgradTile t = wgrad_tile(N1, N2);
     int rc;
-    if (wgrad_t1(N1) == 256)
-        rc = dbias ? launch_tn<4, true>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st)
-                   : launch_tn<4, false>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st);
-    else
-        rc = dbias ? launch_tn<2, true>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st)
-                   : launch_tn<2, false>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st);
+#define CLDRD_TN(T1_, T2_, NW_) (dbias ? launch_tn<T1_, T2_, NW_, true>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st) \
+                                       : launch_tn<T1_, T2_, NW_, false>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st))
+    if (t.t1 == 256 && t.t2 == 256) rc = CLDRD_TN(256, 256, 8);
+    else if (t.t1 == 256) rc = CLDRD_TN(256, 128, 8);
+    else rc = CLDRD_TN(128, 128, 4);
+#undef CLDRD_TN
     if (rc) return rc;
     const size_t n_main4 = (size_t)N1 * N2 / 4, n_all4 = n_main4 + (dbias ? (size_t)N1 / 4 : 0);
     const int rb = (int)((n_all4 + 255) / 256 < 2048 ? (n_all4 + 255) / 256 : 2048);
