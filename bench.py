@@ -30,6 +30,28 @@ def flops_seq_fwd(L):
     return NL * (8 * L * D * D + 4 * L * D * DFF + 4 * L * L * D)
 
 
+EVENT_STRIDE = 5
+
+
+def pmc_traffic(kernel_substr):
+    """Average HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes of this same workload
+    (tools/pmc_train.sh -> profiles/r01_train_step_hbm_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+    MI355X_MICROARCH.md section HBM).  A profiler cannot run inside the timed process, so this is the one number of the JSON
+    line that is not measured live; None when the profile is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_train_step_hbm_traffic.json")
+    try:
+        with open(path) as fh:
+            prof = json.load(fh)
+    except OSError:
+        return None
+    n = b = 0.0
+    for name, v in prof.items():
+        if kernel_substr in name:
+            n += v["launches"]
+            b += v["launches"] * (v["read_bytes_per_launch"] + v["write_bytes_per_launch"])
+    return round(b / n) if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,14 +106,24 @@ def main():
 
         def timed_gemm(A, Bm, out, M=None, **kw):
             m = A.shape[0] if M is None else M
+            # the dominant kernel is gemm_nt_ring_kernel: large-M launches (dispatch rule of cldrd_gemm_nt_ring_dispatch);
+            # the query tower's M = 240 launches run the small-tile kernel on the side stream and are not part of it.
+            # Every EVENT_STRIDE-th such launch of the timed region is bracketed by HIP events (the stride is coprime to
+            # the 42 launches of a step, so every call site is sampled): an event pair per launch costs ~0.5 ms per step
+            ring = m >= 1024 and (Bm.shape[0] % 192 == 0 or Bm.shape[0] % 256 == 0) and Bm.shape[1] % 64 == 0
+            if not (timed_gemm.on and ring):
+                return raw_gemm(A, Bm, out, M, **kw)
+            timed_gemm.count += 1
+            if timed_gemm.count % EVENT_STRIDE:
+                return raw_gemm(A, Bm, out, M, **kw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = raw_gemm(A, Bm, out, M, **kw)
             e1.record()
-            if timed_gemm.on:
-                gemm_events.append((e0, e1, 2.0 * m * Bm.shape[0] * Bm.shape[1]))
+            gemm_events.append((e0, e1, 2.0 * m * Bm.shape[0] * Bm.shape[1]))
             return r
         timed_gemm.on = False
+        timed_gemm.count = 0
         ops.gemm_nt = timed_gemm
 
     def sync_all():
@@ -124,12 +156,12 @@ def main():
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in gemm_events)
         tot_fl = sum(f for _, _, f in gemm_events)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-        roofline = {"kernel": "gemm_nt_kernel (bf16 MFMA, all forward + data-gradient Linear GEMMs)", "bound": "mfma",
-                    "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                    "launches": len(gemm_events), "avg_launch_us": round(1e3 * tot_ms / len(gemm_events), 2),
+        roofline = {"kernel": "gemm_nt_ring_kernel (bf16 MFMA; forward + data-gradient Linear GEMMs of the passage tower)",
+                    "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic("gemm_nt_ring_kernel"),
+                    "launches_timed": len(gemm_events), "launches": timed_gemm.count, "avg_launch_us": round(1e3 * tot_ms / len(gemm_events), 2),
                     "gflop_per_launch": round(tot_fl / len(gemm_events) / 1e9, 2),
-                    "time_share_of_step": round(tot_ms * 1e-3 / dt, 3)}
+                    "time_share_of_step": round(tot_ms * 1e-3 * timed_gemm.count / len(gemm_events) / dt, 3)}
 
     # ---- index path: encode passages/s (retriever/index_text.py: bs = 512) ----
     index = None
