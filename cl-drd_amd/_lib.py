@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcldrd_hip.so")
+LIB_PATH = os.environ.get("CLDRD_LIB") or os.path.join(_HERE, "libcldrd_hip.so")      # CLDRD_LIB: A/B runs of two builds
 
 _lib = None
 
