@@ -18,6 +18,7 @@ struct GemmNtArgs {
     int out_f32;
     // EPI_FILTER (top-k scan): keep C[m][n] >= thr[m] as candidate (n, score) of query m
     const float* thr; int* counts; int* cand_rows; float* cand_scores; int cap;
+    int gn = 0;                   // ring kernel: N tiles are walked in groups of gn inside an XCD's range (0: row-major)
     int stagger = 1;              // ring kernel: waves 4..7 issue their LDS-DMA one k-step after waves 0..3 (0: A/B runs)
 };
 

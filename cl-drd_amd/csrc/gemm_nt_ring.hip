@@ -34,7 +34,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntn = (p.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    // Tile order inside an XCD's contiguous range.  Row-major (all N tiles of an M panel, then the next panel) streams the
+    // whole B operand through the 4-MiB L2 once per round of tiles: for N = 3072, K = 768 that is 4.7 MB of weights + the
+    // A panels + the output stream, and B was re-fetched ~6x per XCD (PMC: 293 MB read for 55 MB of operands).  So the N
+    // tiles are walked in groups of `gn` (<= ~2 MB of B): chunk of `mc` M panels (= one XCD's share) x group x panel x tile.
+    int mt_, nt_;
+    if (p.gn > 0 && p.gn < ntn) {
+        const int ntm = (p.M + BM - 1) / BM;
+        const int mc = (ntm + 7) / 8;
+        const int c = tile / (mc * ntn), r = tile % (mc * ntn);
+        const int mrows = min(mc, ntm - c * mc);
+        const int g = r / (mrows * p.gn);
+        const int r2 = r - g * mrows * p.gn;
+        const int gw = min(p.gn, ntn - g * p.gn);
+        mt_ = c * mc + r2 / gw;
+        nt_ = g * p.gn + r2 % gw;
+    } else {
+        mt_ = tile / ntn;
+        nt_ = tile % ntn;
+    }
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
     const int wm = wid >> 2, wn = wid & 3;
     const int nk_ = p.K / BK;
 
@@ -209,9 +228,13 @@ int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st) { return launch
 // Returns -1 if this variant does not apply (caller falls back to the 128x128 kernel), else the launch status.
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_t st) {
     GemmNtArgs a = a_in;
+    int gn_force;
     static int stagger = -1;
     if (stagger < 0) { const char* e = getenv("CLDRD_GEMM_STAGGER"); stagger = e ? atoi(e) : 1; }
     a.stagger = stagger;
+    static int gn_env = -2;
+    if (gn_env == -2) { const char* e = getenv("CLDRD_GEMM_GN"); gn_env = e ? atoi(e) : -1; }
+    gn_force = gn_env;
     if (a.K % BK != 0) return -1;
     if ((double)a.M * a.lda * 2.0 >= 4.0e9 || (double)a.N * a.ldb * 2.0 >= 4.0e9) return -1;   // 32-bit DMA offsets
     int bn = force_bn;
@@ -229,6 +252,9 @@ int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_
             bn = ok256 ? 256 : 192;
         }
     }
+    // N-tile group: about 2 MB of B (bn rows x K) per group
+    a.gn = gn_force >= 0 ? gn_force : (int)(2.0e6 / ((double)bn * a.K * 2.0) + 0.5);
+    if (a.gn < 1) a.gn = 1;
     if (bn == 256 && a.N % 256 == 0) return launch_ring<256>(a, st);
     if (bn == 192 && a.N % 192 == 0) return launch_ring<192>(a, st);
     return -1;
