@@ -49,7 +49,9 @@ __device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld,
     }
 }
 
-template <int NKB>
+// DROP is a template parameter: as a run-time test hipcc branched on it per element (16 branches per MFMA tile, with the
+// accumulators re-read from AGPRs on both sides), which made these kernels VALU-bound.
+template <int NKB, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
                 float p0 = S[kb][t] * inv, p1 = S[kb][t + 1] * inv;
-                if (drop_thresh) {
+                if (DROP) {
                     const uint32_t hh = drop_pair(rk, (uint32_t)(kb * 32 + rowmap(t, h)));
                     p0 = drop_keep_lo(hh, drop_thresh) ? p0 * drop_scale : 0.f;
                     p1 = drop_keep_hi(hh, drop_thresh) ? p1 * drop_scale : 0.f;
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     }
 }
 
-template <int NKB>
+template <int NKB, bool DROP>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
                 const int q = qb * 32 + rowmap(t, h);
                 const float p = __expf(S[t] * scale + bias_k - sLse[q]);
                 float pdv = p, dp = dP[t];
-                if (drop_thresh) {
+                if (DROP) {
                     const bool keep = dropout_keep(sRk[q], (uint32_t)key, drop_thresh);
                     pdv = keep ? p * drop_scale : 0.f;
                     dp = keep ? dp * drop_scale : 0.f;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
                 const int key = kb * 32 + rowmap(t, h);
                 const float p0 = __expf(ST[t] * scale + sBias[key] - lse_q), p1 = __expf(ST[t + 1] * scale + sBias[key + 1] - lse_q);
                 float dp0 = dPT[t], dp1 = dPT[t + 1];
-                if (drop_thresh) {
+                if (DROP) {
                     const uint32_t hh = drop_pair(rk_q, (uint32_t)key);
                     dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 * drop_scale : 0.f;
                     dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 * drop_scale : 0.f;
@@ -302,26 +304,39 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     }
 }
 
+template <int NKB, bool DROP>
+int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
+                 unsigned long long seed, hipStream_t st) {
+    const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
 template <int NKB>
 int launch_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
                unsigned long long seed, hipStream_t st) {
-    const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_fwd_kernel<NKB>, dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                       (bf16_t*)ctx, lse, L, H, scale, p > 0.f ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, st)
+                                              : launch_fwd_d<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, st);
+}
+template <int NKB, bool DROP>
+int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
+                 int L, int H, float scale, float p, unsigned long long seed, hipStream_t st) {
+    const size_t lds = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                       (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
+                       DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 template <int NKB>
 int launch_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
                int L, int H, float scale, float p, unsigned long long seed, hipStream_t st) {
-    const size_t lds = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(attn_bwd_kernel<NKB>, dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                       (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                       p > 0.f ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
-    CLDRD_LAUNCH_CHECK();
-    return 0;
+    return p > 0.f && dropout_thresh16(p) > 0
+               ? launch_bwd_d<NKB, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, p, seed, st)
+               : launch_bwd_d<NKB, false>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, 0.f, seed, st);
 }
 
 }  // namespace
