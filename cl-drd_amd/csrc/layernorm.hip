@@ -7,6 +7,8 @@
 // mean/variance in registers, wave-level shuffles for the reductions; LN statistics and all parameter
 // gradients are fp32.  Parameter gradients are reduced deterministically: per-block partial rows, then
 // one column-sum pass (no float atomics) - except the embedding-table scatter, which uses fp32 atomics.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -69,10 +71,12 @@ __device__ __forceinline__ void row_stats(const RowF& r, int d, int lane, float 
 
 // out = LN(x) * gamma + beta;   optional fp32 copy of rows r with r % cls_stride == 0 (the CLS pooling of
 // reference models/nway_dual_encoder.py:52,56,64 folded into the last LayerNorm).
+template <int DC>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ out,
-                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int T, int d,
+                                                      float* __restrict__ mean_o, float* __restrict__ rstd_o, int T, int d_rt,
                                                       float eps, float* __restrict__ cls_out, int cls_stride) {
+    const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -97,12 +101,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
 
 // word + position (+ type) embedding -> LN -> dropout.  Tables are the fp32 master weights (HF keeps the
 // embedding lookup and LayerNorm in fp32 under autocast).
+template <int DC, bool DROP>
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
                                                             const float* __restrict__ pos, const float* __restrict__ type0,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             bf16_t* __restrict__ out, float* __restrict__ mean_o,
-                                                            float* __restrict__ rstd_o, int T, int L, int d, int vocab, float eps,
+                                                            float* __restrict__ rstd_o, int T, int L, int d_rt, int vocab, float eps,
                                                             uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float y = (r.v[it][j] - mean) * rstd * gg[j] + bb[j];
-                if (drop_thresh) y = keep[j] ? y * drop_scale : 0.f;
+                if (DROP) y = keep[j] ? y * drop_scale : 0.f;
                 r.v[it][j] = y;
             }
         }
@@ -189,11 +195,13 @@ __device__ __forceinline__ void block_partials(float* smem, RowF& a, RowF& b, Ro
 //   dx  = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))                       -> dx (residual path)
 //   dx2 = dropout-masked dx (the branch that went through dropout before the residual add), or null
 //   partial[blk] = { sum dy*xhat (dgamma), sum dy (dbeta), sum dx2-or-dx (bias grad of the preceding Linear) }
+template <int DC, bool DROP>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
                                                       const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                       const float* __restrict__ gamma, bf16_t* __restrict__ dx,
-                                                      bf16_t* __restrict__ dx2, float* __restrict__ partial, int T, int d,
+                                                      bf16_t* __restrict__ dx2, float* __restrict__ partial, int T, int d_rt,
                                                       uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     const int lane = threadIdx.x & 63;
     RowF dg, db, dbias;
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ 
             for (int j = 0; j < 4; ++j) {
                 float v = (c < d) ? rstd * (g.v[it][j] - s1 - xr.v[it][j] * s2) : 0.f;
                 g.v[it][j] = v;
-                if (drop_thresh && c < d) v = keep[j] ? v * drop_scale : 0.f;
+                if (DROP && c < d) v = keep[j] ? v * drop_scale : 0.f;
                 o2.v[it][j] = v;
                 dbias.v[it][j] += v;
             }
@@ -251,13 +259,15 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ 
 // Embedding backward: dy -> (dropout) -> LN backward (statistics saved, input recomputed from the tables)
 // -> scatter-add into the word / position tables (fp32 atomics); LN-parameter and token-type gradients go
 // through per-block partials {dgamma, dbeta, dtype}.
+template <int DC, bool DROP>
 __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restrict__ dy, const int64_t* __restrict__ ids,
                                                             const float* __restrict__ word, const float* __restrict__ pos,
                                                             const float* __restrict__ type0, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                             float* __restrict__ dword, float* __restrict__ dpos,
-                                                            float* __restrict__ partial, int T, int L, int d, int vocab,
+                                                            float* __restrict__ partial, int T, int L, int d_rt, int vocab,
                                                             uint32_t drop_thresh, float drop_scale, uint64_t seed, int pos_uniform) {
+    const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     const int lane = threadIdx.x & 63;
     // pos_uniform: the row stride of a wave (4 * gridDim.x) is a multiple of L, so every row of this wave sits at the same
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float dyv = g.v[it][j];
-                    if (drop_thresh) dyv = keep[j] ? dyv * drop_scale : 0.f;
+                    if (DROP) dyv = keep[j] ? dyv * drop_scale : 0.f;
                     const float xh = (xr.v[it][j] - mean) * rstd;
                     dg.v[it][j] += dyv * xh; db.v[it][j] += dyv;
                     const float t = dyv * gg[j];
@@ -397,6 +407,16 @@ __global__ void scatter_cls_kernel(const float* __restrict__ dcls, bf16_t* __res
 
 }  // namespace
 
+// run f(integral_constant<int, DC>, bool_constant<DROP>) with DC = d when d is one of the encoder widths, else 0 (run-time d)
+template <class F>
+static void ln_dispatch(int d, bool drop, F&& f) {
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (d == 768) { if (drop) f(std::integral_constant<int, 768>{}, T_{}); else f(std::integral_constant<int, 768>{}, F_{}); }
+    else if (d == 1024) { if (drop) f(std::integral_constant<int, 1024>{}, T_{}); else f(std::integral_constant<int, 1024>{}, F_{}); }
+    else { if (drop) f(std::integral_constant<int, 0>{}, T_{}); else f(std::integral_constant<int, 0>{}, F_{}); }
+}
+
 static inline int ln_bwd_blocks(int T) {
     static int cap = 0;
     if (!cap) { const char* e = getenv("CLDRD_LN_BLOCKS"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 512; }
@@ -409,8 +429,10 @@ extern "C" int cldrd_ln_partial_blocks(int T) { return ln_bwd_blocks(T); }
 extern "C" int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
                                    int T, int d, float eps, float* cls_out, int cls_stride, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_fwd: need 0 < d <= 1024, d % 4 == 0");
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
-                       (bf16_t*)out, mean, rstd, T, d, eps, cls_out, cls_stride > 0 ? cls_stride : 1);
+    ln_dispatch(d, false, [&](auto dc, auto) {
+        hipLaunchKernelGGL((ln_fwd_kernel<decltype(dc)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
+                           (bf16_t*)out, mean, rstd, T, d, eps, cls_out, cls_stride > 0 ? cls_stride : 1);
+    });
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -419,9 +441,12 @@ extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const
                                   const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
                                   int d, int vocab, float eps, float dropout_p, unsigned long long seed, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_fwd: bad shape");
-    hipLaunchKernelGGL(embed_ln_fwd_kernel, dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const int64_t*)ids, word, pos,
-                       type0, gamma, beta, (bf16_t*)out, mean, rstd, T, L, d, vocab, eps,
-                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
+    ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
+        hipLaunchKernelGGL((embed_ln_fwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                           (const int64_t*)ids, word, pos, type0, gamma, beta, (bf16_t*)out, mean, rstd, T, L, d, vocab, eps, th,
+                           1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    });
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -438,9 +463,12 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
                                    int d, float dropout_p, unsigned long long seed, int accumulate, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_bwd: need 0 < d <= 1024, d % 4 == 0");
     const int nb = ln_bwd_blocks(T);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(512), (512 / 128) * 3 * MAX_IT * 64 * sizeof(float4), (hipStream_t)stream, (const bf16_t*)dy,
-                       (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d,
-                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
+    ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
+        hipLaunchKernelGGL((ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3(nb), dim3(512), (512 / 128) * 3 * MAX_IT * 64 * sizeof(float4),
+                           (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_dropped, partial,
+                           T, d, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dbias, accumulate, (hipStream_t)stream);
 }
@@ -456,9 +484,12 @@ extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const fl
     const int step = L / g4;                        // grids that are multiples of this make the wave row stride 4*nb a multiple of L
     const int pos_uniform = nb >= step;
     if (pos_uniform) nb = (nb / step) * step;
-    hipLaunchKernelGGL(embed_ln_bwd_kernel, dim3(nb), dim3(256), (256 / 128) * 3 * MAX_IT * 64 * sizeof(float4), (hipStream_t)stream, (const bf16_t*)dy,
-                       (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial, T, L, d, vocab,
-                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed, pos_uniform);
+    const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
+    ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
+        hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3(nb), dim3(256), (256 / 128) * 3 * MAX_IT * 64 * sizeof(float4),
+                           (hipStream_t)stream, (const bf16_t*)dy, (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial,
+                           T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed, pos_uniform);
+    });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dtype0, accumulate, (hipStream_t)stream);
 }
