@@ -18,6 +18,7 @@ namespace {
 
 constexpr int RSB = 144;                 // LDS row stride in bytes (64 bf16 + 8 pad): b128 row reads conflict-free
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int rowmap(int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; }
 
@@ -86,14 +87,22 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
                 S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], S[kb], 0, 0, 0);
         }
         // S[kb][t] = <K[key], Q[q]> with key = 32 kb + rowmap(t, h), q = 32 qb + r
+        // softmax in the log2 domain (v_exp_f32 is 2^x): scores * scale * log2(e) + bias, bias read 4 keys at a time
+        // (keys rowmap(4u .. 4u+3, h) = 8u + 4h + 0..3 are consecutive)
+        const float scale2 = scale * LOG2E;
         float mx = NEG_BIG * 4.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float v = S[kb][t] * scale + sBias[kb * 32 + rowmap(t, h)];
-                S[kb][t] = v;
-                mx = fmaxf(mx, v);
+            for (int u = 0; u < 4; ++u) {
+                const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = fmaf(S[kb][4 * u + j], scale2, bb[j]);
+                    S[kb][4 * u + j] = v;
+                    mx = fmaxf(mx, v);
+                }
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         float sum = 0.f;
@@ -101,13 +110,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const float e = __expf(S[kb][t] - mx);
+                const float e = __builtin_amdgcn_exp2f(S[kb][t] - mx);
                 S[kb][t] = e;
                 sum += e;
             }
         sum += __shfl_xor(sum, 32, 64);
         const int q = qb * 32 + r;
-        if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = mx + __logf(sum);
+        if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (mx + __log2f(sum)) * LN2;
         const float inv = 1.0f / sum;
         // dropout mask element (row, col) = ((seq*H + hd)*L + q, key); keys rowmap(t, h), t even / odd, are a column pair
         const uint32_t rk = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + q));
@@ -188,13 +197,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     }
     for (int k = threadIdx.x; k < Lp; k += blockDim.x) {
         sBias[k] = (k < L && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
-        sLse[k] = k < L ? lse[((size_t)seq * H + hd) * L + k] : 1.0e30f;      // rows >= L: P = exp(-inf) = 0
+        sLse[k] = k < L ? lse[((size_t)seq * H + hd) * L + k] * LOG2E : 1.0e30f;      // log2 domain; rows >= L: P = 2^-inf = 0
         sRk[k] = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + k));
     }
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
+
+    const float scale2 = scale * LOG2E;      // scores, mask bias and LSE live in the log2 domain (v_exp_f32 is 2^x)
 
     // ---------------- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks ----------------
     for (int kb = wid; kb < NKB; kb += 4) {
@@ -214,17 +225,27 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
             // S[t], dP[t]: query q = 32 qb + rowmap(t, h), key = 32 kb + r
             float pd[16], ds[16];
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int q = qb * 32 + rowmap(t, h);
-                const float p = __expf(S[t] * scale + bias_k - sLse[q]);
-                float pdv = p, dp = dP[t];
-                if (DROP) {
-                    const bool keep = dropout_keep(sRk[q], (uint32_t)key, drop_thresh);
-                    pdv = keep ? p * drop_scale : 0.f;
-                    dp = keep ? dp * drop_scale : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                // queries rowmap(4u .. 4u+3, h) are consecutive: their LSE / delta / dropout row keys come as 16-byte LDS reads
+                const int q4 = qb * 32 + 8 * u + 4 * h;
+                const float4 l4 = *(const float4*)(sLse + q4), d4 = *(const float4*)(sDelta + q4);
+                const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                uint4 k4 = make_uint4(0, 0, 0, 0);
+                if (DROP) k4 = *(const uint4*)(sRk + q4);
+                const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = 4 * u + j;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(S[t], scale2, bias_k) - ll[j]);
+                    float pdv = p, dp = dP[t];
+                    if (DROP) {
+                        const bool keep = dropout_keep(kk[j], (uint32_t)key, drop_thresh);
+                        pdv = keep ? p * drop_scale : 0.f;
+                        dp = keep ? dp * drop_scale : 0.f;
+                    }
+                    pd[t] = pdv;
+                    ds[t] = p * (dp - dd[j]);
                 }
-                pd[t] = pdv;
-                ds[t] = p * (dp - sDelta[q]);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -274,17 +295,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
             }
             float ds[16];
 #pragma unroll
-            for (int t = 0; t < 16; t += 2) {
-                const int key = kb * 32 + rowmap(t, h);
-                const float p0 = __expf(ST[t] * scale + sBias[key] - lse_q), p1 = __expf(ST[t + 1] * scale + sBias[key + 1] - lse_q);
-                float dp0 = dPT[t], dp1 = dPT[t + 1];
-                if (DROP) {
-                    const uint32_t hh = drop_pair(rk_q, (uint32_t)key);
-                    dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 * drop_scale : 0.f;
-                    dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 * drop_scale : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int key4 = kb * 32 + 8 * u + 4 * h;
+                const float4 b4 = *(const float4*)(sBias + key4);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const int t = 4 * u + j;
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(ST[t], scale2, bb[j]) - lse_q);
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(ST[t + 1], scale2, bb[j + 1]) - lse_q);
+                    float dp0 = dPT[t], dp1 = dPT[t + 1];
+                    if (DROP) {
+                        const uint32_t hh = drop_pair(rk_q, (uint32_t)(key4 + j));
+                        dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 * drop_scale : 0.f;
+                        dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 * drop_scale : 0.f;
+                    }
+                    ds[t] = p0 * (dp0 - delta_q);
+                    ds[t + 1] = p1 * (dp1 - delta_q);
                 }
-                ds[t] = p0 * (dp0 - delta_q);
-                ds[t + 1] = p1 * (dp1 - delta_q);
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
