@@ -201,6 +201,26 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(int kind, const floa
     }
 }
 
+// Logit-norm regulariser of the multistep-curriculum trainers (reference nway_listwise_1.py:348-350):
+//   reg = lambda * ||logits||_2 over the whole [B, N] matrix;  loss_out[0] += reg;  grad += lambda * logits / ||logits||_2;
+//   reg_out = reg (the trainer logs it and its ratio to the loss).  One workgroup: B * N is a few hundred numbers.
+__global__ __launch_bounds__(256) void logit_reg_kernel(const float* __restrict__ logits, int n, float lambda, float* __restrict__ loss_out,
+                                                         float* __restrict__ grad, float* __restrict__ reg_out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += logits[i] * logits[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float norm = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    const float inv = norm > 0.f ? lambda / norm : 0.f;      // d||x||/dx at 0: torch gives 0 (subgradient)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) grad[i] += inv * logits[i];
+    if (threadIdx.x == 0) {
+        loss_out[0] += lambda * norm;
+        if (reg_out) *reg_out = lambda * norm;
+    }
+}
+
 }  // namespace
 
 extern "C" int cldrd_score_fwd(const float* q, const float* p, float* logits, int B, int N, int d, int mode, void* stream) {
@@ -236,6 +256,16 @@ extern "C" int cldrd_loss_fwd_bwd(int kind, const float* y_pred, const float* y_
     CLDRD_LAUNCH_CHECK();
     hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, kind, (const float*)workspace, grad, loss_out, B, N,
                        mean_reduction);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+// loss_out[0] += lambda * ||logits||_2, grad += its gradient, *reg_out = the added term (reference nway_listwise_1.py:348-350).
+// Call after cldrd_loss_fwd_bwd on the same stream.
+extern "C" int cldrd_logit_norm_reg(const float* logits, int n, float reg_lambda, float* loss_out, float* grad, float* reg_out,
+                                    void* stream) {
+    CLDRD_CHECK(n > 0 && reg_lambda >= 0.f, "logit_norm_reg: bad arguments");
+    hipLaunchKernelGGL(logit_reg_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, n, reg_lambda, loss_out, grad, reg_out);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

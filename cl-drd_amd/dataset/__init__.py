@@ -1,1 +1,2 @@
 from .sequence_dataset import SequenceDataset, SyntheticSequenceDataset  # noqa: F401
+from .nway_dataset import LABEL_MODES, NwayDataset, TokenCache, labels_for_mode  # noqa: F401

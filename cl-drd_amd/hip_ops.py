@@ -209,6 +209,16 @@ def loss_fwd_bwd(kind, y_pred, y_true, *, batch_weight=None, T=1.0, pad_indicato
     return out, grad
 
 
+def logit_norm_reg(logits, reg_lambda, loss_out, grad, reg_out=None):
+    """loss_out[0] += reg_lambda * ||logits||_2 and grad += its gradient (reference nway_listwise_1.py:348-350)."""
+    _chk(logits, F32, "logits"), _chk(loss_out, F32, "loss_out", 1), _chk(grad, F32, "grad")
+    if not logits.is_contiguous() or not grad.is_contiguous() or grad.numel() != logits.numel():
+        raise ValueError("logit_norm_reg: logits and grad must be contiguous and of the same size")
+    if reg_out is not None:
+        _chk(reg_out, F32, "reg_out", 1)
+    call("cldrd_logit_norm_reg", _p(logits), logits.numel(), float(reg_lambda), _p(loss_out), _p(grad), _p(reg_out), _stream())
+
+
 def sqnorm_blocks() -> int:
     return _lib.load().cldrd_sqnorm_blocks()
 

@@ -16,6 +16,7 @@ Differences from the reference, on purpose (SURVEY.md sections 7, 8a14):
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -56,11 +57,13 @@ def owns_example(line_idx: int, rank: int, nranks: int) -> bool:
 class NwayTrainer:
     def __init__(self, model: NwayDualEncoder, *, loss: str = "lambda_mrr", T: float = 1.0, learning_rate: float = 7e-6,
                  weight_decay: float = 0.01, adam_epsilon: float = 1e-8, max_grad_norm: float = 1.0, warmup_steps: int = 4000,
-                 total_steps: int = 100000, betas=(0.9, 0.999), bucket_layers: int = 1):
+                 total_steps: int = 100000, betas=(0.9, 0.999), bucket_layers: int = 1, reg_lambda: float = 0.0):
         if loss not in LOSS_KINDS:
             raise ValueError(f"loss must be one of {LOSS_KINDS}")
         self.model = model
         self.loss_kind, self.T = loss, T
+        self.reg_lambda = float(reg_lambda)
+        self.last_reg = None
         self.lr0, self.wd, self.eps, self.max_grad_norm = learning_rate, weight_decay, adam_epsilon, max_grad_norm
         self.warmup_steps, self.total_steps, self.betas = warmup_steps, total_steps, betas
         self.global_step = 0
@@ -153,6 +156,9 @@ class NwayTrainer:
         if mode != 0:   # in-batch negatives get the -0.5 label (reference nway_listwise_1.py:341-344)
             labels = torch.cat([labels, torch.full((bz, Np - nway), -0.5, dtype=torch.float32, device=logits.device)], dim=-1)
         loss_out, dlogits = ops.loss_fwd_bwd(self.loss_kind, logits, labels.contiguous(), T=self.T)
+        if self.reg_lambda > 0.0 and mode == 0:     # reference nway_listwise_1.py:346-350: only without in-batch negatives
+            self.last_reg = torch.empty(1, dtype=torch.float32, device=logits.device)
+            ops.logit_norm_reg(logits, self.reg_lambda, loss_out, dlogits, self.last_reg)
         if self.world > 1:
             dlogits.mul_(1.0 / self.world)      # gradient mean over ranks == DDP's all-reduce / world_size
         dq, dp = torch.empty_like(q_cls), torch.empty_like(p_cls)
@@ -234,3 +240,261 @@ class NwayTrainer:
         self.global_step = int(ckpt.get("global_step", 0))
         for t in self.model.towers():
             t.refresh_shadows(need_transposed=True)
+
+
+# =================================================================================================================
+# Command line of reference trainer/multistep-curriculum/nway_listwise_{1,2,3}.py (flags, defaults, log and checkpoint
+# formats), plus: --loss (the reference hard-codes lambda_mrr), --token_cache_dir (tokenise once) and
+# --synthetic_steps (run on generated MSMARCO-shaped batches when no dataset / tokenizer is at hand).
+# =================================================================================================================
+def get_args(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description="N-way listwise distillation training on MI355X (CL-DRD multistep curriculum)")
+    ap.add_argument("--queries_path", default=None)
+    ap.add_argument("--collection_path", default=None)
+    ap.add_argument("--training_path", default=None)
+    ap.add_argument("--experiment_folder", default="experiments/multistep-curriculum/")
+    ap.add_argument("--model_name_or_path", default="sebastian-hofstaetter/distilbert-dot-tas_b-b256-msmarco")
+    ap.add_argument("--tokenizer_name_or_path", default="distilbert-base-uncased")
+    ap.add_argument("--resume", default=None)
+    ap.add_argument("--model_checkpoint", default=None)
+    ap.add_argument("--seed", default=4680, type=int)
+    ap.add_argument("--show_progress", default=True, type=bool)
+    ap.add_argument("--run_folder", default="experiment")
+    ap.add_argument("--log_dir", default="log/")
+    ap.add_argument("--logging_steps", default=50, type=int)
+    ap.add_argument("--evaluate_steps", default=10000, type=int)
+    ap.add_argument("--model_save_dir", default="models")
+    ap.add_argument("--learning_rate", default=7e-6, type=float)
+    ap.add_argument("--weight_decay", default=0.01, type=float)
+    ap.add_argument("--adam_epsilon", default=1e-8, type=float)
+    ap.add_argument("--max_grad_norm", default=1.0, type=float)
+    ap.add_argument("--num_train_epochs", default=4, type=int)
+    ap.add_argument("--warmup_steps", default=4000, type=int)
+    ap.add_argument("--reg_lambda", default=0.0, type=float)
+    ap.add_argument("--query_max_len", default=30, type=int)
+    ap.add_argument("--passage_max_len", default=256, type=int)
+    ap.add_argument("--use_fp16", default=True, type=bool, help="accepted for compatibility: compute is bf16 MFMA with fp32 master weights")
+    ap.add_argument("--train_batch_size", default=8, type=int)
+    ap.add_argument("--share_weights", action="store_true", default=False)
+    ap.add_argument("--label_mode", default="8", type=str)
+    ap.add_argument("--in_batch_loss", action="store_true", default=False)
+    ap.add_argument("--all_in_batch_neg", action="store_true", default=False)
+    ap.add_argument("--n_gpu", default=1, type=int)
+    ap.add_argument("--local_rank", default=-1, type=int)
+    ap.add_argument("--loss", default="lambda_mrr", choices=LOSS_KINDS)
+    ap.add_argument("--token_cache_dir", default=None)
+    ap.add_argument("--synthetic_steps", default=0, type=int, help="steps per epoch on generated batches (no dataset files needed)")
+    ap.add_argument("--synthetic_nway", default=30, type=int)
+    ap.add_argument("--synthetic_model", default="distilbert", choices=("distilbert", "tiny"),
+                    help="random-init architecture for --synthetic_steps runs without a model directory (tiny: selftest.tiny_config)")
+    args = ap.parse_args(argv)
+    args.run_folder = os.path.join(args.experiment_folder, args.run_folder)
+    args.log_dir = os.path.join(args.run_folder, args.log_dir)
+    args.model_save_dir = os.path.join(args.run_folder, args.model_save_dir)
+    return args
+
+
+def set_env(args):
+    """One process per GPU: ranks come from torchrun's environment (or --local_rank as in the reference, :40-49)."""
+    if args.local_rank == -1 and "LOCAL_RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        args.local_rank = int(os.environ["LOCAL_RANK"])
+    if args.local_rank != -1:
+        torch.cuda.set_device(args.local_rank)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl")
+        args.nranks = dist.get_world_size()
+        args.distributed = args.nranks > 1
+    else:
+        args.nranks, args.distributed = 1, False
+    args.device = torch.device("cuda", max(args.local_rank, 0))
+    args.rank = dist.get_rank() if args.distributed else 0
+    return args
+
+
+def write_train_logs(epoch, step, loss_val, mrr_val, recall_val, lr, filename, cutoff=10, **kwargs):
+    """Tab-separated log of reference :78-90 (including its quirk: the first call only writes the header)."""
+    if not os.path.exists(filename):
+        with open(filename, "w") as fh:
+            fh.write("\t".join(["epoch", "step", "loss_val", f"mrr@{cutoff}", f"recall@{cutoff}", "lr"] + list(kwargs)) + "\n")
+    else:
+        with open(filename, "a") as fh:
+            fh.write(f"{epoch}\t{step}\t{loss_val:.3f}\t{mrr_val:.3f}\t{recall_val:.3f}\t{lr:.10f}")
+            for v in kwargs.values():
+                fh.write(f"\t{v:.3f}")
+            fh.write("\n")
+
+
+class _Avg:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.sum, self.n = 0.0, 0
+
+    def update(self, v):
+        self.sum += float(v)
+        self.n += 1
+
+    @property
+    def avg(self):
+        return self.sum / max(self.n, 1)
+
+
+def build_dataloader(args):
+    """Label mode -> file constructor as reference :173-245; per-rank batch = train_batch_size // nranks, shuffle, drop_last."""
+    from transformers import AutoTokenizer
+    from ..dataset.nway_dataset import NwayDataset
+    tok = AutoTokenizer.from_pretrained(args.tokenizer_name_or_path)
+    a = (args.queries_path, args.collection_path, args.training_path, tok)
+    kw = dict(max_query_len=args.query_max_len, max_passage_len=args.passage_max_len, label_mode=args.label_mode)
+    shard = dict(rank=args.rank, nranks=args.nranks) if args.distributed else {}
+    mode = args.label_mode
+    if mode == "1":
+        if args.distributed:
+            raise NotImplementedError
+        ds = NwayDataset.create_from_json_line_file(*a, **kw)
+    elif mode in ("2", "4"):
+        ds = NwayDataset.create_from_relT_most_semi_hard_file(*a, **kw, **shard)
+    elif mode in ("3", "9"):
+        ds = NwayDataset.create_from_10relT_20neg_file(*a, **kw, **shard)
+    elif mode in ("5", "10"):
+        ds = NwayDataset.create_from_20relT_10neg_file(*a, **kw, **shard)
+    elif mode == "6":
+        ds = NwayDataset.create_from_30relT_file(*a, **kw, **shard)
+    elif mode in ("7", "8"):
+        ds = NwayDataset.create_from_5relT_25neg_file(*a, **kw, **shard)
+    else:
+        raise ValueError(f"label mode {mode} not implemented")
+    if args.token_cache_dir:
+        ds.with_token_cache(args.token_cache_dir)
+    assert args.train_batch_size % args.nranks == 0
+    g = torch.Generator()
+    g.manual_seed(args.seed + args.rank)
+    return ds, torch.utils.data.DataLoader(ds, batch_size=args.train_batch_size // args.nranks, shuffle=True, num_workers=1,
+                                           collate_fn=ds.collate_fn, drop_last=True, generator=g)
+
+
+class _SyntheticLoader:
+    """``--synthetic_steps`` batches of the collate_fn layout from the portable generator (synthetic.nway_batch)."""
+
+    def __init__(self, args):
+        self.args = args
+
+    def __len__(self):
+        return self.args.synthetic_steps
+
+    def __iter__(self):
+        from .. import synthetic as syn
+        a = self.args
+        for i in range(a.synthetic_steps):
+            yield syn.nway_batch(a.seed + 1000 * a.rank + i, a.train_batch_size // a.nranks, a.synthetic_nway, a.query_max_len,
+                                 a.passage_max_len, vocab=getattr(a, "synthetic_vocab", syn.VOCAB), ragged=True,
+                                 label_kind="teacher" if a.loss in ("kl_div", "margin_mse") else "mode9")
+
+
+def batch_to_device(batch, dev):
+    out = {}
+    for k, v in batch.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.to(dev, non_blocking=True)
+        elif hasattr(v, "items"):
+            out[k] = {kk: (vv.to(dev, non_blocking=True) if isinstance(vv, torch.Tensor) else vv) for kk, vv in v.items()}
+        else:
+            out[k] = v
+    return out
+
+
+def train(args):
+    """Epoch / step loop of reference :328-426 on top of NwayTrainer.train_step."""
+    import random
+    import numpy as np
+    dev = args.device
+    if args.synthetic_steps > 0:
+        loader, n_examples = _SyntheticLoader(args), args.synthetic_steps * args.train_batch_size
+    else:
+        ds, loader = build_dataloader(args)
+        n_examples = len(ds)
+    if args.synthetic_steps > 0 and not os.path.isdir(str(args.model_name_or_path)):
+        from ..encoder import EncoderConfig
+        if args.synthetic_model == "tiny":
+            from ..selftest import tiny_config
+            cfg = tiny_config()
+        else:
+            cfg = EncoderConfig(arch="distilbert")
+        args.synthetic_vocab = cfg.vocab_size
+        model = NwayDualEncoder(cfg, share_weights=args.share_weights, in_batch_loss=args.in_batch_loss,
+                                all_in_batch_neg=args.all_in_batch_neg)
+    else:
+        model = NwayDualEncoder(args.model_name_or_path, share_weights=args.share_weights, in_batch_loss=args.in_batch_loss,
+                                all_in_batch_neg=args.all_in_batch_neg)
+    model.to(dev)
+    model.train()
+    t_total = len(loader) * args.num_train_epochs
+    trainer = NwayTrainer(model, loss=args.loss, learning_rate=args.learning_rate, weight_decay=args.weight_decay,
+                          adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm, warmup_steps=args.warmup_steps,
+                          total_steps=t_total, reg_lambda=args.reg_lambda)
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)            # after model / loader construction, as the reference does (:282)
+    start_epoch = 0
+    if args.resume:
+        assert args.model_checkpoint is None
+        ckpt = torch.load(args.resume, map_location="cpu", weights_only=False)
+        trainer.load_state_dict(ckpt)
+        start_epoch = ckpt["epoch"] - 1
+    if args.model_checkpoint:
+        assert args.resume is None
+        ckpt = torch.load(args.model_checkpoint, map_location="cpu", weights_only=False)
+        trainer.load_state_dict({"state_dict": ckpt["state_dict"]})
+    main_rank = args.rank == 0
+    if main_rank:
+        os.makedirs(args.log_dir, exist_ok=True)
+        os.makedirs(args.model_save_dir, exist_ok=True)
+    loss_m, mrr_m, rec_m, reg_m, ratio_m = _Avg(), _Avg(), _Avg(), _Avg(), _Avg()
+    topk = 10
+    log_file = os.path.join(args.log_dir, "train_logs.log")
+    for epoch in range(start_epoch, args.num_train_epochs):
+        for batch in loader:
+            batch = batch_to_device(batch, dev)
+            loss_out = trainer.train_step(batch)
+            if main_rank and trainer.global_step % args.logging_steps == 0:
+                # the reference reads loss / MRR back every step (:369-389); here only on logging steps (no per-step sync)
+                labels = batch["labels"]
+                logits = trainer.last_logits
+                if logits.shape[1] != labels.shape[1]:
+                    labels = torch.cat([labels, torch.full((labels.shape[0], logits.shape[1] - labels.shape[1]), -0.5,
+                                                           device=labels.device)], dim=-1)
+                b_mrr, b_rec = trainer.train_metrics(logits, labels, topk)
+                loss_val = float(loss_out[0].item())
+                loss_m.update(loss_val), mrr_m.update(b_mrr), rec_m.update(b_rec)
+                extra = {}
+                if args.reg_lambda > 0.0 and trainer.last_reg is not None:
+                    reg = float(trainer.last_reg.item())
+                    reg_m.update(reg), ratio_m.update(reg / loss_val if loss_val else 0.0)
+                    extra = dict(reg_loss=reg_m.avg, total_aux_ratio=ratio_m.avg)
+                write_train_logs(epoch + 1, trainer.global_step, loss_m.avg, mrr_m.avg, rec_m.avg, trainer.lr(), filename=log_file,
+                                 cutoff=topk, **extra)
+                for m in (loss_m, mrr_m, rec_m, reg_m, ratio_m):
+                    m.reset()
+            if main_rank and trainer.global_step % args.evaluate_steps == 0:
+                ckpt = trainer.state_dict()
+                ckpt["epoch"] = epoch + 1
+                torch.save(ckpt, os.path.join(args.model_save_dir, f"checkpoint_{trainer.global_step}.pth.tar"))
+    if args.distributed:
+        dist.barrier()
+    return trainer
+
+
+def main(argv=None):
+    args = set_env(get_args(argv))
+    if args.rank == 0:
+        os.makedirs(args.run_folder, exist_ok=True)
+        import yaml
+        with open(os.path.join(args.run_folder, "args.yaml"), "w") as fh:
+            yaml.dump({k: (str(v) if isinstance(v, torch.device) else v) for k, v in vars(args).items()}, fh)
+    train(args)
+
+
+if __name__ == "__main__":
+    main()

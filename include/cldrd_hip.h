@@ -102,6 +102,11 @@ int cldrd_loss_fwd_bwd(int kind, const float* y_pred, const float* y_true, const
                        float* grad, float* workspace, int B, int N, float T, float pad_indicator, int mean_reduction,
                        void* stream);
 
+/* Logit-norm regulariser `reg_loss = pred_logits.norm(2) * args.reg_lambda; loss += reg_loss`
+ * (trainer/multistep-curriculum/nway_listwise_1.py:348-350): loss_out[0] += reg, grad[n] += d reg / d logits, *reg_out = reg
+ * (reg_out may be null).  Same stream as, and after, cldrd_loss_fwd_bwd. */
+int cldrd_logit_norm_reg(const float* logits, int n, float reg_lambda, float* loss_out, float* grad, float* reg_out, void* stream);
+
 /* ---- optimizer step (trainer/multistep-curriculum/nway_listwise_1.py:353-367) ------------------------------
  * One flat fp32 buffer for all parameters.  clip out: float[3] = {grad L2 norm, clip coefficient, non-finite flag}. */
 int cldrd_sqnorm_blocks(void);

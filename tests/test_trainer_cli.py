@@ -1,0 +1,81 @@
+"""Command line of cldrd_amd.trainer.nway_listwise (reference trainer/multistep-curriculum/nway_listwise_1.py): flag names and
+defaults, the log file format with the reference's first-call quirk, and (GPU) a short run with checkpoint + resume."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from cldrd_amd.trainer import nway_listwise as T
+
+
+def test_reference_flags_and_defaults():
+    a = T.get_args([])
+    ref = dict(learning_rate=7e-6, weight_decay=0.01, adam_epsilon=1e-8, max_grad_norm=1.0, num_train_epochs=4, warmup_steps=4000,
+               reg_lambda=0.0, query_max_len=30, passage_max_len=256, train_batch_size=8, label_mode="8", logging_steps=50,
+               evaluate_steps=10000, share_weights=False, in_batch_loss=False, all_in_batch_neg=False, n_gpu=1, local_rank=-1,
+               model_name_or_path="sebastian-hofstaetter/distilbert-dot-tas_b-b256-msmarco",
+               tokenizer_name_or_path="distilbert-base-uncased", resume=None, model_checkpoint=None, loss="lambda_mrr")
+    for k, v in ref.items():
+        assert getattr(a, k) == v, k
+    # run_folder / log_dir / model_save_dir are joined under experiment_folder (reference get_args :143-147)
+    b = T.get_args(["--experiment_folder", "/tmp/x", "--run_folder", "r1"])
+    assert b.run_folder == "/tmp/x/r1" and b.log_dir == "/tmp/x/r1/log/" and b.model_save_dir == "/tmp/x/r1/models"
+
+
+def test_train_log_format_and_first_call_quirk(tmp_path):
+    f = str(tmp_path / "train_logs.log")
+    T.write_train_logs(1, 50, 1.23456, 0.5, 0.75, 7e-6, filename=f, cutoff=10)          # header only (reference :78-84)
+    T.write_train_logs(1, 100, 1.23456, 0.5, 0.75, 6.9e-6, filename=f, cutoff=10)
+    lines = open(f).read().splitlines()
+    assert lines[0] == "epoch\tstep\tloss_val\tmrr@10\trecall@10\tlr"
+    assert lines[1] == "1\t100\t1.235\t0.500\t0.750\t0.0000069000" and len(lines) == 2
+    g = str(tmp_path / "reg.log")
+    T.write_train_logs(1, 50, 1.0, 0.0, 0.0, 1e-6, filename=g, reg_loss=0.1, total_aux_ratio=0.2)
+    T.write_train_logs(1, 100, 1.0, 0.0, 0.0, 1e-6, filename=g, reg_loss=0.1, total_aux_ratio=0.2)
+    assert open(g).read().splitlines()[0].endswith("lr\treg_loss\ttotal_aux_ratio")
+    assert open(g).read().splitlines()[1].endswith("\t0.100\t0.200")
+
+
+def test_schedule_and_sharding_helpers():
+    assert T.linear_schedule_factor(0, 4000, 100000) == 0.0 and T.linear_schedule_factor(4000, 4000, 100000) == 1.0
+    assert [i for i in range(10) if T.owns_example(i, 1, 3)] == [1, 4, 7]
+    assert T.no_decay("passage_encoder.embeddings.LayerNorm.weight") and T.no_decay("x.bias")
+    assert not T.no_decay("query_encoder.embeddings.word_embeddings.weight")
+    # substring rule of the reference (:259): DistilBERT's sa_layer_norm / output_layer_norm weights DO get weight decay
+    assert not T.no_decay("passage_encoder.transformer.layer.0.sa_layer_norm.weight")
+
+
+@pytest.mark.gpu
+def test_logit_norm_regulariser_matches_torch():
+    from cldrd_amd import hip_ops as ops
+    x = torch.randn(8, 30, device="cuda")
+    y = torch.zeros(8, 30, device="cuda")
+    y[:, 0] = 1.0
+    loss_out, grad = ops.loss_fwd_bwd("lambda_mrr", x, y)
+    base_loss, base_grad = loss_out.clone(), grad.clone()
+    reg = torch.empty(1, device="cuda")
+    ops.logit_norm_reg(x, 0.05, loss_out, grad, reg)
+    xr = x.clone().requires_grad_(True)
+    r = xr.norm(2) * 0.05
+    r.backward()
+    assert torch.allclose(reg, r.detach().reshape(1), rtol=1e-5)
+    assert torch.allclose(loss_out[0], base_loss[0] + r.detach(), rtol=1e-5)
+    assert torch.allclose(grad, base_grad + xr.grad, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_cli_synthetic_run_checkpoint_and_resume(tmp_path):
+    common = ["--experiment_folder", str(tmp_path), "--run_folder", "run", "--synthetic_steps", "6", "--synthetic_model", "tiny",
+              "--synthetic_nway", "30", "--label_mode", "9", "--passage_max_len", "32", "--query_max_len", "8", "--train_batch_size", "4",
+              "--logging_steps", "2", "--evaluate_steps", "4", "--warmup_steps", "2", "--learning_rate", "1e-3", "--reg_lambda", "0.01"]
+    T.main(common + ["--num_train_epochs", "1"])
+    log = open(os.path.join(str(tmp_path), "run", "log", "train_logs.log")).read().splitlines()
+    assert log[0].split("\t")[:6] == ["epoch", "step", "loss_val", "mrr@10", "recall@10", "lr"] and "reg_loss" in log[0]
+    assert [l.split("\t")[1] for l in log[1:]] == ["4", "6"]              # step 2 only wrote the header (reference quirk)
+    ck = os.path.join(str(tmp_path), "run", "models", "checkpoint_4.pth.tar")
+    c = torch.load(ck, map_location="cpu", weights_only=False)
+    assert c["epoch"] == 1 and c["global_step"] == 4 and all(k.startswith("module.") for k in c["state_dict"])
+    assert {"optimizer", "scheduler"} <= set(c)
+    t2 = T.train(T.set_env(T.get_args(common + ["--num_train_epochs", "2", "--resume", ck])))
+    assert t2.global_step == 4 + 2 * 6          # start_epoch = epoch - 1 = 0 (reference :304): both epochs run again from step 4
