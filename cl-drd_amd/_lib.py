@@ -35,6 +35,7 @@ SIGNATURES = {
     "cldrd_score_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_loss_fwd_bwd": (ci, [ci, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci, vp]),
     "cldrd_logit_norm_reg": (ci, [vp, ci, cf, vp, vp, vp, vp]),
+    "cldrd_lambda_loss_fwd_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cf, cf, ci, ci, ci, vp]),
     "cldrd_sqnorm_blocks": (ci, []),
     "cldrd_grad_clip_coef": (ci, [vp, csz, cf, vp, vp, vp]),
     "cldrd_adamw_step": (ci, [vp, vp, vp, vp, vp, vp, csz, cf, cf, cf, cf, cf, ci, vp, vp]),

@@ -10,7 +10,7 @@
 
 namespace {
 
-enum { LOSS_KL = 0, LOSS_MSE = 1, LOSS_RANKNET = 2, LOSS_LAMBDA = 3 };
+enum { LOSS_KL = 0, LOSS_MSE = 1, LOSS_RANKNET = 2, LOSS_LAMBDA = 3, LOSS_WPOINT = 4 };
 
 __device__ __forceinline__ float NEG_INF_F() { return -__builtin_inff(); }
 
@@ -128,6 +128,16 @@ __global__ __launch_bounds__(256) void loss_row_kernel(int kind, const float* __
             grad[(size_t)b * N + i] = k * dc;
         }
         lsum *= 2.0f / ((float)B * (float)N);              // 2/(B N^2) * N * sum (d - mean)^2
+    } else if (kind == LOSS_WPOINT) {
+        // weighted_pointwise_loss (reference losses/weighted_pointwise.py:3-14): mean over B*N of softplus(-y/T) * weight
+        const float iT = 1.0f / T, k = 1.0f / ((float)B * (float)N);
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            const float z = -s[i] * iT, w = t[i];
+            const float e = __expf(-fabsf(z));
+            lsum += (log1pf(e) + fmaxf(z, 0.f)) * w;
+            grad[(size_t)b * N + i] = -(z > 0.f ? 1.f / (1.f + e) : e / (1.f + e)) * iT * w * k;      // -sigmoid(z)/T * w / (B N)
+        }
+        lsum *= k;
     } else {
         const bool by_rank = (kind == LOSS_LAMBDA);
         if (by_rank) {
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(int kind, const floa
         if (threadIdx.x == 0) { loss_out[0] = l / (float)B; loss_out[1] = 0.f; }
         return;
     }
-    if (kind == LOSS_MSE) {
+    if (kind == LOSS_MSE || kind == LOSS_WPOINT) {
         if (threadIdx.x == 0) { loss_out[0] = l; loss_out[1] = 0.f; }
         return;
     }
@@ -199,6 +209,116 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(int kind, const floa
     } else if (threadIdx.x == 0) {
         loss_out[0] = l; loss_out[1] = c;
     }
+}
+
+// LambdaLoss framework (reference losses/standard_lambda_rank.py:3-117, allRank's lambda_loss): one block per slate.
+// Everything lives in "sorted by prediction" positions p = 0..N-1 (padded items sort last: their keys are -inf):
+//   pair (p, q) counts iff both are real items, p < k and q < k, and (except ndcgLoss1) true[p] > true[q];
+//   term = -log( clamp( clamp(sigmoid(sigma (s_p - s_q)), eps) ^ W_pq, eps) ), natural or base-2 log;
+//   W per weighing scheme from gains G = (2^true - 1 | true - 1) / maxDCG@k and discounts D_p = log2(2 + p).
+// The gradient flows through the score difference only (sort indices and weights are constants for autograd); clamp passes
+// the gradient where its input is >= the bound, as torch.clamp does.
+enum { LL_NONE = 0, LL_NDCG1 = 1, LL_NDCG2 = 2, LL_LAMBDARANK = 3, LL_NDCG2PP = 4, LL_RANKNET = 5, LL_GTDIFF = 6, LL_GTDIFF_POW = 7 };
+
+__global__ __launch_bounds__(256) void lambda_loss_row_kernel(const float* __restrict__ y_pred, const float* __restrict__ y_true,
+                                                               float* __restrict__ grad, float* __restrict__ row_out, int N, int scheme,
+                                                               int k, float eps, float sigma, float mu, float pad, int log2_red,
+                                                               int gain_linear) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* ps = sm;                  // [N] prediction at sorted position (padded: -inf)
+    float* ts = ps + N;              // [N] label at sorted position (padded: -inf)
+    float* G = ts + N;               // [N] gain at sorted position
+    float* gp = G + N;               // [N] gradient at sorted position
+    int* item = (int*)(gp + N);      // [N] original column at sorted position
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* yp = y_pred + (size_t)b * N;
+    const float* yt = y_true + (size_t)b * N;
+    const float NINF = NEG_INF_F();
+    // ---- positions: stable descending order of the (masked) predictions; maxDCG from the descending labels
+    float dcg = 0.f;
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const bool padded = yt[i] == pad;
+        const float si = padded ? NINF : yp[i], ti = padded ? NINF : yt[i];
+        int pos_s = 0, pos_t = 0;
+        for (int j = 0; j < N; ++j) {
+            const bool pj = yt[j] == pad;
+            const float sj = pj ? NINF : yp[j], tj = pj ? NINF : yt[j];
+            pos_s += (sj > si) || (sj == si && j < i);
+            pos_t += (tj > ti) || (tj == ti && j < i);
+        }
+        ps[pos_s] = si; ts[pos_s] = ti; item[pos_s] = i;
+        if (pos_t < k) {
+            const float tc = fmaxf(ti, 0.f);
+            dcg += (gain_linear ? tc - 1.f : exp2f(tc) - 1.f) / log2f(2.f + (float)pos_t);
+        }
+    }
+    const float maxdcg = fmaxf(block_sum(dcg, red), eps);      // block_sum synchronises: ps / ts / item are complete after it
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        const float tc = fmaxf(ts[p], 0.f);
+        G[p] = (gain_linear ? tc - 1.f : exp2f(tc) - 1.f) / maxdcg;
+    }
+    __syncthreads();
+    const float logk = log2_red ? 1.4426950408889634f : 1.0f;
+    auto weight = [&](int p, int q) -> float {
+        const float Dp = log2f(2.f + (float)p), Dq = log2f(2.f + (float)q);
+        float lr = 0.f, n2 = 0.f;
+        if (scheme == LL_LAMBDARANK || scheme == LL_NDCG2PP) lr = fabsf(1.f / Dp - 1.f / Dq) * fabsf(G[p] - G[q]);
+        if (scheme == LL_NDCG2 || scheme == LL_NDCG2PP) {
+            const int dl = p > q ? p - q : q - p;
+            n2 = dl == 0 ? 0.f : fabsf(1.f / log2f(1.f + (float)dl) - 1.f / log2f(2.f + (float)dl)) * fabsf(G[p] - G[q]);
+        }
+        switch (scheme) {
+            case LL_NDCG1: return G[p] / Dp;
+            case LL_NDCG2: return n2;
+            case LL_LAMBDARANK: return lr;
+            case LL_NDCG2PP: return mu * n2 + lr;
+            case LL_GTDIFF: return fabsf(fmaxf(ts[p], 0.f) - fmaxf(ts[q], 0.f));
+            case LL_GTDIFF_POW: { const float a = fmaxf(ts[p], 0.f), c = fmaxf(ts[q], 0.f); return fabsf(a * a - c * c); }
+            default: return 1.f;
+        }
+    };
+    // term(p, q) and d term / d (s_p - s_q)
+    auto term = [&](int p, int q, float& dterm) -> float {
+        const float W = weight(p, q);
+        const float d = fminf(fmaxf(ps[p] - ps[q], -1e8f), 1e8f);
+        const float u = 1.f / (1.f + __expf(-sigma * d));
+        const float a = fmaxf(u, eps);
+        const float bw = powf(a, W);
+        const float c = fmaxf(bw, eps);
+        // d(-log c)/dd = -(1/c) [bw >= eps] W a^(W-1) [u >= eps] sigma u (1-u), and the clamp of d passes inside (-1e8, 1e8)
+        const bool live = bw >= eps && u >= eps && fabsf(ps[p] - ps[q]) <= 1e8f;
+        dterm = live ? -logk * (W * bw / a) / c * sigma * u * (1.f - u) : 0.f;
+        return -logk * __logf(c);
+    };
+    const int kk = k < N ? k : N;
+    float lsum = 0.f, cnt = 0.f;
+    for (int p = threadIdx.x; p < N; p += blockDim.x) {
+        float g = 0.f;
+        if (p < kk && ts[p] != NINF) {
+            for (int q = 0; q < kk; ++q) {
+                if (q == p && scheme != LL_NDCG1) continue;
+                if (ts[q] == NINF) continue;
+                const float td = ts[p] - ts[q];
+                float dt;
+                if (scheme == LL_NDCG1 || td > 0.f) {          // pair (p, q): p is the first index
+                    lsum += term(p, q, dt);
+                    cnt += 1.f;
+                    if (q != p) g += dt;                       // (p, p) only exists for ndcgLoss1: s_p - s_p has no gradient
+                }
+                if (q != p && (scheme == LL_NDCG1 || td < 0.f)) {          // pair (q, p): p is the second index
+                    (void)term(q, p, dt);
+                    g -= dt;
+                }
+            }
+        }
+        gp[p] = g;
+    }
+    __syncthreads();
+    for (int p = threadIdx.x; p < N; p += blockDim.x) grad[(size_t)b * N + item[p]] = gp[p];
+    lsum = block_sum(lsum, red);
+    cnt = block_sum(cnt, red);
+    if (threadIdx.x == 0) { row_out[2 * b] = lsum; row_out[2 * b + 1] = cnt; }
 }
 
 // Logit-norm regulariser of the multistep-curriculum trainers (reference nway_listwise_1.py:348-350):
@@ -248,7 +368,7 @@ extern "C" int cldrd_score_bwd(const float* dlogits, const float* q, const float
 extern "C" int cldrd_loss_fwd_bwd(int kind, const float* y_pred, const float* y_true, const float* batch_weight, float* loss_out,
                                   float* grad, float* workspace, int B, int N, float T, float pad_indicator, int mean_reduction,
                                   void* stream) {
-    CLDRD_CHECK(kind >= 0 && kind <= 3, "loss: unknown kind");
+    CLDRD_CHECK(kind >= 0 && kind <= 4, "loss: unknown kind");
     CLDRD_CHECK(B > 0 && N > 0 && N <= 8192, "loss: need 0 < N <= 8192");
     CLDRD_CHECK(T > 0.f, "loss: T must be positive");
     hipLaunchKernelGGL(loss_row_kernel, dim3(B), dim3(256), 3 * N * sizeof(float), (hipStream_t)stream, kind, y_pred, y_true,
@@ -266,6 +386,23 @@ extern "C" int cldrd_logit_norm_reg(const float* logits, int n, float reg_lambda
                                     void* stream) {
     CLDRD_CHECK(n > 0 && reg_lambda >= 0.f, "logit_norm_reg: bad arguments");
     hipLaunchKernelGGL(logit_reg_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, n, reg_lambda, loss_out, grad, reg_out);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+// lambda_loss of reference losses/standard_lambda_rank.py:3-95.  scheme: 0 None, 1 ndcgLoss1, 2 ndcgLoss2, 3 lambdaRank,
+// 4 ndcgLoss2PP, 5 rankNet, 6 rankNetWeightedByGTDiff, 7 rankNetWeightedByGTDiffPowed; k <= 0 = no truncation.
+// loss_out[2] = {loss, number of pairs}; grad [B, N]; workspace 2*B floats.
+extern "C" int cldrd_lambda_loss_fwd_bwd(const float* y_pred, const float* y_true, float* loss_out, float* grad, float* workspace,
+                                         int B, int N, int scheme, int k, float eps, float sigma, float mu, float pad_indicator,
+                                         int mean_reduction, int log2_reduction, int gain_linear, void* stream) {
+    CLDRD_CHECK(B > 0 && N > 0 && N <= 4096, "lambda_loss: need 0 < N <= 4096");
+    CLDRD_CHECK(scheme >= 0 && scheme <= 7, "lambda_loss: unknown weighing scheme");
+    hipLaunchKernelGGL(lambda_loss_row_kernel, dim3(B), dim3(256), 5 * N * sizeof(float), (hipStream_t)stream, y_pred, y_true, grad,
+                       workspace, N, scheme, k > 0 ? k : N, eps, sigma, mu, pad_indicator, log2_reduction, gain_linear);
+    CLDRD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (int)LOSS_RANKNET, (const float*)workspace, grad,
+                       loss_out, B, N, mean_reduction);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

@@ -187,7 +187,9 @@ def score_bwd(dlogits, q, p, dq, dp, B, N, mode=0):
     call("cldrd_score_bwd", _p(dlogits), _p(q), _p(p), _p(dq), _p(dp), B, N, q.shape[1], mode, _stream())
 
 
-LOSS_KINDS = {"kl_div": 0, "margin_mse": 1, "ranknet": 2, "lambda_mrr": 3}
+LOSS_KINDS = {"kl_div": 0, "margin_mse": 1, "ranknet": 2, "lambda_mrr": 3, "weighted_pointwise": 4}
+LAMBDA_SCHEMES = {None: 0, "ndcgLoss1_scheme": 1, "ndcgLoss2_scheme": 2, "lambdaRank_scheme": 3, "ndcgLoss2PP_scheme": 4, "rankNet_scheme": 5,
+                  "rankNetWeightedByGTDiff_scheme": 6, "rankNetWeightedByGTDiffPowed_scheme": 7}
 
 
 def loss_fwd_bwd(kind, y_pred, y_true, *, batch_weight=None, T=1.0, pad_indicator=-1.0, reduction="mean"):
@@ -206,6 +208,31 @@ def loss_fwd_bwd(kind, y_pred, y_true, *, batch_weight=None, T=1.0, pad_indicato
         _chk(batch_weight, F32, "batch_weight", 1)
     call("cldrd_loss_fwd_bwd", LOSS_KINDS[kind], _p(y_pred), _p(y_true), _p(batch_weight), _p(out), _p(grad), _p(ws), B, N,
          float(T), float(pad_indicator), 1 if reduction == "mean" else 0, _stream())
+    return out, grad
+
+
+def lambda_loss_fwd_bwd(y_pred, y_true, *, eps=1e-4, padded_value_indicator=-1, weighing_scheme=None, k=None, sigma=1.0, mu=10.0,
+                        reduction="mean", reduction_log="natural", gain="power"):
+    """lambda_loss of reference losses/standard_lambda_rank.py:3 -> (loss_out float[2] = {loss, pairs}, grad [B, N])."""
+    if weighing_scheme not in LAMBDA_SCHEMES:
+        raise KeyError(weighing_scheme)               # the reference looks the scheme up in globals()
+    if gain not in ("power", "linear"):
+        raise ValueError(f"{gain} not defined.")
+    if reduction_log not in ("natural", "binary"):
+        raise ValueError("Reduction logarithm base can be either natural or binary")
+    if reduction not in ("mean", "sum"):
+        raise ValueError("Reduction method can be either sum or mean")
+    _chk(y_pred, F32, "y_pred", 2), _chk(y_true, F32, "y_true", 2)
+    if y_pred.shape != y_true.shape:
+        raise ValueError("lambda_loss: y_pred and y_true must have the same shape")
+    y_pred, y_true = y_pred.contiguous(), y_true.contiguous()
+    B, N = y_pred.shape
+    out = torch.empty(2, dtype=F32, device=y_pred.device)
+    grad = torch.empty_like(y_pred)
+    ws = torch.empty(2 * B, dtype=F32, device=y_pred.device)
+    call("cldrd_lambda_loss_fwd_bwd", _p(y_pred), _p(y_true), _p(out), _p(grad), _p(ws), B, N, LAMBDA_SCHEMES[weighing_scheme],
+         0 if k is None else int(k), float(eps), float(sigma), float(mu), float(padded_value_indicator),
+         1 if reduction == "mean" else 0, 1 if reduction_log == "binary" else 0, 1 if gain == "linear" else 0, _stream())
     return out, grad
 
 

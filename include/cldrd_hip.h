@@ -107,6 +107,15 @@ int cldrd_loss_fwd_bwd(int kind, const float* y_pred, const float* y_true, const
  * (reg_out may be null).  Same stream as, and after, cldrd_loss_fwd_bwd. */
 int cldrd_logit_norm_reg(const float* logits, int n, float reg_lambda, float* loss_out, float* grad, float* reg_out, void* stream);
 
+/* lambda_loss of losses/standard_lambda_rank.py:3-95 (allRank LambdaLoss framework): value + d loss / d y_pred in one call.
+ * scheme: 0 None, 1 ndcgLoss1_scheme, 2 ndcgLoss2_scheme, 3 lambdaRank_scheme, 4 ndcgLoss2PP_scheme, 5 rankNet_scheme,
+ * 6 rankNetWeightedByGTDiff_scheme, 7 rankNetWeightedByGTDiffPowed_scheme (:98-127); k <= 0: no truncation; gain_linear:
+ * gain="linear" instead of "power"; log2_reduction: reduction_log="binary".  loss_out[2] = {loss, pairs}; workspace 2*B floats.
+ * cldrd_loss_fwd_bwd kind 4 is weighted_pointwise_loss (losses/weighted_pointwise.py:3-14; y_true carries the weights). */
+int cldrd_lambda_loss_fwd_bwd(const float* y_pred, const float* y_true, float* loss_out, float* grad, float* workspace, int B, int N,
+                              int scheme, int k, float eps, float sigma, float mu, float pad_indicator, int mean_reduction,
+                              int log2_reduction, int gain_linear, void* stream);
+
 /* ---- optimizer step (trainer/multistep-curriculum/nway_listwise_1.py:353-367) ------------------------------
  * One flat fp32 buffer for all parameters.  clip out: float[3] = {grad L2 norm, clip coefficient, non-finite flag}. */
 int cldrd_sqnorm_blocks(void);

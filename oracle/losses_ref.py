@@ -108,3 +108,95 @@ def train_mrr_recall(logits, labels, topk: int = 10):
     if len(keep) == 0:
         return 0.0, 0.0
     return float(np.sum(1.0 / (keep + 1.0)) / len(first)), float(len(keep) / len(first))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# losses/standard_lambda_rank.py:3-127 (allRank lambda_loss + weighing schemes) and losses/weighted_pointwise.py:3-14
+# ---------------------------------------------------------------------------------------------------------------------
+LAMBDA_SCHEMES = (None, "ndcgLoss1_scheme", "ndcgLoss2_scheme", "lambdaRank_scheme", "ndcgLoss2PP_scheme", "rankNet_scheme",
+                  "rankNetWeightedByGTDiff_scheme", "rankNetWeightedByGTDiffPowed_scheme")
+
+
+def lambda_loss(y_pred, y_true, eps=1e-4, padded_value_indicator=-1, weighing_scheme=None, k=None, sigma=1.0, mu=10.0,
+                reduction="mean", reduction_log="natural", gain="power"):
+    """float64 closed form of the reference's lambda_loss: value and d value / d y_pred.
+
+    Slate positions are the stable descending order of the masked predictions; a pair (p, q) of positions counts when both
+    are real, both < k, and (except ndcgLoss1_scheme) label[p] > label[q]; its term is -log(max(max(sigmoid(sigma d), eps)^W, eps))
+    with d = s_p - s_q clamped to +-1e8; the gradient goes through d only."""
+    if weighing_scheme not in LAMBDA_SCHEMES:
+        raise KeyError(weighing_scheme)
+    s, t = _f64(y_pred), _f64(y_true)
+    B, N = s.shape
+    kk = N if k is None else min(int(k), N)
+    grad = np.zeros_like(s)
+    total, count = 0.0, 0
+    logk = 1.0 if reduction_log == "natural" else 1.0 / np.log(2.0)
+    if reduction_log not in ("natural", "binary"):
+        raise ValueError("Reduction logarithm base can be either natural or binary")
+    # the reference builds the discounts in float32 whatever the input dtype (standard_lambda_rank.py:50-51:
+    # torch.log2(1. + pos_idxs.float())), and the discount differences of the schemes are float32 arithmetic too
+    D32 = np.log2((1.0 + np.arange(1, N + 1)).astype(np.float32)).astype(np.float32)
+    inv32 = (np.float32(1.0) / D32).astype(np.float32)
+    D = D32.astype(np.float64)
+    for b in range(B):
+        pad = t[b] == padded_value_indicator
+        sk = np.where(pad, -np.inf, s[b])
+        tk = np.where(pad, -np.inf, t[b])
+        order = np.array(sorted(range(N), key=lambda i: (-sk[i], i)))            # stable descending
+        ps, ts = sk[order], tk[order]
+        tc = np.maximum(ts, 0.0)
+        t_sorted = np.maximum(np.sort(tk)[::-1], 0.0)
+        if gain == "power":
+            maxdcg = max(float(np.sum(((2.0 ** t_sorted - 1.0) / D)[:kk])), eps)
+            G = (2.0 ** tc - 1.0) / maxdcg
+        elif gain == "linear":
+            maxdcg = max(float(np.sum(((t_sorted - 1.0) / D)[:kk])), eps)
+            G = (tc - 1.0) / maxdcg
+        else:
+            raise ValueError(f"{gain} not defined.")
+
+        def weight(p, q):
+            lr = float(np.abs(inv32[p] - inv32[q])) * abs(G[p] - G[q])
+            dl = abs(p - q)
+            n2 = 0.0 if dl == 0 else float(np.abs(inv32[dl - 1] - inv32[dl])) * abs(G[p] - G[q])
+            return {None: 1.0, "rankNet_scheme": 1.0, "ndcgLoss1_scheme": G[p] / D[p], "ndcgLoss2_scheme": n2, "lambdaRank_scheme": lr,
+                    "ndcgLoss2PP_scheme": mu * n2 + lr, "rankNetWeightedByGTDiff_scheme": abs(tc[p] - tc[q]),
+                    "rankNetWeightedByGTDiffPowed_scheme": abs(tc[p] ** 2 - tc[q] ** 2)}[weighing_scheme]
+
+        gp = np.zeros(N)
+        for p in range(kk):
+            if not np.isfinite(ts[p]):
+                continue
+            for q in range(kk):
+                if not np.isfinite(ts[q]):
+                    continue
+                if weighing_scheme != "ndcgLoss1_scheme" and not ts[p] - ts[q] > 0:
+                    continue
+                W = weight(p, q)
+                draw = ps[p] - ps[q]
+                d = min(max(draw, -1e8), 1e8)
+                u = 1.0 / (1.0 + np.exp(-sigma * d))
+                a = max(u, eps)
+                bw = a ** W
+                c = max(bw, eps)
+                total += -logk * np.log(c)
+                count += 1
+                if p != q and bw >= eps and u >= eps and abs(draw) <= 1e8:
+                    dt = -logk * (W * bw / a) / c * sigma * u * (1.0 - u)
+                    gp[p] += dt
+                    gp[q] -= dt
+        grad[b, order] = gp
+    if reduction == "sum":
+        return float(total), grad
+    if reduction == "mean":
+        return (float(total) / count if count else float("nan")), (grad / count if count else grad * np.nan)
+    raise ValueError("Reduction method can be either sum or mean")
+
+
+def weighted_pointwise(y_pred, y_weight, T: float = 1.0):
+    s, w = _f64(y_pred), _f64(y_weight)
+    z = -s / T
+    val = float(np.mean(np.logaddexp(0.0, z) * w))
+    grad = -(1.0 / (1.0 + np.exp(-z))) / T * w / s.size
+    return val, grad

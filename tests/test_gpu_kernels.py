@@ -434,3 +434,62 @@ def test_attention_dropout_fwd_bwd_against_the_oracle_mask(nseq, L, H):
     ops.attention_bwd(qkv.to(DEV), None, ctx, dctx.to(DEV), lse, dqkv, nseq, L, H, dropout_p=p, seed=seed)
     g = qv.grad.float()
     close(dqkv, g, 1 / 32, 2e-2 * g.abs().max().item(), "attention bwd with dropout")
+
+
+# ------------------------------------------------------------------------------------------------ lambda_loss / weighted pointwise
+import json as _json
+
+from oracle import losses_ref as LR
+
+_G2 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses2.npz"))
+_META2 = _json.loads(str(_G2["meta"]))
+
+
+@pytest.mark.parametrize("name", sorted(_META2, key=lambda s: int(s[4:])))
+def test_lambda_loss_kernel_against_reference_goldens(name):
+    """fp32 kernel vs the reference's float64 autograd (tests/golden/losses2.npz): 2e-4 relative on the value, 2e-4 of the largest
+    gradient entry on the gradient (exp2 / pow / log in fp32)."""
+    from cldrd_amd.losses import lambda_loss
+    kw = _META2[name]
+    yp = torch.tensor(_G2["y_pred"], dtype=torch.float32, device=DEV, requires_grad=True)
+    yt = torch.tensor(_G2["y_true"], dtype=torch.float32, device=DEV)
+    out = lambda_loss(yp, yt, **kw)
+    out.backward()
+    ref_v, ref_g = float(_G2[name + ".value"]), _G2[name + ".grad"]
+    assert abs(out.item() - ref_v) <= 2e-4 * abs(ref_v) + 1e-6, (kw, out.item(), ref_v)
+    assert np.abs(yp.grad.cpu().numpy() - ref_g).max() <= 2e-4 * np.abs(ref_g).max() + 1e-7, kw
+
+
+def test_lambda_loss_demo_and_bigger_slate_vs_oracle():
+    from cldrd_amd.losses import lambda_loss
+    for t, printed in (("demo.t1", 0.0127), ("demo.t2", 0.0110)):
+        yp = torch.tensor(_G2["demo.y_pred"], device=DEV)
+        out = lambda_loss(yp, torch.tensor(_G2[t], device=DEV), weighing_scheme="ndcgLoss1_scheme", reduction_log="natural")
+        assert round(out.item(), 4) == printed
+    B, N = 8, 200                                              # cfg3-sized slates, against the float64 oracle
+    yp = rnd(50, (B, N), 3.0)
+    yt = torch.from_numpy(syn.labels_mode9(B, 30)).repeat(1, 7)[:, :N].contiguous()
+    yt[:, 190:] = -1.0
+    for sch in (None, "ndcgLoss2PP_scheme", "lambdaRank_scheme", "rankNetWeightedByGTDiffPowed_scheme"):
+        ypd = yp.to(DEV).requires_grad_(True)
+        out = lambda_loss(ypd, yt.to(DEV), weighing_scheme=sch, k=50)
+        out.backward()
+        v, g = LR.lambda_loss(yp.numpy(), yt.numpy(), weighing_scheme=sch, k=50)
+        assert abs(out.item() - v) <= 2e-4 * abs(v) + 1e-6
+        assert np.abs(ypd.grad.cpu().numpy() - g).max() <= 5e-4 * np.abs(g).max() + 1e-8
+
+
+def test_weighted_pointwise_kernel():
+    from cldrd_amd.losses import weighted_pointwise_loss
+    for i in (0, 1):
+        yp = torch.tensor(_G2[f"wp.demo{i}.pred"], dtype=torch.float32, device=DEV, requires_grad=True)
+        out = weighted_pointwise_loss(yp, torch.tensor(_G2["wp.weight"], device=DEV))
+        out.backward()
+        assert abs(out.item() - float(_G2[f"wp.demo{i}.value"])) < 1e-6
+        assert np.allclose(yp.grad.cpu().numpy(), _G2[f"wp.demo{i}.grad"], rtol=1e-4, atol=1e-8)
+    yp = torch.tensor(_G2["y_pred"], dtype=torch.float32, device=DEV, requires_grad=True)
+    out = weighted_pointwise_loss(yp, torch.tensor(_G2["wp.rand.weight"], dtype=torch.float32, device=DEV), T=0.7)
+    out.backward()
+    assert abs(out.item() - float(_G2["wp.rand.value"])) < 1e-5 and np.allclose(yp.grad.cpu().numpy(), _G2["wp.rand.grad"], rtol=1e-4, atol=1e-8)
+    with pytest.raises(AssertionError):
+        weighted_pointwise_loss(yp, -torch.ones_like(yp))
