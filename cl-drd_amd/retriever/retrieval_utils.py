@@ -268,12 +268,90 @@ class FlatIPIndex:
         return idx
 
 
-def write_index(index: FlatIPIndex, path: str):
-    index.write(path)
+def write_index(index: FlatIPIndex, path: str, faiss_format: bool = False):
+    """``faiss.write_index`` of the reference (index_text.py:103).  Default: this package's memory-mappable pair of files;
+    ``faiss_format=True`` writes faiss' own ``IndexIDMap(IndexFlatIP)`` serialisation to ``path`` (see ``write_faiss_index``)."""
+    if faiss_format:
+        write_faiss_index(index, path)
+    else:
+        index.write(path)
 
 
 def read_index(path: str) -> FlatIPIndex:
+    """``faiss.read_index`` of the reference (retrieve_top_passages.py:77): reads either format (a faiss file starts with the
+    fourcc ``IxMp`` / ``IxM2`` / ``IxFI``)."""
+    if os.path.isfile(path):
+        with open(path, "rb") as fh:
+            magic = fh.read(4)
+        if magic in (b"IxMp", b"IxM2", b"IxFI"):
+            return read_faiss_index(path)
     return FlatIPIndex.read(path)
+
+
+# ---- faiss binary interop (SURVEY.md section 8f row 4) -----------------------------------------------------------------
+# Layout restated from faiss' published serialisation (faiss/impl/index_write.cpp, v1.7+), little endian:
+#   index header : int32 d | int64 ntotal | int64 dummy (1 << 20) | int64 dummy | uint8 is_trained | int32 metric_type
+#                  (0 = inner product, 1 = L2; a float32 metric_arg follows only for metric_type > 1)
+#   "IxFI" flat  : header | uint64 n_floats (= ntotal * d) | n_floats float32, row major
+#   "IxMp" idmap : header | <nested index> | uint64 n_ids | n_ids int64            ("IxM2" = IndexIDMap2, same payload)
+# PARITY UNPINNED: faiss is not installed in the build image, so these two functions are checked against each other and
+# against a hand-assembled byte string only (tests/test_oracle_optim_retrieval.py), not against a file written by faiss.
+def _faiss_header(d: int, ntotal: int) -> bytes:
+    import struct
+    return struct.pack("<iqqqBi", d, ntotal, 1 << 20, 1 << 20, 1, 0)
+
+
+def write_faiss_index(index: "FlatIPIndex", path: str):
+    import struct
+    emb = np.ascontiguousarray(index.embeddings, dtype=np.float32)
+    n, d = emb.shape
+    ids = np.asarray(index.ids if index.ids is not None else np.arange(n) + index.id_offset, dtype=np.int64)
+    with open(path, "wb") as fh:
+        fh.write(b"IxMp" + _faiss_header(d, n))
+        fh.write(b"IxFI" + _faiss_header(d, n) + struct.pack("<Q", n * d))
+        fh.write(emb.tobytes())
+        fh.write(struct.pack("<Q", n))
+        fh.write(ids.tobytes())
+
+
+def read_faiss_index(path: str) -> "FlatIPIndex":
+    import struct
+
+    def header(fh):
+        d, ntotal, _, _, trained, metric = struct.unpack("<iqqqBi", fh.read(33))
+        if metric > 1:
+            fh.read(4)
+        if metric != 0:
+            raise ValueError("only inner-product flat indexes are supported (the reference builds IndexFlatIP)")
+        return d, ntotal
+
+    def flat(fh):
+        d, ntotal = header(fh)
+        (nfl,) = struct.unpack("<Q", fh.read(8))
+        if nfl != ntotal * d:
+            raise ValueError("faiss flat index: vector size does not match ntotal * d")
+        return d, np.frombuffer(fh.read(4 * nfl), dtype=np.float32).reshape(ntotal, d)
+
+    with open(path, "rb") as fh:
+        magic = fh.read(4)
+        if magic in (b"IxMp", b"IxM2"):
+            header(fh)
+            if fh.read(4) != b"IxFI":
+                raise ValueError("faiss id map: nested index is not IndexFlatIP")
+            d, emb = flat(fh)
+            (nid,) = struct.unpack("<Q", fh.read(8))
+            ids = np.frombuffer(fh.read(8 * nid), dtype=np.int64)
+        elif magic == b"IxFI":
+            d, emb = flat(fh)
+            ids = None
+        else:
+            raise ValueError(f"not a faiss flat inner-product index (fourcc {magic!r})")
+    idx = FlatIPIndex(d)
+    if ids is None:
+        idx.add(emb)
+    else:
+        idx.add_with_ids(emb, ids)
+    return idx
 
 
 def construct_flatindex_from_embeddings(embeddings, ids):

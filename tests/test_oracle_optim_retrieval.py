@@ -79,3 +79,29 @@ def test_merge_shards_equals_global():
     parts = [R.flat_ip_search(emb[lo:lo + 250], np.arange(lo, lo + 250), q, 20) for lo in range(0, 1000, 250)]
     Dm, Im = R.merge_shard_results([p[0] for p in parts], [p[1] for p in parts], 20)
     assert np.array_equal(Im, I) and np.array_equal(Dm, D)
+
+
+def test_faiss_binary_layout_round_trip_and_hand_assembled_bytes(tmp_path):
+    """IndexIDMap(IndexFlatIP) file layout (restated from faiss' index_write.cpp; faiss itself is absent -> unpinned):
+    the writer produces exactly the hand-assembled byte string, the reader inverts it, read_index auto-detects the format."""
+    import struct
+    from cldrd_amd.retriever import retrieval_utils as RU
+    emb = (np.arange(12, dtype=np.float32).reshape(4, 3) - 5.0) / 4.0
+    ids = np.array([7, 8, 100, 3], dtype=np.int64)
+    idx = RU.FlatIPIndex(3)
+    idx.add_with_ids(emb, ids)
+    path = str(tmp_path / "small.index")
+    RU.write_index(idx, path, faiss_format=True)
+    hdr = struct.pack("<i", 3) + struct.pack("<q", 4) + struct.pack("<q", 1 << 20) * 2 + b"\x01" + struct.pack("<i", 0)
+    want = b"IxMp" + hdr + b"IxFI" + hdr + struct.pack("<Q", 12) + emb.tobytes() + struct.pack("<Q", 4) + ids.tobytes()
+    assert open(path, "rb").read() == want
+    back = RU.read_index(path)
+    assert back.ntotal == 4 and back.d == 3 and np.array_equal(np.asarray(back.embeddings), emb) and np.array_equal(back.ids, ids)
+    # a bare IndexFlatIP file (no id map)
+    bare = str(tmp_path / "bare.index")
+    open(bare, "wb").write(b"IxFI" + hdr + struct.pack("<Q", 12) + emb.tobytes())
+    b2 = RU.read_index(bare)
+    assert b2.ntotal == 4 and np.array_equal(np.asarray(b2.embeddings), emb)
+    with pytest.raises(ValueError):
+        open(bare, "wb").write(b"IxFI" + hdr[:-4] + struct.pack("<i", 1) + struct.pack("<Q", 12) + emb.tobytes())     # L2 metric
+        RU.read_index(bare)
