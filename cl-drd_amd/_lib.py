@@ -41,6 +41,7 @@ SIGNATURES = {
     "cldrd_adamw_step": (ci, [vp, vp, vp, vp, vp, vp, csz, cf, cf, cf, cf, cf, ci, vp, vp]),
     "cldrd_cast_bf16": (ci, [vp, vp, csz, vp]),
     "cldrd_transpose_cast_batched": (ci, [vp, vp, vp, vp, ci, ci, vp]),
+    "cldrd_transpose_bf16_batched": (ci, [vp, vp, vp, vp, ci, ci, vp]),
     "cldrd_topk_scan_filter": (ci, [vp, vp, ci, C.c_longlong, ci, vp, vp, vp, vp, ci, vp]),
     "cldrd_topk_scan_filter_tiled": (ci, [vp, vp, ci, C.c_longlong, ci, vp, vp, vp, vp, ci, vp]),
     "cldrd_topk_kth_largest": (ci, [vp, ci, ci, ci, ci, vp, vp]),

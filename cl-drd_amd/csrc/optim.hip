@@ -115,6 +115,37 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
     }
 }
 
+// Same batch of transposes from the bf16 shadow (already written by the optimizer step) instead of the fp32 master: half the
+// bytes read, 64 x 64 tiles, 16-byte global accesses on both sides.  Needs rows % 64 == 0 and cols % 64 == 0; tile_prefix
+// counts 64 x 64 tiles here.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                              const long long* __restrict__ desc, const int* __restrict__ tile_prefix,
+                                                              int ndesc) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];          // 144-byte rows: the column gathers below spread over banks
+    int i = 0;
+    while (i + 1 < ndesc && (int)blockIdx.x >= tile_prefix[i + 1]) ++i;
+    const long long so = desc[4 * i], dof = desc[4 * i + 1];
+    const int rows = (int)desc[4 * i + 2], cols = (int)desc[4 * i + 3];
+    const int t = blockIdx.x - tile_prefix[i];
+    const int tcols = cols / 64;
+    const int r0 = (t / tcols) * 64, c0 = (t % tcols) * 64;
+    const int part = threadIdx.x & 7, line = threadIdx.x >> 3;            // 8 threads x 16 B per 64-element line, 32 lines per pass
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int r = pass * 32 + line;
+        *(uint4*)&tile[r][part * 8] = *(const uint4*)(src + so + (long long)(r0 + r) * cols + c0 + part * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int c = pass * 32 + line;                                    // output line c holds source rows r0 .. r0 + 63
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[part * 8 + 2 * j][c] | ((uint32_t)tile[part * 8 + 2 * j + 1][c] << 16);
+        *(uint4*)(dst + dof + (long long)(c0 + c) * rows + r0 + part * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 }  // namespace
 
 static inline int stream_blocks(size_t n4) {
@@ -163,6 +194,17 @@ extern "C" int cldrd_transpose_cast_batched(const float* src, void* dst, const l
                                             int total_tiles, void* stream) {
     CLDRD_CHECK(ndesc > 0 && total_tiles > 0, "transpose_cast_batched: empty");
     hipLaunchKernelGGL(transpose_cast_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, desc, tile_prefix, ndesc);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+// dst[cols, rows] (bf16) = src[rows, cols]^T (bf16) for a batch of matrices; desc / tile_prefix as above with 64 x 64 tiles.
+extern "C" int cldrd_transpose_bf16_batched(const void* src, void* dst, const long long* desc, const int* tile_prefix, int ndesc,
+                                            int total_tiles, void* stream) {
+    CLDRD_CHECK(ndesc > 0 && total_tiles > 0, "transpose_bf16_batched: empty");
+    CLDRD_CHECK(((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0), "transpose_bf16_batched: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, desc,
+                       tile_prefix, ndesc);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

@@ -305,6 +305,14 @@ class HipEncoder(nn.Module):
         dev = self.flat_p.device
         self._t_desc = (torch.tensor(desc, dtype=torch.int64, device=dev), torch.tensor(prefix, dtype=torch.int32, device=dev),
                         len(desc) // 4, tiles)
+        # the same batch for the bf16 -> bf16 kernel (64 x 64 tiles) when every matrix allows it
+        self._t_desc64 = None
+        if all(desc[k + 2] % 64 == 0 and desc[k + 3] % 64 == 0 and desc[k] % 8 == 0 and desc[k + 1] % 8 == 0 for k in range(0, len(desc), 4)):
+            p64, t64 = [0], 0
+            for k in range(0, len(desc), 4):
+                t64 += (desc[k + 2] // 64) * (desc[k + 3] // 64)
+                p64.append(t64)
+            self._t_desc64 = (torch.tensor(p64, dtype=torch.int32, device=dev), t64)
 
     def refresh_shadows(self, need_transposed: bool = True, cast: bool = True):
         """bf16 copies of the weights for the MFMA GEMMs (+ transposed copies for the data-gradient GEMMs)."""
@@ -320,7 +328,10 @@ class HipEncoder(nn.Module):
             if self._t_desc is None:
                 self._build_t_desc()
             desc, prefix, nd, tiles = self._t_desc
-            ops.transpose_cast_batched(self.flat_p, self.flat_t, desc, prefix, nd, tiles)
+            if self._t_desc64 is not None:          # flat_h is current here (cast above, or written by the optimizer step)
+                ops.transpose_bf16_batched(self.flat_h, self.flat_t, desc, self._t_desc64[0], nd, self._t_desc64[1])
+            else:
+                ops.transpose_cast_batched(self.flat_p, self.flat_t, desc, prefix, nd, tiles)
             self._t_fresh = True
         else:
             self._t_fresh = False

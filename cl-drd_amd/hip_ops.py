@@ -272,6 +272,11 @@ def transpose_cast_batched(src, dst, desc, tile_prefix, ndesc, total_tiles):
     call("cldrd_transpose_cast_batched", _p(src), _p(dst), _p(desc), _p(tile_prefix), ndesc, total_tiles, _stream())
 
 
+def transpose_bf16_batched(src, dst, desc, tile_prefix, ndesc, total_tiles):
+    _chk(src, BF16, "src", 1), _chk(dst, BF16, "dst", 1)
+    call("cldrd_transpose_bf16_batched", _p(src), _p(dst), _p(desc), _p(tile_prefix), ndesc, total_tiles, _stream())
+
+
 # ---------------------------------------------------------------------------------------------------- top-k search
 def topk_scan_filter(Qb, Pb, thr, counts, cand_rows, cand_scores, tiled=False):
     _chk(Qb, BF16, "Qb", 2), _chk(Pb, BF16, "Pb", 2), _chk(thr, F32, "thr", 1)

@@ -126,6 +126,9 @@ int cldrd_adamw_step(float* p, const float* g, float* m, float* v, const unsigne
 int cldrd_cast_bf16(const float* src, void* dst, size_t n, void* stream);
 int cldrd_transpose_cast_batched(const float* src, void* dst, const long long* desc, const int* tile_prefix, int ndesc,
                                  int total_tiles, void* stream);
+/* Same transposes from the bf16 shadow (rows and cols multiples of 64, offsets multiples of 8 elements; tile_prefix in 64x64 tiles). */
+int cldrd_transpose_bf16_batched(const void* src, void* dst, const long long* desc, const int* tile_prefix, int ndesc, int total_tiles,
+                                 void* stream);
 
 /* ---- exact inner-product top-k over one index shard (retriever/retrieval_utils.py:131-153 -> faiss IndexFlatIP.search) ---
  * scan:    bf16 MFMA scores Q[nq,d] . P[rows,d]^T; (query, row) pairs with score >= thr[query] are appended to the query's

@@ -493,3 +493,22 @@ def test_weighted_pointwise_kernel():
     assert abs(out.item() - float(_G2["wp.rand.value"])) < 1e-5 and np.allclose(yp.grad.cpu().numpy(), _G2["wp.rand.grad"], rtol=1e-4, atol=1e-8)
     with pytest.raises(AssertionError):
         weighted_pointwise_loss(yp, -torch.ones_like(yp))
+
+
+def test_transpose_bf16_batched_matches_torch():
+    shapes = [(128, 64), (768, 2304), (192, 3072)]
+    total = sum(r * c for r, c in shapes)
+    src = bf(rnd(60, (total,))).to(DEV)
+    dst = torch.zeros(total, dtype=torch.bfloat16, device=DEV)
+    desc, prefix, off, tiles = [], [0], 0, 0
+    for r, c in shapes:
+        desc += [off, off, r, c]
+        off += r * c
+        tiles += (r // 64) * (c // 64)
+        prefix.append(tiles)
+    ops.transpose_bf16_batched(src, dst, torch.tensor(desc, dtype=torch.int64, device=DEV), torch.tensor(prefix, dtype=torch.int32, device=DEV),
+                               len(shapes), tiles)
+    off = 0
+    for r, c in shapes:
+        assert torch.equal(dst[off:off + r * c].view(c, r), src[off:off + r * c].view(r, c).T), (r, c)
+        off += r * c
