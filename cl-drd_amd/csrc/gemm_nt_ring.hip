@@ -20,7 +20,11 @@ namespace {
 constexpr int BM = 256, BK = 64;
 constexpr int A_BYTES = BM * BK * 2;     // 32 KiB
 
-template <int BN, int EPI>
+// ABL != 0: timing experiments only (tools/gemm_ablate.py; results are wrong): 1 no s_barrier, 2 no LDS-DMA inside the K loop,
+// 3 neither (and no vmcnt waits), 4 no fragment reads inside the K loop, 6 DMA issued but never waited for.
+// Measured at M = 32768, N = 768, K = 3072 (us): full 144 | 1: 139-144 | 2: 118 | 3: 112 | 4: 145 | 6: 140 -> the fragment reads are
+// free, barrier + waits cost ~4 %, the ISSUE of the LDS-DMA pieces ~16 % (spreading them one per MFMA row was worse: 157).
+template <int BN, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int B_BYTES = BN * BK * 2;
@@ -118,15 +122,24 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
         __builtin_amdgcn_sched_barrier(0);
         if (sync) {
             // K tile kt+1 must have landed; with a third slot K tile kt+2 (issued one tile ago) stays in flight
-            if (NSLOT == 3 && kt + 2 < nk_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+            if (ABL == 3 || ABL == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (NSLOT == 3 && kt + 2 < nk_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (ABL != 1 && ABL != 3) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (!late_wave && kt + NSLOT < nk_) stage(slot, kt + NSLOT);  // slot of K tile kt: its fragments are in registers everywhere
+            if (ABL != 2 && ABL != 3 && !late_wave && kt + NSLOT < nk_) stage(slot, kt + NSLOT);  // slot of K tile kt: its fragments are in registers everywhere
             __builtin_amdgcn_sched_barrier(0);
-        } else if (late_wave && slot >= 0 && kt + NSLOT < nk_) {
+        } else if (ABL != 2 && ABL != 3 && late_wave && slot >= 0 && kt + NSLOT < nk_) {
             stage(slot, kt + NSLOT);                        // (slot, kt) of the previous K tile, freed at its barrier
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ABL == 4) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bn[t] = bc[t];
+#pragma unroll
+            for (int mt = 2; mt < 8; ++mt) mfma_row(mt, bc);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
         }
         af[0] = *(const bf16x8*)(na);
         af[1] = *(const bf16x8*)(na + 16 * 128);
@@ -191,8 +204,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     }
 }
 
+template <int BN, int ABL>
+int launch_ring_abl(const GemmNtArgs& a, hipStream_t st) {
+    constexpr int lds = ((3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2) * (A_BYTES + BN * BK * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, 0, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nblk = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, 0, ABL>), dim3(nblk), dim3(512), lds, st, a);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int BN, int EPI>
 int launch_ring_epi(const GemmNtArgs& a, hipStream_t st) {
+    if (EPI == 0 && BN == 192) {                       // ablations exist for the plain BN = 192 instance only
+        static int abl = -1;
+        if (abl < 0) { const char* e = getenv("CLDRD_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
+        switch (abl) {
+            case 1: return launch_ring_abl<192, 1>(a, st);
+            case 2: return launch_ring_abl<192, 2>(a, st);
+            case 3: return launch_ring_abl<192, 3>(a, st);
+            case 4: return launch_ring_abl<192, 4>(a, st);
+            case 6: return launch_ring_abl<192, 6>(a, st);
+            default: break;
+        }
+    }
     constexpr int lds = ((3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2) * (A_BYTES + BN * BK * 2);
     static bool attr_set = false;
     if (!attr_set) {
