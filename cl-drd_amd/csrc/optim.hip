@@ -50,15 +50,27 @@ struct AdamArgs {
     size_t n4; float lr, beta1, beta2, eps, wd, step_size; const float* coef;
 };
 
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ntload4(const float4* p) {
+    const f32x4_t t = __builtin_nontemporal_load((const f32x4_t*)p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void ntstore4(float4* p, const float4& v) {
+    const f32x4_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (f32x4_t*)p);
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     const float coef = a.coef ? a.coef[1] : 1.0f;
     const bool skip = a.coef && a.coef[2] != 0.f;        // non-finite gradient norm: leave the weights untouched
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += stride) {
-        float4 p = ((float4*)a.p)[i];
+        // p, g, m, v are streamed once per step (4 GB): non-temporal, so they do not push the bf16 shadows (read by the next
+        // step's GEMMs) and the activations out of the Infinity Cache
+        float4 p = ntload4((const float4*)a.p + i);
         if (!skip) {
-            const float4 g = ((const float4*)a.g)[i];
-            float4 m = ((float4*)a.m)[i], v = ((float4*)a.v)[i];
+            const float4 g = ntload4((const float4*)a.g + i);
+            float4 m = ntload4((const float4*)a.m + i), v = ntload4((const float4*)a.v + i);
             const bool dec = a.decay[i >> 4] != 0;         // flag per 64 elements
             const float gg[4] = {g.x * coef, g.y * coef, g.z * coef, g.w * coef};
             float pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
@@ -70,9 +82,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
                 if (dec) pp[j] -= a.lr * a.wd * pp[j];
             }
             p = make_float4(pp[0], pp[1], pp[2], pp[3]);
-            ((float4*)a.p)[i] = p;
-            ((float4*)a.m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-            ((float4*)a.v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            ntstore4((float4*)a.p + i, p);
+            ntstore4((float4*)a.m + i, make_float4(mm[0], mm[1], mm[2], mm[3]));
+            ntstore4((float4*)a.v + i, make_float4(vv[0], vv[1], vv[2], vv[3]));
         }
         if (a.shadow) {
             uint2 o; o.x = pack2bf(p.x, p.y); o.y = pack2bf(p.z, p.w);
