@@ -52,8 +52,11 @@ __device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld,
 
 // DROP is a template parameter: as a run-time test hipcc branched on it per element (16 branches per MFMA tile, with the
 // accumulators re-read from AGPRs on both sides), which made these kernels VALU-bound.
+//
+// Forward with all the scores of a query block in registers (16 NKB accumulators): for L <= 128 this is ~7 % faster than the
+// streaming form below (16 score MFMAs back to back, one softmax pass, 16 P.V MFMAs) and is what the train step uses.
 template <int NKB, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
+__global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -153,13 +156,121 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     }
 }
 
+
+// Forward, streaming over the key blocks with a running maximum (one pass, "flash" form): per 32-key block
+//   S^T = K_kb . Q^T (lane = query column)  ->  m' = max(m, colmax)  ->  O^T *= 2^(m - m'),  l = l 2^(m - m') + sum p,
+//   p = 2^(s - m')  ->  O^T += V_kb^T . (keep . p)         (the S^T tile is the B operand as it is; V through ds_read_tr)
+// and at the end ctx = O^T / l (x 1/(1-p_drop)), LSE = m + log2 l.  Everything per query is a per-lane scalar because the
+// output is accumulated TRANSPOSED (lane = query column, registers = head dimension): no cross-lane traffic but one
+// shuffle per block, and 16 + 32 accumulator registers whatever L is (the first version kept all of S in registers:
+// 16 NKB of them, which spilled from L = 192 up and ran 2x slower at L = 256).
 template <int NKB, bool DROP>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
+__global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                        bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
+                                                        float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Lp = 32 * NKB;
+    constexpr int NWAVES = NKB > 4 ? 8 : 4;          // one query / key block per wave up to L = 256 (2 waves per SIMD at one workgroup per CU)
+    char* sQ = smem;
+    char* sK = sQ + Lp * RSB;
+    char* sV = sK + Lp * RSB;
+    float* sBias = (float*)(sV + Lp * RSB);
+    const int seq = blockIdx.x / H, hd = blockIdx.x % H;
+    const int dm = H * 64, ld = 3 * dm;
+    const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
+    load_tile(sQ, base, ld, L, Lp);
+    load_tile(sK, base + dm, ld, L, Lp);
+    load_tile(sV, base + 2 * dm, ld, L, Lp);
+    for (int k = threadIdx.x; k < Lp; k += blockDim.x)
+        sBias[k] = (k < L && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const float scale2 = scale * LOG2E;      // scores in the log2 domain (v_exp_f32 is 2^x)
+    for (int qb = wid; qb < NKB; qb += NWAVES) {
+        bf16x8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = row_frag(sQ, qb * 32 + r, s, h);
+        const int q = qb * 32 + r;
+        // dropout mask element (row, col) = ((seq*H + hd)*L + q, key); keys rowmap(t, h), t even / odd, are a column pair
+        const uint32_t rk = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + q));
+        float m = NEG_BIG * 4.f, lsum = 0.f;                       // lsum: this half's share of the denominator
+        f32x16 O[2] = {(f32x16){0.f}, (f32x16){0.f}};              // O[dt][t] = ctx^T[d = 32 dt + rowmap(t, h)][q]
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 S = (f32x16){0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], S, 0, 0, 0);
+            // S[t] = <K[key], Q[q]> with key = 32 kb + rowmap(t, h); keys rowmap(4u .. 4u+3, h) = 8u + 4h + 0..3 are consecutive
+            float v[16];
+            float mloc = NEG_BIG * 4.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[4 * u + j] = fmaf(S[4 * u + j], scale2, bb[j]);
+                    mloc = fmaxf(mloc, v[4 * u + j]);
+                }
+            }
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            const float mn = fmaxf(m, mloc);
+            const float alpha = __builtin_amdgcn_exp2f(m - mn);
+            m = mn;
+            float psum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
+                float p0 = __builtin_amdgcn_exp2f(v[t] - mn), p1 = __builtin_amdgcn_exp2f(v[t + 1] - mn);
+                psum += p0 + p1;
+                if (DROP) {
+                    const uint32_t hh = drop_pair(rk, (uint32_t)(kb * 32 + rowmap(t, h)));
+                    p0 = drop_keep_lo(hh, drop_thresh) ? p0 : 0.f;
+                    p1 = drop_keep_hi(hh, drop_thresh) ? p1 : 0.f;
+                }
+                v[t] = p0; v[t + 1] = p1;
+            }
+            lsum = fmaf(lsum, alpha, psum);
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int t = 0; t < 16; ++t) O[dt][t] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = pack8(v + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, O[dt], 0, 0, 0);
+            }
+        }
+        const float l = lsum + __shfl_xor(lsum, 32, 64);
+        if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (m + __log2f(l)) * LN2;
+        const float inv = (DROP ? drop_scale : 1.0f) / l;
+        if (q < L) {
+            bf16_t* orow = ctx + ((size_t)seq * L + q) * dm + hd * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    uint2 o;
+                    o.x = pack2bf(O[dt][4 * u] * inv, O[dt][4 * u + 1] * inv);
+                    o.y = pack2bf(O[dt][4 * u + 2] * inv, O[dt][4 * u + 3] * inv);
+                    *(uint2*)(orow + dt * 32 + 8 * u + 4 * h) = o;
+                }
+        }
+    }
+}
+
+template <int NKB, bool DROP>
+__global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
+    constexpr int NWAVES = NKB > 4 ? 8 : 4;          // one query / key block per wave up to L = 256 (2 waves per SIMD at one workgroup per CU)
     char* sQ = smem;
     char* sK = sQ + Lp * RSB;
     char* sV = sK + Lp * RSB;
@@ -208,7 +319,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     const float scale2 = scale * LOG2E;      // scores, mask bias and LSE live in the log2 domain (v_exp_f32 is 2^x)
 
     // ---------------- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks ----------------
-    for (int kb = wid; kb < NKB; kb += 4) {
+    for (int kb = wid; kb < NKB; kb += NWAVES) {
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { kf[s] = row_frag(sK, kb * 32 + r, s, h); vf[s] = row_frag(sV, kb * 32 + r, s, h); }
@@ -278,7 +389,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
     }
 
     // ---------------- sweep B: query on lane; dQ for 32 queries accumulates over all key blocks ----------------
-    for (int qb = wid; qb < NKB; qb += 4) {
+    for (int qb = wid; qb < NKB; qb += NWAVES) {
         bf16x8 qf[4], dof[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { qf[s] = row_frag(sQ, qb * 32 + r, s, h); dof[s] = row_frag(sdO, qb * 32 + r, s, h); }
@@ -336,9 +447,15 @@ template <int NKB, bool DROP>
 int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
                  unsigned long long seed, hipStream_t st) {
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+    if constexpr (NKB <= 4) {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+    } else {
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(512), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+    }
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -353,7 +470,7 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
                  int L, int H, float scale, float p, unsigned long long seed, hipStream_t st) {
     const size_t lds = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+    hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                        (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
                        DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();

@@ -412,7 +412,7 @@ def test_layernorm_bwd_dropout_branch_uses_the_oracle_mask(T, d):
     close(dbias, torch.where(keep, ref / (1 - p), torch.zeros(())).sum(0), 1e-3, 1e-2, "bias gradient of the dropped branch")
 
 
-@pytest.mark.parametrize("nseq,L,H", [(2, 64, 2), (3, 128, 1), (2, 30, 2)])
+@pytest.mark.parametrize("nseq,L,H", [(2, 64, 2), (3, 128, 1), (2, 30, 2), (1, 256, 2), (2, 192, 1), (1, 130, 1)])
 def test_attention_dropout_fwd_bwd_against_the_oracle_mask(nseq, L, H):
     """softmax -> dropout(mask of oracle/dropout_ref.py, scale 1/(1-p)) -> . V, forward and both backward sweeps."""
     p, seed = 0.25, 4242
