@@ -25,6 +25,15 @@ namespace {
 constexpr int BK = 64;                 // tokens per LDS slot
 
 __device__ __forceinline__ int swz(int m) { return 2 * ((m & 3) | (((m >> 3) & 1) << 2)); }
+// 16-byte chunk c of token row m -> position inside the row.  Rows of 256 / 512 bytes: c ^ swz(m).  Rows of 384 bytes (24 chunks,
+// the 192-column B tile): chunks 0..15 as before, chunks 16..23 permute among themselves with 2 ((m>>1)&1 | ((m>>3)&1)<<1); odd
+// rows start 128 bytes into a 256-byte bank window, and tools/lds_bank_sim.py shows every transposed read still touches each of
+// the 64 banks once.  The map is an involution, so the DMA applies it on the source side.
+template <int ROWB>
+__device__ __forceinline__ int chunk_pos(int c, int m) {
+    if (ROWB == 384 && c >= 16) return 16 + ((c - 16) ^ (2 * (((m >> 1) & 1) | (((m >> 3) & 1) << 1))));
+    return c ^ swz(m);
+}
 
 // One MFMA operand = two transposing reads (token rows m and m + 4: same swizzle, fixed byte distance HI).  They are issued
 // by hand: hipcc models the ds_read_tr builtin as an LDS access that may alias the LDS-DMA in flight and puts
@@ -43,11 +52,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
                                                          float* __restrict__ slabs, int M, int N1, int N2, int lda, int ldb,
                                                          int splits, int ksteps_per_split, size_t slab_stride, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int WGN = T2 / 64, WGM = NW / WGN;        // wave grid; a wave owns (16 FA) x 64 of the tile
+    constexpr int NBF = T2 == 192 ? 3 : 4;              // B fragments (16 n2 columns each) per wave
+    constexpr int WGN = T2 / (16 * NBF), WGM = NW / WGN;        // wave grid; a wave owns (16 FA) x (16 NBF) of the tile
     constexpr int FA = T1 / WGM / 16;                   // A fragments (16 n1 columns each) per wave
     constexpr int A_BYTES = BK * T1 * 2, B_BYTES = BK * T2 * 2, SLOT = A_BYTES + B_BYTES;
     constexpr int LPR_A = T1 / 8, RA = 64 / LPR_A;      // lanes per A row, A rows per 1-KiB piece
-    constexpr int LPR_B = T2 / 8, RB = 64 / LPR_B;
     constexpr int APW = A_BYTES / 1024 / NW, BPW = B_BYTES / 1024 / NW;     // pieces per wave
     constexpr int NSLOT = 3 * SLOT <= 160 * 1024 ? 3 : 2;                   // 3: K tiles kt+1 and kt+2 stay in flight
     constexpr int G = APW + BPW;                        // LDS-DMA instructions per wave per K tile
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
     const int wm = wid / WGN, wn = wid % WGN;
     const bool do_bias = BIAS && c2 == 0 && wn == 0;
 
-    // ---- LDS-DMA.  A piece = RA token rows x (T1*2) B, B piece = RB token rows x (T2*2) B; wave w owns pieces APW*w.. / BPW*w..
+    // ---- LDS-DMA.  A piece = RA token rows x (T1*2) B; a B piece = 1 KiB of the row-major B image; wave w owns pieces APW*w.. / BPW*w..
     uint32_t oa[APW], ob[BPW];
 #pragma unroll
     for (int i = 0; i < APW; ++i) {
@@ -73,8 +82,9 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
     }
 #pragma unroll
     for (int i = 0; i < BPW; ++i) {
-        const int r = RB * (BPW * wid + i) + lane / LPR_B;
-        ob[i] = (uint32_t)r * (uint32_t)(ldb * 2) + (uint32_t)(c2 * 2) + (uint32_t)(((lane % LPR_B) ^ swz(r)) * 16);
+        const int byte = (BPW * wid + i) * 1024 + lane * 16;            // position in the LDS image of the B tile (row-major, T2*2-byte rows)
+        const int r = byte / (T2 * 2), pos = (byte % (T2 * 2)) / 16;
+        ob[i] = (uint32_t)r * (uint32_t)(ldb * 2) + (uint32_t)(c2 * 2) + (uint32_t)(chunk_pos<T2 * 2>(pos, r) * 16);
     }
     auto stage = [&](int slot, int kt) {
         char* base = smem + slot * SLOT;
@@ -93,51 +103,55 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
     // k-step (ks: + 32 rows) and both reads (r: + 4 rows) through the instruction's immediate offset.
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     const int m0 = 8 * g + q;
-    uint32_t ra[FA], rb[4];
+    uint32_t ra[FA], rb[NBF];
 #pragma unroll
     for (int t = 0; t < FA; ++t) {
         const int ca = wm * (16 * FA) + t * 16 + 4 * pp;
         ra[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + m0 * (T1 * 2) + (((ca >> 3) ^ swz(m0)) * 16) + (ca & 7) * 2;
     }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int cb = wn * 64 + t * 16 + 4 * pp;
-        rb[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + A_BYTES + m0 * (T2 * 2) + (((cb >> 3) ^ swz(m0)) * 16) + (cb & 7) * 2;
+    for (int t = 0; t < NBF; ++t) {
+        const int cb = wn * (16 * NBF) + t * 16 + 4 * pp;
+        rb[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + A_BYTES + m0 * (T2 * 2) + chunk_pos<T2 * 2>(cb >> 3, m0) * 16 + (cb & 7) * 2;
     }
 
-    f32x4 acc[FA][4];
+    f32x4 acc[FA][NBF];
     f32x4 accb[BIAS ? FA : 1];
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
         if (BIAS) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NBF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const short one = (short)0x3F80;     // bf16 1.0
     const bf16x8 ones = (bf16x8){one, one, one, one, one, one, one, one};
 
-    Frag af[FA], b0[4], b1[4];
-    auto mfma_row = [&](int t1, Frag (&bc)[4]) {
+    Frag af[FA], b0[NBF], b1[NBF];
+    auto mfma_row = [&](int t1, Frag (&bc)[NBF]) {
         const bf16x8 a = frag8(af[t1]);
 #pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2)
+        for (int t2 = 0; t2 < NBF; ++t2)
             // swapped operands: D'[n2][n1] so the lane's 4 accumulators run along n2 (contiguous in dW rows)
             acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(bc[t2]), a, acc[t1][t2], 0, 0, 0);
         if (BIAS && do_bias) accb[BIAS ? t1 : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a, accb[BIAS ? t1 : 0], 0, 0, 0);
     };
     // LDS returns in issue order.  Issue order per k-step: A0, B'0..B'3, A1, .., A(FA-1) (2 reads each; B' = next k-step's B).
     // Row 0 needs A0 and B, the 2 (FA-1) reads of A1.. are younger.  Row t1 >= 1 needs A[t1] of the previous k-step:
-    // 2 FA + 6 younger reads (the lgkmcnt field stops at 15: for FA = 8 a few older refills are waited for too).
-    constexpr int W0 = 2 * (FA - 1), WR = 2 * FA + 6 < 15 ? 2 * FA + 6 : 15;
-    auto wait_row0 = [&](Frag (&bc)[4]) {
-        asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo), "+v"(bc[1].hi),
-                     "+v"(bc[2].lo), "+v"(bc[2].hi), "+v"(bc[3].lo), "+v"(bc[3].hi) : "n"(W0));
+    // 2 FA + 2 NBF - 2 younger reads (the lgkmcnt field stops at 15: for FA = 8 a few older refills are waited for too).
+    constexpr int W0 = 2 * (FA - 1), WR = 2 * FA + 2 * NBF - 2 < 15 ? 2 * FA + 2 * NBF - 2 : 15;
+    auto wait_row0 = [&](Frag (&bc)[NBF]) {
+        if constexpr (NBF == 4)
+            asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo),
+                         "+v"(bc[1].hi), "+v"(bc[2].lo), "+v"(bc[2].hi), "+v"(bc[3].lo), "+v"(bc[3].hi) : "n"(W0));
+        else
+            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo),
+                         "+v"(bc[1].hi), "+v"(bc[2].lo), "+v"(bc[2].hi) : "n"(W0));
     };
     // waves w and w + NW/2 share a SIMD: the second half issues its LDS-DMA one k-step later, so the two do not stall the
     // MFMA pipe at the same time (measured on the NT kernel: +2..9 %)
     const bool late_wave = NW == 8 && wid >= 4 && stagger;
     // one 32-token k-step over (af, bc); the next fragments come from slot offset noff, k-step NKS of that slot
-    auto kstep = [&](Frag (&bc)[4], Frag (&bn)[4], uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
+    auto kstep = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
         constexpr int NKS = decltype(nks_tag)::value;
         constexpr int OA = NKS * 32 * T1 * 2, OB = NKS * 32 * T2 * 2;
         wait_row0(bc);
@@ -158,7 +172,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
         }
         tr_issue<OA, 4 * T1 * 2>(af[0], ra[0] + noff);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) tr_issue<OB, 4 * T2 * 2>(bn[t], rb[t] + noff);
+        for (int t = 0; t < NBF; ++t) tr_issue<OB, 4 * T2 * 2>(bn[t], rb[t] + noff);
 #pragma unroll
         for (int t1 = 1; t1 < FA; ++t1) {
             __builtin_amdgcn_sched_barrier(0);
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
         if (NSLOT == 3) { if (nk > 2) stage(2, 2); } else { if (nk > 1) stage(1, 1); }
         tr_issue<0, 4 * T1 * 2>(af[0], ra[0]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) tr_issue<0, 4 * T2 * 2>(b0[t], rb[t]);
+        for (int t = 0; t < NBF; ++t) tr_issue<0, 4 * T2 * 2>(b0[t], rb[t]);
 #pragma unroll
         for (int t = 1; t < FA; ++t) tr_issue<0, 4 * T1 * 2>(af[t], ra[t]);
         int cs = 0, ps = -1;                               // slots of K tiles kt and kt-1
@@ -213,8 +227,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
     for (int t1 = 0; t1 < FA; ++t1) {
         const int n1 = c1 + wm * (16 * FA) + t1 * 16 + (lane & 15);
 #pragma unroll
-        for (int t2 = 0; t2 < 4; ++t2) {
-            const int n2 = c2 + wn * 64 + t2 * 16 + 4 * (lane >> 4);
+        for (int t2 = 0; t2 < NBF; ++t2) {
+            const int n2 = c2 + wn * (16 * NBF) + t2 * 16 + 4 * (lane >> 4);
             *(float4*)(slab + (size_t)n1 * N2 + n2) = make_float4(acc[t1][t2][0], acc[t1][t2][1], acc[t1][t2][2], acc[t1][t2][3]);
         }
         if (BIAS && do_bias && lane < 16) slab[(size_t)N1 * N2 + n1] = accb[BIAS ? t1 : 0][0];       // every n2 row of D' holds the same column sums
@@ -250,6 +264,10 @@ static inline WgradTile wgrad_tile(int N1, int N2) {
     // measured (T = 32768): the 256 x 256 tile needs all 256 VGPRs, spills, and has room for two LDS slots only:
     // 430-480 TF/s against 690-810 TF/s for 256 x 128.  It stays instantiable for experiments (CLDRD_WGRAD_TILE=256).
     if (N1 % 256 == 0 && N2 % 256 == 0 && force == 256) return {256, 256};
+    // 256 x 192 (8 waves of 128 x 48): 7 LDS-DMA pieces per 48 MFMAs per wave instead of 6 per 32, the ratio of the NT kernel's BN = 192
+    // (measured at T = 32768: 2304 x 768 +6 %, 3072 x 768 +3 %, 768 x 3072 +10 %; 768 x 768 -7 %: with 12 tiles the 21 slabs
+    // per tile make the reduction the larger part, so small outputs stay on 256 x 128)
+    if (N1 % 256 == 0 && N2 % 192 == 0 && force != 128 && ((N1 / 256) * (N2 / 192) >= 24 || force == 192)) return {256, 192};
     if (N1 % 256 == 0) return {256, 128};
     return {128, 128};
 }
@@ -302,7 +320,7 @@ static int launch_tn(const void* A, const void* B, float* ws, int M, int N1, int
 extern "C" int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, float* dbias, int M, int N1, int N2, int lda, int ldb,
                                 float* workspace, size_t workspace_bytes, int accumulate, void* stream) {
     CLDRD_CHECK(M > 0, "wgrad: empty problem");
-    CLDRD_CHECK(N1 % 128 == 0 && N2 % 128 == 0, "wgrad: N1 and N2 must be multiples of 128");
+    CLDRD_CHECK(N1 % 128 == 0 && (N2 % 128 == 0 || (N1 % 256 == 0 && N2 % 192 == 0)), "wgrad: N1 and N2 must be multiples of 128 (or 256 x 192)");
     CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0, "wgrad: lda/ldb must be multiples of 8");
     CLDRD_CHECK(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)dW % 16 == 0) && ((uintptr_t)workspace % 16 == 0),
                 "wgrad: operands must be 16-byte aligned");
@@ -319,6 +337,7 @@ extern "C" int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, float* 
 #define CLDRD_TN(T1_, T2_, NW_) (dbias ? launch_tn<T1_, T2_, NW_, true>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st) \
                                        : launch_tn<T1_, T2_, NW_, false>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st))
     if (t.t1 == 256 && t.t2 == 256) rc = CLDRD_TN(256, 256, 8);
+    else if (t.t1 == 256 && t.t2 == 192) rc = CLDRD_TN(256, 192, 8);
     else if (t.t1 == 256) rc = CLDRD_TN(256, 128, 8);
     else rc = CLDRD_TN(128, 128, 4);
 #undef CLDRD_TN
