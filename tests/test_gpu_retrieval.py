@@ -141,6 +141,17 @@ def test_encode_and_cli_end_to_end(tmp_path):
     ranks = [int(l.split("\t")[2]) for l in lines[:7]]
     scores = [float(l.split("\t")[3]) for l in lines[:7]]
     assert ranks == list(range(1, 8)) and scores == sorted(scores, reverse=True)
+    # the run file feeds the evaluator (reference evaluation/retrieval_evaluator.py): with the rank-3 document of every query marked
+    # relevant, MRR@10 = 1/3, Recall@5 = 1, and every query is counted
+    from cldrd_amd.evaluation import RankingEvaluator
+    qrels = tmp_path / "qrels.tsv"
+    with open(qrels, "w") as fh:
+        for l in lines:
+            q_, d_, r_, _ = l.split("\t")
+            if r_ == "3":
+                fh.write(f"{q_}\t0\t{d_}\t1\n")
+    m = RankingEvaluator(str(qrels), mrr_at_k=[10], ndcg_at_k=[10], recall_at_k=[5], map_at_k=10).compute_metrics(str(out))
+    assert m["QueriesRanked"] == 20 and m["MRR@10"] == pytest.approx(1 / 3) and m["Recall@5"] == 1.0
 
 
 @pytest.mark.parametrize("nq,rows,d", [(128, 40000, 768), (37, 5003, 768), (16, 9000, 128), (128, 70001, 256)])
