@@ -20,34 +20,38 @@ from ..models.nway_dual_encoder import NwayDualEncoder
 from .retrieval_utils import ShardedFlatIPIndex, construct_flatindex_from_embeddings, get_embeddings_from_scratch, write_index
 
 
+# flag name -> argparse keyword arguments: names and defaults of the reference's command line (index_text.py:30-41)
+_FLAGS = {
+    "resume": dict(default=""),
+    "model_name_or_path": dict(default="distilbert-base-uncased"),
+    "tokenizer_name_or_path": dict(default="distilbert-base-uncased"),
+    "passages_path": dict(default=""),
+    "max_length": dict(default=256),
+    "index_dir": dict(default=""),
+    "is_query": dict(default=False),
+    "is_parallel": dict(default=True),
+    "share_weights": dict(action="store_true", default=False),
+    "synthetic_rows": dict(type=int, default=0),          # ours: encode N generated MSMARCO-shaped passages
+}
+
+
 def get_args(argv=None):
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--resume", default="")
-    parser.add_argument("--model_name_or_path", default="distilbert-base-uncased")
-    parser.add_argument("--tokenizer_name_or_path", default="distilbert-base-uncased")
-    parser.add_argument("--passages_path", default="")
-    parser.add_argument("--max_length", default=256)
-    parser.add_argument("--index_dir", default="")
-    parser.add_argument("--is_query", default=False)
-    parser.add_argument("--is_parallel", default=True)
-    parser.add_argument("--share_weights", action="store_true", default=False)
-    parser.add_argument("--synthetic_rows", type=int, default=0)
-    args = parser.parse_args(argv)
-    args.max_length = int(args.max_length)      # the reference leaves it a str when passed on the command line
-    if not os.path.exists(args.index_dir):
-        os.makedirs(args.index_dir, exist_ok=True)
+    ap = argparse.ArgumentParser(description="encode a collection with the passage tower and write the flat inner-product index")
+    for name, kw in _FLAGS.items():
+        ap.add_argument("--" + name, **kw)
+    args = ap.parse_args(argv)
+    args.max_length = int(args.max_length)      # a str when given on the command line (the reference declares no type)
+    os.makedirs(args.index_dir, exist_ok=True)
     return args
 
 
 def load_checkpoint_into(model, path, is_parallel=True):
-    checkpoint = torch.load(path, map_location="cpu")
-    state_dict = checkpoint["state_dict"]
+    """``checkpoint["state_dict"]`` of a trainer checkpoint into ``model``; DDP's ``module.`` prefix goes when ``is_parallel``
+    (reference index_text.py:63-73)."""
+    sd = torch.load(path, map_location="cpu")["state_dict"]
     if is_parallel:
-        new_state_dict = OrderedDict()
-        for k, v in state_dict.items():
-            new_state_dict[k[7:] if k.startswith("module.") else k] = v     # remove `module.`
-        state_dict = new_state_dict
-    model.load_state_dict(state_dict)
+        sd = OrderedDict((k[len("module."):] if k.startswith("module.") else k, v) for k, v in sd.items())
+    model.load_state_dict(sd)
 
 
 def main(args):

@@ -17,20 +17,27 @@ from .index_text import load_checkpoint_into
 from .retrieval_utils import ShardedFlatIPIndex, convert_index_to_gpu, get_embeddings_from_scratch, index_retrieve, read_index
 
 
+# names and defaults of the reference's command line (retrieve_top_passages.py:28-40) + ours
+_FLAGS = {
+    "resume": dict(default=""),
+    "model_name_or_path": dict(default="distilbert-base-uncased"),
+    "tokenizer_name_or_path": dict(default="distilbert-base-uncased"),
+    "queries_path": dict(default=""),
+    "index_path": dict(default=""),
+    "max_length": dict(default=30),
+    "top_k": dict(default=1000),
+    "is_parallel": dict(default=True),
+    "share_weights": dict(action="store_true", default=False),
+    "output_path": dict(default=""),
+    "synthetic_queries": dict(type=int, default=0),       # ours: N generated queries instead of --queries_path
+}
+
+
 def get_args(argv=None):
-    parser = argparse.ArgumentParser()
-    parser.add_argument("--resume", default="")
-    parser.add_argument("--model_name_or_path", default="distilbert-base-uncased")
-    parser.add_argument("--tokenizer_name_or_path", default="distilbert-base-uncased")
-    parser.add_argument("--queries_path", default="")
-    parser.add_argument("--index_path", default="")
-    parser.add_argument("--max_length", default=30)
-    parser.add_argument("--top_k", default=1000)
-    parser.add_argument("--is_parallel", default=True)
-    parser.add_argument("--share_weights", action="store_true", default=False)
-    parser.add_argument("--output_path", default="")
-    parser.add_argument("--synthetic_queries", type=int, default=0)
-    args = parser.parse_args(argv)
+    ap = argparse.ArgumentParser(description="encode queries, search the flat index (top-k), write the run file")
+    for name, kw in _FLAGS.items():
+        ap.add_argument("--" + name, **kw)
+    args = ap.parse_args(argv)
     args.max_length, args.top_k = int(args.max_length), int(args.top_k)
     return args
 
