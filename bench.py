@@ -280,8 +280,35 @@ def cpu_baseline(N, L, Lq):
             p.addcdiv_(mm, vv.sqrt().add_(1e-8), value=-7e-6 * (1 - 0.999) ** 0.5 / (1 - 0.9))
             p.mul_(1 - 7e-6 * 0.01)
     dt = time.perf_counter() - t0
-    return {"value": round(Bc / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"1 fp32 step (fwd+loss+bwd+clip+AdamW) of the same workload at B={Bc} (N={N}, L={L}), oracle/encoder_ref.py on torch-CPU, {dt:.1f} s"}
+    out = {"value": round(Bc / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"1 fp32 step (fwd+loss+bwd+clip+AdamW) of the same workload at B={Bc} (N={N}, L={L}), oracle/encoder_ref.py on torch-CPU, {dt:.1f} s"}
+    # the other two legs of the metric on the same cores: encode 64 x L passages; exact top-1000 of 128 queries
+    # over a 200 000-row fp32 shard (oracle/retrieval_ref.py: the faiss IndexFlatIP contract)
+    from oracle import retrieval_ref as RR
+    with torch.no_grad():
+        pn = {k: t.detach() for k, t in pp.items()}
+        seq = syn.seq_batch(7, 64, L)["seq"]
+        E.cls_embs(pn, cfg, {k: t[:2] for k, t in seq.items()})
+        t0 = time.perf_counter()
+        E.cls_embs(pn, cfg, seq)
+        de = time.perf_counter() - t0
+    rng = np.random.default_rng(0)
+    Pm = rng.standard_normal((200000, 768), dtype=np.float32)
+    Qm = rng.standard_normal((128, 768), dtype=np.float32)
+    t0 = time.perf_counter()
+    S = Qm @ Pm.T                                              # fp32 SGEMM on the host cores, as faiss IndexFlatIP does
+    part = np.argpartition(-S, 1000, axis=1)[:, :1000]
+    top = np.take_along_axis(S, part, axis=1)
+    order = np.lexsort((part, -top), axis=1)                   # score desc, row asc
+    I_cpu = np.take_along_axis(part, order, axis=1)
+    dk = time.perf_counter() - t0
+    D_ref, I_ref = RR.flat_ip_search(Pm[:20000], None, Qm[:4], 50)          # the timed formulation agrees with the oracle's contract
+    S4 = Qm[:4] @ Pm[:20000].T
+    assert np.array_equal(np.sort(np.argpartition(-S4, 50, axis=1)[:, :50], axis=1), np.sort(I_ref, axis=1)), "cpu top-k disagrees with the oracle"
+    out["encode"] = {"value": round(64 / de, 2), "unit": "passages/s", "sample": f"64 passages x {L} tokens, fp32 forward, {de:.1f} s"}
+    out["topk"] = {"value": round(128 / dk, 1), "unit": "queries/s", "rows": 200000,
+                   "sample": f"128 queries x 200 000 x 768 fp32 rows, top-1000 by fp32 SGEMM + argpartition + sort (numpy), {dk:.1f} s"}
+    return out
 
 
 if __name__ == "__main__":
