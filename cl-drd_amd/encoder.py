@@ -495,26 +495,26 @@ class HipEncoder(nn.Module):
         ops.scatter_cls_grad(dcls.contiguous(), gc, M, 1, M)
         ds2 = self._buf(M, d, dev)
         ds2m = self._buf(M, d, dev) if p_h > 0 else None
-        ops.layernorm_bwd(gc, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], partial, M, p_h, s_l + 3)
+        ops.layernorm_bwd(gc, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], partial, M, p_h, s_l + 3, accumulate=self._acc)
         dF = ds2m if ds2m is not None else ds2
-        ops.wgrad(dF, a["h"], G["W2"], M, ws, accumulate=True)
+        ops.wgrad(dF, a["h"], G["W2"], M, ws, accumulate=self._acc)
         dpre = self._buf(M, f, dev)
         ops.gemm_nt(dF, self.ht(i, "f2"), dpre, M, gelu_pre=a["pre"])
-        ops.wgrad(dpre, a["x1"], G["W1"], M, ws, accumulate=True, dbias=G["bf1"])
+        ops.wgrad(dpre, a["x1"], G["W1"], M, ws, accumulate=self._acc, dbias=G["bf1"])
         dx1 = self._buf(M, d, dev)
         ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, M, residual=ds2)
         ds1 = self._buf(M, d, dev)
         ds1m = self._buf(M, d, dev) if p_out > 0 else None
-        ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], partial, M, p_out, s_l + 2)
+        ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], partial, M, p_out, s_l + 2, accumulate=self._acc)
         dA = ds1m if ds1m is not None else ds1
-        ops.wgrad(dA, a["ctx"], G["Wo"], M, ws, accumulate=True)
+        ops.wgrad(dA, a["ctx"], G["Wo"], M, ws, accumulate=self._acc)
         dctx = self._buf(M, d, dev)
         ops.gemm_nt(dA, self.ht(i, "o"), dctx, M)
         dqc = self._buf(M, d, dev)
         dkv = self._buf(T, 2 * d, dev)
         ops.attention_cls_bwd(a["qc"], a["kv"], a["probs"], dctx, dqc, dkv, M, L, H, p_a, s_l + 1)
-        ops.wgrad(dqc, a["xc"], G["Wqkv"][:d], M, ws, accumulate=True, dbias=G["bqkv"][:d])
-        ops.wgrad(dkv, a["x_in"], G["Wqkv"][d:], T, ws, accumulate=True, dbias=G["bqkv"][d:])
+        ops.wgrad(dqc, a["xc"], G["Wqkv"][:d], M, ws, accumulate=self._acc, dbias=G["bqkv"][:d])
+        ops.wgrad(dkv, a["x_in"], G["Wqkv"][d:], T, ws, accumulate=self._acc, dbias=G["bqkv"][d:])
         wt = self.ht(i, "qkv")                                      # [d, 3d] = Wqkv^T
         g = self._buf(T, d, dev)
         ops.gemm_nt(dkv, wt[:, d:], g, T)                           # through K and V: every token
@@ -524,11 +524,15 @@ class HipEncoder(nn.Module):
         return g
 
     # ------------------------------------------------------------------ backward
-    def backward_from_cls(self, tape: _Tape, dcls: torch.Tensor, after_layer=None):
+    def backward_from_cls(self, tape: _Tape, dcls: torch.Tensor, after_layer=None, accumulate: bool = True):
         """Accumulate parameter gradients of this tower into ``flat_g`` given dL/dCLS (fp32 [M, d]).
 
         ``after_layer(i)`` (optional) is called when the gradients of transformer layer i are complete (and with
-        -1 after the embedding gradients): the hook the trainer uses to launch that bucket's all-reduce."""
+        -1 after the embedding gradients): the hook the trainer uses to launch that bucket's all-reduce.
+
+        ``accumulate=False`` (trainer, unshared towers): every weight / bias / LayerNorm gradient is WRITTEN instead of added
+        to, so ``flat_g`` needs no zeroing except the embedding tables (scatter-add by atomics)."""
+        self._acc = bool(accumulate)
         cfg = self.cfg
         self.ensure_grads()
         M, L, T = tape.M, tape.L, tape.T
@@ -555,26 +559,26 @@ class HipEncoder(nn.Module):
             ds2 = self._buf(T, d, dev)
             ds2m = self._buf(T, d, dev) if p_h > 0 else None
             ops.layernorm_bwd(g, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], partial, T,
-                              p_h, s_l + 3)
+                              p_h, s_l + 3, accumulate=self._acc)
             dF = ds2m if ds2m is not None else ds2
-            ops.wgrad(dF, a["h"], G["W2"], T, ws, accumulate=True)
+            ops.wgrad(dF, a["h"], G["W2"], T, ws, accumulate=self._acc)
             dpre = self._buf(T, f, dev)
             ops.gemm_nt(dF, self.ht(i, "f2"), dpre, T, gelu_pre=a["pre"])
-            ops.wgrad(dpre, a["x1"], G["W1"], T, ws, accumulate=True, dbias=G["bf1"])
+            ops.wgrad(dpre, a["x1"], G["W1"], T, ws, accumulate=self._acc, dbias=G["bf1"])
             dx1 = self._buf(T, d, dev)
             ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T, residual=ds2)
             # --- attention-output LayerNorm + attention ---
             ds1 = self._buf(T, d, dev)
             ds1m = self._buf(T, d, dev) if p_out > 0 else None
             ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], partial, T,
-                              p_out, s_l + 2)
+                              p_out, s_l + 2, accumulate=self._acc)
             dA = ds1m if ds1m is not None else ds1
-            ops.wgrad(dA, a["ctx"], G["Wo"], T, ws, accumulate=True)
+            ops.wgrad(dA, a["ctx"], G["Wo"], T, ws, accumulate=self._acc)
             dctx = self._buf(T, d, dev)
             ops.gemm_nt(dA, self.ht(i, "o"), dctx, T)
             dqkv = self._buf(T, 3 * d, dev)
             ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1)
-            ops.wgrad(dqkv, a["x_in"], G["Wqkv"], T, ws, accumulate=True, dbias=G["bqkv"])
+            ops.wgrad(dqkv, a["x_in"], G["Wqkv"], T, ws, accumulate=self._acc, dbias=G["bqkv"])
             g = self._buf(T, d, dev)
             ops.gemm_nt(dqkv, self.ht(i, "qkv"), g, T, residual=ds1)
             tape.layers[i] = None        # free this layer's activations
@@ -586,7 +590,7 @@ class HipEncoder(nn.Module):
                          self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
                          tape.mean0, tape.rstd0, self.g("embeddings.word_embeddings.weight"),
                          self.g("embeddings.position_embeddings.weight"), dtype0, self.g("embeddings.LayerNorm.weight"),
-                         self.g("embeddings.LayerNorm.bias"), partial, T, L, tape.p_embed, tape.seed)
+                         self.g("embeddings.LayerNorm.bias"), partial, T, L, tape.p_embed, tape.seed, accumulate=self._acc)
         if after_layer is not None:
             after_layer(-1)
 

@@ -169,6 +169,34 @@ def test_trainer_step_matches_oracle_update():
     assert torch.equal(t.ht(0, "f2").float(), w2.T.contiguous().to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("arch", ["distilbert", "bert"])
+def test_write_once_gradients_equal_zeroed_accumulation(arch, monkeypatch):
+    """The trainer zeroes only the embedding tables and lets every other gradient be WRITTEN once per step: the gradient buffer
+    must equal what the zero-everything + accumulate path produces, also on the second step (no stale values), bit for bit outside
+    the embedding tables (their scatter-add order is not fixed)."""
+    cfg = small_cfg(arch=arch)
+    model = selftest.build_tiny_model(cfg).cuda()
+    model.train()
+    tr = NwayTrainer(model, loss="kl_div", learning_rate=1e-3, warmup_steps=1, total_steps=100)
+    b1 = syn.nway_batch(4680, 3, 4, 8, 32, vocab=cfg.vocab_size, ragged=True)
+    b2 = syn.nway_batch(4681, 3, 4, 8, 32, vocab=cfg.vocab_size, ragged=True)
+    grads = {}
+    for mode in ("full", ""):
+        monkeypatch.setenv("CLDRD_GRAD_ZERO", mode)
+        tr.flat_g.fill_(123.0)                   # garbage: whatever is not zeroed must be overwritten
+        tr.forward_backward(b1)
+        tr.forward_backward(b2)                  # second pass over different data: nothing of the first may survive
+        torch.cuda.synchronize()
+        grads[mode] = tr.flat_g.clone()
+    emb = torch.zeros_like(tr.flat_g, dtype=torch.bool)
+    for tower, toff in zip(model.towers(), model._tower_offsets):
+        a, b = tower.layout.embed_range
+        emb[toff + a:toff + b] = True
+    assert torch.equal(grads["full"][~emb], grads[""][~emb])
+    assert torch.allclose(grads["full"][emb], grads[""][emb], rtol=1e-4, atol=1e-6)
+    assert (grads[""] != 123.0).all()
+
+
 def test_loss_decreases_over_steps_with_dropout():
     cfg = small_cfg()
     cfg.dropout = cfg.attention_dropout = 0.1
