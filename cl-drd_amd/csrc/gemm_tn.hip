@@ -267,7 +267,7 @@ static inline WgradTile wgrad_tile(int N1, int N2) {
     // 256 x 192 (8 waves of 128 x 48): 7 LDS-DMA pieces per 48 MFMAs per wave instead of 6 per 32, the ratio of the NT kernel's BN = 192
     // (measured at T = 32768: 2304 x 768 +6 %, 3072 x 768 +3 %, 768 x 3072 +10 %; 768 x 768 -7 %: with 12 tiles the 21 slabs
     // per tile make the reduction the larger part, so small outputs stay on 256 x 128)
-    if (N1 % 256 == 0 && N2 % 192 == 0 && force != 128 && ((N1 / 256) * (N2 / 192) >= 24 || force == 192)) return {256, 192};
+    if (N1 % 256 == 0 && N2 % 192 == 0 && ((force != 128 && ((N1 / 256) * (N2 / 192) >= 24 || force == 192)) || N2 % 128 != 0)) return {256, 192};
     if (N1 % 256 == 0) return {256, 128};
     return {128, 128};
 }

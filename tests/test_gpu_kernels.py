@@ -101,7 +101,9 @@ def test_gemm_nt_dropout_is_deterministic_and_unbiased():
 
 # ------------------------------------------------------------------------------------------------ weight gradient
 @pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (200, 128, 256), (1024, 384, 128), (4096, 768, 768), (3000, 256, 768),
-                                     (8192, 2304, 768), (2048, 768, 3072), (130, 512, 128)])
+                                     (8192, 2304, 768), (2048, 768, 3072), (130, 512, 128),
+                                     # 256 x 192 tile (chosen from 24 such tiles up; forced below): token tails, one K tile, N2 = 192
+                                     (130, 256, 192), (4000, 512, 384), (777, 256, 768), (64, 1536, 768), (5000, 1536, 768)])
 def test_wgrad(M, N1, N2):
     Mp = ops.pad_rows(M)
     dY, X = torch.zeros(Mp, N1), torch.zeros(Mp, N2)
