@@ -36,7 +36,10 @@ def close(got, ref, rtol, atol, what=""):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 256, 128), (1000, 768, 768), (2048, 2304, 768), (240, 768, 3072),
                                    (4096, 3072, 768), (77, 384, 192),
                                    # large-M ring kernel: BN=192 / BN=256 variants, M tails, 1..4 K slices, K=3072
-                                   (1100, 384, 192), (1030, 512, 64), (1024, 1024, 128), (2000, 768, 3072), (1500, 256, 320)])
+                                   (1100, 384, 192), (1030, 512, 64), (1024, 1024, 128), (2000, 768, 3072), (1500, 256, 320),
+                                   # grouped N-tile order (K <= 1024, more N tiles than a group): M panels not a multiple of 8,
+                                   # a partial last group, BN = 192 and BN = 256
+                                   (1100, 3072, 768), (2900, 2304, 1024), (2300, 1920, 512), (1281, 2560, 1024)])
 def test_gemm_nt_plain(M, N, K):
     A, B = bf(rnd(1, (M, K))), bf(rnd(2, (N, K)))
     ref = A.float() @ B.float().T
