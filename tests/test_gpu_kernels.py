@@ -148,7 +148,8 @@ def attn_ref(qkv, mask, nseq, L, H):
 
 
 @pytest.mark.parametrize("nseq,L,H,masked", [(3, 32, 2, False), (2, 30, 2, True), (4, 128, 2, True), (2, 100, 3, True),
-                                              (2, 64, 12, False), (2, 256, 2, True), (1, 160, 1, True), (5, 8, 1, True)])
+                                              (2, 64, 12, False), (2, 256, 2, True), (1, 160, 1, True), (5, 8, 1, True),
+                                              (1, 200, 2, True), (2, 129, 1, False), (1, 224, 1, True)])
 def test_attention_fwd_bwd(nseq, L, H, masked):
     d = H * 64
     T = nseq * L
