@@ -14,6 +14,7 @@ not the target).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -165,64 +166,81 @@ def main():
 
     # ---- index path: encode passages/s (retriever/index_text.py: bs = 512) ----
     index = None
-    if not args.no_index:
-        model.eval()
-        ib = syn.seq_batch(99 + rank, 512, L)["seq"]
-        ids, mask = ib["input_ids"].to(dev), ib["attention_mask"].to(dev)
-        with torch.no_grad():
-            for _ in range(2):
-                model.passage_embs({"input_ids": ids, "attention_mask": mask})
-            sync_all()
-            t1 = time.perf_counter()
-            it = 10
-            for _ in range(it):
-                emb = model.passage_embs({"input_ids": ids, "attention_mask": mask})
-            sync_all()
-            di = time.perf_counter() - t1
-        ti = torch.tensor([di], dtype=torch.float64, device=dev)
+    try:
+        if not args.no_index:
+            model.eval()
+            ib = syn.seq_batch(99 + rank, 512, L)["seq"]
+            ids, mask = ib["input_ids"].to(dev), ib["attention_mask"].to(dev)
+            with torch.no_grad():
+                for _ in range(2):
+                    model.passage_embs({"input_ids": ids, "attention_mask": mask})
+                sync_all()
+                t1 = time.perf_counter()
+                it = 10
+                for _ in range(it):
+                    emb = model.passage_embs({"input_ids": ids, "attention_mask": mask})
+                torch.cuda.synchronize()
+                di = time.perf_counter() - t1
+            index = {"seconds": di, "it": it}
+    except Exception as exc:      # a secondary leg must not take the headline line down with it
+        index = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    if not args.no_index:         # the collective sits outside the try: every rank reaches it whatever happened above
+        ti = torch.tensor([index.get("seconds", float("inf"))], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(ti, op=dist.ReduceOp.MAX)
-        pps = world * 512 * it / float(ti.item())
-        index = {"value": round(pps, 1), "unit": "passages/s", "batch": 512, "seq_len": L,
-                 "mfma_frac": round(pps * flops_seq_fwd(L) / (world * PEAK_BF16_TFLOPS * 1e12), 4)}
+        if math.isfinite(float(ti.item())) and "error" not in index:
+            pps = world * 512 * index["it"] / float(ti.item())
+            index = {"value": round(pps, 1), "unit": "passages/s", "batch": 512, "seq_len": L,
+                     "mfma_frac": round(pps * flops_seq_fwd(L) / (world * PEAK_BF16_TFLOPS * 1e12), 4)}
+        elif "error" not in index:
+            index = {"error": "another rank failed in the index leg"}
 
     # ---- retrieve path: cfg5 shard (8 841 823 / 8 rows x 768), 128-query batches, k = 1000 ----
     retrieve = None
-    if not args.no_retrieve:
-        from cldrd_amd.retriever.retrieval_utils import FlatIPIndex
-        del trainer, model
-        torch.cuda.empty_cache()
-        rows = args.retrieve_rows
-        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-        P = torch.randn(rows, D, device=dev, generator=gen)
-        P *= ((9.0 + 3.0 * torch.rand(rows, 1, device=dev, generator=gen)) / P.norm(dim=1, keepdim=True))
-        flat_index = FlatIPIndex.from_device_rows(P, id_offset=rank * rows)
-        flat_index.profile = True
-        qn = torch.randn(3 * 128, D, device=dev, generator=gen)
-        qn *= (10.0 / qn.norm(dim=1, keepdim=True))
-        qh = qn.cpu().numpy()
-        flat_index.search(qh[:128], 1000)                  # warm-up
-        sync_all()
-        t2 = time.perf_counter()
-        Dq, Iq = flat_index.search(qh, 1000)
-        sync_all()
-        dr = time.perf_counter() - t2
-        if world > 1:                                      # every rank searches its own shard for the same queries
-            tr_ = torch.tensor([dr], dtype=torch.float64, device=dev)
+    try:
+        if not args.no_retrieve:
+            from cldrd_amd.retriever.retrieval_utils import FlatIPIndex
+            del trainer, model
+            torch.cuda.empty_cache()
+            rows = args.retrieve_rows
+            gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+            P = torch.randn(rows, D, device=dev, generator=gen)
+            P *= ((9.0 + 3.0 * torch.rand(rows, 1, device=dev, generator=gen)) / P.norm(dim=1, keepdim=True))
+            flat_index = FlatIPIndex.from_device_rows(P, id_offset=rank * rows)
+            flat_index.profile = True
+            qn = torch.randn(3 * 128, D, device=dev, generator=gen)
+            qn *= (10.0 / qn.norm(dim=1, keepdim=True))
+            qh = qn.cpu().numpy()
+            flat_index.search(qh[:128], 1000)                  # warm-up
+            sync_all()
+            t2 = time.perf_counter()
+            Dq, Iq = flat_index.search(qh, 1000)
+            sync_all()
+            dr = time.perf_counter() - t2
+            st = flat_index.last_stats
+            scan_ms = sum(st["scan_ms"]) / len(st["scan_ms"])
+            scan_bytes = rows * D * 2 + 128 * D * 2
+            # the index is row-sharded: a query is done when every shard has been searched, so queries/s does not grow with the
+            # number of GPUs - the index does (rows_total); the host-side merge of the per-shard lists is not part of this leg
+            retrieve = {"seconds": dr, "nq": int(qh.shape[0]), "rows_per_shard": rows, "rows_total": world * rows, "k": 1000, "batch": 128,
+                        "scans": st["scans"], "rescans": st["rescans"], "candidates_per_query": round(st["candidates"] / qh.shape[0], 1),
+                        "scan_kernel_ms": round(scan_ms, 3), "scan_hbm_gb_s": round(scan_bytes / scan_ms / 1e6, 1),
+                        "scan_hbm_frac": round(scan_bytes / scan_ms / 1e6 / 8000.0, 4),
+                        "scan_tflops": round(2.0 * 128 * rows * D / scan_ms / 1e9, 1)}
+            del flat_index, P
+    except Exception as exc:      # a secondary leg must not take the headline line down with it
+        retrieve = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+    if not args.no_retrieve:      # every rank searches its own shard for the same queries: the slowest one sets the rate
+        tr_ = torch.tensor([retrieve.get("seconds", float("inf"))], dtype=torch.float64, device=dev)
+        if world > 1:
             dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+        if math.isfinite(float(tr_.item())) and "error" not in retrieve:
             dr = float(tr_.item())
-        st = flat_index.last_stats
-        scan_ms = sum(st["scan_ms"]) / len(st["scan_ms"])
-        scan_bytes = rows * D * 2 + 128 * D * 2
-        # the index is row-sharded: a query is done when every shard has been searched, so queries/s does not grow with the
-        # number of GPUs - the index does (rows_total); the host-side merge of the per-shard lists is not part of this leg
-        retrieve = {"queries_per_s": round(qh.shape[0] / dr, 1), "rows_per_shard": rows, "rows_total": world * rows,
-                    "row_scans_per_s": round(world * rows * qh.shape[0] / dr, 1), "k": 1000, "batch": 128,
-                    "scans": st["scans"], "rescans": st["rescans"], "candidates_per_query": round(st["candidates"] / qh.shape[0], 1),
-                    "scan_kernel_ms": round(scan_ms, 3), "scan_hbm_gb_s": round(scan_bytes / scan_ms / 1e6, 1),
-                    "scan_hbm_frac": round(scan_bytes / scan_ms / 1e6 / 8000.0, 4),
-                    "scan_tflops": round(2.0 * 128 * rows * D / scan_ms / 1e9, 1)}
-        del flat_index, P
+            nq_ = retrieve.pop("nq")
+            retrieve.pop("seconds")
+            retrieve = {"queries_per_s": round(nq_ / dr, 1), "row_scans_per_s": round(retrieve["rows_total"] * nq_ / dr, 1), **retrieve}
+        elif "error" not in retrieve:
+            retrieve = {"error": "another rank failed in the retrieve leg"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
