@@ -244,7 +244,10 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(N, L, Lq)
+        try:
+            cpu = cpu_baseline(N, L, Lq)
+        except Exception as exc:
+            cpu = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     if rank == 0:
         flops_per_sample = 3.0 * (N * flops_seq_fwd(L) + flops_seq_fwd(Lq))
