@@ -6,8 +6,9 @@ struct GemmNtArgs {
     const bf16_t* A; const bf16_t* B; void* C;
     int M, N, K, lda, ldb, ldc;
     const float* bias;            // [N] or null
-    const bf16_t* residual;       // [M, ldr] or null, added last
+    const void* residual;         // [M, ldr] or null, added last; bf16, or fp32 when res_f32 (the fp32 residual stream)
     int ldr;
+    int res_f32 = 0;
     bf16_t* preact;               // [M, ldc] or null: (alpha*acc + bias) before the activation
     const bf16_t* gelu_pre;       // [M, ldc] or null: multiply by gelu'(gelu_pre)
     int act;                      // 0 none, 1 erf-GELU
@@ -26,11 +27,12 @@ struct GemmNtArgs {
 // only the code it needs); EPI_GENERIC reads every switch from GemmNtArgs at run time.
 enum : int {
     EPI_BIAS = 1, EPI_PREACT = 2, EPI_GELU = 4, EPI_GELUGRAD = 8, EPI_DROPOUT = 16, EPI_RESIDUAL = 32, EPI_F32 = 64, EPI_FILTER = 128,
+    EPI_RES32 = 256,              // the residual operand is fp32 (only with EPI_RESIDUAL)
     EPI_GENERIC = 1 << 20
 };
 
 template <int EPI> struct EpiFlags {
-    const bool bias, preact, gelu, gelugrad, dropout, residual, f32;
+    const bool bias, preact, gelu, gelugrad, dropout, residual, f32, res32;
     __device__ __forceinline__ explicit EpiFlags(const GemmNtArgs& p)
         : bias(EPI == EPI_GENERIC ? p.bias != nullptr : (EPI & EPI_BIAS) != 0),
           preact(EPI == EPI_GENERIC ? p.preact != nullptr : (EPI & EPI_PREACT) != 0),
@@ -38,12 +40,14 @@ template <int EPI> struct EpiFlags {
           gelugrad(EPI == EPI_GENERIC ? p.gelu_pre != nullptr : (EPI & EPI_GELUGRAD) != 0),
           dropout(EPI == EPI_GENERIC ? p.drop_thresh != 0 : (EPI & EPI_DROPOUT) != 0),
           residual(EPI == EPI_GENERIC ? p.residual != nullptr : (EPI & EPI_RESIDUAL) != 0),
-          f32(EPI == EPI_GENERIC ? p.out_f32 != 0 : (EPI & EPI_F32) != 0) {}
+          f32(EPI == EPI_GENERIC ? p.out_f32 != 0 : (EPI & EPI_F32) != 0),
+          res32(EPI == EPI_GENERIC ? (p.residual != nullptr && p.res_f32 != 0) : (EPI & EPI_RES32) != 0) {}
 };
 
 static inline int epi_flavour(const GemmNtArgs& a) {
     return (a.bias ? EPI_BIAS : 0) | (a.preact ? EPI_PREACT : 0) | (a.act == 1 ? EPI_GELU : 0) | (a.gelu_pre ? EPI_GELUGRAD : 0) |
-           (a.drop_thresh ? EPI_DROPOUT : 0) | (a.residual ? EPI_RESIDUAL : 0) | (a.out_f32 ? EPI_F32 : 0);
+           (a.drop_thresh ? EPI_DROPOUT : 0) | (a.residual ? EPI_RESIDUAL : 0) | (a.out_f32 ? EPI_F32 : 0) |
+           ((a.residual && a.res_f32) ? EPI_RES32 : 0);
 }
 
 __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
@@ -62,7 +66,7 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
 // order: alpha*acc + bias -> (store preact) -> GELU -> * gelu'(gelu_pre) -> dropout -> + residual -> store
 template <int EPI>
 __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFlags<EPI>& fl, float (&v)[8], int m, int n,
-                                               const float (&bias8)[8], const uint4& res, const uint4& gp) {
+                                               const float (&bias8)[8], const uint4& res, const uint4& res_hi, const uint4& gp) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
     if (fl.bias) {
@@ -92,7 +96,12 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
     }
     if (fl.residual) {
         float r[8];
-        unpack8(res, r);
+        if (fl.res32) {         // fp32 residual stream: res = columns n..n+3, res_hi = n+4..n+7 (raw float bits)
+            r[0] = __uint_as_float(res.x); r[1] = __uint_as_float(res.y); r[2] = __uint_as_float(res.z); r[3] = __uint_as_float(res.w);
+            r[4] = __uint_as_float(res_hi.x); r[5] = __uint_as_float(res_hi.y); r[6] = __uint_as_float(res_hi.z); r[7] = __uint_as_float(res_hi.w);
+        } else {
+            unpack8(res, r);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += r[j];
     }
@@ -133,16 +142,25 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
         bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
         bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
     }
-    uint4 res[NPASS], gp[NPASS];
+    uint4 res[NPASS], resh[NPASS], gp[NPASS];
     auto prefetch = [&](int mh) {
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             const int r = pass * RPP + rr;
             const int m = row0 + mh * 32 + r;
             res[pass] = make_uint4(0, 0, 0, 0);
+            resh[pass] = make_uint4(0, 0, 0, 0);
             gp[pass] = make_uint4(0, 0, 0, 0);
             if (lane_ok && r < 32 && m < p.M) {
-                if (fl.residual) res[pass] = *(const uint4*)(p.residual + (size_t)m * p.ldr + n);
+                if (fl.residual) {
+                    if (fl.res32) {
+                        const uint4* rp = (const uint4*)((const float*)p.residual + (size_t)m * p.ldr + n);
+                        res[pass] = rp[0];
+                        resh[pass] = rp[1];
+                    } else {
+                        res[pass] = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + n);
+                    }
+                }
                 if (fl.gelugrad) gp[pass] = *(const uint4*)(p.gelu_pre + (size_t)m * p.ldc + n);
             }
         }
@@ -155,9 +173,9 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 *(f32x4*)(patch + (t * 16 + frow) * RS + nt * 16 + fq * 4) = acc[2 * mh + t][nt];
-        uint4 cres[NPASS], cgp[NPASS];
+        uint4 cres[NPASS], cresh[NPASS], cgp[NPASS];
 #pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) { cres[pass] = res[pass]; cgp[pass] = gp[pass]; }
+        for (int pass = 0; pass < NPASS; ++pass) { cres[pass] = res[pass]; cresh[pass] = resh[pass]; cgp[pass] = gp[pass]; }
         if ((fl.residual || fl.gelugrad) && mh + 1 < MT / 2) prefetch(mh + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float v[NPASS][8];
@@ -174,7 +192,7 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
         for (int pass = 0; pass < NPASS; ++pass) {
             const int r = pass * RPP + rr;
             const int m = row0 + mh * 32 + r;
-            if (lane_ok && r < 32 && m < p.M) gemm_nt_apply8<EPI>(p, fl, v[pass], m, n, bias8, cres[pass], cgp[pass]);
+            if (lane_ok && r < 32 && m < p.M) gemm_nt_apply8<EPI>(p, fl, v[pass], m, n, bias8, cres[pass], cresh[pass], cgp[pass]);
         }
     }
 }

@@ -124,18 +124,19 @@ int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows,
 
 extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
-                                  int act, float alpha, float dropout_p, unsigned long long seed, int out_f32,
+                                  int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                   void* stream) {
     CLDRD_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
     CLDRD_CHECK(K % 32 == 0, "gemm_nt: K must be a multiple of 32");
     CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && N % 8 == 0 && (residual == nullptr || ldr % 8 == 0),
                 "gemm_nt: N, lda, ldb, ldc, ldr must be multiples of 8");
-    CLDRD_CHECK(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0), "gemm_nt: operands must be 16-byte aligned");
+    CLDRD_CHECK(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)residual % 16 == 0),
+                "gemm_nt: operands must be 16-byte aligned");
     CLDRD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, "gemm_nt: dropout_p out of range");
     GemmNtArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-    a.bias = bias; a.residual = (const bf16_t*)residual; a.ldr = ldr;
+    a.bias = bias; a.residual = residual; a.ldr = ldr; a.res_f32 = (residual != nullptr && res_f32) ? 1 : 0;
     a.preact = (bf16_t*)preact; a.gelu_pre = (const bf16_t*)gelu_pre;
     a.act = act; a.alpha = alpha;
     a.drop_thresh = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
@@ -159,6 +160,9 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
         case EPI_GELUGRAD: return launch_nt<EPI_GELUGRAD>(a, (hipStream_t)stream);
         case EPI_RESIDUAL: return launch_nt<EPI_RESIDUAL>(a, (hipStream_t)stream);
         case EPI_F32: return launch_nt<EPI_F32>(a, (hipStream_t)stream);
+        case EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32: return launch_nt<EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
+        case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
+            return launch_nt<EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
         default: return launch_nt<EPI_GENERIC>(a, (hipStream_t)stream);
     }
 }

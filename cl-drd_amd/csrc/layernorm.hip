@@ -52,6 +52,13 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* row, int d, int lane, con
         }
     }
 }
+__device__ __forceinline__ void store_row_f32(float* row, int d, int lane, const RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) *(float4*)(row + c) = make_float4(r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
+    }
+}
 __device__ __forceinline__ void row_stats(const RowF& r, int d, int lane, float eps, float& mean, float& rstd) {
     float s = 0.f;
 #pragma unroll
@@ -71,9 +78,11 @@ __device__ __forceinline__ void row_stats(const RowF& r, int d, int lane, float 
 
 // out = LN(x) * gamma + beta;   optional fp32 copy of rows r with r % cls_stride == 0 (the CLS pooling of
 // reference models/nway_dual_encoder.py:52,56,64 folded into the last LayerNorm).
-template <int DC>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, bf16_t* __restrict__ out,
+// X32: the input (pre-LN residual sum) is fp32 and, when out32 != null, the output is also kept in fp32 next to the bf16 copy the
+// GEMMs read (the fp32 residual stream: the reference's autocast keeps LayerNorm inputs / outputs in fp32, nway_listwise_1.py:334).
+template <int DC, bool X32>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, bf16_t* __restrict__ out, float* __restrict__ out32,
                                                       float* __restrict__ mean_o, float* __restrict__ rstd_o, int T, int d_rt,
                                                       float eps, float* __restrict__ cls_out, int cls_stride) {
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
@@ -81,7 +90,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= T) return;
     RowF r;
-    load_row_bf16(x + (size_t)row * d, d, lane, r);
+    if (X32) load_row_f32((const float*)x + (size_t)row * d, d, lane, r);
+    else load_row_bf16((const bf16_t*)x + (size_t)row * d, d, lane, r);
     float mean, rstd;
     row_stats(r, d, lane, eps, mean, rstd);
     const bool cls = cls_out && (row % cls_stride == 0);
@@ -96,6 +106,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* __restrict__ 
         }
     }
     store_row_bf16(out + (size_t)row * d, d, lane, r);
+    if (X32 && out32) store_row_f32(out32 + (size_t)row * d, d, lane, r);
     if (lane == 0) { if (mean_o) mean_o[row] = mean; if (rstd_o) rstd_o[row] = rstd; }
 }
 
@@ -105,7 +116,7 @@ template <int DC, bool DROP>
 __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ word,
                                                             const float* __restrict__ pos, const float* __restrict__ type0,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            bf16_t* __restrict__ out, float* __restrict__ mean_o,
+                                                            bf16_t* __restrict__ out, float* __restrict__ out32, float* __restrict__ mean_o,
                                                             float* __restrict__ rstd_o, int T, int L, int d_rt, int vocab, float eps,
                                                             uint32_t drop_thresh, float drop_scale, uint64_t seed) {
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
@@ -148,6 +159,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
         }
     }
     store_row_bf16(out + (size_t)row * d, d, lane, r);
+    if (out32) store_row_f32(out32 + (size_t)row * d, d, lane, r);
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
 
@@ -195,8 +207,8 @@ __device__ __forceinline__ void block_partials(float* smem, RowF& a, RowF& b, Ro
 //   dx  = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))                       -> dx (residual path)
 //   dx2 = dropout-masked dx (the branch that went through dropout before the residual add), or null
 //   partial[blk] = { sum dy*xhat (dgamma), sum dy (dbeta), sum dx2-or-dx (bias grad of the preceding Linear) }
-template <int DC, bool DROP>
-__global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+template <int DC, bool DROP, bool X32>
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x,
                                                       const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                       const float* __restrict__ gamma, bf16_t* __restrict__ dx,
                                                       bf16_t* __restrict__ dx2, float* __restrict__ partial, int T, int d_rt,
@@ -213,7 +225,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < T; row += gridDim.x * wpb) {
         RowF g, xr;
         load_row_bf16(dy + (size_t)row * d, d, lane, g);
-        load_row_bf16(x + (size_t)row * d, d, lane, xr);
+        if (X32) load_row_f32((const float*)x + (size_t)row * d, d, lane, xr);
+        else load_row_bf16((const bf16_t*)x + (size_t)row * d, d, lane, xr);
         const float mean = mean_i[row], rstd = rstd_i[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -427,11 +440,12 @@ static inline int ln_bwd_blocks(int T) {
 extern "C" int cldrd_ln_partial_blocks(int T) { return ln_bwd_blocks(T); }
 
 extern "C" int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
-                                   int T, int d, float eps, float* cls_out, int cls_stride, void* stream) {
+                                   int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_fwd: need 0 < d <= 1024, d % 4 == 0");
-    ln_dispatch(d, false, [&](auto dc, auto) {
-        hipLaunchKernelGGL((ln_fwd_kernel<decltype(dc)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, gamma, beta,
-                           (bf16_t*)out, mean, rstd, T, d, eps, cls_out, cls_stride > 0 ? cls_stride : 1);
+    CLDRD_CHECK(x_f32 || out32 == nullptr, "layernorm_fwd: an fp32 output copy goes with an fp32 input (the fp32 residual stream)");
+    ln_dispatch(d, x_f32 != 0, [&](auto dc, auto x32) {
+        hipLaunchKernelGGL((ln_fwd_kernel<decltype(dc)::value, decltype(x32)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                           (bf16_t*)out, out32, mean, rstd, T, d, eps, cls_out, cls_stride > 0 ? cls_stride : 1);
     });
     CLDRD_LAUNCH_CHECK();
     return 0;
@@ -439,12 +453,12 @@ extern "C" int cldrd_layernorm_fwd(const void* x, const float* gamma, const floa
 
 extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
                                   const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
-                                  int d, int vocab, float eps, float dropout_p, unsigned long long seed, void* stream) {
+                                  int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_fwd: bad shape");
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
         hipLaunchKernelGGL((embed_ln_fwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                           (const int64_t*)ids, word, pos, type0, gamma, beta, (bf16_t*)out, mean, rstd, T, L, d, vocab, eps, th,
+                           (const int64_t*)ids, word, pos, type0, gamma, beta, (bf16_t*)out, out32, mean, rstd, T, L, d, vocab, eps, th,
                            1.0f / (1.0f - dropout_p), (uint64_t)seed);
     });
     CLDRD_LAUNCH_CHECK();
@@ -460,14 +474,20 @@ static int launch_reduce(const float* partial, int nblk, int d, float* o0, float
 // partial must hold cldrd_ln_partial_blocks(T) * 3 * d floats.  dgamma/dbeta/dbias are accumulated (+=) when accumulate != 0.
 extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                    void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
-                                   int d, float dropout_p, unsigned long long seed, int accumulate, void* stream) {
+                                   int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_bwd: need 0 < d <= 1024, d % 4 == 0");
     const int nb = ln_bwd_blocks(T);
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
-        hipLaunchKernelGGL((ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3(nb), dim3(512), (512 / 128) * 3 * MAX_IT * 64 * sizeof(float4),
-                           (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (bf16_t*)dx, (bf16_t*)dx_dropped, partial,
-                           T, d, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+        constexpr int DCV = decltype(dc)::value;
+        constexpr bool DRV = decltype(dr)::value;
+        const size_t lds = (512 / 128) * 3 * MAX_IT * 64 * sizeof(float4);
+        if (x_f32)
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true>), dim3(nb), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dy, x, mean, rstd, gamma,
+                               (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+        else
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, false>), dim3(nb), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dy, x, mean, rstd, gamma,
+                               (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
     });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dbias, accumulate, (hipStream_t)stream);

@@ -118,14 +118,35 @@ class TokenCache:
                 lens[a + j] = len(row)
         return cls(keys, ids, lens)
 
-    def save(self, stem: str):
-        np.save(stem + ".keys.npy", self.keys)
-        np.save(stem + ".ids.npy", self.ids)
-        np.save(stem + ".lens.npy", self.lens)
+    def save(self, stem: str, meta: Optional[dict] = None):
+        """Each file is written under a temporary name and renamed into place (a reader never sees a half-written array); the
+        ``.meta.json`` (max_len, tokenizer, row count) goes last and is what :meth:`load` looks for."""
+        for suffix, arr in ((".keys.npy", self.keys), (".ids.npy", self.ids), (".lens.npy", self.lens)):
+            tmp = f"{stem}{suffix}.tmp{os.getpid()}.npy"
+            np.save(tmp, arr)
+            os.replace(tmp, stem + suffix)
+        tmp = f"{stem}.meta.json.tmp{os.getpid()}"
+        with open(tmp, "w") as fh:
+            json.dump({"rows": int(len(self.keys)), "max_len": int(self.ids.shape[1]), **(meta or {})}, fh)
+        os.replace(tmp, stem + ".meta.json")
+
+    @staticmethod
+    def exists(stem: str) -> bool:
+        return os.path.exists(stem + ".meta.json")
 
     @classmethod
-    def load(cls, stem: str) -> "TokenCache":
-        return cls(np.load(stem + ".keys.npy"), np.load(stem + ".ids.npy", mmap_mode="r"), np.load(stem + ".lens.npy"))
+    def load(cls, stem: str, expect: Optional[dict] = None) -> "TokenCache":
+        """``expect``: metadata the cache must have been built with (max_len, tokenizer name); a mismatch raises instead of
+        silently serving tokens of another tokenizer / truncation."""
+        with open(stem + ".meta.json") as fh:
+            meta = json.load(fh)
+        for k, v in (expect or {}).items():
+            if meta.get(k) != v:
+                raise ValueError(f"token cache {stem}: built with {k}={meta.get(k)!r}, this run wants {v!r}; delete it or use another --token_cache_dir")
+        c = cls(np.load(stem + ".keys.npy"), np.load(stem + ".ids.npy", mmap_mode="r"), np.load(stem + ".lens.npy"))
+        if len(c.keys) != meta["rows"] or c.ids.shape != (meta["rows"], meta["max_len"]):
+            raise ValueError(f"token cache {stem}: arrays do not match their metadata (truncated write?)")
+        return c
 
     def batch(self, keys, pad_id: int = 0) -> Dict[str, torch.Tensor]:
         """``{'input_ids', 'attention_mask'}`` int64 ``[len(keys), longest]``: what ``tokenizer(texts, padding=True, ...)`` returns."""
@@ -257,16 +278,21 @@ class NwayDataset(torch.utils.data.Dataset):
                                                         max_passage_len, label_mode, rank=rank, nranks=nranks, _modes=("7", "8"))
 
     # ---- pre-tokenised cache ------------------------------------------------------------------------------------
-    def with_token_cache(self, cache_dir: Optional[str] = None) -> "NwayDataset":
-        """Tokenise every query / passage once (or load ``cache_dir/{queries,passages}.*.npy`` if present) and serve batches from
-        the cache from now on."""
+    def with_token_cache(self, cache_dir: Optional[str] = None, build: bool = True) -> "NwayDataset":
+        """Tokenise every query / passage once (or load ``cache_dir/{queries,passages}.*`` if present) and serve batches from
+        the cache from now on.  ``build=False`` (ranks > 0 of a distributed run, after rank 0 has built and a barrier): load only."""
+        tok_name = str(getattr(self.tokenizer, "name_or_path", type(self.tokenizer).__name__))
+
         def get(stem, table, max_len):
-            if cache_dir and os.path.exists(os.path.join(cache_dir, stem + ".ids.npy")):
-                return TokenCache.load(os.path.join(cache_dir, stem))
+            meta = {"max_len": int(max_len), "tokenizer": tok_name}
+            if cache_dir and TokenCache.exists(os.path.join(cache_dir, stem)):
+                return TokenCache.load(os.path.join(cache_dir, stem), expect=meta)
+            if not build:
+                raise FileNotFoundError(f"token cache {os.path.join(str(cache_dir), stem)} is missing (rank 0 builds it)")
             c = TokenCache.build(table, self.tokenizer, max_len)
             if cache_dir:
                 os.makedirs(cache_dir, exist_ok=True)
-                c.save(os.path.join(cache_dir, stem))
+                c.save(os.path.join(cache_dir, stem), meta)
             return c
         self.query_cache = get("queries", self.qid_to_query, self.max_query_len)
         self.passage_cache = get("passages", self.pid_to_passage, self.max_passage_len)

@@ -91,6 +91,12 @@ class EncoderConfig:
                     initializer_range=self.initializer_range)
 
 
+def tiny_config() -> EncoderConfig:
+    """2-layer, d = 128 DistilBERT-shaped preset (``--synthetic_model tiny`` of the trainer CLI, smoke test)."""
+    return EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=2,
+                         max_position_embeddings=64, dropout=0.0, attention_dropout=0.0)
+
+
 def layer_param_names(cfg: EncoderConfig, i: int):
     """HF names of one layer in flat-buffer order: q, k, v (weights), q, k, v (biases), out, ln1, ffn1, ffn2, ln2."""
     if cfg.arch == "distilbert":
@@ -122,6 +128,23 @@ def param_table(cfg: EncoderConfig):
               (n["f1"] + ".weight", (f, d)), (n["f1"] + ".bias", (f,)),
               (n["f2"] + ".weight", (d, f)), (n["f2"] + ".bias", (d,)),
               (n["ln2"] + ".weight", (d,)), (n["ln2"] + ".bias", (d,))]
+    return t
+
+
+def hf_parameter_order(cfg: EncoderConfig, with_pooler: bool = True):
+    """Names in the order of HF ``DistilBertModel`` / ``BertModel`` ``.named_parameters()`` (weight, bias per Linear; BERT ends with
+    the pooler, which this package does not hold: the reference's optimizer counts those two in its parameter indices,
+    trainer/multistep-curriculum/nway_listwise_1.py:259-263).  Checked against the installed transformers in tests/test_interop.py."""
+    t = ["embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"]
+    if cfg.arch == "bert":
+        t.append("embeddings.token_type_embeddings.weight")
+    t += ["embeddings.LayerNorm.weight", "embeddings.LayerNorm.bias"]
+    for i in range(cfg.n_layers):
+        n = layer_param_names(cfg, i)
+        for key in ("q", "k", "v", "o", "ln1", "f1", "f2", "ln2"):
+            t += [n[key] + ".weight", n[key] + ".bias"]
+    if cfg.arch == "bert" and with_pooler:
+        t += ["pooler.dense.weight", "pooler.dense.bias"]
     return t
 
 
@@ -210,6 +233,11 @@ class HipEncoder(nn.Module):
         self.step_seed = 0
         # last layer: compute only the CLS row after the K/V projection (CLDRD_CLS_ONLY=0 restores the full layer)
         self.cls_only_last = os.environ.get("CLDRD_CLS_ONLY", "1") != "0"
+        # residual stream: fp32 (default) keeps every LayerNorm input (pre-LN sum) and output in fp32 between kernels, as the
+        # reference's autocast does (LayerNorm / residual adds run in fp32 there, nway_listwise_1.py:334); the GEMMs still read bf16
+        # copies.  CLDRD_RESIDUAL=bf16 stores them in bf16 (round-1 behaviour: ~7 % faster, 2.4x the reference's own
+        # mixed-precision logit drift instead of 0.7x - tools/drift_emulation.py).
+        self.stream32 = os.environ.get("CLDRD_RESIDUAL", "fp32") != "bf16"
 
     # ------------------------------------------------------------------ parameters
     def named_flat(self):
@@ -233,6 +261,17 @@ class HipEncoder(nn.Module):
         self._reflatten()
         return self
 
+    def _rebind(self, flat: torch.Tensor):
+        """Make every parameter a TRUE view of ``flat`` (fresh ``nn.Parameter`` objects created from the view): a Parameter made
+        from a view shares the base tensor's version counter, so ``optimizer.step()`` / ``load_state_dict`` / any in-place
+        write through a parameter bumps ``flat_p._version`` and the bf16 shadows are known to be stale.  (Rebinding with
+        ``param.data = view`` would give each parameter a private counter: torch 2.10.)"""
+        old = dict(self.named_parameters())
+        for n in self._names:
+            off, shape = self.layout.entries[n]
+            _attach(self, n, nn.Parameter(flat[off:off + _numel(shape)].view(shape), requires_grad=old[n].requires_grad))
+        self.flat_p = flat
+
     def _reflatten(self):
         """Re-establish the flat aliasing after .to()/.cuda() moved the parameters one by one."""
         params = dict(self.named_parameters())
@@ -243,8 +282,7 @@ class HipEncoder(nn.Module):
             for n in self._names:
                 off, shape = self.layout.entries[n]
                 flat[off:off + _numel(shape)].view(shape).copy_(params[n].data.to(torch.float32))
-                params[n].data = flat[off:off + _numel(shape)].view(shape)
-            self.flat_p = flat
+            self._rebind(flat)
             self.flat_g = None
             self.flat_h = self.flat_t = self._t_desc = None
             self._shadow_version = -1
@@ -253,11 +291,7 @@ class HipEncoder(nn.Module):
         """Move this tower's parameters into a slice of a model-level flat buffer (same device)."""
         assert flat_p.numel() == self.layout.total and flat_p.dtype == torch.float32
         flat_p.copy_(self.flat_p.to(flat_p.device))
-        params = dict(self.named_parameters())
-        for n in self._names:
-            off, shape = self.layout.entries[n]
-            params[n].data = flat_p[off:off + _numel(shape)].view(shape)
-        self.flat_p = flat_p
+        self._rebind(flat_p)
         self.flat_g = flat_g
         if flat_g is not None:
             self._bind_grads()
@@ -269,9 +303,31 @@ class HipEncoder(nn.Module):
             off, shape = self.layout.entries[n]
             params[n].grad = self.flat_g[off:off + _numel(shape)].view(shape)
 
-    def ensure_grads(self):
+    def ensure_grads(self, check_all: bool = False):
+        """``param.grad`` of every parameter is a view of ``flat_g``.  ``check_all`` (autograd bridge, i.e. the reference-style
+        ``loss.backward()`` loop): ``optimizer.zero_grad()`` / ``model.zero_grad()`` default to ``set_to_none=True``, which drops
+        the views; the gradients they would have held are stale then, so the flat buffer is zeroed before the views come back
+        (once per step: the second tape of a shared tower finds the views in place and accumulates)."""
         if self.flat_g is None or self.flat_g.device != self.flat_p.device:
             self.flat_g = torch.zeros_like(self.flat_p)
+            self._bind_grads()
+            return
+        if check_all:
+            params = dict(self.named_parameters())
+            missing = []
+            for n in self._names:
+                off, _ = self.layout.entries[n]
+                gr = params[n].grad
+                if gr is None or gr.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                    missing.append(n)
+            if len(missing) == len(self._names):
+                self.flat_g.zero_()
+            else:
+                for n in missing:
+                    self.g(n).zero_()
+            if missing:
+                self._bind_grads()
+            return
         p0 = next(self.parameters())
         if p0.grad is None or p0.grad.data_ptr() != self.flat_g.data_ptr():
             self._bind_grads()
@@ -373,9 +429,10 @@ class HipEncoder(nn.Module):
     @staticmethod
     def _buf(rows, cols, dev, dtype=torch.bfloat16):
         rp = ops.pad_rows(rows)
-        if rp == rows:
-            return torch.empty(rp, cols, dtype=dtype, device=dev)
-        return torch.zeros(rp, cols, dtype=dtype, device=dev)      # zero tail: contract of cldrd_wgrad_bf16
+        t = torch.empty(rp, cols, dtype=dtype, device=dev)
+        if rp != rows and dtype == torch.bfloat16:
+            t[rows:].zero_()        # zero tail (<= 63 rows): contract of cldrd_wgrad_bf16; fp32 buffers never feed it
+        return t
 
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None, *, train: bool | None = None,
                save: bool = False, seed: int | None = None):
@@ -404,12 +461,15 @@ class HipEncoder(nn.Module):
             tape.M, tape.L, tape.T, tape.ids, tape.mask, tape.seed, tape.layers = M, L, T, ids, mask, seed, []
             tape.p_embed = p_h
         f32 = dict(dtype=torch.float32, device=dev)
+        S32 = self.stream32
+        sdt = torch.float32 if S32 else torch.bfloat16         # storage type of the pre-LN sums
         x = self._buf(T, d, dev)
+        x32 = self._buf(T, d, dev, torch.float32) if S32 else None      # fp32 copy of the layer input: the residual operand
         mean0, rstd0 = torch.empty(T, **f32), torch.empty(T, **f32)
         type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
         ops.embed_ln_fwd(ids.view(-1), self.w("embeddings.word_embeddings.weight"),
                          self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
-                         self.w("embeddings.LayerNorm.bias"), x, mean0, rstd0, T, L, cfg.eps, p_h, seed)
+                         self.w("embeddings.LayerNorm.bias"), x, mean0, rstd0, T, L, cfg.eps, p_h, seed, out32=x32)
         if save:
             tape.mean0, tape.rstd0 = mean0, rstd0
         cls = torch.empty(M, d, **f32)
@@ -418,37 +478,39 @@ class HipEncoder(nn.Module):
             W = self._layer_weights(i)
             s_l = seed + 7919 * (i + 1)
             if i == cfg.n_layers - 1 and self.cls_only_last:
-                self._last_layer_cls_fwd(x, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls)
+                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls)
                 break
             qkv = self._buf(T, 3 * d, dev)
             ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
             ctx = self._buf(T, d, dev)
             lse = torch.empty(M, H, L, **f32) if save else None
             ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1)
-            s1 = self._buf(T, d, dev)
-            ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x, dropout_p=p_out, seed=s_l + 2)
+            s1 = self._buf(T, d, dev, sdt)
+            ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out, seed=s_l + 2)
             x1 = self._buf(T, d, dev)
+            x1_32 = self._buf(T, d, dev, torch.float32) if S32 else None
             mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if save else (None, None)
-            ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps)
+            ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps, out32=x1_32)
             hbuf = self._buf(T, f, dev)
             pre = self._buf(T, f, dev) if save else None
             ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=1)
-            s2 = self._buf(T, d, dev)
-            ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=x1, dropout_p=p_h, seed=s_l + 3)
+            s2 = self._buf(T, d, dev, sdt)
+            ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
             xo = self._buf(T, d, dev)
-            mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if save else (None, None)
             last = i == cfg.n_layers - 1
-            ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, T, cfg.eps, cls if last else None, L)
+            xo32 = self._buf(T, d, dev, torch.float32) if (S32 and not last) else None
+            mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if save else (None, None)
+            ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32)
             if save:
                 tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
                                         h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h, p_a=p_a, p_out=p_out))
-            x = xo
+            x, x32 = xo, xo32
         if cfg.n_layers == 0:
             cls.copy_(x.view(ops.pad_rows(T), d)[:T].view(M, L, d)[:, 0].float())
         return (cls, tape) if save else cls
 
     # ------------------------------------------------------------------ last layer, CLS row only
-    def _last_layer_cls_fwd(self, x, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls):
+    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls):
         """Only ``last_hidden_state[:, 0, :]`` is consumed (reference models/nway_dual_encoder.py:52,56,64), so the last
         layer projects K and V for every token but Q, attention, out-proj, FFN and both LayerNorms for token 0 only:
         identical CLS output, ~1/6 of the layer's FLOPs."""
@@ -458,23 +520,30 @@ class HipEncoder(nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         kv = self._buf(T, 2 * d, dev)
         ops.gemm_nt(x, W["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
+        S32 = x32 is not None
+        sdt = torch.float32 if S32 else torch.bfloat16
         xc = self._buf(M, d, dev)
         xc[:M].copy_(x[:T].view(M, L, d)[:, 0, :])                 # gather the CLS rows (a copy, no arithmetic)
+        xc32 = None
+        if S32:
+            xc32 = self._buf(M, d, dev, torch.float32)
+            xc32[:M].copy_(x32[:T].view(M, L, d)[:, 0, :])
         qc = self._buf(M, d, dev)
         ops.gemm_nt(xc, W["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
         ctxc = self._buf(M, d, dev)
         probs = torch.empty(M, H, L, **f32)
         ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1)
-        s1 = self._buf(M, d, dev)
-        ops.gemm_nt(ctxc, W["Wo"], s1, M, bias=W["bo"], residual=xc, dropout_p=p_out, seed=s_l + 2)
+        s1 = self._buf(M, d, dev, sdt)
+        ops.gemm_nt(ctxc, W["Wo"], s1, M, bias=W["bo"], residual=xc32 if S32 else xc, dropout_p=p_out, seed=s_l + 2)
         x1 = self._buf(M, d, dev)
+        x1_32 = self._buf(M, d, dev, torch.float32) if S32 else None
         mean1, rstd1 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
-        ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, M, cfg.eps)
+        ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, M, cfg.eps, out32=x1_32)
         hbuf = self._buf(M, f, dev)
         pre = self._buf(M, f, dev) if save else None
         ops.gemm_nt(x1, W["W1"], hbuf, M, bias=W["bf1"], preact=pre, act=1)
-        s2 = self._buf(M, d, dev)
-        ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1, dropout_p=p_h, seed=s_l + 3)
+        s2 = self._buf(M, d, dev, sdt)
+        ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
         xo = self._buf(M, d, dev)
         mean2, rstd2 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
         ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, M, cfg.eps, cls, 1)
@@ -524,7 +593,7 @@ class HipEncoder(nn.Module):
         return g
 
     # ------------------------------------------------------------------ backward
-    def backward_from_cls(self, tape: _Tape, dcls: torch.Tensor, after_layer=None, accumulate: bool = True):
+    def backward_from_cls(self, tape: _Tape, dcls: torch.Tensor, after_layer=None, accumulate: bool = True, check_grads: bool = False):
         """Accumulate parameter gradients of this tower into ``flat_g`` given dL/dCLS (fp32 [M, d]).
 
         ``after_layer(i)`` (optional) is called when the gradients of transformer layer i are complete (and with
@@ -534,7 +603,7 @@ class HipEncoder(nn.Module):
         to, so ``flat_g`` needs no zeroing except the embedding tables (scatter-add by atomics)."""
         self._acc = bool(accumulate)
         cfg = self.cfg
-        self.ensure_grads()
+        self.ensure_grads(check_all=check_grads)
         M, L, T = tape.M, tape.L, tape.T
         d, f, H = cfg.dim, cfg.hidden_dim, cfg.n_heads
         dev = self.flat_p.device
@@ -607,7 +676,7 @@ class HipEncoder(nn.Module):
         torch.save({k: v.detach().cpu().clone() for k, v in self.state_dict().items()}, os.path.join(path, "pytorch_model.bin"))
 
     @classmethod
-    def from_pretrained(cls, name_or_path, seed: int | None = None) -> "HipEncoder":
+    def from_pretrained(cls, name_or_path, seed: int | None = None, allow_random_init: bool = False) -> "HipEncoder":
         if isinstance(name_or_path, EncoderConfig):
             return cls(name_or_path, seed=seed)
         if os.path.isdir(str(name_or_path)):
@@ -622,12 +691,24 @@ class HipEncoder(nn.Module):
                 sd = torch.load(os.path.join(name_or_path, "pytorch_model.bin"), map_location="cpu")
             enc.load_hf_state_dict(sd)
             return enc
-        if str(name_or_path) in _KNOWN:
-            # no network in this environment: architecture of the named checkpoint, seeded random weights
+        # a hub name: the reference calls AutoModel.from_pretrained(name), which resolves through the local HF cache first
+        local = None
+        try:
+            from huggingface_hub import snapshot_download
+            local = snapshot_download(str(name_or_path), local_files_only=True)
+        except Exception:
+            local = None
+        if local is not None and os.path.exists(os.path.join(local, "config.json")):
+            return cls.from_pretrained(local, seed=seed)
+        if str(name_or_path) in _KNOWN and (allow_random_init or os.environ.get("CLDRD_ALLOW_RANDOM_INIT", "") == "1"):
+            # explicit opt-in only (synthetic benchmarks / tests without network): architecture of the named checkpoint, seeded
+            # random weights.  Silently distilling into a random student instead of TAS-B would be a wrong result, not a fallback.
             import warnings
-            warnings.warn(f"{name_or_path}: pretrained weights are not available offline; using seeded random init")
+            warnings.warn(f"{name_or_path}: pretrained weights not found in the local HF cache; seeded RANDOM init (opt-in)")
             return cls(EncoderConfig(**_KNOWN[str(name_or_path)]), seed=seed)
-        raise FileNotFoundError(f"{name_or_path}: not a local model directory and not a known architecture name")
+        raise FileNotFoundError(
+            f"{name_or_path}: not a local model directory and not in the local HuggingFace cache (no network here). Pass a model "
+            f"directory, an EncoderConfig, or opt in to random weights with CLDRD_ALLOW_RANDOM_INIT=1 / allow_random_init=True.")
 
     def load_hf_state_dict(self, sd: dict):
         """Accepts HF DistilBertModel / BertModel keys (optional ``distilbert.`` / ``bert.`` prefix; pooler ignored)."""
@@ -673,7 +754,7 @@ class _EncodeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcls):
-        ctx.enc.backward_from_cls(ctx.tape, dcls.contiguous().float())
+        ctx.enc.backward_from_cls(ctx.tape, dcls.contiguous().float(), check_grads=True)
         ctx.tape = None
         return None, None, None, None
 

@@ -55,12 +55,18 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
         _chk(out, BF16, "out", 2)
     if bias is not None:
         _chk(bias, F32, "bias", 1)
-    for t, n in ((residual, "residual"), (preact, "preact"), (gelu_pre, "gelu_pre")):
+    for t, n in ((preact, "preact"), (gelu_pre, "gelu_pre")):
         if t is not None:
             _chk(t, BF16, n, 2)
+    res_f32 = 0
+    if residual is not None:
+        res_f32 = 1 if residual.dtype == F32 else 0        # fp32: the residual stream kept in full precision
+        _chk(residual, F32 if res_f32 else BF16, "residual", 2)
+        if residual.shape[0] < M or residual.shape[1] != N:
+            raise ValueError("gemm_nt: residual must be [>= M, N]")
     call("cldrd_gemm_nt_bf16", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
          _p(residual), residual.stride(0) if residual is not None else 0, _p(preact), _p(gelu_pre), act, alpha,
-         dropout_p, seed, out_f32, _stream())
+         dropout_p, seed, out_f32, res_f32, _stream())
     return out
 
 
@@ -133,11 +139,13 @@ def ln_partial_elems(T, d) -> int:
     return _lib.load().cldrd_ln_partial_blocks(T) * 3 * d
 
 
-def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps, dropout_p=0.0, seed=0):
+def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps, dropout_p=0.0, seed=0, out32=None):
     _chk(ids, torch.int64, "ids")
     d = word.shape[1]
+    if out32 is not None:
+        _chk(out32, F32, "out32", 2)
     call("cldrd_embed_ln_fwd", _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd),
-         T, L, d, word.shape[0], eps, dropout_p, seed, _stream())
+         T, L, d, word.shape[0], eps, dropout_p, seed, _p(out32), _stream())
     return out
 
 
@@ -149,20 +157,25 @@ def embed_ln_bwd(dy, ids, word, pos, type0, gamma, mean, rstd, dword, dpos, dtyp
          1 if accumulate else 0, _stream())
 
 
-def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_stride=0):
-    _chk(x, BF16, "x", 2), _chk(out, BF16, "out", 2), _chk(gamma, F32, "gamma", 1), _chk(beta, F32, "beta", 1)
+def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_stride=0, out32=None):
+    """x bf16, or fp32 (pre-LN sum of the fp32 residual stream; then out32, optional, receives the fp32 output as well)."""
+    x_f32 = 1 if x.dtype == F32 else 0
+    _chk(x, F32 if x_f32 else BF16, "x", 2), _chk(out, BF16, "out", 2), _chk(gamma, F32, "gamma", 1), _chk(beta, F32, "beta", 1)
+    if out32 is not None:
+        _chk(out32, F32, "out32", 2)
     d = x.shape[1]
     call("cldrd_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), T, d, eps, _p(cls_out),
-         cls_stride, _stream())
+         cls_stride, x_f32, _p(out32), _stream())
     return out
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_dropped, dgamma, dbeta, dbias, partial, T, dropout_p=0.0, seed=0,
                   accumulate=True):
-    _chk(dy, BF16, "dy", 2), _chk(x, BF16, "x", 2), _chk(dx, BF16, "dx", 2)
+    x_f32 = 1 if x.dtype == F32 else 0
+    _chk(dy, BF16, "dy", 2), _chk(x, F32 if x_f32 else BF16, "x", 2), _chk(dx, BF16, "dx", 2)
     d = x.shape[1]
     call("cldrd_layernorm_bwd", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dx_dropped), _p(dgamma),
-         _p(dbeta), _p(dbias), _p(partial), T, d, dropout_p, seed, 1 if accumulate else 0, _stream())
+         _p(dbeta), _p(dbias), _p(partial), T, d, dropout_p, seed, 1 if accumulate else 0, x_f32, _stream())
 
 
 def colsum(x, out, partial, T, accumulate=True):

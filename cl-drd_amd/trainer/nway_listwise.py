@@ -67,6 +67,8 @@ class NwayTrainer:
         self.lr0, self.wd, self.eps, self.max_grad_norm = learning_rate, weight_decay, adam_epsilon, max_grad_norm
         self.warmup_steps, self.total_steps, self.betas = warmup_steps, total_steps, betas
         self.global_step = 0
+        self.adam_step = 0          # bias-correction step of AdamW: differs from global_step only after resuming a reference fp16
+                                    # checkpoint whose GradScaler skipped steps (state["step"] < global_step there)
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.distributed else 1
         self.flat_p, self.flat_g = model.fuse_flat()
@@ -191,13 +193,14 @@ class NwayTrainer:
     def optimizer_step(self):
         """clip_grad_norm_ + AdamW + scheduler.step of reference nway_listwise_1.py:355-367 (bf16: no GradScaler)."""
         self.global_step += 1
+        self.adam_step += 1
         lr = self.lr(self.global_step - 1)          # the lr in effect during this step (scheduler steps afterwards)
         ops.grad_clip_coef(self.flat_g, self.max_grad_norm, self.norm_partial, self.clip)
         towers = self.model.towers()
         # one AdamW launch over the joint buffer; it also writes the bf16 shadow of every tower
         shadow = self._joint_shadow()
         ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, shadow, lr=lr, beta1=self.betas[0],
-                       beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=self.global_step, clip=self.clip)
+                       beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=self.adam_step, clip=self.clip)
         for t in towers:
             t.refresh_shadows(need_transposed=True, cast=False)
         return lr
@@ -232,20 +235,109 @@ class NwayTrainer:
             return 0.0, 0.0
         return float(np.sum(1.0 / (keep + 1.0)) / len(first)), float(len(keep) / len(first))
 
+    # ---- checkpoint payload (reference nway_listwise_1.py:418-426 / :300-304) --------------------------------------------
+    def _optimizer_names(self):
+        """Parameter names in the reference optimizer's index order: ``model.named_parameters()`` of the DDP-wrapped
+        NwayDualEncoder (HF module order, shared towers listed once) split into the decayed group, then the no-decay group
+        (nway_listwise_1.py:259-263).  Returns [(name, tower index or None, hf name)] per group."""
+        from ..encoder import hf_parameter_order
+        model = self.model
+        names = []
+        for ti, (prefix, tower) in enumerate((("query_encoder", model.query_encoder), ("passage_encoder", model.passage_encoder))):
+            if ti == 1 and model.share_weights:
+                break
+            for n in hf_parameter_order(tower.cfg, with_pooler=True):
+                names.append((f"{prefix}.{n}", ti if n in tower.layout.entries else None, n))
+        return [[e for e in names if not no_decay(e[0])], [e for e in names if no_decay(e[0])]]
+
+    def _slice(self, buf, ti, hf_name):
+        tower, toff = self.model.towers()[ti], self.model._tower_offsets[ti]
+        off, shape = tower.layout.entries[hf_name]
+        numel = 1
+        for d in shape:
+            numel *= d
+        return buf[toff + off:toff + off + numel].view(shape)
+
+    def optimizer_state_dict(self):
+        """``torch.optim.Optimizer.state_dict()`` layout of the reference's AdamW (state: step / exp_avg / exp_avg_sq per parameter
+        index; two param groups), so a reference run can resume from a checkpoint written here and vice versa."""
+        groups = self._optimizer_names()
+        state, param_groups, idx = {}, [], 0
+        for gi, entries in enumerate(groups):
+            ids = []
+            for _, ti, n in entries:
+                if ti is not None and self.adam_step > 0:
+                    state[idx] = {"step": self.adam_step, "exp_avg": self._slice(self.m, ti, n).detach().cpu().clone(),
+                                  "exp_avg_sq": self._slice(self.v, ti, n).detach().cpu().clone()}
+                ids.append(idx)
+                idx += 1
+            param_groups.append({"weight_decay": self.wd if gi == 0 else 0.0, "lr": self.lr(), "initial_lr": self.lr0,
+                                 "betas": tuple(self.betas), "eps": self.eps, "correct_bias": True, "params": ids})
+        return {"state": state, "param_groups": param_groups}
+
+    def load_optimizer_state_dict(self, sd):
+        """Accepts the torch layout above (a reference checkpoint's ``optimizer``) or this package's round-1 flat ``{"m","v"}``
+        blob; anything else raises (the reference's ``optimizer.load_state_dict`` would, :302)."""
+        if not isinstance(sd, dict):
+            raise ValueError(f"optimizer state must be a dict, got {type(sd).__name__}")
+        if "m" in sd and "v" in sd:
+            if sd["m"].numel() != self.m.numel() or sd["v"].numel() != self.v.numel():
+                raise ValueError("optimizer state: flat m/v size does not match this model")
+            self.m.copy_(sd["m"])
+            self.v.copy_(sd["v"])
+            self._opt_step_loaded = int(sd["step"]) if "step" in sd else None
+            return
+        if "state" not in sd or "param_groups" not in sd:
+            raise ValueError(f"optimizer state: unknown layout (keys {sorted(sd)[:6]})")
+        groups = self._optimizer_names()
+        pg = sd["param_groups"]
+        if len(pg) != 2 or any(len(g["params"]) != len(e) for g, e in zip(pg, groups)):
+            raise ValueError("optimizer state: parameter groups do not match this model "
+                             f"(expected sizes {[len(e) for e in groups]}, got {[len(g['params']) for g in pg]})")
+        self.m.zero_()
+        self.v.zero_()
+        steps = set()
+        index = {}
+        for g, entries in zip(pg, groups):
+            for pid, e in zip(g["params"], entries):
+                index[pid] = e
+        for pid, st in sd["state"].items():
+            if pid not in index:
+                raise ValueError(f"optimizer state: unknown parameter index {pid}")
+            name, ti, n = index[pid]
+            if ti is None:
+                continue                                  # BERT pooler: never has a gradient on this path
+            for key, buf in (("exp_avg", self.m), ("exp_avg_sq", self.v)):
+                t = st[key]
+                dst = self._slice(buf, ti, n)
+                if tuple(t.shape) != tuple(dst.shape):
+                    raise ValueError(f"optimizer state: {name}.{key} has shape {tuple(t.shape)}, expected {tuple(dst.shape)}")
+                dst.copy_(t.to(torch.float32))
+            steps.add(int(st["step"]))
+        if len(steps) > 1:
+            raise ValueError(f"optimizer state: per-parameter step counts differ ({sorted(steps)[:4]}...): one fused step counter here")
+        self._opt_step_loaded = steps.pop() if steps else None
+
     def state_dict(self):
-        """Checkpoint payload in the reference's shape (nway_listwise_1.py:418-426): DDP-style ``module.`` prefixed keys."""
+        """Checkpoint payload in the reference's shape (nway_listwise_1.py:418-426): DDP-style ``module.`` prefixed keys, the
+        optimizer in torch's ``state_dict()`` layout, the scheduler as ``LambdaLR.state_dict()`` would give it."""
         return {"global_step": self.global_step,
                 "state_dict": {"module." + k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
-                "optimizer": {"m": self.m.cpu(), "v": self.v.cpu(), "step": self.global_step},
-                "scheduler": {"last_epoch": self.global_step, "warmup_steps": self.warmup_steps, "total_steps": self.total_steps}}
+                "optimizer": self.optimizer_state_dict(),
+                "scheduler": {"base_lrs": [self.lr0, self.lr0], "last_epoch": self.global_step, "_step_count": self.global_step + 1,
+                              "_get_lr_called_within_step": False, "_last_lr": [self.lr(), self.lr()], "lr_lambdas": [None, None],
+                              "warmup_steps": self.warmup_steps, "total_steps": self.total_steps}}
 
     def load_state_dict(self, ckpt):
         sd = {k[7:] if k.startswith("module.") else k: v for k, v in ckpt["state_dict"].items()}
         self.model.load_state_dict(sd)
-        if "optimizer" in ckpt and isinstance(ckpt["optimizer"], dict) and "m" in ckpt["optimizer"]:
-            self.m.copy_(ckpt["optimizer"]["m"])
-            self.v.copy_(ckpt["optimizer"]["v"])
+        self._opt_step_loaded = None
+        if "optimizer" in ckpt:
+            self.load_optimizer_state_dict(ckpt["optimizer"])
         self.global_step = int(ckpt.get("global_step", 0))
+        if "scheduler" in ckpt and isinstance(ckpt["scheduler"], dict) and "last_epoch" in ckpt["scheduler"] and "global_step" not in ckpt:
+            self.global_step = int(ckpt["scheduler"]["last_epoch"])
+        self.adam_step = self.global_step if self._opt_step_loaded is None else self._opt_step_loaded
         for t in self.model.towers():
             t.refresh_shadows(need_transposed=True)
 
@@ -295,7 +387,7 @@ def get_args(argv=None):
     ap.add_argument("--synthetic_steps", default=0, type=int, help="steps per epoch on generated batches (no dataset files needed)")
     ap.add_argument("--synthetic_nway", default=30, type=int)
     ap.add_argument("--synthetic_model", default="distilbert", choices=("distilbert", "tiny"),
-                    help="random-init architecture for --synthetic_steps runs without a model directory (tiny: selftest.tiny_config)")
+                    help="random-init architecture for --synthetic_steps runs without a model directory (tiny: encoder.tiny_config)")
     args = ap.parse_args(argv)
     args.run_folder = os.path.join(args.experiment_folder, args.run_folder)
     args.log_dir = os.path.join(args.run_folder, args.log_dir)
@@ -375,7 +467,16 @@ def build_dataloader(args):
     else:
         raise ValueError(f"label mode {mode} not implemented")
     if args.token_cache_dir:
-        ds.with_token_cache(args.token_cache_dir)
+        # every rank holds the full query / passage tables, so the cache is the same everywhere: rank 0 builds and writes it
+        # (atomic renames), the others load it after the barrier instead of racing on the same files
+        if args.distributed:
+            if args.rank == 0:
+                ds.with_token_cache(args.token_cache_dir)
+            dist.barrier()
+            if args.rank != 0:
+                ds.with_token_cache(args.token_cache_dir, build=False)
+        else:
+            ds.with_token_cache(args.token_cache_dir)
     assert args.train_batch_size % args.nranks == 0
     g = torch.Generator()
     g.manual_seed(args.seed + args.rank)
@@ -399,6 +500,17 @@ class _SyntheticLoader:
             yield syn.nway_batch(a.seed + 1000 * a.rank + i, a.train_batch_size // a.nranks, a.synthetic_nway, a.query_max_len,
                                  a.passage_max_len, vocab=getattr(a, "synthetic_vocab", syn.VOCAB), ragged=True,
                                  label_kind="teacher" if a.loss in ("kl_div", "margin_mse") else "mode9")
+
+
+def common_steps_per_epoch(local_steps: int, distributed: bool, dev=None, group=None) -> int:
+    """Examples are sharded ``line_idx % nranks`` with ``drop_last`` (reference dataset/nway_dataset.py:305), so ranks can differ by
+    one batch per epoch; every rank runs MIN over ranks steps: same schedule length (t_total) everywhere and no rank left alone in
+    a gradient all-reduce at the end of an epoch."""
+    if not distributed:
+        return int(local_steps)
+    t = torch.tensor([int(local_steps)], dtype=torch.int64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
 
 
 def batch_to_device(batch, dev):
@@ -426,7 +538,7 @@ def train(args):
     if args.synthetic_steps > 0 and not os.path.isdir(str(args.model_name_or_path)):
         from ..encoder import EncoderConfig
         if args.synthetic_model == "tiny":
-            from ..selftest import tiny_config
+            from ..encoder import tiny_config
             cfg = tiny_config()
         else:
             cfg = EncoderConfig(arch="distilbert")
@@ -438,7 +550,8 @@ def train(args):
                                 all_in_batch_neg=args.all_in_batch_neg)
     model.to(dev)
     model.train()
-    t_total = len(loader) * args.num_train_epochs
+    steps_per_epoch = common_steps_per_epoch(len(loader), args.distributed, dev)
+    t_total = steps_per_epoch * args.num_train_epochs
     trainer = NwayTrainer(model, loss=args.loss, learning_rate=args.learning_rate, weight_decay=args.weight_decay,
                           adam_epsilon=args.adam_epsilon, max_grad_norm=args.max_grad_norm, warmup_steps=args.warmup_steps,
                           total_steps=t_total, reg_lambda=args.reg_lambda)
@@ -463,7 +576,9 @@ def train(args):
     topk = 10
     log_file = os.path.join(args.log_dir, "train_logs.log")
     for epoch in range(start_epoch, args.num_train_epochs):
-        for batch in loader:
+        for step_i, batch in enumerate(loader):
+            if step_i >= steps_per_epoch:       # ranks whose shard is one batch longer stop with the others (no unmatched all-reduce)
+                break
             batch = batch_to_device(batch, dev)
             loss_out = trainer.train_step(batch)
             if main_rank and trainer.global_step % args.logging_steps == 0:

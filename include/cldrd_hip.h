@@ -34,10 +34,12 @@ int cldrd_device_ok(void);            /* 1 if device 0 is a gfx950 */
  * transformers DistilBERT q_lin/k_lin/v_lin/out_lin/ffn.lin1/ffn.lin2, BERT query/key/value/dense).
  *   C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T)
  *   epilogue order: + bias[N] -> (store preact) -> act (1 = erf-GELU) -> * gelu'(gelu_pre) -> dropout -> + residual
- *   K % 64 == 0; A/B/C 16-byte aligned; out_f32 != 0 stores fp32 instead of bf16. */
+ *   K % 64 == 0; A/B/C 16-byte aligned; out_f32 != 0 stores fp32 instead of bf16; res_f32 != 0: `residual` is fp32
+ *   (the fp32 residual stream: out-projection / FFN2 add the fp32 LayerNorm output and store the fp32 pre-LN sum, as the
+ *   reference's autocast does - trainer/multistep-curriculum/nway_listwise_1.py:334). */
 int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                        const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
-                       int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, void* stream);
+                       int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, void* stream);
 
 /* Weight gradient dW[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (A = dY, B = layer input; autograd's Linear backward), and,
  * when dbias != NULL, the bias gradient dbias[N1] (+)= column sums of A in the same pass.
@@ -70,20 +72,22 @@ int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_
 int cldrd_ln_partial_blocks(int T);
 int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
-                       int d, int vocab, float eps, float dropout_p, unsigned long long seed, void* stream);
+                       int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, void* stream);
 int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
                        float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,
                        float dropout_p, unsigned long long seed, int accumulate, void* stream);
 /* out = LN(x)*gamma+beta (bf16); cls_out (fp32 [T/cls_stride, d], optional) receives rows r % cls_stride == 0:
- * the `[0][:, 0, :]` CLS pooling of models/nway_dual_encoder.py:52,56,64. */
+ * the `[0][:, 0, :]` CLS pooling of models/nway_dual_encoder.py:52,56,64.
+ * x_f32 != 0: x is fp32 (the pre-LN sum of the fp32 residual stream) and out32 (optional) receives the fp32 output next to
+ * the bf16 copy the GEMMs read; cldrd_embed_ln_fwd has the same optional out32. */
 int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
-                        int T, int d, float eps, float* cls_out, int cls_stride, void* stream);
+                        int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, void* stream);
 /* dx = LN backward of dy; dx_dropped (optional) = dropout-masked dx for the branch that passed through dropout;
  * dgamma/dbeta/dbias (each optional) receive sum(dy*xhat), sum(dy), sum(dx_dropped or dx). */
 int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
-                        int d, float dropout_p, unsigned long long seed, int accumulate, void* stream);
+                        int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, void* stream);
 /* out[N] (+)= column sums of bf16 x[T,N] (bias gradients).  partial: ceil(T/128) * N floats. */
 int cldrd_colsum_bf16(const void* x, float* out, float* partial, int T, int N, int ld, int accumulate, void* stream);
 /* g = zeros(bf16 [T,d]); g[r*stride] = dcls[r]  (gradient of the CLS pooling). */

@@ -1,5 +1,6 @@
 """``__graft_entry__.smoke()``: one tiny N-way training step of the hot path on cuda:0, checked against the CPU
-oracle (test infrastructure under ``oracle/``; imported here only as the checker)."""
+oracle (test infrastructure under ``oracle/``; imported here only as the checker).  Lives at the repo root, outside the
+product package: nothing under ``cl-drd_amd/`` imports ``oracle``."""
 from __future__ import annotations
 
 import numpy as np
@@ -7,14 +8,13 @@ import torch
 
 
 def tiny_config():
-    from .encoder import EncoderConfig
-    return EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=2,
-                         max_position_embeddings=64, dropout=0.0, attention_dropout=0.0)
+    from cldrd_amd.encoder import tiny_config as _tc
+    return _tc()
 
 
 def build_tiny_model(cfg=None, share_weights=False, seed=3, std=0.1):
-    from . import synthetic as syn
-    from .models import NwayDualEncoder
+    import cldrd_amd.synthetic as syn
+    from cldrd_amd.models import NwayDualEncoder
     cfg = cfg or tiny_config()
     model = NwayDualEncoder(cfg, share_weights=share_weights)
     with torch.no_grad():
@@ -41,8 +41,8 @@ def oracle_cfg(cfg):
 def smoke():
     from oracle import encoder_ref as E
     from oracle import losses_ref as LR
-    from . import synthetic as syn
-    from .trainer import NwayTrainer
+    import cldrd_amd.synthetic as syn
+    from cldrd_amd.trainer import NwayTrainer
 
     torch.cuda.set_device(0)
     cfg = tiny_config()

@@ -13,7 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import cldrd_amd.synthetic as syn
-from cldrd_amd import selftest
+import selftest
 from cldrd_amd.encoder import EncoderConfig
 from cldrd_amd.models import NwayDualEncoder
 from cldrd_amd.trainer import NwayTrainer

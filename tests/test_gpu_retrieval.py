@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 import cldrd_amd.synthetic as syn
 from cldrd_amd import hip_ops as ops
-from cldrd_amd import selftest
+import selftest
 from cldrd_amd.retriever import retrieval_utils as RU
 from oracle import retrieval_ref as R
 
