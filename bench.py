@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-retrieve", action="store_true")
     ap.add_argument("--retrieve-rows", type=int, default=1105228, help="index rows per GPU (8 841 823 / 8)")
+    ap.add_argument("--retrieve-queries", type=int, default=6980, help="queries searched against the shard (MS MARCO dev: 6980)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -203,38 +204,68 @@ def main():
         elif "error" not in index:
             index = {"error": "another rank failed in the index leg"}
 
-    # ---- retrieve path: cfg5 shard (8 841 823 / 8 rows x 768), 128-query batches, k = 1000 ----
+    # ---- retrieve path: cfg5, one shard per GPU (8 841 823 / 8 rows x 768), ALL 6980 queries in 128-query batches, k = 1000 ----
     retrieve = None
     try:
         if not args.no_retrieve:
             from cldrd_amd.retriever.retrieval_utils import FlatIPIndex
             del trainer, model
             torch.cuda.empty_cache()
-            rows = args.retrieve_rows
+            rows, nq_r, kq = args.retrieve_rows, args.retrieve_queries, 1000
             gen = torch.Generator(device=dev).manual_seed(1234 + rank)
             P = torch.randn(rows, D, device=dev, generator=gen)
             P *= ((9.0 + 3.0 * torch.rand(rows, 1, device=dev, generator=gen)) / P.norm(dim=1, keepdim=True))
             flat_index = FlatIPIndex.from_device_rows(P, id_offset=rank * rows)
-            flat_index.profile = True
-            qn = torch.randn(3 * 128, D, device=dev, generator=gen)
+            qn = torch.randn(nq_r, D, device=dev, generator=gen)
             qn *= (10.0 / qn.norm(dim=1, keepdim=True))
-            qh = qn.cpu().numpy()
-            flat_index.search(qh[:128], 1000)                  # warm-up
+            flat_index.search_device(qn[:256], kq)             # warm-up
             sync_all()
+            nb = (nq_r + 127) // 128
+            # (1) device-resident search: queries and results stay in HBM, one host sync (the proof flags)
             t2 = time.perf_counter()
-            Dq, Iq = flat_index.search(qh, 1000)
-            sync_all()
+            Dq, Iq, st = flat_index.search_device(qn, kq)
+            torch.cuda.synchronize()
             dr = time.perf_counter() - t2
-            st = flat_index.last_stats
-            scan_ms = sum(st["scan_ms"]) / len(st["scan_ms"])
-            scan_bytes = rows * D * 2 + 128 * D * 2
-            # the index is row-sharded: a query is done when every shard has been searched, so queries/s does not grow with the
-            # number of GPUs - the index does (rows_total); the host-side merge of the per-shard lists is not part of this leg
-            retrieve = {"seconds": dr, "nq": int(qh.shape[0]), "rows_per_shard": rows, "rows_total": world * rows, "k": 1000, "batch": 128,
-                        "scans": st["scans"], "rescans": st["rescans"], "candidates_per_query": round(st["candidates"] / qh.shape[0], 1),
+            # (2) the same with HIP events around the enqueued pipeline, and candidate statistics
+            flat_index.profile = True
+            _, _, st = flat_index.search_device(qn, kq)
+            flat_index.profile = False
+            # (3) the reference-shaped host API (numpy in, numpy out: PCIe both ways + id mapping), for the record
+            qh = qn.cpu().numpy()
+            sync_all()
+            t3 = time.perf_counter()
+            flat_index.search(qh, kq)
+            dh = time.perf_counter() - t3
+            # (4) the dominant kernel alone: the fp16 streaming scan of one 128-query batch, HIP events on its stream
+            from cldrd_amd import hip_ops as ops2
+            qh16 = qn[:128].half().contiguous()
+            thr = torch.full((128,), 11.5, device=dev)
+            counts = torch.zeros(129, dtype=torch.int32, device=dev)
+            cr = torch.empty(128, 8192, dtype=torch.int32, device=dev)
+            cs_ = torch.empty(128, 8192, dtype=torch.float32, device=dev)
+            ops2.topk_scan_filter(qh16, flat_index._p16, thr, counts, cr, cs_)
+            evs = []
+            for _ in range(10):
+                counts.zero_()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                ops2.topk_scan_filter(qh16, flat_index._p16, thr, counts, cr, cs_)
+                e1.record()
+                evs.append((e0, e1))
+            torch.cuda.synchronize()
+            scan_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            scan_bytes = rows * D * 2 + 128 * D * 2            # bytes of one 128-query batch x one shard scan (16-bit rows)
+            batch_ms = st["search_ms"] / nb
+            retrieve = {"seconds": dr, "nq": nq_r, "rows_per_shard": rows, "rows_total": world * rows, "k": kq, "batch": 128,
+                        "scans": st["scans"], "rescans": st["rescans"], "unproven_first_pass": st["unproven_first_pass"],
+                        "candidates_per_query": round(st["candidates"] / nq_r, 1), "rescored_per_query": round(st["rescored"] / nq_r, 1),
                         "scan_kernel_ms": round(scan_ms, 3), "scan_hbm_gb_s": round(scan_bytes / scan_ms / 1e6, 1),
                         "scan_hbm_frac": round(scan_bytes / scan_ms / 1e6 / 8000.0, 4),
-                        "scan_tflops": round(2.0 * 128 * rows * D / scan_ms / 1e9, 1)}
+                        "scan_tflops": round(2.0 * 128 * rows * D / scan_ms / 1e9, 1),
+                        "path_ms_per_batch": round(batch_ms, 3), "path_hbm_gb_s": round(scan_bytes / batch_ms / 1e6, 1),
+                        "path_hbm_frac": round(scan_bytes / batch_ms / 1e6 / 8000.0, 4),
+                        "wall_ms_per_batch": round(1e3 * dr / nb, 3), "wall_hbm_frac": round(scan_bytes / (1e3 * dr / nb) / 1e6 / 8000.0, 4),
+                        "host_api_queries_per_s": round(nq_r / dh, 1)}
             del flat_index, P
     except Exception as exc:      # a secondary leg must not take the headline line down with it
         retrieve = {"error": f"{type(exc).__name__}: {exc}"[:300]}
@@ -294,45 +325,50 @@ def spawn_ranks(n: int) -> int:
 
 
 def cpu_baseline(N, L, Lq):
-    """The CPU oracle (oracle/, a port of the reference path pinned to it by tests/golden) timed on this box's host cores:
-    one fp32 training step (forward + loss + backward + clip + AdamW) of the same workload at B=2."""
+    """The CPU oracle (oracle/, a port of the reference path pinned to it by tests/golden) timed on this box's host cores: fp32
+    training steps (forward + loss + backward + clip + AdamW) of the same workload (cfg2: N=32, L=128, kl_div) at B=2 - one untimed
+    warm-up step, then two timed ones: a bounded sample (~10-20 s of CPU work), all cores the process may use."""
     import numpy as np
     import torch
     from oracle import encoder_ref as E
     from oracle import losses_ref as LR
     import cldrd_amd.synthetic as syn
-    cores = min(len(os.sched_getaffinity(0)), 32)      # more threads than this only adds contention in torch-CPU
+    cores = len(os.sched_getaffinity(0))
     torch.set_num_threads(cores)
-    Bc = 4
+    Bc, timed = 2, 2
     cfg = E.RefConfig()
     shapes = E.param_shapes(cfg)
     g = torch.Generator().manual_seed(0)
     qp = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in shapes.items()}
     pp = {k: (torch.randn(s, generator=g) * 0.02).requires_grad_(True) for k, s in shapes.items()}
-    batch = syn.nway_batch(1, Bc, N, Lq, L)
-    warm = syn.nway_batch(2, 1, 2, 8, 16)
-    E.nway_forward(qp, pp, cfg, warm["query"], warm["nway_passages"]).sum().backward()
     params = list(qp.values()) + list(pp.values())
-    for p in params:
-        p.grad = None
     m = [torch.zeros_like(p) for p in params]
     v = [torch.zeros_like(p) for p in params]
+
+    def step(batch, t):
+        for p in params:
+            p.grad = None
+        logits = E.nway_forward(qp, pp, cfg, batch["query"], batch["nway_passages"])
+        _, dl = LR.kl_div(logits.detach().numpy(), batch["labels"].numpy())
+        logits.backward(torch.from_numpy(dl).float())
+        with torch.no_grad():
+            total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)).item()
+            coef = min(1.0, 1.0 / (total + 1e-6))
+            for p, mm, vv in zip(params, m, v):
+                gq = p.grad * coef
+                mm.mul_(0.9).add_(gq, alpha=0.1)
+                vv.mul_(0.999).addcmul_(gq, gq, value=0.001)
+                p.addcdiv_(mm, vv.sqrt().add_(1e-8), value=-7e-6 * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t))
+                p.mul_(1 - 7e-6 * 0.01)
+
+    step(syn.nway_batch(2, 1, 4, 8, 32), 1)                    # warm-up (thread pool, allocator)
     t0 = time.perf_counter()
-    logits = E.nway_forward(qp, pp, cfg, batch["query"], batch["nway_passages"])
-    _, dl = LR.kl_div(logits.detach().numpy(), batch["labels"].numpy())
-    logits.backward(torch.from_numpy(dl).float())
-    with torch.no_grad():
-        total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in params)).item()
-        coef = min(1.0, 1.0 / (total + 1e-6))
-        for p, mm, vv in zip(params, m, v):
-            gq = p.grad * coef
-            mm.mul_(0.9).add_(gq, alpha=0.1)
-            vv.mul_(0.999).addcmul_(gq, gq, value=0.001)
-            p.addcdiv_(mm, vv.sqrt().add_(1e-8), value=-7e-6 * (1 - 0.999) ** 0.5 / (1 - 0.9))
-            p.mul_(1 - 7e-6 * 0.01)
+    for i in range(timed):
+        step(syn.nway_batch(10 + i, Bc, N, Lq, L), 2 + i)
     dt = time.perf_counter() - t0
+    Bc = Bc * timed
     out = {"value": round(Bc / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-           "sample": f"1 fp32 step (fwd+loss+bwd+clip+AdamW) of the same workload at B={Bc} (N={N}, L={L}), oracle/encoder_ref.py on torch-CPU, {dt:.1f} s"}
+           "sample": f"{timed} fp32 steps (fwd+loss+bwd+clip+AdamW) of the same workload at B={Bc // timed} (N={N}, L={L}) after 1 warm-up step, oracle/encoder_ref.py on torch-CPU, {dt:.1f} s"}
     # the other two legs of the metric on the same cores (SURVEY.md section 8d): encode 64 x L passages; exact top-1000 of 128 queries
     # over a 200 000-row fp32 shard (oracle/retrieval_ref.py: the faiss IndexFlatIP contract)
     from oracle import retrieval_ref as RR

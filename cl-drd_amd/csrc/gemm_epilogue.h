@@ -19,6 +19,7 @@ struct GemmNtArgs {
     int out_f32;
     // EPI_FILTER (top-k scan): keep C[m][n] >= thr[m] as candidate (n, score) of query m
     const float* thr; int* counts; int* cand_rows; float* cand_scores; int cap;
+    int in_f16 = 0;               // top-k scan only: the operands are fp16 (EPI_F16IN instances), not bf16
     int gn = 0;                   // ring kernel: N tiles are walked in groups of gn inside an XCD's range (0: row-major)
     int stagger = 1;              // ring kernel: waves 4..7 issue their LDS-DMA one k-step after waves 0..3 (0: A/B runs)
 };
@@ -28,8 +29,18 @@ struct GemmNtArgs {
 enum : int {
     EPI_BIAS = 1, EPI_PREACT = 2, EPI_GELU = 4, EPI_GELUGRAD = 8, EPI_DROPOUT = 16, EPI_RESIDUAL = 32, EPI_F32 = 64, EPI_FILTER = 128,
     EPI_RES32 = 256,              // the residual operand is fp32 (only with EPI_RESIDUAL)
+    EPI_F16IN = 512,              // A and B hold fp16, not bf16 (top-k scan over the fp16 index shadow; only with EPI_FILTER)
     EPI_GENERIC = 1 << 20
 };
+
+typedef _Float16 gemm_f16x8 __attribute__((ext_vector_type(8)));
+template <int EPI>
+__device__ __forceinline__ f32x4 gemm_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (EPI != EPI_GENERIC && (EPI & EPI_F16IN) != 0)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(gemm_f16x8, a), __builtin_bit_cast(gemm_f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 template <int EPI> struct EpiFlags {
     const bool bias, preact, gelu, gelugrad, dropout, residual, f32, res32;

@@ -90,11 +90,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
                     // operands swapped on purpose: D'[n][m], so a lane's 4 accumulators are 4 consecutive n
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[nt], af[mt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = gemm_mfma<EPI>(bfr[nt], af[mt], acc[mt][nt]);
         }
     }
 
-    if constexpr (EPI == EPI_FILTER) {
+    if constexpr ((EPI & EPI_FILTER) != 0 && EPI != EPI_GENERIC) {
         gemm_nt_filter_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
     } else {
         __syncthreads();      // all fragment reads of the last K tile are done: the staging buffers become epilogue scratch
@@ -120,7 +120,7 @@ int launch_nt(const GemmNtArgs& a, hipStream_t st) {
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a, int force_bn, hipStream_t st);   // gemm_nt_ring.hip
 int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st);                     // gemm_nt_ring.hip
 int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts, int* cand_rows,
-                           float* cand_scores, int cap, hipStream_t st);            // topk.hip
+                           float* cand_scores, int cap, int f16, hipStream_t st);   // topk.hip
 
 extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
@@ -171,7 +171,7 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
 // Top-k scan over one index shard: scores = Q[nq,d] . P[rows,d]^T on bf16 MFMA; every (query, row) with score >= thr[query]
 // is appended to the query's candidate list (counts must be zeroed by the caller; counts[q] may exceed cap = overflow).
 static int scan_filter_impl(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
-                            int* cand_rows, float* cand_scores, int cap, void* stream, bool tiled) {
+                            int* cand_rows, float* cand_scores, int cap, int f16, void* stream, bool tiled) {
     CLDRD_CHECK(nq > 0 && rows > 0 && rows < 2147483647LL && d % BK == 0 && cap > 0, "topk_scan_filter: bad arguments");
     CLDRD_CHECK(((uintptr_t)Q % 16 == 0) && ((uintptr_t)P % 16 == 0), "topk_scan_filter: operands must be 16-byte aligned");
     GemmNtArgs a;
@@ -180,9 +180,10 @@ static int scan_filter_impl(const void* Q, const void* P, int nq, long long rows
     a.bias = nullptr; a.residual = nullptr; a.ldr = 0; a.preact = nullptr; a.gelu_pre = nullptr; a.act = 0; a.alpha = 1.0f;
     a.drop_thresh = 0; a.drop_scale = 1.0f; a.seed = 0; a.out_f32 = 0;
     a.thr = thr; a.counts = counts; a.cand_rows = cand_rows; a.cand_scores = cand_scores; a.cap = cap;
+    a.in_f16 = f16 ? 1 : 0;
     const char* env_scan = getenv("CLDRD_SCAN");          // "gemm" forces the tiled-GEMM scan (A/B experiments)
     if (!tiled && !(env_scan && env_scan[0] == 'g')) {
-        const int rc = cldrd_topk_scan_stream(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, (hipStream_t)stream);
+        const int rc = cldrd_topk_scan_stream(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, f16, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
     const char* env_tile = getenv("CLDRD_GEMM_TILE");
@@ -191,16 +192,16 @@ static int scan_filter_impl(const void* Q, const void* P, int nq, long long rows
         a.A = (const bf16_t*)P; a.B = (const bf16_t*)Q; a.M = (int)rows; a.N = nq;
         return cldrd_gemm_nt_ring_scan(a, (hipStream_t)stream);
     }
-    return launch_nt<EPI_FILTER>(a, (hipStream_t)stream);
+    return f16 ? launch_nt<EPI_FILTER | EPI_F16IN>(a, (hipStream_t)stream) : launch_nt<EPI_FILTER>(a, (hipStream_t)stream);
 }
 
 extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
-                                      int* cand_rows, float* cand_scores, int cap, void* stream) {
-    return scan_filter_impl(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, stream, false);
+                                      int* cand_rows, float* cand_scores, int cap, int f16, void* stream) {
+    return scan_filter_impl(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, f16, stream, false);
 }
 
 // Same contract, always through the tiled kernels (hits go straight to the global lists: never sets counts[nq]).
 extern "C" int cldrd_topk_scan_filter_tiled(const void* Q, const void* P, int nq, long long rows, int d, const float* thr,
-                                            int* counts, int* cand_rows, float* cand_scores, int cap, void* stream) {
-    return scan_filter_impl(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, stream, true);
+                                            int* counts, int* cand_rows, float* cand_scores, int cap, int f16, void* stream) {
+    return scan_filter_impl(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, f16, stream, true);
 }

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     auto mfma_row = [&](int mt, bf16x8 (&bc)[NT]) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[nt], af[mt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = gemm_mfma<EPI>(bc[nt], af[mt], acc[mt][nt]);
     };
     // One 32-deep k-step.  A fragments are refilled IN PLACE for the next k-step as soon as their last MFMA has issued
     // (the refill of af[mt] has 6*NT MFMAs to land); only the B fragments are double-buffered (bc -> bn).
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
         klast(b1);
     }
 
-    if constexpr (EPI == EPI_FILTER) {
+    if constexpr ((EPI & EPI_FILTER) != 0 && EPI != EPI_GENERIC) {
         gemm_nt_filter_epilogue_cols<8, NT>(p, acc, m0 + wm * 128, n0 + wn * WN, lane);
     } else {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -255,6 +255,7 @@ int launch_ring(const GemmNtArgs& a, hipStream_t st) {
         case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL: return launch_ring_epi<BN, EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL>(a, st);
         case EPI_GELUGRAD: return launch_ring_epi<BN, EPI_GELUGRAD>(a, st);
         case EPI_RESIDUAL: return launch_ring_epi<BN, EPI_RESIDUAL>(a, st);
+        case EPI_F32: return launch_ring_epi<BN, EPI_F32>(a, st);
         case EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32: return launch_ring_epi<BN, EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, st);
         case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
             return launch_ring_epi<BN, EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, st);
@@ -265,7 +266,9 @@ int launch_ring(const GemmNtArgs& a, hipStream_t st) {
 }  // namespace
 
 // Top-k scan with the index rows as M (256-row tiles) and up to 128 queries as N.
-int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st) { return launch_ring_epi<128, EPI_FILTER>(a, st); }
+int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st) {
+    return a.in_f16 ? launch_ring_epi<128, EPI_FILTER | EPI_F16IN>(a, st) : launch_ring_epi<128, EPI_FILTER>(a, st);
+}
 
 // Returns -1 if this variant does not apply (caller falls back to the 128x128 kernel), else the launch status.
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_t st) {

@@ -146,6 +146,150 @@ __global__ __launch_bounds__(256) void gather_cast_rows_kernel(const float* __re
 }
 
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// fp16 shadow of the index / the queries.  fp16 (11-bit significand) instead of bf16 (8): |scan - exact| shrinks 8x, and with it
+// the band of candidates that must be re-scored in fp32 (retrieval_utils.py docstring).  flag <- 1 when a value does not fit
+// (|x| > 65504 or NaN): the caller refuses the index / the query instead of scanning infinities.
+__device__ __forceinline__ uint32_t pack2h(float lo, float hi) {
+    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+__global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n4,
+                                                        unsigned int* __restrict__ flag) {
+    bool bad = false;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 a = ((const float4*)src)[i];
+        bad |= !(fabsf(a.x) <= 65504.f) | !(fabsf(a.y) <= 65504.f) | !(fabsf(a.z) <= 65504.f) | !(fabsf(a.w) <= 65504.f);
+        uint2 u; u.x = pack2h(a.x, a.y); u.y = pack2h(a.z, a.w);
+        ((uint2*)dst)[i] = u;
+    }
+    if (bad && flag) atomicOr(flag, 1u);
+}
+
+// one block per query: fp16 + bf16 copies, L2 norm (fp32, fixed order), range flag
+__global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, uint16_t* __restrict__ qh, bf16_t* __restrict__ qb,
+                                                            float* __restrict__ qnorm, int d, unsigned int* __restrict__ flag) {
+    __shared__ float red[4];
+    const float* row = q + (size_t)blockIdx.x * d;
+    float s = 0.f;
+    bool bad = false;
+    for (int j = threadIdx.x * 4; j < d; j += 1024) {
+        const float4 a = *(const float4*)(row + j);
+        s += a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w;
+        bad |= !(fabsf(a.x) <= 65504.f) | !(fabsf(a.y) <= 65504.f) | !(fabsf(a.z) <= 65504.f) | !(fabsf(a.w) <= 65504.f);
+        uint2 u; u.x = pack2h(a.x, a.y); u.y = pack2h(a.z, a.w);
+        *(uint2*)(qh + (size_t)blockIdx.x * d + j) = u;
+        uint2 v; v.x = pack2bf(a.x, a.y); v.y = pack2bf(a.z, a.w);
+        *(uint2*)(qb + (size_t)blockIdx.x * d + j) = v;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) qnorm[blockIdx.x] = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    if (bad && flag) atomicOr(flag, 1u);
+}
+
+// eps[q] >= |fp16 scan score - fp32 exact score| for every index row (pmax = largest row norm, both operands rounded to fp16):
+//   rounding of q and p (RNE, u = 2^-11 each, Cauchy-Schwarz)            |q| pmax (2^-10 + 2^-22)
+//   fp32 accumulation inside the MFMA chain and inside the re-score      |q| pmax d 2^-21      (2 ulp per add, both sums)
+//   values below the fp16 normal range (flushed or rounded, <= 2^-14)    2^-14 sqrt(d) (|q| + pmax) + d 2^-28
+// thr[q] = est[q] - 2 eps[q]: the scan keeps a row when its fp16 score reaches thr (cldrd_topk_select explains the 2).
+__global__ void thresholds_kernel(const float* __restrict__ est, const float* __restrict__ qnorm, float pmax, int d, float* __restrict__ thr,
+                                  float* __restrict__ eps, int nq) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const double qn = qnorm[i], pm = pmax, dd = d;
+    double e = qn * pm * (0x1p-10 + 0x1p-22 + dd * 0x1p-21) + 0x1p-14 * sqrt(dd) * (qn + pm) + dd * 0x1p-28;
+    const float ef = (float)(e * (1.0 + 1e-6)) + 1e-30f;
+    eps[i] = ef;
+    if (est) thr[i] = est[i] - 2.0f * ef;
+}
+
+// exhaustive mode (rows <= cap): every row is a candidate of every query
+__global__ void all_candidates_kernel(int* __restrict__ counts, int* __restrict__ cand_rows, float* __restrict__ cand_scores, int rows, int cap) {
+    const int q = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += gridDim.x * blockDim.x) {
+        cand_rows[(size_t)q * cap + i] = i;
+        cand_scores[(size_t)q * cap + i] = 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) counts[q] = rows;
+}
+
+// Per query, on the fp16 scan scores s^ of its candidate list (c = counts[q] entries, all rows with s^ >= thr[q]):
+//   t^ = the kk-th largest s^  (the true kk-th largest over the whole shard as soon as c >= kk);
+//   keep the candidates with s^ >= t^ - 2 eps.  Why that is enough: a row with s^ < t^ - 2 eps has exact score
+//   s <= s^ + eps < t^ - eps, while each of the kk rows with s^ >= t^ has s >= t^ - eps: kk rows beat it strictly.
+//   Every row with s^ >= t^ - 2 eps is IN the list when thr <= t^ - 2 eps; that, c >= kk, no overflow and no dropped hit make
+//   the query PROVEN: the exact top-kk is inside the kept set, which the next two kernels re-score in fp32 and sort.
+// status[q]: 0 proven | 1 fewer than kk candidates | 2 list overflow (c > cap) | 4 hits dropped by the scan | 8 threshold above
+// t^ - 2 eps | 16 kept set larger than cap2.  khat[q] = t^ (or -inf).  exhaustive != 0: the list holds every row; keep all.
+__global__ __launch_bounds__(1024) void select_compact_kernel(const int* __restrict__ counts, const int* __restrict__ dropped,
+                                                               const int* __restrict__ cand_rows, const float* __restrict__ cand_scores, int cap,
+                                                               int kk, const float* __restrict__ thr, const float* __restrict__ eps,
+                                                               int* __restrict__ rows2, int cap2, int* __restrict__ n2, int* __restrict__ status,
+                                                               float* __restrict__ khat, int exhaustive) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int sc[];      // cap orderable scores
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int sel_prefix, sel_remaining, nkeep;
+    const int q = blockIdx.x;
+    const int c = counts[q];
+    const int n = min(c, cap);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sc[i] = orderable(cand_scores[(size_t)q * cap + i]);
+    if (threadIdx.x == 0) { sel_prefix = 0; sel_remaining = (unsigned)kk; nkeep = 0; }
+    __syncthreads();
+    int st = 0;
+    float cut = -__builtin_inff(), t_hat = -__builtin_inff();
+    if (!exhaustive) {
+        if (c < kk) st |= 1;
+        if (c > cap) st |= 2;
+        if (*dropped != 0) st |= 4;
+        if (n >= kk) {
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+                __syncthreads();
+                const unsigned int prefix = sel_prefix;
+                const unsigned int pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+                for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                    const uint32_t o = sc[i];
+                    if ((o & pmask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    unsigned int rem = sel_remaining, b = 255;
+                    for (;; --b) {
+                        const unsigned int cnt = hist[b];
+                        if (cnt >= rem || b == 0) break;
+                        rem -= cnt;
+                    }
+                    sel_prefix = prefix | (b << shift);
+                    sel_remaining = rem;
+                }
+                __syncthreads();
+            }
+            t_hat = from_orderable(sel_prefix);
+            cut = t_hat - 2.0f * eps[q];
+            if (!(thr[q] <= cut)) st |= 8;
+        }
+    }
+    const unsigned int ocut = orderable(cut);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (sc[i] >= ocut) {
+            const unsigned int pos = atomicAdd(&nkeep, 1u);
+            if (pos < (unsigned)cap2) rows2[(size_t)q * cap2 + pos] = cand_rows[(size_t)q * cap + i];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (nkeep > (unsigned)cap2) st |= 16;
+        n2[q] = (int)min(nkeep, (unsigned)cap2);
+        status[q] = st;
+        khat[q] = t_hat;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Streaming scan: the HBM-bound part of the search.  The 128 queries of a batch stay in REGISTERS (wave w keeps the
 // MFMA B fragments of queries 16w..16w+15 for the whole K range: KS*4 VGPRs), the index streams through a 3-slot LDS
@@ -154,16 +298,24 @@ __global__ __launch_bounds__(256) void gather_cast_rows_kernel(const float* __re
 // CU walks tiles b, b+grid, ...; two tiles (96 KiB at d = 768) stay in flight per CU behind a counted vmcnt.
 // Hits (score >= thr[query], ~0.2 % of the scores) go to a small LDS list and are flushed to the per-query candidate
 // lists with global atomics only when the list fills up or at the end, so the DMA queue is never drained in the loop.
-template <int KS, int ablate>     // d = 32 * KS; ablate != 0: timing experiments only (tools/scan_bench.py)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int KS, int ablate, bool F16>     // d = 32 * KS; ablate != 0: timing experiments only (tools/scan_bench.py); F16: fp16 shadow
 __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q, int nq,
                                                               long long rows, const float* __restrict__ thr,
                                                               int* __restrict__ counts, int* __restrict__ cand_rows,
                                                               float* __restrict__ cand_scores, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int R = 32, ROWB = KS * 64, TILEB = R * ROWB, PIECES = TILEB / 1024, NW = 8, PPW = PIECES / NW, NSLOT = 3;
-    constexpr int LCAP = (160 * 1024 - NSLOT * TILEB - 16) / 12 < 4096 ? (160 * 1024 - NSLOT * TILEB - 16) / 12 : 4096;   // LDS hit list
+    constexpr int LCAP = (160 * 1024 - NSLOT * TILEB - 16 - 1024) / 12 < 4096 ? (160 * 1024 - NSLOT * TILEB - 16 - 1024) / 12 : 4096;   // LDS hit list
     int* lcount = (int*)(smem + NSLOT * TILEB);
-    int* lq = lcount + 4;
+    int* qcnt = lcount + 4;                    // [0,128) per-query hit counts, [128,256) global bases (flush scratch)
+    int* lq = qcnt + 256;
     int* lrow = lq + LCAP;
     float* lscore = (float*)(lrow + LCAP);
     const int lane = threadIdx.x & 63;
@@ -180,10 +332,11 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bq[ks]));      // wait for the loads here, not inside the tile loop
     }
-    const float thr_lane = qn < nq ? thr[qn] : __builtin_inff();
+    float thr_lane = qn < nq ? thr[qn] : __builtin_inff();
+    asm volatile("" : "+v"(thr_lane));       // consume the load HERE: otherwise hipcc waits vmcnt(0) at its first use inside the tile loop
     const uint32_t lcount_off = (uint32_t)(uintptr_t)LDS_PTR(lcount), lq_off = (uint32_t)(uintptr_t)LDS_PTR(lq);
     static_assert(8 * LCAP < 65536, "ds_write offset field");
-    if (threadIdx.x == 0) *lcount = 0;
+    if (threadIdx.x < 4) lcount[threadIdx.x] = 0;               // [0] list length, [1], [2] its snapshots (see the flush check)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing but LDS-DMA is in flight from here on
 
     // ---- DMA addressing: piece p = wid*PPW + j covers LDS bytes [1024 p, 1024 p + 1024) of the tile image
@@ -209,17 +362,48 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
 #pragma unroll
     for (int kr = 0; kr < 4; ++kr)
         rd_off[kr] = (lane & 15) * ROWB + ((((kr << 2) ^ (lane & 12)) | ((lane >> 4) ^ (lane & 3))) * 16);
+    // Move the LDS hit list to the per-query candidate lists: one global atomic per (block, query) reserves the block's range in
+    // that query's list (per-hit atomics on 128 addresses serialise in L2).  Called by the whole workgroup (barriers inside).
+    auto flush = [&]() {
+        if (threadIdx.x < 256) qcnt[threadIdx.x] = 0;
+        __syncthreads();
+        const int nhits = *lcount;
+        const int n = min(nhits, LCAP);
+        for (int e = threadIdx.x; e < n; e += blockDim.x) lq[e] |= atomicAdd(qcnt + lq[e], 1) << 8;      // rank inside the block
+        __syncthreads();
+        if (threadIdx.x < 128 && qcnt[threadIdx.x] > 0) qcnt[128 + threadIdx.x] = atomicAdd(counts + threadIdx.x, qcnt[threadIdx.x]);
+        __syncthreads();
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const int q = lq[e] & 255;
+            const int pos = qcnt[128 + q] + (lq[e] >> 8);
+            if (pos < cap) { cand_rows[(size_t)q * cap + pos] = lrow[e]; cand_scores[(size_t)q * cap + pos] = lscore[e]; }
+        }
+        if (threadIdx.x == 0 && nhits > LCAP) atomicAdd(counts + nq, nhits - LCAP);      // counts[nq] = hits dropped (the caller rescans)
+        __syncthreads();
+        if (threadIdx.x == 0) *lcount = 0;
+        __syncthreads();
+    };
     const long long t0 = blockIdx.x, step = gridDim.x;
     if (t0 < ntiles) stage(0, t0);
     if (t0 + step < ntiles) stage(1, t0 + step);
-    int cs = 0;
-    for (long long t = t0; t < ntiles; t += step) {
+    int cs = 0, it = 0;
+    for (long long t = t0; t < ntiles; t += step, ++it) {
         // tile t must have landed; tile t+step may stay in flight.  NO global memory operation other than the DMA may appear
         // inside this loop: hipcc would put s_waitcnt vmcnt(0) next to it and drain the two tiles in flight (measured: ~1 us per hit)
         if (t + step < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                       // ... for every wave; slot of tile t-step is free
         asm volatile("" ::: "memory");
+        // Hit-list level check.  The decision must be workgroup-uniform (flush() has barriers) but lcount moves as soon as a fast
+        // wave emits hits of THIS tile, so everybody reads the snapshot wave 0 took during the PREVIOUS tile (two slots: wave 0 can
+        // only overwrite slot (it-1)&1 in tile it+1, i.e. after every wave has passed the next barrier).  Rare - about once per
+        // launch and workgroup; the global traffic inside drains the DMA queue.
+        if (ablate == 0) {
+            uint32_t snap;
+            if (it & 1) asm volatile("ds_read_b32 %0, %1 offset:4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(snap) : "v"(lcount_off) : "memory");
+            else asm volatile("ds_read_b32 %0, %1 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(snap) : "v"(lcount_off) : "memory");
+            if (__builtin_amdgcn_readfirstlane(snap) > (uint32_t)(LCAP / 2)) flush();
+        }
         const int fs = cs == 0 ? NSLOT - 1 : cs - 1;                        // slot of tile t-step
         const char* sb = smem + cs * TILEB;
         cs = cs == NSLOT - 1 ? 0 : cs + 1;
@@ -272,46 +456,36 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
             __builtin_amdgcn_sched_barrier(0);
             if (c % NCM == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < CH; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab[c & 1][i], bq[(c % NCM) * CH + i], acc, 0, 0, 0);
+            for (int i = 0; i < CH; ++i) acc = mfma16<F16>(ab[c & 1][i], bq[(c % NCM) * CH + i], acc);
             __builtin_amdgcn_sched_barrier(0);
             if (c + 2 < NC) fetch(ab[c & 1], c + 2);
             if (c % NCM == NCM - 1) emit(acc, c / NCM);
         }
+        if (ablate == 0 && wid == 0) {           // snapshot of the list level for the next tile's check (hand-issued: see emit)
+            uint32_t v;
+            if (it & 1) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:8" : "=&v"(v) : "v"(lcount_off) : "memory");
+            else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:4" : "=&v"(v) : "v"(lcount_off) : "memory");
+        }
     }
-    // ---- the only global writes of the kernel: move the hit list to the per-query candidate lists.  One global atomic
-    // per (block, query) reserves the block's range in that query's list (per-hit atomics on 128 addresses serialise in L2).
+    // ---- what is left in the list
     __syncthreads();
-    int* qcnt = (int*)smem;                    // the tile ring is dead: [0,128) per-query hit counts, [128,256) global bases
-    if (threadIdx.x < 256) qcnt[threadIdx.x] = 0;
-    __syncthreads();
-    const int nhits = *lcount;
-    const int n = min(nhits, LCAP);
-    for (int e = threadIdx.x; e < n; e += blockDim.x) lq[e] |= atomicAdd(qcnt + lq[e], 1) << 8;      // rank inside the block
-    __syncthreads();
-    if (threadIdx.x < 128 && qcnt[threadIdx.x] > 0) qcnt[128 + threadIdx.x] = atomicAdd(counts + threadIdx.x, qcnt[threadIdx.x]);
-    __syncthreads();
-    for (int e = threadIdx.x; e < n; e += blockDim.x) {
-        const int q = lq[e] & 255;
-        const int pos = qcnt[128 + q] + (lq[e] >> 8);
-        if (pos < cap) { cand_rows[(size_t)q * cap + pos] = lrow[e]; cand_scores[(size_t)q * cap + pos] = lscore[e]; }
-    }
-    if (threadIdx.x == 0 && nhits > LCAP) atomicAdd(counts + nq, nhits - LCAP);      // counts[nq] = hits dropped (host rescans with the tiled kernel)
+    flush();
 }
 
-template <int KS, int ABL>
+template <int KS, int ABL, bool F16>
 int launch_scan_stream_abl(const void* Q, const void* P, int nq, long long rows, const float* thr, int* counts, int* cand_rows,
                            float* cand_scores, int cap, hipStream_t st) {
     constexpr int tb = 3 * 32 * KS * 64;
-    constexpr int lcap = (160 * 1024 - tb - 16) / 12 < 4096 ? (160 * 1024 - tb - 16) / 12 : 4096;
-    constexpr int lds = tb + 16 + lcap * 12;
+    constexpr int lcap = (160 * 1024 - tb - 16 - 1024) / 12 < 4096 ? (160 * 1024 - tb - 16 - 1024) / 12 : 4096;
+    constexpr int lds = tb + 16 + 1024 + lcap * 12;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)scan_stream_kernel<KS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)scan_stream_kernel<KS, ABL, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const long long ntiles = (rows + 31) / 32;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL((scan_stream_kernel<KS, ABL>), dim3(grid), dim3(512), lds, st, (const bf16_t*)P, (const bf16_t*)Q, nq, rows, thr,
+    hipLaunchKernelGGL((scan_stream_kernel<KS, ABL, F16>), dim3(grid), dim3(512), lds, st, (const bf16_t*)P, (const bf16_t*)Q, nq, rows, thr,
                        counts, cand_rows, cand_scores, cap);
     CLDRD_LAUNCH_CHECK();
     return 0;
@@ -319,16 +493,17 @@ int launch_scan_stream_abl(const void* Q, const void* P, int nq, long long rows,
 
 template <int KS>
 int launch_scan_stream(const void* Q, const void* P, int nq, long long rows, const float* thr, int* counts, int* cand_rows,
-                       float* cand_scores, int cap, hipStream_t st) {
-    if (KS == 24) {                                    // ablations exist for the d = 768 instance only
+                       float* cand_scores, int cap, bool f16, hipStream_t st) {
+    if (KS == 24 && !f16) {                            // ablations exist for the d = 768 bf16 instance only
         const char* ab = getenv("CLDRD_SCAN_ABLATE");
         switch (ab ? atoi(ab) : 0) {
-            case 1: return launch_scan_stream_abl<24, 1>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
-            case 2: return launch_scan_stream_abl<24, 2>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+            case 1: return launch_scan_stream_abl<24, 1, false>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+            case 2: return launch_scan_stream_abl<24, 2, false>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
             default: break;
         }
     }
-    return launch_scan_stream_abl<KS, 0>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+    if (f16) return launch_scan_stream_abl<KS, 0, true>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+    return launch_scan_stream_abl<KS, 0, false>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
 }
 
 }  // namespace
@@ -381,14 +556,101 @@ extern "C" int cldrd_gather_cast_rows(const float* src, void* dst, size_t n_out,
     return 0;
 }
 
+
+extern "C" int cldrd_cast_f16(const float* src, void* dst, size_t n, unsigned int* flag, void* stream) {
+    CLDRD_CHECK(n % 4 == 0 && ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 8 == 0), "cast_f16: n % 4 == 0 and aligned operands");
+    if (n == 0) return 0;
+    const size_t n4 = n / 4;
+    const int nb = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(cast_f16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, n4, flag);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_topk_prep_queries(const float* q, void* qh, void* qb, float* qnorm, int nq, int d, unsigned int* flag, void* stream) {
+    CLDRD_CHECK(nq > 0 && d > 0 && d % 4 == 0, "topk_prep_queries: bad arguments");
+    hipLaunchKernelGGL(prep_queries_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, q, (uint16_t*)qh, (bf16_t*)qb, qnorm, d, flag);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_topk_thresholds(const float* est, const float* qnorm, float pmax, int d, float* thr, float* eps, int nq, void* stream) {
+    CLDRD_CHECK(nq > 0 && d > 0 && (est == nullptr || thr != nullptr), "topk_thresholds: bad arguments");
+    hipLaunchKernelGGL(thresholds_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, est, qnorm, pmax, d, thr, eps, nq);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_select(const int* counts, const int* dropped, const int* cand_rows, const float* cand_scores, int nq, int cap, int kk,
+                         const float* thr, const float* eps, int* rows2, int cap2, int* n2, int* status, float* khat, int exhaustive,
+                         hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)select_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 4);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(select_compact_kernel, dim3(nq), dim3(1024), (size_t)cap * 4, st, counts, dropped, cand_rows, cand_scores, cap, kk, thr,
+                       eps, rows2, cap2, n2, status, khat, exhaustive);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_topk_select(const int* counts, const int* cand_rows, const float* cand_scores, int nq, int cap, int kk, const float* thr,
+                                 const float* eps, int* rows2, int cap2, int* n2, int* status, float* khat, int exhaustive, void* stream) {
+    CLDRD_CHECK(nq > 0 && cap > 0 && cap <= 8192 && cap2 > 0 && kk > 0, "topk_select: need 0 < cap <= 8192");
+    return launch_select(counts, counts + nq, cand_rows, cand_scores, nq, cap, kk, thr, eps, rows2, cap2, n2, status, khat, exhaustive,
+                         (hipStream_t)stream);
+}
+
+int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts, int* cand_rows,
+                           float* cand_scores, int cap, int f16, hipStream_t st);
+extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
+                                      int* cand_rows, float* cand_scores, int cap, int f16, void* stream);
+
+// The whole search of one shard for nq queries (device resident, fp32 + fp16 copies), in batches of 128 as the reference searches
+// (retriever/retrieve_top_passages.py:88, retrieval_utils.py:131-153), enqueued back to back on `stream` with no host round trip:
+//   scan (fp16 MFMA, HBM-bound) -> select t^ and the 2 eps band -> exact fp32 re-score -> sort + cut -> D, I, status.
+// counts: int[nb * 129] zeroed by the caller (nb = ceil(nq / 128); per batch 128 list lengths + 1 dropped-hit counter);
+// cand_rows / cand_scores: [128, cap] scratch; rows2 / scores2: [128, cap2] scratch; n2, status, khat: [nq]; D, I: [nq, k].
+// exhaustive != 0 (rows <= cap): no scan, every row is re-scored.  The caller reads `status` once at the end and redoes the
+// (rare) unproven queries with thresholds of its choice through this same entry point.
+extern "C" int cldrd_flatip_search(const float* q32, const void* qh, const float* thr, const float* eps, const void* Ph, const float* P32,
+                                   long long rows, int d, int nq, int k, int* counts, int* cand_rows, float* cand_scores, int cap,
+                                   int* rows2, float* scores2, int cap2, int* n2, int* status, float* khat, float* D, int* I,
+                                   int exhaustive, void* stream) {
+    CLDRD_CHECK(nq > 0 && rows > 0 && k > 0 && cap > 0 && cap <= 8192 && cap2 > 0 && cap2 <= 8192 && d % 4 == 0, "flatip_search: bad arguments");
+    CLDRD_CHECK(!exhaustive || rows <= cap, "flatip_search: exhaustive mode needs rows <= cap");
+    hipStream_t st = (hipStream_t)stream;
+    const int kk = (int)(k < rows ? k : rows);
+    for (int lo = 0, b = 0; lo < nq; lo += 128, ++b) {
+        const int m = nq - lo < 128 ? nq - lo : 128;
+        int* cb = counts + (size_t)b * 129;
+        int rc;
+        if (exhaustive) {
+            hipLaunchKernelGGL(all_candidates_kernel, dim3((unsigned)((rows + 255) / 256), m), dim3(256), 0, st, cb, cand_rows, cand_scores, (int)rows, cap);
+            CLDRD_LAUNCH_CHECK();
+        } else {
+            rc = cldrd_topk_scan_filter(qh ? (const char*)qh + (size_t)lo * d * 2 : nullptr, Ph, m, rows, d, thr + lo, cb, cand_rows, cand_scores, cap, 1, st);
+            if (rc) return rc;
+        }
+        rc = launch_select(cb, cb + m, cand_rows, cand_scores, m, cap, kk, thr + lo, eps + lo, rows2, cap2, n2 + lo, status + lo, khat + lo, exhaustive, st);
+        if (rc) return rc;
+        rc = cldrd_topk_rescore(q32 + (size_t)lo * d, P32, d, n2 + lo, rows2, scores2, m, cap2, st);
+        if (rc) return rc;
+        rc = cldrd_topk_sort(n2 + lo, rows2, scores2, m, cap2, k, D + (size_t)lo * k, I + (size_t)lo * k, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // Streaming form of cldrd_topk_scan_filter for d in {128, 256, 768} and nq <= 128 (returns -1 when it does not apply).
 int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts, int* cand_rows,
-                           float* cand_scores, int cap, hipStream_t st) {
+                           float* cand_scores, int cap, int f16, hipStream_t st) {
     if (nq > 128 || rows < 64 || rows >= 2147483647LL / 32) return -1;
     switch (d) {
-        case 128: return launch_scan_stream<4>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
-        case 256: return launch_scan_stream<8>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
-        case 768: return launch_scan_stream<24>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+        case 128: return launch_scan_stream<4>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, f16 != 0, st);
+        case 256: return launch_scan_stream<8>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, f16 != 0, st);
+        case 768: return launch_scan_stream<24>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, f16 != 0, st);
         default: return -1;
     }
 }

@@ -291,14 +291,65 @@ def transpose_bf16_batched(src, dst, desc, tile_prefix, ndesc, total_tiles):
 
 
 # ---------------------------------------------------------------------------------------------------- top-k search
-def topk_scan_filter(Qb, Pb, thr, counts, cand_rows, cand_scores, tiled=False):
-    _chk(Qb, BF16, "Qb", 2), _chk(Pb, BF16, "Pb", 2), _chk(thr, F32, "thr", 1)
+F16 = torch.float16
+
+
+def topk_scan_filter(Q, P, thr, counts, cand_rows, cand_scores, tiled=False):
+    """Q, P: both fp16 or both bf16 (the MFMA type follows)."""
+    dt = Q.dtype
+    if dt not in (BF16, F16):
+        raise TypeError("topk_scan_filter: Q must be fp16 or bf16")
+    _chk(Q, dt, "Q", 2), _chk(P, dt, "P", 2), _chk(thr, F32, "thr", 1)
     _chk(counts, torch.int32, "counts", 1), _chk(cand_rows, torch.int32, "cand_rows", 2), _chk(cand_scores, F32, "cand_scores", 2)
-    nq, d = Qb.shape
-    if Pb.shape[1] != d or not Qb.is_contiguous() or not Pb.is_contiguous() or counts.numel() < nq + 1:
+    nq, d = Q.shape
+    if P.shape[1] != d or not Q.is_contiguous() or not P.is_contiguous() or counts.numel() < nq + 1:
         raise ValueError("topk_scan_filter: shape mismatch (counts needs nq + 1 entries)")
-    call("cldrd_topk_scan_filter_tiled" if tiled else "cldrd_topk_scan_filter", _p(Qb), _p(Pb), nq, Pb.shape[0], d, _p(thr), _p(counts), _p(cand_rows), _p(cand_scores),
-         cand_rows.shape[1], _stream())
+    call("cldrd_topk_scan_filter_tiled" if tiled else "cldrd_topk_scan_filter", _p(Q), _p(P), nq, P.shape[0], d, _p(thr), _p(counts), _p(cand_rows), _p(cand_scores),
+         cand_rows.shape[1], 1 if dt == F16 else 0, _stream())
+
+
+def cast_f16(src, dst, flag=None):
+    """fp32 -> fp16 (RNE); flag (uint32/int32 [1], optional) |= 1 when a value does not fit fp16."""
+    _chk(src, F32, "src", 1), _chk(dst, F16, "dst", 1)
+    call("cldrd_cast_f16", _p(src), _p(dst), src.numel(), _p(flag), _stream())
+
+
+def topk_prep_queries(q32, qh, qb, qnorm, flag):
+    _chk(q32, F32, "q32", 2), _chk(qh, F16, "qh", 2), _chk(qb, BF16, "qb", 2), _chk(qnorm, F32, "qnorm", 1)
+    if not (q32.is_contiguous() and qh.is_contiguous() and qb.is_contiguous()):
+        raise ValueError("topk_prep_queries: operands must be contiguous")
+    call("cldrd_topk_prep_queries", _p(q32), _p(qh), _p(qb), _p(qnorm), q32.shape[0], q32.shape[1], _p(flag), _stream())
+
+
+def topk_thresholds(est, qnorm, pmax, d, thr, eps):
+    _chk(qnorm, F32, "qnorm", 1), _chk(eps, F32, "eps", 1)
+    call("cldrd_topk_thresholds", _p(est), _p(qnorm), float(pmax), int(d), _p(thr), _p(eps), qnorm.numel(), _stream())
+
+
+def topk_select(counts, cand_rows, cand_scores, kk, thr, eps, rows2, n2, status, khat, exhaustive=False):
+    nq = cand_rows.shape[0]
+    _chk(counts, torch.int32, "counts", 1), _chk(rows2, torch.int32, "rows2", 2), _chk(n2, torch.int32, "n2", 1), _chk(status, torch.int32, "status", 1)
+    if counts.numel() < nq + 1:
+        raise ValueError("topk_select: counts needs nq + 1 entries")
+    call("cldrd_topk_select", _p(counts), _p(cand_rows), _p(cand_scores), nq, cand_rows.shape[1], int(kk), _p(thr), _p(eps), _p(rows2),
+         rows2.shape[1], _p(n2), _p(status), _p(khat), 1 if exhaustive else 0, _stream())
+
+
+def flatip_search(q32, qh, thr, eps, P16, P32, k, counts, cand_rows, cand_scores, rows2, scores2, n2, status, khat, D, I, exhaustive=False):
+    """The whole search of one shard (include/cldrd_hip.h: cldrd_flatip_search); everything device resident, no host sync."""
+    _chk(q32, F32, "q32", 2), _chk(P32, F32, "P32", 2), _chk(thr, F32, "thr", 1), _chk(eps, F32, "eps", 1)
+    _chk(D, F32, "D", 2), _chk(I, torch.int32, "I", 2)
+    nq, d = q32.shape
+    rows = P32.shape[0]
+    if not exhaustive:
+        _chk(qh, F16, "qh", 2), _chk(P16, F16, "P16", 2)
+    if counts.numel() < ((nq + 127) // 128) * 129 or n2.numel() < nq or status.numel() < nq or khat.numel() < nq or D.shape != (nq, k) or I.shape != (nq, k):
+        raise ValueError("flatip_search: buffer sizes do not match nq / k")
+    if not (q32.is_contiguous() and P32.is_contiguous() and D.is_contiguous() and I.is_contiguous()):
+        raise ValueError("flatip_search: operands must be contiguous")
+    call("cldrd_flatip_search", _p(q32), _p(qh), _p(thr), _p(eps), _p(P16), _p(P32), rows, d, nq, int(k), _p(counts), _p(cand_rows),
+         _p(cand_scores), cand_rows.shape[1], _p(rows2), _p(scores2), rows2.shape[1], _p(n2), _p(status), _p(khat), _p(D), _p(I),
+         1 if exhaustive else 0, _stream())
 
 
 def topk_kth_largest(scores, S, kth, thr):

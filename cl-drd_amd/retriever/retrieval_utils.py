@@ -3,17 +3,24 @@
 Same call surface: ``get_embeddings_from_scratch`` (:30-58), ``construct_flatindex_from_embeddings`` (:116-129),
 ``index_retrieve`` (:131-153), ``convert_index_to_gpu`` (:155-184).  faiss is replaced by :class:`FlatIPIndex`
 (``IndexIDMap(IndexFlatIP)`` semantics: exact fp32 inner product, results sorted by score descending, ids mapped,
-missing results id -1) whose ``search`` runs on the GPU:
+missing results id -1) whose ``search`` runs on the GPU, device resident from the query upload to the result download:
 
-    1. threshold estimate  : bf16 MFMA scores of the queries against a strided row sample -> per-query k_s-th largest
-    2. scan                : bf16 MFMA GEMM over the bf16 shadow of the whole shard with a filter epilogue that keeps
-                             (row, score) pairs >= thr_q - eps_q  (HBM-bound: 2 B per index element per 128-query batch)
-    3. exact re-score      : fp32 dot products of the candidates from the fp32 rows (what faiss would have computed)
-    4. sort + cut          : (score desc, row position asc) -> top-k
-    5. proof of exactness  : on the host, per query: thr_q <= (k-th exact candidate score) - eps_q with
-                             eps_q = 2^-8 * |q| * max|p| >= |scan score - exact score|, so no row outside the candidate
-                             list can be in the top-k; any query failing it (or overflowing the candidate buffer) is
-                             rescanned with an adjusted threshold.
+    0. queries             : one H2D copy; fp16 / bf16 copies and norms in one kernel
+    1. threshold estimate  : bf16 MFMA scores of the queries against a strided row sample -> per-query k_s-th largest = est_q;
+                             thr_q = est_q - 2 eps_q  (a heuristic: it only decides how many candidates the scan emits)
+    2. scan                : fp16 MFMA scores of 128 queries against the fp16 shadow of the whole shard, streamed once through
+                             LDS (HBM-bound: 2 B per index element per 128-query batch); (row, score) pairs >= thr_q are kept
+    3. select              : t^_q = k-th largest scan score; only rows with scan score >= t^_q - 2 eps_q can be in the exact
+                             top-k, where eps_q >= |scan score - exact score| bounds the fp16 rounding of both operands
+                             (2^-10 |q| max|p|), the fp32 accumulation and fp16 underflow (csrc/topk.hip: thresholds_kernel)
+    4. exact re-score      : fp32 dot products of those rows from the fp32 rows (what faiss would have computed)
+    5. sort + cut          : (score desc, row position asc) -> top-k
+    6. proof of exactness  : per query ON THE DEVICE: the list is complete down to t^_q - 2 eps_q (thr_q <= that, >= k candidates,
+                             no overflow, no dropped hit).  The host reads the flags once per search; a query that fails is
+                             searched again with a corrected threshold (rare: the estimate is 4.5 sigma conservative).
+
+Steps 2-6 of every 128-query batch are enqueued back to back by one C-ABI call (``cldrd_flatip_search``): no host round trip,
+no allocation inside the search.
 
 Multi-GPU (SURVEY.md section 8e): one process per GPU, rank r holds the contiguous row shard r; queries are replicated;
 each rank returns its shard's top-k with GLOBAL ids and rank 0 merges on the host (score desc, tie -> lower id position).
@@ -32,8 +39,10 @@ import torch
 from .. import hip_ops as ops
 
 SAMPLE_ROWS = 65536          # rows scored for the threshold estimate
-CAND_CAP = 8192              # candidate slots per query (LDS sort limit of cldrd_topk_sort)
+CAND_CAP = 8192              # candidate slots per query (LDS limit of cldrd_topk_select / cldrd_topk_sort)
 QUERY_TILE = 128             # queries per scan (one MFMA tile row; the reference also searches in batches of 128)
+EST_CHUNK = 1024             # queries per threshold-estimate GEMM
+MAX_ATTEMPTS = 12
 
 
 def batch_to_device(batch, target_device: torch.device):
@@ -91,9 +100,9 @@ class FlatIPIndex:
         self.ids = None              # np.int64 [n] or None (ids = row positions + id_offset)
         self.id_offset = 0
         self.device = None
-        self._p32 = self._pbf = self._sample = None
+        self._p32 = self._p16 = self._sample = None
         self.last_stats = {}
-        self.profile = False          # bench.py: time the scan kernel with HIP events
+        self.profile = False          # bench.py: time the search with HIP events and count candidates
 
     # -- construction -----------------------------------------------------------------------------------------
     def add_with_ids(self, embeddings, ids):
@@ -109,7 +118,7 @@ class FlatIPIndex:
             self.embeddings = np.concatenate([self.embeddings, emb])
             self.ids = None if self.ids is None or ids is None else np.concatenate([self.ids, ids])
         self.ntotal = self.embeddings.shape[0]
-        self._p32 = self._pbf = self._sample = None
+        self._p32 = self._p16 = self._sample = self._ids_dev = None
 
     def add(self, embeddings):
         self.add_with_ids(embeddings, None)
@@ -123,7 +132,7 @@ class FlatIPIndex:
         return idx
 
     def to_gpu(self, device):
-        """Make the shard resident in HBM: fp32 rows (exact re-score), bf16 shadow (scan), bf16 row sample (threshold)."""
+        """Make the shard resident in HBM: fp32 rows (exact re-score), fp16 shadow (scan), bf16 row sample (threshold)."""
         device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
         if device.type != "cuda":
             raise RuntimeError("FlatIPIndex.search runs on the GPU only (no CPU path)")
@@ -137,16 +146,29 @@ class FlatIPIndex:
         with torch.cuda.device(device):
             self._p32 = p32
             n, d = self._p32.shape
-            self._pbf = torch.empty(n, d, dtype=torch.bfloat16, device=device)
-            ops.cast_bf16(self._p32.view(-1), self._pbf.view(-1))
+            if d % 4:
+                raise ValueError("FlatIPIndex: the embedding width must be a multiple of 4")
+            flag = torch.zeros(1, dtype=torch.int32, device=device)
+            self._p16 = torch.empty(n, d, dtype=torch.float16, device=device)
+            ops.cast_f16(self._p32.view(-1), self._p16.view(-1), flag)
             self._s_stride = max(1, n // SAMPLE_ROWS)
             self._s_rows = min(n, (n + self._s_stride - 1) // self._s_stride)
             # the GEMM wants a column count that is a multiple of 8: zero rows pad the sample (never read by the select)
             self._sample = torch.zeros((self._s_rows + 7) // 8 * 8, d, dtype=torch.bfloat16, device=device)
             ops.gather_cast_rows(self._p32, self._sample, self._s_rows, self._s_stride)
             self._max_norm = math.sqrt(ops.row_sqnorm_max(self._p32))
+            if int(flag.item()) or not math.isfinite(self._max_norm):
+                raise ValueError("FlatIPIndex: embeddings must be finite and inside the fp16 range (|x| <= 65504) for the scan shadow")
 
     # -- search -------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _cap2(kk: int) -> int:
+        """slots for the rows that survive the select (k + the 2 eps band + ties), a power of two for the bitonic sort"""
+        need, c = kk + max(512, kk // 2), 1024
+        while c < need:
+            c *= 2
+        return min(c, CAND_CAP)
+
     def search(self, queries, k: int):
         """(D np.float32 [nq, k] descending, I np.int64 [nq, k]); missing results: id -1, score -inf."""
         if self._p32 is None:
@@ -155,101 +177,151 @@ class FlatIPIndex:
         if q.ndim != 2 or q.shape[1] != self.d:
             raise ValueError("queries must be [nq, d]")
         k = int(k)
+        if k <= 0:
+            raise ValueError("k must be positive")
         nq = q.shape[0]
-        D = np.full((nq, k), -np.inf, dtype=np.float32)
-        I = np.full((nq, k), -1, dtype=np.int64)
-        stats = dict(scans=0, rescans=0, candidates=0)
+        if nq == 0:
+            return np.full((0, k), -np.inf, dtype=np.float32), np.full((0, k), -1, dtype=np.int64)
         with torch.cuda.device(self.device):
-            for lo in range(0, nq, QUERY_TILE):
-                d_, rows = self._search_tile(q[lo:lo + QUERY_TILE], k, stats)
-                kk = d_.shape[1]
-                D[lo:lo + QUERY_TILE, :kk] = d_
-                valid = rows >= 0
-                if self.ids is None:
-                    glob = np.where(valid, rows + self.id_offset, -1)
-                else:
-                    glob = np.where(valid, self.ids[np.maximum(rows, 0)], -1)
-                I[lo:lo + QUERY_TILE, :kk] = glob
-        if "scan_events" in stats:
-            torch.cuda.synchronize()
-            stats["scan_ms"] = [a.elapsed_time(b) for a, b in stats.pop("scan_events")]
+            Dd, Id, stats = self.search_device(torch.from_numpy(q).to(self.device), k)
+            # row position -> id on the device (IndexIDMap), then one D2H copy per output
+            if self.ids is None:
+                ids64 = torch.where(Id >= 0, Id.to(torch.int64) + int(self.id_offset), torch.full_like(Id, -1, dtype=torch.int64))
+            else:
+                if getattr(self, "_ids_dev", None) is None or self._ids_dev.device != self.device:
+                    self._ids_dev = torch.from_numpy(np.ascontiguousarray(self.ids, dtype=np.int64)).to(self.device)
+                ids64 = torch.where(Id >= 0, self._ids_dev[Id.clamp(min=0).to(torch.int64)], torch.full_like(Id, -1, dtype=torch.int64))
+            D, I = Dd.cpu().numpy(), ids64.cpu().numpy()
         self.last_stats = stats
         return D, I
 
-    def _search_tile(self, q_np: np.ndarray, k: int, stats):
+    def search_device(self, q32: torch.Tensor, k: int):
+        """Search with device-resident fp32 queries [nq, d]; returns device tensors (D fp32 [nq, k], I int32 row positions
+        [nq, k], -1 = missing) and the statistics dict.  ONE host synchronisation (the proof flags) when nothing is redone."""
         dev = self.device
-        nq, d = q_np.shape
-        n = self._p32.shape[0]
-        kk = min(k, n, CAND_CAP)
-        q32 = torch.from_numpy(q_np).to(dev)
+        n, d = self._p32.shape
+        nq = q32.shape[0]
+        kk = min(k, n)
+        exhaustive = n <= CAND_CAP
+        if not exhaustive and kk > CAND_CAP // 2:
+            raise ValueError(f"top_k = {k} is not supported on an index of {n} rows: the candidate lists hold {CAND_CAP} entries "
+                             f"(top_k <= {CAND_CAP // 2}, or an index of at most {CAND_CAP} rows)")
+        i32, f32 = dict(dtype=torch.int32, device=dev), dict(dtype=torch.float32, device=dev)
+        q32 = q32.contiguous()
+        qh = torch.empty(nq, d, dtype=torch.float16, device=dev)
         qb = torch.empty(nq, d, dtype=torch.bfloat16, device=dev)
-        ops.cast_bf16(q32.view(-1), qb.view(-1))
-        eps = (2.0 ** -8) * np.linalg.norm(q_np.astype(np.float64), axis=1) * self._max_norm + 1e-30
-        # 1. threshold estimate from the row sample
-        S = self._s_rows
-        samp = torch.empty(nq, self._sample.shape[0], dtype=torch.float32, device=dev)
-        ops.gemm_nt(qb, self._sample, samp, nq)
-        lam = kk * S / n
-        # lam = expected number of sample rows inside the global top-kk; +4.5 sigma makes a too-high estimate (-> rescan)
-        # a ~1e-5 event per query at the price of ~25 % more candidates
-        kth = int(min(S, math.ceil(lam + 4.5 * math.sqrt(lam) + 1.0))) if S < n else kk
-        thr_dev = torch.empty(nq, dtype=torch.float32, device=dev)
-        ops.topk_kth_largest(samp, S, kth, thr_dev)
-        thr = thr_dev.cpu().numpy().astype(np.float64) - eps
-        counts = torch.empty(nq + 1, dtype=torch.int32, device=dev)      # [nq]: hits the streaming scan had to drop
-        cand_rows = torch.empty(nq, CAND_CAP, dtype=torch.int32, device=dev)
-        cand_scores = torch.empty(nq, CAND_CAP, dtype=torch.float32, device=dev)
-        D = torch.empty(nq, kk, dtype=torch.float32, device=dev)
-        I = torch.empty(nq, kk, dtype=torch.int32, device=dev)
-        out_D = np.empty((nq, kk), dtype=np.float32)
-        out_I = np.empty((nq, kk), dtype=np.int64)
-        todo = np.ones(nq, dtype=bool)
-        for attempt in range(12):
-            thr_dev.copy_(torch.from_numpy(thr.astype(np.float32)))
-            counts.zero_()
-            if self.profile:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            ops.topk_scan_filter(qb, self._pbf, thr_dev, counts, cand_rows, cand_scores)      # 2. scan
-            if self.profile:
-                e1.record()
-                stats.setdefault("scan_events", []).append((e0, e1))
-            ops.topk_rescore(q32, self._p32, counts, cand_rows, cand_scores)                    # 3. exact re-score
-            ops.topk_sort(counts, cand_rows, cand_scores, kk, D, I)                             # 4. sort + cut
-            stats["scans"] += 1
-            stats["rescans"] += attempt > 0
-            c = counts.cpu().numpy()
-            if c[nq] != 0:        # the streaming kernel's on-chip hit list overflowed: redo this scan with the tiled kernel
-                counts.zero_()
-                ops.topk_scan_filter(qb, self._pbf, thr_dev, counts, cand_rows, cand_scores, tiled=True)
-                ops.topk_rescore(q32, self._p32, counts, cand_rows, cand_scores)
-                ops.topk_sort(counts, cand_rows, cand_scores, kk, D, I)
-                stats["scans"] += 1
-                stats["tiled_rescans"] = stats.get("tiled_rescans", 0) + 1
-                c = counts.cpu().numpy()
-            c = c[:nq]
-            Dh, Ih = D.cpu().numpy(), I.cpu().numpy().astype(np.int64)
-            stats["candidates"] += int(np.minimum(c, CAND_CAP)[todo].sum())
-            # 5. proof of exactness per query
-            kth_exact = Dh[:, kk - 1].astype(np.float64)
-            enough = c >= kk
-            overflow = c > CAND_CAP
-            proven = enough & ~overflow & (thr <= kth_exact - eps)
-            done_now = todo & proven
-            out_D[done_now], out_I[done_now] = Dh[done_now], Ih[done_now]
-            todo &= ~proven
-            if not todo.any():
-                break
-            # adjust: too few / not proven -> lower the threshold below the proven bound; overflow -> raise it half-way
-            low = todo & ~overflow
-            thr[low] = np.where(enough[low], kth_exact[low] - 2.0 * eps[low], thr[low] - np.maximum(4.0 * eps[low], 0.05 * np.abs(thr[low]) + 1e-3))
-            ov = todo & overflow
-            thr[ov] = thr[ov] + 0.5 * eps[ov] + 1e-3 * np.abs(thr[ov])
-            if attempt >= 8:
-                thr[todo & ~overflow] = -np.inf      # exhaustive: every row is a candidate (only valid for n <= CAND_CAP)
+        qnorm, flag = torch.empty(nq, **f32), torch.zeros(1, **i32)
+        ops.topk_prep_queries(q32, qh, qb, qnorm, flag)
+        thr, eps = torch.full((nq,), -float("inf"), **f32), torch.empty(nq, **f32)
+        stats = dict(scans=0, rescans=0, candidates=0, rescored=0, unproven_first_pass=0, exhaustive=bool(exhaustive))
+        if exhaustive:
+            ops.topk_thresholds(None, qnorm, self._max_norm, d, None, eps)
         else:
-            raise RuntimeError("top-k search did not converge (candidate buffer too small for this score distribution)")
-        return out_D, out_I
+            # 1. threshold estimate from the row sample.  lam = expected number of sample rows inside the global top-kk; +4.5 sigma
+            # makes a too-high estimate (-> that query is searched again) a ~1e-5 event per query
+            S = self._s_rows
+            lam = kk * S / n
+            kth = int(min(S, math.ceil(lam + 4.5 * math.sqrt(lam) + 1.0))) if S < n else kk
+            est = torch.empty(nq, **f32)
+            samp = torch.empty(min(nq, EST_CHUNK), self._sample.shape[0], **f32)
+            for lo in range(0, nq, EST_CHUNK):
+                m = min(EST_CHUNK, nq - lo)
+                ops.gemm_nt(qb[lo:lo + m], self._sample, samp[:m], m)
+                ops.topk_kth_largest(samp[:m], S, kth, est[lo:lo + m])
+            del samp
+            ops.topk_thresholds(est, qnorm, self._max_norm, d, thr, eps)
+        cap2 = CAND_CAP if exhaustive else self._cap2(kk)
+        D, I = torch.empty(nq, k, **f32), torch.empty(nq, k, **i32)
+        ws = self._workspace(cap2)
+        if self.profile:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        st, counts, n2, khat = self._run(q32, qh, thr, eps, k, ws, D, I, exhaustive)
+        if self.profile:
+            e1.record()
+        status = st.cpu().numpy()                       # the one synchronisation of a search
+        if int(flag.item()):
+            raise ValueError("queries must be finite and inside the fp16 range (|x| <= 65504)")
+        nb = (nq + QUERY_TILE - 1) // QUERY_TILE
+        stats["scans"] = 0 if exhaustive else nb
+        c_all = counts.view(nb, QUERY_TILE + 1)[:, :QUERY_TILE].reshape(-1)[:nq] if nq % QUERY_TILE == 0 else None
+        if self.profile:
+            stats["search_ms"] = e0.elapsed_time(e1)
+            stats["rescored"] = int(n2.sum().item())
+            if c_all is not None:
+                stats["candidates"] = int(c_all.clamp(max=CAND_CAP).sum().item())
+        bad = np.nonzero(status)[0]
+        stats["unproven_first_pass"] = int(bad.size)
+        attempt = 0
+        thr_h = eps_h = None
+        while bad.size:
+            attempt += 1
+            if attempt > MAX_ATTEMPTS or exhaustive:
+                raise RuntimeError("top-k search did not converge (more ties / near-ties at the k-th score than the candidate "
+                                   f"buffers hold: status bits {sorted(set(status[bad].tolist()))})")
+            if thr_h is None:
+                thr_h, eps_h = thr.cpu().numpy().astype(np.float64), eps.cpu().numpy().astype(np.float64)
+            khat_h = khat.cpu().numpy().astype(np.float64)
+            st_b, t_b, e_b, kh_b = status[bad], thr_h[bad].copy(), eps_h[bad], khat_h[bad]
+            has_k = np.isfinite(kh_b)
+            over = (st_b & 2) != 0
+            few = ((st_b & 1) != 0) & ~over
+            high = ((st_b & 8) != 0) & ~over & ~few
+            # proven bound: the list was complete and long enough, only the threshold sat above t^ - 2 eps
+            t_b[high] = kh_b[high] - 2.0 * e_b[high] * (1.0 + 1e-3) - 1e-6 * np.abs(kh_b[high]) - 1e-30
+            # too few candidates: the estimate was too high; lower it, faster every attempt
+            t_b[few] = t_b[few] - np.maximum(4.0 * e_b[few], 0.05 * np.abs(t_b[few]) + 1e-3) * (2.0 ** (attempt - 1))
+            # overflow: the list holds an arbitrary `cap` of the c rows above thr; its k-th largest score is a (low) estimate of t^
+            up = np.where(has_k, kh_b - 2.0 * e_b, -np.inf)
+            t_b[over] = np.maximum(t_b[over] + np.maximum(e_b[over], 1e-3 * np.abs(t_b[over])) * (2.0 ** (attempt - 1)), up[over])
+            cap2_b = CAND_CAP if ((st_b & 16) != 0).any() else cap2
+            idx = torch.from_numpy(bad).to(dev)
+            qb32, qbh = q32.index_select(0, idx), qh.index_select(0, idx)
+            thr_b = torch.from_numpy(t_b.astype(np.float32)).to(dev)
+            eps_b = eps.index_select(0, idx)
+            Db, Ib = torch.empty(bad.size, k, **f32), torch.empty(bad.size, k, **i32)
+            st2, _, _, khat2 = self._run(qb32, qbh, thr_b, eps_b, k, self._workspace(cap2_b), Db, Ib, False)
+            status_b = st2.cpu().numpy()
+            good = status_b == 0
+            if good.any():
+                gi = torch.from_numpy(bad[good]).to(dev)
+                sel = torch.from_numpy(np.nonzero(good)[0]).to(dev)
+                D.index_copy_(0, gi, Db.index_select(0, sel))
+                I.index_copy_(0, gi, Ib.index_select(0, sel))
+            thr_h[bad] = t_b
+            khat.index_copy_(0, idx, khat2)
+            status[bad] = status_b
+            nbad = (bad.size + QUERY_TILE - 1) // QUERY_TILE
+            stats["scans"] += nbad
+            stats["rescans"] += nbad
+            bad = bad[~good]
+        return D, I, stats
+
+    def _workspace(self, cap2: int):
+        """Per-batch scratch of the search (reused by every 128-query batch of every search: same stream, so no hazard)."""
+        key = int(cap2)
+        ws = getattr(self, "_ws", None)
+        if ws is None:
+            ws = self._ws = {}
+        if key not in ws:
+            dev = self.device
+            ws[key] = dict(cand_rows=torch.empty(QUERY_TILE, CAND_CAP, dtype=torch.int32, device=dev),
+                           cand_scores=torch.empty(QUERY_TILE, CAND_CAP, dtype=torch.float32, device=dev),
+                           rows2=torch.empty(QUERY_TILE, cap2, dtype=torch.int32, device=dev),
+                           scores2=torch.empty(QUERY_TILE, cap2, dtype=torch.float32, device=dev))
+        return ws[key]
+
+    def _run(self, q32, qh, thr, eps, k, ws, D, I, exhaustive):
+        dev = self.device
+        nq = q32.shape[0]
+        nb = (nq + QUERY_TILE - 1) // QUERY_TILE
+        counts = torch.zeros(nb * (QUERY_TILE + 1), dtype=torch.int32, device=dev)
+        n2 = torch.empty(nq, dtype=torch.int32, device=dev)
+        status = torch.empty(nq, dtype=torch.int32, device=dev)
+        khat = torch.empty(nq, dtype=torch.float32, device=dev)
+        ops.flatip_search(q32, qh, thr, eps, self._p16, self._p32, k, counts, ws["cand_rows"], ws["cand_scores"], ws["rows2"], ws["scores2"],
+                          n2, status, khat, D, I, exhaustive=exhaustive)
+        return status, counts, n2, khat
 
     # -- persistence (own format; faiss' binary layout is not reproduced, SURVEY.md section 8b) ----------------
     def write(self, path: str):
@@ -407,7 +479,7 @@ def merge_shard_results(shard_D, shard_I, k):
 def convert_index_to_gpu(index, faiss_gpu_index, useFloat16=False):
     """reference :155-184.  int (or 1-element list): whole index on that GPU.  list of several devices: not supported in one
     process - shard with one process per GPU and :class:`ShardedFlatIPIndex` instead.  ``useFloat16`` is ignored: the scan
-    already reads a 16-bit shadow and the returned scores are exact fp32 either way."""
+    always reads an fp16 shadow and the returned scores are exact fp32 either way."""
     if type(faiss_gpu_index) == list and len(faiss_gpu_index) == 1:
         faiss_gpu_index = faiss_gpu_index[0]
     if isinstance(faiss_gpu_index, int):
@@ -423,15 +495,17 @@ def index_retrieve(index, query_embeddings, topk, batch=None):
     if batch is None:
         nn_scores, nearest_neighbors = index.search(query_embeddings, topk)
     else:
+        # The reference searches slice by slice (:141-149).  Here the whole query set goes to the index in ONE call - the search
+        # itself walks it in batches of 128 on the device, and a sharded index gathers / merges once instead of once per slice -
+        # and only the conversion to the nested lists the reference returns is done per `batch` slice.
+        all_scores, all_nn = index.search(query_embeddings, topk)
         query_offset_base = 0
         nearest_neighbors = []
         nn_scores = []
         while query_offset_base < len(query_embeddings):
-            batch_query_embeddings = query_embeddings[query_offset_base:query_offset_base + batch]
-            batch_nn_scores, batch_nn = index.search(batch_query_embeddings, topk)
-            nearest_neighbors.extend(batch_nn.tolist())
-            nn_scores.extend(batch_nn_scores.tolist())
-            query_offset_base += len(batch_query_embeddings)
+            nearest_neighbors.extend(all_nn[query_offset_base:query_offset_base + batch].tolist())
+            nn_scores.extend(all_scores[query_offset_base:query_offset_base + batch].tolist())
+            query_offset_base += batch
     elapsed_time = timer() - start
     elapsed_time_per_query = 1000 * elapsed_time / len(query_embeddings)
     print(f"Elapsed Time: {elapsed_time:.1f}s, Elapsed Time per query: {elapsed_time_per_query:.1f}ms")

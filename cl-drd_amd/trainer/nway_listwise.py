@@ -54,6 +54,21 @@ def owns_example(line_idx: int, rank: int, nranks: int) -> bool:
     return line_idx % nranks == rank
 
 
+def optimizer_param_groups(model):
+    """Parameter names in the reference optimizer's index order: ``model.named_parameters()`` of the (DDP-wrapped)
+    NwayDualEncoder - HF module order, a shared tower listed once under ``query_encoder`` - split into the decayed group, then
+    the no-decay group (nway_listwise_1.py:259-263); torch numbers the parameters consecutively over the groups.
+    Returns [[(full name, tower index or None for parameters this package does not hold (BERT pooler), HF name)]] per group."""
+    from ..encoder import hf_parameter_order
+    names = []
+    for ti, (prefix, tower) in enumerate((("query_encoder", model.query_encoder), ("passage_encoder", model.passage_encoder))):
+        if ti == 1 and model.share_weights:
+            break
+        for n in hf_parameter_order(tower.cfg, with_pooler=True):
+            names.append((f"{prefix}.{n}", ti if n in tower.layout.entries else None, n))
+    return [[e for e in names if not no_decay(e[0])], [e for e in names if no_decay(e[0])]]
+
+
 class NwayTrainer:
     def __init__(self, model: NwayDualEncoder, *, loss: str = "lambda_mrr", T: float = 1.0, learning_rate: float = 7e-6,
                  weight_decay: float = 0.01, adam_epsilon: float = 1e-8, max_grad_norm: float = 1.0, warmup_steps: int = 4000,
@@ -237,18 +252,7 @@ class NwayTrainer:
 
     # ---- checkpoint payload (reference nway_listwise_1.py:418-426 / :300-304) --------------------------------------------
     def _optimizer_names(self):
-        """Parameter names in the reference optimizer's index order: ``model.named_parameters()`` of the DDP-wrapped
-        NwayDualEncoder (HF module order, shared towers listed once) split into the decayed group, then the no-decay group
-        (nway_listwise_1.py:259-263).  Returns [(name, tower index or None, hf name)] per group."""
-        from ..encoder import hf_parameter_order
-        model = self.model
-        names = []
-        for ti, (prefix, tower) in enumerate((("query_encoder", model.query_encoder), ("passage_encoder", model.passage_encoder))):
-            if ti == 1 and model.share_weights:
-                break
-            for n in hf_parameter_order(tower.cfg, with_pooler=True):
-                names.append((f"{prefix}.{n}", ti if n in tower.layout.entries else None, n))
-        return [[e for e in names if not no_decay(e[0])], [e for e in names if no_decay(e[0])]]
+        return optimizer_param_groups(self.model)
 
     def _slice(self, buf, ti, hf_name):
         tower, toff = self.model.towers()[ti], self.model._tower_offsets[ti]

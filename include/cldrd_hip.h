@@ -135,18 +135,39 @@ int cldrd_transpose_bf16_batched(const void* src, void* dst, const long long* de
                                  void* stream);
 
 /* ---- exact inner-product top-k over one index shard (retriever/retrieval_utils.py:131-153 -> faiss IndexFlatIP.search) ---
- * scan:    bf16 MFMA scores Q[nq,d] . P[rows,d]^T; (query, row) pairs with score >= thr[query] are appended to the query's
- *          candidate list (cand_rows / cand_scores: [nq, cap]).  counts has nq + 1 ints zeroed by the caller:
- *          counts[q] may exceed cap (= overflow of that list), counts[nq] != 0 means the streaming kernel dropped hits
- *          (its on-chip list was full): rescan with cldrd_topk_scan_filter_tiled, which has no such list;
- * kth:     thr[q] = kth largest of scores[q][0..S) (threshold estimate from the sample scores);
- * rescore: cand_scores <- exact fp32 <q, P32[row]>;
- * sort:    per query (score desc, row asc), first k -> D[nq,k], I[nq,k] (row index, -1 = missing). */
+ * The shard lives in HBM twice: fp32 rows (exact scores) and a 16-bit shadow the scan streams (fp16 by default: 11-bit
+ * significand, so |scan - exact| <= eps is 8x tighter than with bf16; `f16` selects the MFMA type of the scan entry points).
+ *
+ * cldrd_flatip_search is the whole search of nq device-resident queries in batches of 128 (the reference's batching,
+ * retrieve_top_passages.py:88), enqueued back to back with no host round trip; per batch:
+ *   scan:    16-bit MFMA scores Q[128,d] . P[rows,d]^T; (query, row) pairs with score >= thr[query] are appended to the query's
+ *            candidate list (cand_rows / cand_scores: [128, cap]).  counts = 128 list lengths + 1 counter of hits the
+ *            streaming kernel had to drop (its on-chip list overflowed within one tile), zeroed by the caller;
+ *   select:  t^ = kk-th largest scan score of the list; rows with scan score >= t^ - 2 eps[query] are kept (rows2, n2) - no other
+ *            row can be in the exact top-kk (proof in csrc/topk.hip); status[query] = 0 when that proof holds, else a bit mask
+ *            (1 fewer than kk candidates, 2 list overflow, 4 dropped hits, 8 thr above t^ - 2 eps, 16 kept set > cap2);
+ *   rescore: exact fp32 <q, P32[row]> of the kept rows (fixed summation order);
+ *   sort:    (score desc, row asc), first k -> D[nq,k], I[nq,k] (row index, -1 / -inf = missing).
+ * The caller reads `status` once per search and redoes unproven queries with thresholds of its choice (same entry point).
+ * exhaustive != 0 (rows <= cap): no scan, every row is re-scored.
+ * Pieces, also callable one by one: prep (fp16 + bf16 copies and norms of the queries; *flag |= 1 if a value exceeds the fp16
+ * range), kth (thr estimate: kth largest of sample scores), thresholds (eps[q] = bound on |scan - exact|, thr = est - 2 eps). */
+int cldrd_cast_f16(const float* src, void* dst, size_t n, unsigned int* flag, void* stream);
+int cldrd_topk_prep_queries(const float* q, void* q_f16, void* q_bf16, float* qnorm, int nq, int d, unsigned int* flag, void* stream);
+int cldrd_topk_thresholds(const float* est, const float* qnorm, float pmax, int d, float* thr, float* eps, int nq, void* stream);
+int cldrd_flatip_search(const float* q32, const void* q16, const float* thr, const float* eps, const void* P16, const float* P32,
+                        long long rows, int d, int nq, int k, int* counts, int* cand_rows, float* cand_scores, int cap,
+                        int* rows2, float* scores2, int cap2, int* n2, int* status, float* khat, float* D, int* I,
+                        int exhaustive, void* stream);
 int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
-                           int* cand_rows, float* cand_scores, int cap, void* stream);
+                           int* cand_rows, float* cand_scores, int cap, int f16, void* stream);
+/* same contract through the tiled GEMM kernels (any d % 64 == 0; hits go straight to the global lists, nothing is dropped) */
 int cldrd_topk_scan_filter_tiled(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
-                           int* cand_rows, float* cand_scores, int cap, void* stream);
+                           int* cand_rows, float* cand_scores, int cap, int f16, void* stream);
 int cldrd_topk_kth_largest(const float* scores, int ld, int nq, int S, int kth, float* thr, void* stream);
+/* counts has nq + 1 entries (counts[nq] = dropped hits of the scan) */
+int cldrd_topk_select(const int* counts, const int* cand_rows, const float* cand_scores, int nq, int cap, int kk, const float* thr,
+                      const float* eps, int* rows2, int cap2, int* n2, int* status, float* khat, int exhaustive, void* stream);
 int cldrd_topk_rescore(const float* q, const float* P, int d, const int* counts, const int* cand_rows, float* cand_scores,
                        int nq, int cap, void* stream);
 int cldrd_topk_sort(const int* counts, const int* cand_rows, const float* cand_scores, int nq, int cap, int k, float* D,

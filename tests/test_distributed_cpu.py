@@ -104,3 +104,20 @@ def test_run_file_writer_matches_reference_format(tmp_path):
     p = tmp_path / "dev" / "x.run"
     write_run_file(str(p), [11, 12], [[5, 6], [7, 8]], [[2.5, 1.25], [0.5, 0.25]])
     assert open(p).read() == "".join(R.run_file_lines([11, 12], [[5, 6], [7, 8]], [[2.5, 1.25], [0.5, 0.25]]))
+
+
+def _steps_worker(rank, world, port, out):
+    _init(rank, world, port)
+    # line_idx % nranks sharding + drop_last leaves rank r with 7 + r batches: everybody must run MIN = 7 (reference hazard,
+    # dataset/nway_dataset.py:305; a rank alone in a bucket all-reduce at the end of the epoch hangs)
+    assert TL.common_steps_per_epoch(7 + rank, True) == 7
+    if rank == 0:
+        open(out, "w").write("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_equal_steps_per_epoch_gloo_world2(tmp_path):
+    out = str(tmp_path / "ok")
+    mp.spawn(_steps_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read() == "ok"

@@ -1,0 +1,83 @@
+"""The data-parallel training path executed for real: two ranks, one process each, BOTH on the one GPU of the
+test box, torch.distributed over gloo (it accepts device tensors) - so the code under test is exactly what runs over RCCL on an
+8-GPU node except for the transport: DDP-style constructor broadcast (reference nway_listwise_1.py:250-255), per-layer gradient
+buckets all-reduced from the backward hooks on the side stream while earlier layers are still in backward, 1/world folded into
+dlogits, write-once gradients.  The reduced gradient must equal the single-process gradient of the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out, share):
+    import numpy as np
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import cldrd_amd.synthetic as syn
+    import selftest
+    from cldrd_amd.encoder import EncoderConfig
+    from cldrd_amd.trainer import NwayTrainer
+    from cldrd_amd.trainer.nway_listwise import common_steps_per_epoch
+
+    cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=3,
+                        max_position_embeddings=64, dropout=0.0, attention_dropout=0.0)
+    # different initial weights per rank: the constructor broadcast must make rank 0's win
+    model = selftest.build_tiny_model(cfg, share_weights=share, seed=3 + 10 * rank).cuda()
+    model.train()
+    tr = NwayTrainer(model, loss="margin_mse", learning_rate=1e-3, warmup_steps=0, total_steps=10)
+    assert tr.distributed and tr.world == world
+    ref_model = selftest.build_tiny_model(cfg, share_weights=share, seed=3).cuda()
+    ref_model.fuse_flat()
+    assert torch.equal(tr.flat_p, ref_model._flat_p), "rank 0's parameters were not broadcast"
+    B = 2
+    full = syn.nway_batch(4680, B * world, 5, 10, 40, vocab=cfg.vocab_size, ragged=True)
+
+    def rows(t, lo, hi):
+        return t[lo:hi]
+    mine = {k: ({kk: rows(vv, rank * B, (rank + 1) * B) for kk, vv in v.items()} if isinstance(v, dict) else rows(v, rank * B, (rank + 1) * B))
+            for k, v in full.items()}
+    tr.flat_g.fill_(77.0)                      # garbage: every gradient must be written (and reduced) exactly once
+    loss_out, _ = tr.forward_backward(mine)
+    torch.cuda.synchronize()
+    reduced = tr.flat_g.clone()
+    # every rank holds the same reduced gradient
+    gathered = [torch.empty_like(reduced) for _ in range(world)]
+    dist.all_gather(gathered, reduced)
+    assert all(torch.equal(gathered[0], g) for g in gathered), "ranks disagree on the reduced gradient"
+    # equal step counts: rank r would have 5 + r batches
+    assert common_steps_per_epoch(5 + rank, True, torch.device("cuda", 0)) == 5
+    if rank == 0:
+        tr.distributed, tr.world = False, 1            # the same trainer, single process, the concatenated batch
+        tr.flat_g.fill_(-5.0)
+        tr.forward_backward(full)
+        torch.cuda.synchronize()
+        single = tr.flat_g
+        scale = single.abs().max().item()
+        err = (reduced - single).abs().max().item()
+        # same kernels on the same rows; only the token-split of the weight-gradient reduction and the embedding atomics differ
+        assert err <= 2e-3 * scale, f"DDP gradient differs from the single-process gradient: {err:.3e} vs scale {scale:.3e}"
+        # one optimizer step on the reduced gradients keeps the ranks' weights identical
+        open(out, "w").write(f"ok {err / scale:.2e}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("share", [False, True])
+def test_ddp_bucket_hooks_world2_on_one_gpu(tmp_path, share):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok")
+    mp.spawn(_worker, args=(2, _free_port(), out, share), nprocs=2, join=True)
+    assert open(out).read().startswith("ok")

@@ -140,7 +140,7 @@ def test_trainer_step_matches_oracle_update():
     model.train()
     batch = syn.nway_batch(4680, 2, 3, 8, 16, vocab=cfg.vocab_size)
     tr = NwayTrainer(model, loss="margin_mse", learning_rate=1e-3, warmup_steps=2, total_steps=10, weight_decay=0.01)
-    tr.global_step = 1          # lr factor 0.5 in effect
+    tr.global_step = tr.adam_step = 1          # lr factor 0.5 in effect
     p0 = tr.flat_p.clone()
     tr.forward_backward(batch)
     g = tr.flat_g.clone()
@@ -209,44 +209,189 @@ def test_loss_decreases_over_steps_with_dropout():
     assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[1:6]), losses
 
 
-def test_full_size_cfg1_matches_reference_golden():
-    """BASELINE.json configs[0] (DistilBERT, N=8, batch=4, margin_mse, L=128) on the GPU against the logits/loss the
-    REFERENCE produced for the same seeded weights and batch (tests/golden/full_distilbert_cfg1.npz)."""
-    path = os.path.join(GOLDEN, "full_distilbert_cfg1.npz")
-    g = np.load(path)
-    cfg = EncoderConfig(arch="distilbert", dropout=0.0, attention_dropout=0.0)
+def _full_size_model(arch, n_layers):
+    cfg = EncoderConfig(arch=arch, n_layers=n_layers, dropout=0.0, attention_dropout=0.0)
     model = NwayDualEncoder(cfg, share_weights=False)
     with torch.no_grad():
         for seed, tower in ((11, model.query_encoder), (12, model.passage_encoder)):
             for name, p in tower.named_flat():
                 p.copy_(syn.init_param(seed, name, tuple(p.shape), std=0.02, perturb=True))
-    model.cuda().train()
-    batch = syn.nway_batch(4680, int(g["B"]), int(g["N"]), int(g["Lq"]), int(g["Lp"]), ragged=True)
-    tr = NwayTrainer(model, loss="margin_mse")
-    loss_out, logits = tr.forward_backward(batch)
+    return model.cuda().train()
+
+
+# (golden file, arch, layers, [(golden loss kind, trainer loss, oracle loss fn)])     BASELINE.json configs[0..3]
+FULL_CONFIGS = {
+    "cfg1": ("full_distilbert_cfg1.npz", "distilbert", 6, [("mse", "margin_mse")]),
+    "cfg2": ("full_distilbert_cfg2.npz", "distilbert", 6, [("kl", "kl_div")]),
+    "cfg3": ("full_distilbert_cfg3.npz", "distilbert", 6, [("mse", "margin_mse")]),
+    "cfg4": ("full_bert_cfg4.npz", "bert", 12, [("ranknet", "ranknet"), ("lambda", "lambda_mrr")]),
+}
+ORACLE_LOSS = {"mse": LR.margin_mse, "kl": lambda a, b: LR.kl_div(a, b, 1.0), "ranknet": LR.ranknet, "lambda": LR.lambda_mrr}
+
+
+@pytest.mark.parametrize("name", list(FULL_CONFIGS))
+def test_full_size_configs_match_reference_goldens(name):
+    """Every training config of BASELINE.json at full size on the GPU against what the REFERENCE produced for the same seeded
+    weights and batch (tests/golden/make_golden.py, make_full_golden.py: models/nway_dual_encoder.py:21-49 over HF AutoModel, the
+    reference's losses), dropout off.  cfg1 DistilBERT B=4 N=8 margin_mse; cfg2 B=8 N=32 kl_div (the bench workload); cfg3 B=4
+    N=200 margin_mse; cfg4 BERT-base B=4 N=64 L=256 ranknet + lambda_mrr.
+
+    Bar: the logit error is NO LARGER than the drift of the reference's own mixed-precision path on the same inputs (its
+    bf16-autocast logits are stored in the golden; the reference trains under autocast, nway_listwise_1.py:334): ratio <= 1.0.
+    The loss moves by no more than that path's loss does (floor 0.2 %); per-tensor gradient norms within 5 %."""
+    fname, arch, layers, kinds = FULL_CONFIGS[name]
+    g = np.load(os.path.join(GOLDEN, fname))
+    model = _full_size_model(arch, layers)
+    assert model.passage_encoder.stream32, "the parity bar is defined for the default fp32 residual stream"
+    B, N, Lq, Lp = int(g["B"]), int(g["N"]), int(g["Lq"]), int(g["Lp"])
+    label_kind = str(g["label_kind"]) if "label_kind" in g.files else "teacher"
+    batch = syn.nway_batch(4680, B, N, Lq, Lp, ragged=True, label_kind=label_kind)
     ref = g["logits"]
-    # A logit is a 768-term dot product of two CLS vectors; with random weights they are nearly orthogonal
-    # (|logit| ~ 15 vs |q||p| ~ 760), so the natural error scale is |q||p|: tolerance 5e-3 of it (cosine error).
-    qn = np.linalg.norm(g["q_cls"], axis=1)[:, None]
-    pn = np.linalg.norm(g["p_cls"], axis=2)
-    abs_err = np.abs(logits.cpu().numpy() - ref)
-    assert (abs_err / (qn * pn)).max() <= 5e-3, f"logit error {np.max(abs_err / (qn * pn)):.3e} of |q||p|"
-    # ... and no worse than 3x the drift of the reference's own bf16-autocast path on the same inputs
     amp_err = np.abs(g["logits_autocast_bf16"] - ref).max()
-    assert abs_err.max() <= 3.0 * amp_err, f"bf16 drift {abs_err.max():.3f} vs reference autocast drift {amp_err:.3f}"
-    # MarginMSE squares differences of nearly-orthogonal random-weight logits, so it amplifies logit noise: the reference's
-    # own bf16-autocast logits move its loss by 0.94 % on these inputs; allow 3x that (and never less than 1 %)
-    amp_loss, _ = LR.margin_mse(g["logits_autocast_bf16"], batch["labels"].numpy())
-    tol = max(1e-2, 3.0 * abs(amp_loss - float(g["loss"])) / float(g["loss"]))
-    assert loss_out[0].item() == pytest.approx(float(g["loss"]), rel=tol)
-    # per-tensor gradient norms from the reference's backward
-    names, vals = [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]
-    params = {f"query_encoder.{n}": p for n, p in model.query_encoder.named_flat()}
-    params.update({f"passage_encoder.{n}": p for n, p in model.passage_encoder.named_flat()})
-    big = vals.max()
-    checked = 0
-    for n, v in zip(names, vals):
-        if v > 1e-3 * big:
-            assert params[n].grad.norm().item() == pytest.approx(v, rel=5e-2), n
-            checked += 1
-    assert checked > 100
+    for gk, loss_kind in kinds:
+        tr = NwayTrainer(model, loss=loss_kind)
+        loss_out, logits = tr.forward_backward(batch)
+        got = logits.cpu().numpy()
+        err = np.abs(got - ref).max()
+        ratio = err / amp_err
+        print(f"{name}/{loss_kind}: max|dlogit| {err:.4f} = {ratio:.2f} x the reference's autocast drift {amp_err:.4f} (max|logit| {np.abs(ref).max():.2f})")
+        assert ratio <= 1.0, f"{name}: bf16 drift {err:.4f} exceeds the reference's own autocast drift {amp_err:.4f}"
+        if "loss" in g.files:                                # cfg1 golden (round 1 layout)
+            ref_loss, names, vals = float(g["loss"]), [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]
+            amp_loss, _ = ORACLE_LOSS[gk](g["logits_autocast_bf16"], batch["labels"].numpy())
+        else:
+            ref_loss = float(g[f"loss_{gk}"])
+            names, vals = [str(n) for n in g[f"grad_norm_names_{gk}"]], g[f"grad_norm_values_{gk}"]
+            amp_loss = float(g[f"loss_{gk}_autocast"])
+            # the oracle's loss restatement agrees with the reference on these logits (ties the two checkers together)
+            assert ORACLE_LOSS[gk](ref, batch["labels"].numpy())[0] == pytest.approx(ref_loss, rel=1e-5)
+        tol = max(2e-3, abs(amp_loss - ref_loss) / abs(ref_loss))
+        assert loss_out[0].item() == pytest.approx(ref_loss, rel=tol), f"{name}/{loss_kind}: loss"
+        params = {f"query_encoder.{n}": p for n, p in model.query_encoder.named_flat()}
+        params.update({f"passage_encoder.{n}": p for n, p in model.passage_encoder.named_flat()})
+        big, checked, worst = vals.max(), 0, 0.0
+        for n, v in zip(names, vals):
+            if n in params and v > 1e-3 * big:
+                rel = abs(params[n].grad.norm().item() - v) / v
+                worst = max(worst, rel)
+                tol_g = 0.10 if (loss_kind == "lambda_mrr") else 0.05      # rank weights flip on bf16-level logit noise
+                assert rel <= tol_g, f"{name}/{loss_kind}: grad norm of {n} off by {rel:.3f}"
+                checked += 1
+        assert checked > 100
+        print(f"{name}/{loss_kind}: loss {loss_out[0].item():.6f} vs {ref_loss:.6f}; worst per-tensor grad-norm error {worst:.4f} over {checked} tensors")
+        del tr
+
+
+def test_bf16_residual_stream_option_drift(monkeypatch):
+    """CLDRD_RESIDUAL=bf16 (round-1 numerics: pre-LN sums and LayerNorm outputs stored in bf16) stays available as the fast
+    mode; its drift is bounded at 3x the reference's autocast drift and must exceed the default mode's (or the switch is dead)."""
+    monkeypatch.setenv("CLDRD_RESIDUAL", "bf16")
+    g = np.load(os.path.join(GOLDEN, "full_distilbert_cfg2.npz"))
+    model = _full_size_model("distilbert", 6)
+    assert not model.passage_encoder.stream32
+    batch = syn.nway_batch(4680, int(g["B"]), int(g["N"]), int(g["Lq"]), int(g["Lp"]), ragged=True, label_kind="teacher")
+    _, logits = NwayTrainer(model, loss="kl_div").forward_backward(batch)
+    err = np.abs(logits.cpu().numpy() - g["logits"]).max()
+    amp_err = np.abs(g["logits_autocast_bf16"] - g["logits"]).max()
+    print(f"bf16 residual stream: max|dlogit| {err:.4f} = {err / amp_err:.2f} x the reference's autocast drift")
+    assert 1.0 < err / amp_err <= 3.0
+
+
+def test_torch_optimizer_loop_sees_fresh_weights():
+    """Reference-style loop (nway_listwise_1.py:328-367 with a torch optimizer): the bf16 weight shadows must follow
+    optimizer.step() and load_state_dict (parameters share flat_p's version counter now)."""
+    from cldrd_amd.losses import MarginMSE
+    cfg = small_cfg()
+    model = selftest.build_tiny_model(cfg).cuda()
+    model.train()
+    batch = syn.nway_batch(4680, 2, 3, 8, 32, vocab=cfg.vocab_size, ragged=True)
+    dev_batch = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in batch.items()}
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-3)
+    seen = []
+    for _ in range(3):
+        logits = model(dev_batch["query"], dev_batch["nway_passages"])
+        loss = MarginMSE()(logits, dev_batch["labels"])
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        seen.append(logits.detach().clone())
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+    model.eval()
+    with torch.no_grad():
+        before = model.query_embs(dev_batch["query"]).clone()
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        for k in sd:
+            if k.endswith("ffn.lin1.weight"):
+                sd[k] = sd[k] * 1.5
+        model.load_state_dict(sd)
+        after = model.query_embs(dev_batch["query"])
+    assert not torch.equal(before, after)
+
+
+def test_zero_grad_between_steps_gives_single_step_gradients():
+    """optimizer.zero_grad() defaults to set_to_none=True: the next backward must not add onto the previous step's flat
+    gradient."""
+    from cldrd_amd.losses import MarginMSE
+    cfg = small_cfg()
+    model = selftest.build_tiny_model(cfg).cuda()
+    model.train()
+    batch = syn.nway_batch(4680, 2, 3, 8, 32, vocab=cfg.vocab_size, ragged=True)
+    dev_batch = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in batch.items()}
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)          # lr 0: the weights stay put, so both steps see the same problem
+    grads = []
+    for _ in range(2):
+        loss = MarginMSE()(model(dev_batch["query"], dev_batch["nway_passages"]), dev_batch["labels"])
+        loss.backward()
+        grads.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone())
+        opt.step()
+        opt.zero_grad()
+        assert all(p.grad is None for p in model.parameters())
+    assert torch.allclose(grads[0], grads[1], rtol=1e-4, atol=1e-6 * grads[0].abs().max().item())
+
+
+def test_checkpoint_optimizer_state_round_trip_and_torch_layout(tmp_path):
+    """trainer.state_dict() carries the optimizer in torch's layout (what the reference saves / loads, nway_listwise_1.py:302,
+    :423); it loads back bit for bit, a state written by torch.optim.AdamW over the same parameters loads too, junk raises."""
+    cfg = small_cfg(layers=1)
+    model = selftest.build_tiny_model(cfg).cuda()
+    model.train()
+    batch = syn.nway_batch(4680, 2, 3, 8, 16, vocab=cfg.vocab_size)
+    tr = NwayTrainer(model, loss="margin_mse", learning_rate=1e-3, warmup_steps=1, total_steps=10)
+    for _ in range(2):
+        tr.train_step(batch)
+    ck = tr.state_dict()
+    assert set(ck["optimizer"]) == {"state", "param_groups"} and len(ck["optimizer"]["param_groups"]) == 2
+    torch.save(ck, tmp_path / "c.pth.tar")
+    ck = torch.load(tmp_path / "c.pth.tar", map_location="cpu", weights_only=False)
+    model2 = selftest.build_tiny_model(cfg, seed=9).cuda()
+    tr2 = NwayTrainer(model2, loss="margin_mse", learning_rate=1e-3, warmup_steps=1, total_steps=10)
+    tr2.load_state_dict(ck)
+    assert tr2.global_step == 2 and tr2.adam_step == 2
+    assert torch.equal(tr2.m, tr.m) and torch.equal(tr2.v, tr.v) and torch.equal(tr2.flat_p, tr.flat_p)
+    # a state dict produced by a torch optimizer built the reference's way over this model's parameters
+    groups = T_optimizer_groups(model2)
+    opt = torch.optim.AdamW(groups, lr=1e-3)
+    for p in model2.parameters():
+        p.grad = torch.full_like(p, 0.25)
+    opt.step()
+    sd = opt.state_dict()
+    tr2.load_optimizer_state_dict(sd)
+    name = "passage_encoder.transformer.layer.0.ffn.lin1.weight"
+    pid = [i for g_, e in zip(sd["param_groups"], tr2._optimizer_names()) for i, x in zip(g_["params"], e) if x[0] == name][0]
+    assert torch.equal(tr2._slice(tr2.m, 1, "transformer.layer.0.ffn.lin1.weight").cpu(), sd["state"][pid]["exp_avg"].cpu())
+    assert tr2._opt_step_loaded == 1
+    with pytest.raises(ValueError):
+        tr2.load_optimizer_state_dict({"what": 1})
+    with pytest.raises(ValueError):
+        bad = {"state": sd["state"], "param_groups": [sd["param_groups"][0]]}
+        tr2.load_optimizer_state_dict(bad)
+
+
+def T_optimizer_groups(model):
+    """the reference's grouping (nway_listwise_1.py:259-263) over our model's named_parameters, in HF order"""
+    from cldrd_amd.trainer.nway_listwise import optimizer_param_groups
+    params = dict(model.named_parameters())
+    out = []
+    for g_, wd in zip(optimizer_param_groups(model), (0.01, 0.0)):
+        out.append({"params": [params[e[0]] for e in g_ if e[1] is not None], "weight_decay": wd})
+    return out

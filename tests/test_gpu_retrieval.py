@@ -29,21 +29,30 @@ def test_kth_largest_matches_numpy():
 
 
 def same_ranking(D, I, Dr, Ir, rel=1e-5):
-    """identical ids and ranks wherever adjacent reference scores differ by more than rel*|score|; scores within rel."""
+    """Identical ids and ranks wherever adjacent reference scores differ by more than rel * |score|; scores within rel.
+    Inside a run of near-equal reference scores (adjacent gaps <= rel * |score| + 1e-6) the order may differ but the id SET of
+    the run must be the same; only the run that is cut by the list end may differ in membership (ties across the cut-off)."""
     assert D.shape == Dr.shape and I.shape == Ir.shape
     finite = np.isfinite(Dr)
     assert np.array_equal(np.isfinite(D), finite)
     assert np.allclose(D[finite], Dr[finite], rtol=rel, atol=1e-6)
+    assert np.array_equal(I[~finite], Ir[~finite])          # padding: -1 in both
+    swaps = 0
     for q in range(D.shape[0]):
         if np.array_equal(I[q], Ir[q]):
             continue
-        bad = np.where(I[q] != Ir[q])[0]
-        for j in bad:      # a swap is only tolerated inside a group of near-equal scores
-            lo = max(0, j - 1)
-            hi = min(D.shape[1] - 1, j + 1)
-            near = min(abs(Dr[q, j] - Dr[q, lo]) if lo != j else np.inf, abs(Dr[q, j] - Dr[q, hi]) if hi != j else np.inf)
-            assert near <= rel * abs(Dr[q, j]) + 1e-6, (q, j, I[q, j], Ir[q, j], Dr[q, lo:hi + 1])
-        assert sorted(I[q].tolist()) == sorted(Ir[q].tolist()) or True
+        kq = int(finite[q].sum())
+        dr = Dr[q, :kq].astype(np.float64)
+        gap_ok = np.abs(np.diff(dr)) <= rel * np.abs(dr[1:]) + 1e-6          # True: j and j+1 are near-ties
+        start = 0
+        for j in range(kq):
+            if j == kq - 1 or not gap_ok[j]:
+                run = slice(start, j + 1)
+                if j + 1 < kq or kq < D.shape[1]:           # a complete run: same members, any order
+                    assert sorted(I[q, run].tolist()) == sorted(Ir[q, run].tolist()), (q, start, j, I[q, run], Ir[q, run], dr[run])
+                swaps += int((I[q, run] != Ir[q, run]).sum())
+                start = j + 1
+    return swaps
 
 
 @pytest.mark.parametrize("n,d,nq,k", [(20000, 768, 7, 1000), (20000, 768, 150, 100), (3000, 128, 5, 10), (500, 128, 3, 1000),
@@ -63,7 +72,8 @@ def test_flat_ip_search_matches_oracle(n, d, nq, k):
     if k > n:
         assert np.all(I[:, n:] == -1) and np.all(np.isneginf(D[:, n:]))
     st = index.last_stats
-    assert st["scans"] >= (nq + 127) // 128
+    assert st["exhaustive"] == (n <= RU.CAND_CAP)
+    assert st["exhaustive"] or st["scans"] >= (nq + 127) // 128
 
 
 def test_duplicate_rows_tie_break_and_no_ids():
@@ -154,12 +164,13 @@ def test_encode_and_cli_end_to_end(tmp_path):
     assert m["QueriesRanked"] == 20 and m["MRR@10"] == pytest.approx(1 / 3) and m["Recall@5"] == 1.0
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("nq,rows,d", [(128, 40000, 768), (37, 5003, 768), (16, 9000, 128), (128, 70001, 256)])
-def test_scan_stream_and_tiled_report_the_same_candidates(nq, rows, d):
-    """The streaming scan (hit list on chip) and the tiled scan must report the same (query, row) sets with the same bf16
-    scores; only the order inside a query's list is unspecified."""
-    Q = torch.from_numpy(syn.normal(21, nq * d).reshape(nq, d).astype(np.float32)).to(DEV).bfloat16()
-    P = torch.from_numpy(syn.normal(22, rows * d).reshape(rows, d).astype(np.float32)).to(DEV).bfloat16()
+def test_scan_stream_and_tiled_report_the_same_candidates(nq, rows, d, dtype):
+    """The streaming scan (hit list on chip, flushed when it fills) and the tiled scan must report the same (query, row) sets
+    with the same 16-bit-operand scores; only the order inside a query's list is unspecified."""
+    Q = torch.from_numpy(syn.normal(21, nq * d).reshape(nq, d).astype(np.float32)).to(DEV).to(dtype)
+    P = torch.from_numpy(syn.normal(22, rows * d).reshape(rows, d).astype(np.float32)).to(DEV).to(dtype)
     S = Q.float() @ P.float().T
     thr = torch.quantile(S[:, :4096], 1.0 - 40.0 / 4096, dim=1).contiguous()
     got = []
@@ -188,8 +199,8 @@ def test_scan_stream_and_tiled_report_the_same_candidates(nq, rows, d):
 def test_scan_stream_marks_dropped_hits_and_search_recovers():
     """A threshold far too low overflows the streaming kernel's on-chip list: counts[nq] must say so (never silent)."""
     nq, rows, d = 128, 30000, 768
-    Q = torch.from_numpy(syn.normal(23, nq * d).reshape(nq, d).astype(np.float32)).to(DEV).bfloat16()
-    P = torch.from_numpy(syn.normal(24, rows * d).reshape(rows, d).astype(np.float32)).to(DEV).bfloat16()
+    Q = torch.from_numpy(syn.normal(23, nq * d).reshape(nq, d).astype(np.float32)).to(DEV).half()
+    P = torch.from_numpy(syn.normal(24, rows * d).reshape(rows, d).astype(np.float32)).to(DEV).half()
     thr = torch.full((nq,), -1e30, device=DEV)
     counts = torch.zeros(nq + 1, dtype=torch.int32, device=DEV)
     cr = torch.empty(nq, 64, dtype=torch.int32, device=DEV)
@@ -201,3 +212,110 @@ def test_scan_stream_marks_dropped_hits_and_search_recovers():
     ops.topk_scan_filter(Q, P, thr, counts, cr, cs, tiled=True)
     c = counts.cpu().numpy()
     assert c[nq] == 0 and (c[:nq] == rows).all()
+
+
+def test_scan_stream_flushes_its_hit_list():
+    """~1000 hits per workgroup: more than half the on-chip list, so every workgroup flushes mid-stream at least once; the candidate
+    sets must still equal the tiled kernel's (nothing lost, nothing duplicated, nothing reported as dropped)."""
+    nq, rows, d, cap = 128, 40000, 768, 4096
+    Q = torch.from_numpy(syn.normal(31, nq * d).reshape(nq, d).astype(np.float32)).to(DEV).half()
+    P = torch.from_numpy(syn.normal(32, rows * d).reshape(rows, d).astype(np.float32)).to(DEV).half()
+    S = Q.float() @ P.float().T
+    thr = torch.quantile(S[:, :8000], 1.0 - 0.05, dim=1).contiguous()          # ~2000 hits per query
+    got = []
+    for tiled in (False, True):
+        counts = torch.zeros(nq + 1, dtype=torch.int32, device=DEV)
+        cr = torch.full((nq, cap), -1, dtype=torch.int32, device=DEV)
+        cs = torch.zeros(nq, cap, device=DEV)
+        ops.topk_scan_filter(Q, P, thr, counts, cr, cs, tiled=tiled)
+        c = counts.cpu().numpy()
+        assert c[nq] == 0 and (c[:nq] <= cap).all() and c[:nq].mean() > 1200
+        crh = cr.cpu().numpy()
+        got.append([np.sort(crh[q, :c[q]]) for q in range(nq)])
+    for q in range(nq):
+        assert len(np.unique(got[0][q])) == len(got[0][q])
+        # the two kernels accumulate in different orders: rows within 1e-3 of the threshold may differ
+        diff = np.setxor1d(got[0][q], got[1][q])
+        assert len(diff) <= 4 and (np.abs(S[q, diff].cpu().numpy() - thr[q].item()) < 2e-3).all()
+
+
+def _bench_corpus(rows, d, seed, chunk=1 << 20):
+    """The bench.py corpus (unit-variance Gaussian direction x per-row norm ~ U(9, 12)), generated on the
+    device in row chunks so the transient memory stays small at 8.8 M rows."""
+    gen = torch.Generator(device=DEV).manual_seed(seed)
+    P = torch.empty(rows, d, device=DEV)
+    for lo in range(0, rows, chunk):
+        blk = torch.randn(min(chunk, rows - lo), d, device=DEV, generator=gen)
+        blk *= (9.0 + 3.0 * torch.rand(blk.shape[0], 1, device=DEV, generator=gen)) / blk.norm(dim=1, keepdim=True)
+        P[lo:lo + blk.shape[0]] = blk
+    return P
+
+
+def _device_fp64_topk(P32, q32, k, chunk=1 << 19):
+    """Independent exact reference on the device: fp64 scores rounded to fp32 once (the oracle's definition), running top-k over
+    row chunks with torch, final order (score desc, row asc) fixed on the host."""
+    nq = q32.shape[0]
+    q64 = q32.double()
+    best_s = torch.full((nq, 0), -float("inf"), device=DEV)
+    best_i = torch.zeros((nq, 0), dtype=torch.int64, device=DEV)
+    for lo in range(0, P32.shape[0], chunk):
+        s = (q64 @ P32[lo:lo + chunk].double().T).float()
+        idx = torch.arange(lo, lo + s.shape[1], device=DEV).expand(nq, -1)
+        cs, ci = torch.cat([best_s, s], 1), torch.cat([best_i, idx], 1)
+        top = torch.topk(cs, min(k + 8, cs.shape[1]), dim=1)
+        best_s, best_i = top.values, torch.gather(ci, 1, top.indices)
+    s, i = best_s.cpu().numpy().astype(np.float64), best_i.cpu().numpy()
+    order = np.lexsort((i, -s), axis=1)[:, :k]
+    return np.take_along_axis(s, order, 1).astype(np.float32), np.take_along_axis(i, order, 1)
+
+
+def test_cfg5_shard_search_matches_oracle_at_full_size():
+    """BASELINE.json configs[4], one shard: 1 105 228 x 768 rows (8 841 823 / 8), 6 980 queries, k = 1000 (reference loop
+    retriever/retrieval_utils.py:131-153).  The first 128-query batch is checked against the CPU oracle (oracle/retrieval_ref.py),
+    64 queries spread over the rest against an independent fp64 reference on the device, and every query for the properties any
+    exact top-k has.  The threshold / proof logic depends on the corpus size (lam = k S / n): this is the size the bench searches."""
+    rows, d, nq, k = 1105228, 768, 6980, 1000
+    P = _bench_corpus(rows, d, 1234)
+    gen = torch.Generator(device=DEV).manual_seed(99)
+    Q = torch.randn(nq, d, device=DEV, generator=gen)
+    Q *= 10.0 / Q.norm(dim=1, keepdim=True)
+    index = RU.FlatIPIndex.from_device_rows(P, id_offset=7 * rows)
+    index.profile = True
+    D, I = index.search(Q.cpu().numpy(), k)
+    st = index.last_stats
+    print(f"cfg5 shard: scans {st['scans']} rescans {st['rescans']} unproven after the first pass {st['unproven_first_pass']} "
+          f"candidates/query {st['candidates'] / nq:.0f} rescored/query {st['rescored'] / nq:.0f} search {st['search_ms']:.1f} ms")
+    assert st["scans"] >= 55 and st["rescans"] <= 2
+    assert st["rescored"] / nq < 1.6 * k              # the 2 eps band stays a fraction of k: the re-score is not a second scan
+    assert np.all(np.diff(D, axis=1) <= 0) and I.min() >= 7 * rows and I.max() < 8 * rows
+    assert all(len(np.unique(I[q])) == k for q in range(0, nq, 97))
+    Ph = P.cpu().numpy()
+    Dr, Ir = R.flat_ip_search(Ph, None, Q[:128].cpu().numpy(), k)
+    swaps = same_ranking(D[:128], I[:128] - 7 * rows, Dr, Ir)
+    del Ph
+    sel = np.arange(128 + 53, nq, (nq - 181) // 64)[:64]
+    Dg, Ig = _device_fp64_topk(P, Q[torch.from_numpy(sel).to(DEV)], k)
+    swaps += same_ranking(D[sel], I[sel] - 7 * rows, Dg, Ig)
+    print(f"cfg5 shard: {swaps} positions differ inside near-tie runs (1e-5 relative) over {128 + 64} checked queries")
+
+
+def test_cfg5_full_index_on_one_gpu_sampled_check():
+    """The whole 8 841 823-row index on one MI355X (27 GB fp32 + 14 GB fp16 of the 288 GB): 128 queries, k = 1000; 16 of them are
+    checked against the independent fp64 device reference, all of them for order / range / uniqueness."""
+    rows, d, nq, k = 8841823, 768, 128, 1000
+    P = _bench_corpus(rows, d, 4321)
+    gen = torch.Generator(device=DEV).manual_seed(98)
+    Q = torch.randn(nq, d, device=DEV, generator=gen)
+    Q *= 10.0 / Q.norm(dim=1, keepdim=True)
+    index = RU.FlatIPIndex.from_device_rows(P)
+    index.profile = True
+    D, I = index.search(Q.cpu().numpy(), k)
+    st = index.last_stats
+    print(f"cfg5 full: scans {st['scans']} rescans {st['rescans']} candidates/query {st['candidates'] / nq:.0f} "
+          f"rescored/query {st['rescored'] / nq:.0f} search {st['search_ms']:.2f} ms")
+    assert st["rescans"] <= 1
+    assert np.all(np.diff(D, axis=1) <= 0) and I.min() >= 0 and I.max() < rows
+    assert all(len(np.unique(I[q])) == k for q in range(nq))
+    sel = np.arange(3, nq, 8)[:16]
+    Dg, Ig = _device_fp64_topk(P, Q[torch.from_numpy(sel).to(DEV)], k)
+    same_ranking(D[sel], I[sel], Dg, Ig)
