@@ -333,7 +333,9 @@ def cpu_baseline(N, L, Lq):
     from oracle import encoder_ref as E
     from oracle import losses_ref as LR
     import cldrd_amd.synthetic as syn
-    cores = len(os.sched_getaffinity(0))
+    # threads: every core the process may use, up to 32.  Measured on the MI355X host (256 logical CPUs visible): the same two
+    # steps took 496 s on 256 torch threads and 6.8 s on 32 - beyond that torch-CPU's intra-op parallelism only adds contention.
+    cores = min(len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(cores)
     Bc, timed = 2, 2
     cfg = E.RefConfig()

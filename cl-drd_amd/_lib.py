@@ -19,6 +19,8 @@ SIGNATURES = {
     "cldrd_gemm_nt_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, vp]),
     "cldrd_wgrad_splits": (ci, [ci, ci, ci]),
     "cldrd_wgrad_bf16": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, csz, ci, vp]),
+    "cldrd_wgrad_group_workspace": (csz, [vp, vp, vp, ci]),
+    "cldrd_wgrad_group": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, csz, ci, vp]),
     "cldrd_attention_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
     "cldrd_attention_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
     "cldrd_attention_cls_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),

@@ -14,8 +14,16 @@
 // fp32 slab and a second pass sums the slabs in a fixed order (bitwise reproducible, no float atomics).
 // The bias gradient costs one extra MFMA per A fragment in the n2 == 0 tiles: B = all-ones.
 //
-// Contract: A and B must have ceil(M/64)*64 rows allocated and rows >= M must be zero (the host allocates
-// activation / gradient buffers that way and no kernel writes past row M).
+// Rows >= M of the last 64-token K tile are fetched from a zero page instead of the operands (the LDS-DMA source address is per
+// lane), so the operands need neither padding nor a zeroed tail.
+//
+// GROUPED launch (cldrd_wgrad_group): the weight gradients are not on the critical path of the backward (only the data gradients
+// are), so the trainer defers them and hands all of a tower's problems - 4 per layer - to ONE launch.  Work item = (problem, token
+// split, output tile), ordered tile-fastest so that the workgroups running at the same time on one XCD compute neighbouring tiles
+// of the same problem at the same token position (shared A / B panels in that XCD's L2).  With 700+ tiles in a group no token split
+// is needed any more (744 tiles = 2.9 rounds of 256 CUs for DistilBERT at cfg2): every workgroup sweeps ALL tokens of its tile and
+// writes dW once - no fp32 slabs through HBM, no reduction launches (round 1: 25 GEMM + 25 reduction launches and ~1 GB of slab
+// traffic per step).  Token splits + slabs remain for small groups (few tiles), chosen by the same cost model as before.
 #include <type_traits>
 
 #include "common.h"
@@ -23,6 +31,22 @@
 namespace {
 
 constexpr int BK = 64;                 // tokens per LDS slot
+constexpr int MAXP = 32;               // problems per launch (kernel-argument block: 32 x 72 B)
+
+struct TnProblem {
+    const bf16_t* A; const bf16_t* B; float* dW; float* dbias;      // dbias may be null
+    int M, N1, N2, lda, ldb;
+    int tiles, nt2;                    // (N1 / T1) * (N2 / T2), N2 / T2
+    int first;                         // first work item of this problem; items of a problem: split-major, tile-minor
+    long long slab_off;                // splits > 1: float offset of this problem's slabs in the workspace
+};
+struct TnGroupArgs {
+    int n, splits, accumulate, stagger;
+    float* slabs;
+    TnProblem p[MAXP];
+};
+
+__device__ __attribute__((aligned(4096))) uint4 g_zero_page[256];     // 4 KiB of zeros: DMA source of token rows >= M
 
 __device__ __forceinline__ int swz(int m) { return 2 * ((m & 3) | (((m >> 3) & 1) << 2)); }
 // 16-byte chunk c of token row m -> position inside the row.  Rows of 256 / 512 bytes: c ^ swz(m).  Rows of 384 bytes (24 chunks,
@@ -47,11 +71,10 @@ __device__ __forceinline__ void tr_issue(Frag& f, uint32_t addr) {
 }
 __device__ __forceinline__ bf16x8 frag8(const Frag& f) { return (bf16x8){f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]}; }
 
-template <int T1, int T2, int NW, bool BIAS>
-__global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         float* __restrict__ slabs, int M, int N1, int N2, int lda, int ldb,
-                                                         int splits, int ksteps_per_split, size_t slab_stride, int stagger) {
+template <int T1, int T2, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool BIAS = true;                         // bias columns are a per-problem run-time choice (dbias != null)
     constexpr int NBF = T2 == 192 ? 3 : 4;              // B fragments (16 n2 columns each) per wave
     constexpr int WGN = T2 / (16 * NBF), WGM = NW / WGN;        // wave grid; a wave owns (16 FA) x (16 NBF) of the tile
     constexpr int FA = T1 / WGM / 16;                   // A fragments (16 n1 columns each) per wave
@@ -62,16 +85,25 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
     constexpr int G = APW + BPW;                        // LDS-DMA instructions per wave per K tile
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nt2 = N2 / T2;
-    const int ntiles = (N1 / T1) * nt2;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int split = id / ntiles, tile = id % ntiles;      // the tiles of one split are neighbours: they share A/B rows
+    int pi = 0;
+    while (pi + 1 < ga.n && id >= ga.p[pi + 1].first) ++pi;               // wave-uniform: scalar loads from the argument block
+    const TnProblem& P = ga.p[pi];
+    const bf16_t* __restrict__ A = P.A;
+    const bf16_t* __restrict__ B = P.B;
+    const int M = P.M, N1 = P.N1, N2 = P.N2, lda = P.lda, ldb = P.ldb;
+    const int nt2 = P.nt2, ntiles = P.tiles;
+    const int local = id - P.first;
+    const int split = local / ntiles, tile = local % ntiles;      // the tiles of one split are neighbours: they share A/B rows
     const int c1 = (tile / nt2) * T1, c2 = (tile % nt2) * T2;
     const int ktotal = (M + BK - 1) / BK;
+    const int ksteps_per_split = (ktotal + ga.splits - 1) / ga.splits;
     const int kbeg = split * ksteps_per_split;
     const int nk = min(ktotal, kbeg + ksteps_per_split) - kbeg;
     const int wm = wid / WGN, wn = wid % WGN;
-    const bool do_bias = BIAS && c2 == 0 && wn == 0;
+    const bool do_bias = P.dbias != nullptr && c2 == 0 && wn == 0;
+    const int stagger = ga.stagger;
+    const int mtail = M & (BK - 1);                    // valid rows of the last K tile (0: it is complete)
 
     // ---- LDS-DMA.  A piece = RA token rows x (T1*2) B; a B piece = 1 KiB of the row-major B image; wave w owns pieces APW*w.. / BPW*w..
     uint32_t oa[APW], ob[BPW];
@@ -90,6 +122,22 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
         char* base = smem + slot * SLOT;
         const char* pa = (const char*)A + (size_t)(kbeg + kt) * BK * lda * 2;
         const char* pb = (const char*)B + (size_t)(kbeg + kt) * BK * ldb * 2;
+        if (mtail != 0 && kbeg + kt == ktotal - 1) {
+            // last, partial K tile: token rows >= M come from the zero page (once per workgroup at most; rows recomputed here
+            // instead of being kept in registers)
+            const char* zp = (const char*)g_zero_page + lane * 16;
+#pragma unroll
+            for (int i = 0; i < APW; ++i) {
+                const int r = RA * (APW * wid + i) + lane / LPR_A;
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(r < mtail ? pa + oa[i] : zp), LDS_PTR(base + (APW * wid + i) * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BPW; ++i) {
+                const int r = ((BPW * wid + i) * 1024 + lane * 16) / (T2 * 2);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(r < mtail ? pb + ob[i] : zp), LDS_PTR(base + A_BYTES + (BPW * wid + i) * 1024), 16, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < APW; ++i)
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + oa[i]), LDS_PTR(base + (APW * wid + i) * 1024), 16, 0, 0);
@@ -222,16 +270,27 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(const bf16_t* __res
         }
     }
 
-    float* slab = slabs + (size_t)split * slab_stride;
+    // ---- output.  One split: the tile is complete, write (or add to) dW / dbias directly.  Several: this split's slab.
+    const bool direct = ga.splits == 1;
+    float* outW = direct ? P.dW : ga.slabs + P.slab_off + (size_t)split * ((size_t)N1 * N2 + (size_t)N1);
+    float* outB = direct ? P.dbias : outW + (size_t)N1 * N2;
+    const bool add = direct && ga.accumulate != 0;
 #pragma unroll
     for (int t1 = 0; t1 < FA; ++t1) {
         const int n1 = c1 + wm * (16 * FA) + t1 * 16 + (lane & 15);
 #pragma unroll
         for (int t2 = 0; t2 < NBF; ++t2) {
             const int n2 = c2 + wn * (16 * NBF) + t2 * 16 + 4 * (lane >> 4);
-            *(float4*)(slab + (size_t)n1 * N2 + n2) = make_float4(acc[t1][t2][0], acc[t1][t2][1], acc[t1][t2][2], acc[t1][t2][3]);
+            float4 v = make_float4(acc[t1][t2][0], acc[t1][t2][1], acc[t1][t2][2], acc[t1][t2][3]);
+            float4* dst = (float4*)(outW + (size_t)n1 * N2 + n2);
+            if (add) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *dst = v;
         }
-        if (BIAS && do_bias && lane < 16) slab[(size_t)N1 * N2 + n1] = accb[BIAS ? t1 : 0][0];       // every n2 row of D' holds the same column sums
+        if (do_bias && lane < 16) {       // every n2 row of D' holds the same column sums
+            float b = accb[t1][0];
+            if (add) b += outB[n1];
+            outB[n1] = b;
+        }
     }
 }
 
@@ -256,41 +315,62 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 
 }  // namespace
 
-// tile choice: 256 x 256 (8 waves of 128 x 64) when both extents allow, else 256 x 128 (8 waves of 64 x 64), else 128 x 128 (4 waves)
+// ---- host side ---------------------------------------------------------------------------------------------------------
 struct WgradTile { int t1, t2; };
-static inline WgradTile wgrad_tile(int N1, int N2) {
+
+// One tile shape per launch: 256 x 192 (8 waves of 128 x 48: 7 LDS-DMA pieces per 48 MFMAs per wave, the ratio of the NT kernel's
+// BN = 192) when every problem allows it, else 256 x 128 (8 waves of 64 x 64), else 128 x 128 (4 waves).  The 256 x 256 tile of
+// round 1 (all 256 VGPRs, spills, two LDS slots: 430-480 TF/s against 690-810) is gone.  CLDRD_WGRAD_TILE=128|192 forces one.
+static WgradTile wgrad_tile_group(const int* N1, const int* N2, int n) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("CLDRD_WGRAD_TILE"); force = e ? atoi(e) : 0; }
-    // measured (T = 32768): the 256 x 256 tile needs all 256 VGPRs, spills, and has room for two LDS slots only:
-    // 430-480 TF/s against 690-810 TF/s for 256 x 128.  It stays instantiable for experiments (CLDRD_WGRAD_TILE=256).
-    if (N1 % 256 == 0 && N2 % 256 == 0 && force == 256) return {256, 256};
-    // 256 x 192 (8 waves of 128 x 48): 7 LDS-DMA pieces per 48 MFMAs per wave instead of 6 per 32, the ratio of the NT kernel's BN = 192
-    // (measured at T = 32768: 2304 x 768 +6 %, 3072 x 768 +3 %, 768 x 3072 +10 %; 768 x 768 -7 %: with 12 tiles the 21 slabs
-    // per tile make the reduction the larger part, so small outputs stay on 256 x 128)
-    if (N1 % 256 == 0 && N2 % 192 == 0 && ((force != 128 && ((N1 / 256) * (N2 / 192) >= 24 || force == 192)) || N2 % 128 != 0)) return {256, 192};
-    if (N1 % 256 == 0) return {256, 128};
+    bool ok192 = true, ok128w = true;
+    for (int i = 0; i < n; ++i) {
+        ok192 = ok192 && N1[i] % 256 == 0 && N2[i] % 192 == 0;
+        ok128w = ok128w && N1[i] % 256 == 0 && N2[i] % 128 == 0;
+    }
+    if (ok192 && force != 128 && (force == 192 || !ok128w || n > 1)) return {256, 192};
+    if (ok192 && force != 128) {
+        // single problem: small outputs stay on 256 x 128 (measured at T = 32768: 768 x 768 -7 % on 256 x 192, the others +3..10 %)
+        if ((N1[0] / 256) * (N2[0] / 192) >= 24) return {256, 192};
+    }
+    if (ok128w) return {256, 128};
     return {128, 128};
 }
 
-// Token-range splits per output tile.  One workgroup occupies a CU (LDS), so tiles * splits workgroups run in
-// ceil(tiles * splits / 256) rounds of ceil(ktotal / splits) K tiles each, plus a per-workgroup cost (pipeline fill, slab
-// write) of about OVERHEAD K-tile times.  Pick the split count with the smallest modelled time: e.g. 72 tiles -> 7 splits
-// (504 workgroups = 1.97 rounds) beats 3 splits (216 workgroups, 40 idle CUs); 270 workgroups would be the worst case.
-extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
-    const WgradTile t = wgrad_tile(N1, N2);
-    const int tiles = (N1 / t.t1) * (N2 / t.t2);
-    const int ktotal = (M + BK - 1) / BK;
+// Token splits per output tile.  One workgroup occupies a CU (LDS), so items = tiles * splits workgroups run in
+// ceil(items / 256) rounds of ceil(ktotal / splits) K tiles each, plus a per-workgroup cost (pipeline fill, output write) of about
+// OVERHEAD K-tile times, plus - for splits > 1 - the fp32 slabs written and read back (bytes / ~5 TB/s, in units of the ~1.5 us a
+// K tile takes) and the reduction launch.  Smallest modelled time wins; ties go to fewer splits.
+static int wgrad_splits_group(const int* M, const int* N1, const int* N2, int n, WgradTile t) {
+    long tiles = 0;
+    int ktotal = 1;
+    double out_bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        tiles += (long)(N1[i] / t.t1) * (N2[i] / t.t2);
+        ktotal = ktotal > (M[i] + BK - 1) / BK ? ktotal : (M[i] + BK - 1) / BK;
+        out_bytes += 4.0 * N1[i] * N2[i];
+    }
     if (tiles <= 0) return 1;
     static int overhead = -1;
     if (overhead < 0) { const char* e = getenv("CLDRD_WGRAD_OVERHEAD"); overhead = e ? atoi(e) : 6; }
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("CLDRD_WGRAD_SPLITS"); force = e ? atoi(e) : 0; }
+    if (force > 0) return force < ktotal ? force : ktotal;
     int best = 1;
-    long best_cost = -1;
+    double best_cost = -1.0;
     for (int sp = 1; sp <= 64 && sp <= ktotal; ++sp) {
-        const long rounds = ((long)tiles * sp + 255) / 256;
-        const long cost = rounds * ((ktotal + sp - 1) / sp + overhead);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = sp; }
+        const long rounds = (tiles * sp + 255) / 256;
+        double cost = (double)rounds * ((ktotal + sp - 1) / sp + overhead);
+        if (sp > 1) cost += 2.0 * sp * out_bytes / 5.0e12 / 1.5e-6 + 4.0;
+        if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }
     return best;
+}
+
+extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
+    if (N1 % 128 != 0 || !(N2 % 128 == 0 || (N1 % 256 == 0 && N2 % 192 == 0))) return 1;
+    return wgrad_splits_group(&M, &N1, &N2, 1, wgrad_tile_group(&N1, &N2, 1));
 }
 
 static inline int wgrad_stagger() {
@@ -299,53 +379,95 @@ static inline int wgrad_stagger() {
     return v;
 }
 
-template <int T1, int T2, int NW, bool BIAS>
-static int launch_tn(const void* A, const void* B, float* ws, int M, int N1, int N2, int lda, int ldb, int splits, int kps,
-                     size_t slab_stride, hipStream_t st) {
+template <int T1, int T2, int NW>
+static int launch_tn_group(const TnGroupArgs& g, int items, hipStream_t st) {
     constexpr int slot = BK * (T1 + T2) * 2;
     constexpr int lds = (3 * slot <= 160 * 1024 ? 3 : 2) * slot;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T1, T2, NW, BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T1, T2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    const int tiles = (N1 / T1) * (N2 / T2);
-    hipLaunchKernelGGL((gemm_tn_kernel<T1, T2, NW, BIAS>), dim3(tiles * splits), dim3(64 * NW), lds, st, (const bf16_t*)A, (const bf16_t*)B, ws,
-                       M, N1, N2, lda, ldb, splits, kps, slab_stride, wgrad_stagger());
+    hipLaunchKernelGGL((gemm_tn_kernel<T1, T2, NW>), dim3(items), dim3(64 * NW), lds, st, g);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 
-// workspace floats needed: splits * (N1*N2 + N1)
+// floats of workspace a group needs (0 when no token split is used)
+extern "C" size_t cldrd_wgrad_group_workspace(const int* M, const int* N1, const int* N2, int n) {
+    if (n <= 0) return 0;
+    const WgradTile t = wgrad_tile_group(N1, N2, n);
+    const int splits = wgrad_splits_group(M, N1, N2, n, t);
+    if (splits == 1) return 0;
+    size_t tot = 0;
+    for (int i = 0; i < n; ++i) tot += (size_t)splits * ((size_t)N1[i] * N2[i] + (size_t)N1[i]);
+    return tot;
+}
+
+// dW[i][N1[i], N2[i]] (+)= A[i][:M[i]]^T . B[i][:M[i]] and dbias[i][N1[i]] (+)= column sums of A[i] (dbias[i] may be null) for n
+// problems in one launch (more than 32: several launches).  The pointer / shape arrays live on the HOST.
+extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, float* const* dW, float* const* dbias, const int* M,
+                                 const int* N1, const int* N2, const int* lda, const int* ldb, int n, float* workspace,
+                                 size_t workspace_bytes, int accumulate, void* stream) {
+    CLDRD_CHECK(n > 0, "wgrad_group: no problems");
+    for (int i = 0; i < n; ++i) {
+        CLDRD_CHECK(M[i] > 0, "wgrad: empty problem");
+        CLDRD_CHECK(N1[i] % 128 == 0 && (N2[i] % 128 == 0 || (N1[i] % 256 == 0 && N2[i] % 192 == 0)),
+                    "wgrad: N1 and N2 must be multiples of 128 (or 256 x 192)");
+        CLDRD_CHECK(lda[i] % 8 == 0 && ldb[i] % 8 == 0, "wgrad: lda/ldb must be multiples of 8");
+        CLDRD_CHECK(((uintptr_t)A[i] % 16 == 0) && ((uintptr_t)B[i] % 16 == 0) && ((uintptr_t)dW[i] % 16 == 0), "wgrad: operands must be 16-byte aligned");
+        CLDRD_CHECK(dbias[i] == nullptr || (uintptr_t)dbias[i] % 16 == 0, "wgrad: dbias must be 16-byte aligned");
+        CLDRD_CHECK((double)lda[i] * 2.0 * 72.0 < 4.0e9 && (double)ldb[i] * 2.0 * 72.0 < 4.0e9, "wgrad: row pitch too large");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const WgradTile t = wgrad_tile_group(N1, N2, n);
+    bool any128 = false;
+    for (int i = 0; i < n; ++i) any128 = any128 || N2[i] % 128 != 0;
+    CLDRD_CHECK(!(t.t2 != 192 && any128), "wgrad_group: problems with N2 % 128 != 0 need every problem to fit the 256 x 192 tile");
+    const int splits = wgrad_splits_group(M, N1, N2, n, t);
+    if (splits > 1) {
+        size_t need = 0;
+        for (int i = 0; i < n; ++i) need += (size_t)splits * ((size_t)N1[i] * N2[i] + (size_t)N1[i]);
+        CLDRD_CHECK(workspace != nullptr && ((uintptr_t)workspace % 16 == 0) && workspace_bytes >= need * sizeof(float), "wgrad: workspace too small");
+    }
+    size_t slab_off = 0;
+    for (int lo = 0; lo < n; lo += MAXP) {
+        const int m = n - lo < MAXP ? n - lo : MAXP;
+        TnGroupArgs g;
+        g.n = m; g.splits = splits; g.accumulate = accumulate; g.stagger = wgrad_stagger(); g.slabs = workspace;
+        int items = 0;
+        for (int i = 0; i < m; ++i) {
+            TnProblem& P = g.p[i];
+            const int j = lo + i;
+            P.A = (const bf16_t*)A[j]; P.B = (const bf16_t*)B[j]; P.dW = dW[j]; P.dbias = dbias[j];
+            P.M = M[j]; P.N1 = N1[j]; P.N2 = N2[j]; P.lda = lda[j]; P.ldb = ldb[j];
+            P.nt2 = N2[j] / t.t2; P.tiles = (N1[j] / t.t1) * P.nt2;
+            P.first = items; P.slab_off = (long long)slab_off;
+            items += P.tiles * splits;
+            if (splits > 1) slab_off += (size_t)splits * ((size_t)N1[j] * N2[j] + (size_t)N1[j]);
+        }
+        int rc;
+        if (t.t1 == 256 && t.t2 == 192) rc = launch_tn_group<256, 192, 8>(g, items, st);
+        else if (t.t1 == 256) rc = launch_tn_group<256, 128, 8>(g, items, st);
+        else rc = launch_tn_group<128, 128, 4>(g, items, st);
+        if (rc) return rc;
+        if (splits > 1) {
+            for (int i = 0; i < m; ++i) {
+                const TnProblem& P = g.p[i];
+                const size_t n_main4 = (size_t)P.N1 * P.N2 / 4, n_all4 = n_main4 + (P.dbias ? (size_t)P.N1 / 4 : 0);
+                const size_t stride = (size_t)P.N1 * P.N2 + (size_t)P.N1;
+                const int rb = (int)((n_all4 + 255) / 256 < 2048 ? (n_all4 + 255) / 256 : 2048);
+                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace + P.slab_off, P.dW, P.dbias, n_main4,
+                                   n_all4, splits, stride / 4, accumulate);
+                CLDRD_LAUNCH_CHECK();
+            }
+        }
+    }
+    return 0;
+}
+
+// the single-problem form (a group of one).  workspace floats needed: cldrd_wgrad_splits(M, N1, N2) * (N1*N2 + N1)
 extern "C" int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, float* dbias, int M, int N1, int N2, int lda, int ldb,
                                 float* workspace, size_t workspace_bytes, int accumulate, void* stream) {
-    CLDRD_CHECK(M > 0, "wgrad: empty problem");
-    CLDRD_CHECK(N1 % 128 == 0 && (N2 % 128 == 0 || (N1 % 256 == 0 && N2 % 192 == 0)), "wgrad: N1 and N2 must be multiples of 128 (or 256 x 192)");
-    CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0, "wgrad: lda/ldb must be multiples of 8");
-    CLDRD_CHECK(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)dW % 16 == 0) && ((uintptr_t)workspace % 16 == 0),
-                "wgrad: operands must be 16-byte aligned");
-    CLDRD_CHECK(dbias == nullptr || (uintptr_t)dbias % 16 == 0, "wgrad: dbias must be 16-byte aligned");
-    CLDRD_CHECK((double)lda * 2.0 * 72.0 < 4.0e9 && (double)ldb * 2.0 * 72.0 < 4.0e9, "wgrad: row pitch too large");
-    const int splits = cldrd_wgrad_splits(M, N1, N2);
-    const size_t slab_stride = (size_t)N1 * N2 + (size_t)N1;
-    CLDRD_CHECK(workspace_bytes >= (size_t)splits * slab_stride * sizeof(float), "wgrad: workspace too small");
-    const int ktotal = (M + BK - 1) / BK;
-    const int kps = (ktotal + splits - 1) / splits;
-    hipStream_t st = (hipStream_t)stream;
-    const WgradTile t = wgrad_tile(N1, N2);
-    int rc;
-#define CLDRD_TN(T1_, T2_, NW_) (dbias ? launch_tn<T1_, T2_, NW_, true>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st) \
-                                       : launch_tn<T1_, T2_, NW_, false>(A, B, workspace, M, N1, N2, lda, ldb, splits, kps, slab_stride, st))
-    if (t.t1 == 256 && t.t2 == 256) rc = CLDRD_TN(256, 256, 8);
-    else if (t.t1 == 256 && t.t2 == 192) rc = CLDRD_TN(256, 192, 8);
-    else if (t.t1 == 256) rc = CLDRD_TN(256, 128, 8);
-    else rc = CLDRD_TN(128, 128, 4);
-#undef CLDRD_TN
-    if (rc) return rc;
-    const size_t n_main4 = (size_t)N1 * N2 / 4, n_all4 = n_main4 + (dbias ? (size_t)N1 / 4 : 0);
-    const int rb = (int)((n_all4 + 255) / 256 < 2048 ? (n_all4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace, dW, dbias, n_main4,
-                       n_all4, splits, slab_stride / 4, accumulate);
-    CLDRD_LAUNCH_CHECK();
-    return 0;
+    return cldrd_wgrad_group(&A, &B, &dW, &dbias, &M, &N1, &N2, &lda, &ldb, 1, workspace, workspace_bytes, accumulate, stream);
 }

@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
     asm volatile("" : "+v"(thr_lane));       // consume the load HERE: otherwise hipcc waits vmcnt(0) at its first use inside the tile loop
     const uint32_t lcount_off = (uint32_t)(uintptr_t)LDS_PTR(lcount), lq_off = (uint32_t)(uintptr_t)LDS_PTR(lq);
     static_assert(8 * LCAP < 65536, "ds_write offset field");
-    if (threadIdx.x < 4) lcount[threadIdx.x] = 0;               // [0] list length, [1], [2] its snapshots (see the flush check)
+    if (threadIdx.x < 4) lcount[threadIdx.x] = 0;               // [0] list length, [1..3] its snapshots (see the flush check)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing but LDS-DMA is in flight from here on
 
     // ---- DMA addressing: piece p = wid*PPW + j covers LDS bytes [1024 p, 1024 p + 1024) of the tile image
@@ -388,22 +388,26 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
     if (t0 + step < ntiles) stage(1, t0 + step);
     int cs = 0, it = 0;
     for (long long t = t0; t < ntiles; t += step, ++it) {
+        // Level of the hit list for the flush decision below.  The decision must be workgroup-uniform (flush() has barriers) but
+        // lcount moves as soon as a fast wave emits hits of the current tile, so everybody reads a SNAPSHOT wave 0 took at the end
+        // of tile it-2 (three rotating slots; that write is ordered by the barrier of tile it-1, and wave 0 cannot overwrite the slot
+        // before the end of tile it+1, i.e. after every wave has passed the next barrier).  Issued here, consumed after the waits
+        // below: no extra LDS round trip on the critical path.
+        uint32_t snap = 0;
+        if (ablate == 0) {
+            const int sl = (it + 1) % 3;
+            if (sl == 0) asm volatile("ds_read_b32 %0, %1 offset:4" : "=v"(snap) : "v"(lcount_off) : "memory");
+            else if (sl == 1) asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(snap) : "v"(lcount_off) : "memory");
+            else asm volatile("ds_read_b32 %0, %1 offset:12" : "=v"(snap) : "v"(lcount_off) : "memory");
+        }
         // tile t must have landed; tile t+step may stay in flight.  NO global memory operation other than the DMA may appear
         // inside this loop: hipcc would put s_waitcnt vmcnt(0) next to it and drain the two tiles in flight (measured: ~1 us per hit)
-        if (t + step < ntiles) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (t + step < ntiles) asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(snap) : "n"(PPW) : "memory");     // (also lands the snapshot read)
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(snap) :: "memory");
         __builtin_amdgcn_s_barrier();                                       // ... for every wave; slot of tile t-step is free
         asm volatile("" ::: "memory");
-        // Hit-list level check.  The decision must be workgroup-uniform (flush() has barriers) but lcount moves as soon as a fast
-        // wave emits hits of THIS tile, so everybody reads the snapshot wave 0 took during the PREVIOUS tile (two slots: wave 0 can
-        // only overwrite slot (it-1)&1 in tile it+1, i.e. after every wave has passed the next barrier).  Rare - about once per
-        // launch and workgroup; the global traffic inside drains the DMA queue.
-        if (ablate == 0) {
-            uint32_t snap;
-            if (it & 1) asm volatile("ds_read_b32 %0, %1 offset:4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(snap) : "v"(lcount_off) : "memory");
-            else asm volatile("ds_read_b32 %0, %1 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(snap) : "v"(lcount_off) : "memory");
-            if (__builtin_amdgcn_readfirstlane(snap) > (uint32_t)(LCAP / 2)) flush();
-        }
+        // Hit-list level check: `snap` was read at the top of this iteration (see there); the decision is workgroup-uniform.
+        if (ablate == 0 && __builtin_amdgcn_readfirstlane(snap) > (uint32_t)(LCAP / 2)) flush();      // rare: about once per launch and workgroup
         const int fs = cs == 0 ? NSLOT - 1 : cs - 1;                        // slot of tile t-step
         const char* sb = smem + cs * TILEB;
         cs = cs == NSLOT - 1 ? 0 : cs + 1;
@@ -461,10 +465,12 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
             if (c + 2 < NC) fetch(ab[c & 1], c + 2);
             if (c % NCM == NCM - 1) emit(acc, c / NCM);
         }
-        if (ablate == 0 && wid == 0) {           // snapshot of the list level for the next tile's check (hand-issued: see emit)
+        if (ablate == 0 && wid == 0) {           // snapshot of the list level for the check two tiles on (hand-issued: see emit)
             uint32_t v;
-            if (it & 1) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:8" : "=&v"(v) : "v"(lcount_off) : "memory");
-            else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:4" : "=&v"(v) : "v"(lcount_off) : "memory");
+            const int sl = it % 3;
+            if (sl == 0) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:4" : "=&v"(v) : "v"(lcount_off) : "memory");
+            else if (sl == 1) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:8" : "=&v"(v) : "v"(lcount_off) : "memory");
+            else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:12" : "=&v"(v) : "v"(lcount_off) : "memory");
         }
     }
     // ---- what is left in the list

@@ -428,11 +428,9 @@ class HipEncoder(nn.Module):
 
     @staticmethod
     def _buf(rows, cols, dev, dtype=torch.bfloat16):
-        rp = ops.pad_rows(rows)
-        t = torch.empty(rp, cols, dtype=dtype, device=dev)
-        if rp != rows and dtype == torch.bfloat16:
-            t[rows:].zero_()        # zero tail (<= 63 rows): contract of cldrd_wgrad_bf16; fp32 buffers never feed it
-        return t
+        # rows rounded up to 64: allocation granularity only (no kernel reads past `rows`; the weight-gradient kernel takes the
+        # missing token rows of its last K tile from a zero page, so nothing is zero-filled here - round 1 spent 102 fills a step)
+        return torch.empty(ops.pad_rows(rows), cols, dtype=dtype, device=dev)
 
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None, *, train: bool | None = None,
                save: bool = False, seed: int | None = None):
@@ -552,7 +550,7 @@ class HipEncoder(nn.Module):
                                     rstd1=rstd1, x1=x1, pre=pre, h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h,
                                     p_a=p_a, p_out=p_out))
 
-    def _last_layer_cls_bwd(self, i, a, tape, dcls, partial, ws):
+    def _last_layer_cls_bwd(self, i, a, tape, dcls, partial):
         """Backward of :meth:`_last_layer_cls_fwd`; returns dL/d(layer input) as a full [T, d] bf16 tensor."""
         cfg = self.cfg
         d, f, H = cfg.dim, cfg.hidden_dim, cfg.n_heads
@@ -566,24 +564,24 @@ class HipEncoder(nn.Module):
         ds2m = self._buf(M, d, dev) if p_h > 0 else None
         ops.layernorm_bwd(gc, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], partial, M, p_h, s_l + 3, accumulate=self._acc)
         dF = ds2m if ds2m is not None else ds2
-        ops.wgrad(dF, a["h"], G["W2"], M, ws, accumulate=self._acc)
+        self._wq.add(dF, a["h"], G["W2"], M)
         dpre = self._buf(M, f, dev)
         ops.gemm_nt(dF, self.ht(i, "f2"), dpre, M, gelu_pre=a["pre"])
-        ops.wgrad(dpre, a["x1"], G["W1"], M, ws, accumulate=self._acc, dbias=G["bf1"])
+        self._wq.add(dpre, a["x1"], G["W1"], M, dbias=G["bf1"])
         dx1 = self._buf(M, d, dev)
         ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, M, residual=ds2)
         ds1 = self._buf(M, d, dev)
         ds1m = self._buf(M, d, dev) if p_out > 0 else None
         ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], partial, M, p_out, s_l + 2, accumulate=self._acc)
         dA = ds1m if ds1m is not None else ds1
-        ops.wgrad(dA, a["ctx"], G["Wo"], M, ws, accumulate=self._acc)
+        self._wq.add(dA, a["ctx"], G["Wo"], M)
         dctx = self._buf(M, d, dev)
         ops.gemm_nt(dA, self.ht(i, "o"), dctx, M)
         dqc = self._buf(M, d, dev)
         dkv = self._buf(T, 2 * d, dev)
         ops.attention_cls_bwd(a["qc"], a["kv"], a["probs"], dctx, dqc, dkv, M, L, H, p_a, s_l + 1)
-        ops.wgrad(dqc, a["xc"], G["Wqkv"][:d], M, ws, accumulate=self._acc, dbias=G["bqkv"][:d])
-        ops.wgrad(dkv, a["x_in"], G["Wqkv"][d:], T, ws, accumulate=self._acc, dbias=G["bqkv"][d:])
+        self._wq.add(dqc, a["xc"], G["Wqkv"][:d], M, dbias=G["bqkv"][:d])
+        self._wq.add(dkv, a["x_in"], G["Wqkv"][d:], T, dbias=G["bqkv"][d:])
         wt = self.ht(i, "qkv")                                      # [d, 3d] = Wqkv^T
         g = self._buf(T, d, dev)
         ops.gemm_nt(dkv, wt[:, d:], g, T)                           # through K and V: every token
@@ -604,21 +602,33 @@ class HipEncoder(nn.Module):
         self._acc = bool(accumulate)
         cfg = self.cfg
         self.ensure_grads(check_all=check_grads)
+        # Weight gradients are deferred (hip_ops.WgradQueue): only the data gradients are on the critical path.  They are launched
+        # as one group at the end of the backward, or every `wgrad_flush_layers` layers when somebody (the trainer's all-reduce
+        # hooks) wants layers to complete early; `after_layer(i)` is only called once layer i's weight gradients have been launched.
+        self._wq = ops.WgradQueue()
+        flush_every = int(getattr(self, "wgrad_flush_layers", 0) or 0)
+        waiting = []
+
+        def layer_done(i, force=False):
+            waiting.append(i)
+            if force or (flush_every > 0 and len(waiting) >= flush_every):
+                self._wq.flush(accumulate=self._acc)
+                if after_layer is not None:
+                    for j in waiting:
+                        after_layer(j)
+                waiting.clear()
         M, L, T = tape.M, tape.L, tape.T
         d, f, H = cfg.dim, cfg.hidden_dim, cfg.n_heads
         dev = self.flat_p.device
         f32 = dict(dtype=torch.float32, device=dev)
         partial = torch.empty(max(ops.ln_partial_elems(T, d), ((T + 127) // 128) * max(3 * d, f)), **f32)
-        ws = torch.empty(max(ops.wgrad_workspace_elems(r, n1, n2) for r in (T, M)
-                             for n1, n2 in ((3 * d, d), (2 * d, d), (d, d), (f, d), (d, f))), **f32)
         g = None
         for i in reversed(range(cfg.n_layers)):
             W, G, a = self._layer_weights(i), self._layer_grads(i), tape.layers[i]
             if a.get("cls_only"):
-                g = self._last_layer_cls_bwd(i, a, tape, dcls, partial, ws)
+                g = self._last_layer_cls_bwd(i, a, tape, dcls, partial)
                 tape.layers[i] = None
-                if after_layer is not None:
-                    after_layer(i)
+                layer_done(i)
                 continue
             if g is None:
                 g = self._buf(T, d, dev)
@@ -630,10 +640,10 @@ class HipEncoder(nn.Module):
             ops.layernorm_bwd(g, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], partial, T,
                               p_h, s_l + 3, accumulate=self._acc)
             dF = ds2m if ds2m is not None else ds2
-            ops.wgrad(dF, a["h"], G["W2"], T, ws, accumulate=self._acc)
+            self._wq.add(dF, a["h"], G["W2"], T)
             dpre = self._buf(T, f, dev)
             ops.gemm_nt(dF, self.ht(i, "f2"), dpre, T, gelu_pre=a["pre"])
-            ops.wgrad(dpre, a["x1"], G["W1"], T, ws, accumulate=self._acc, dbias=G["bf1"])
+            self._wq.add(dpre, a["x1"], G["W1"], T, dbias=G["bf1"])
             dx1 = self._buf(T, d, dev)
             ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T, residual=ds2)
             # --- attention-output LayerNorm + attention ---
@@ -642,17 +652,16 @@ class HipEncoder(nn.Module):
             ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], partial, T,
                               p_out, s_l + 2, accumulate=self._acc)
             dA = ds1m if ds1m is not None else ds1
-            ops.wgrad(dA, a["ctx"], G["Wo"], T, ws, accumulate=self._acc)
+            self._wq.add(dA, a["ctx"], G["Wo"], T)
             dctx = self._buf(T, d, dev)
             ops.gemm_nt(dA, self.ht(i, "o"), dctx, T)
             dqkv = self._buf(T, 3 * d, dev)
             ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1)
-            ops.wgrad(dqkv, a["x_in"], G["Wqkv"], T, ws, accumulate=self._acc, dbias=G["bqkv"])
+            self._wq.add(dqkv, a["x_in"], G["Wqkv"], T, dbias=G["bqkv"])
             g = self._buf(T, d, dev)
             ops.gemm_nt(dqkv, self.ht(i, "qkv"), g, T, residual=ds1)
-            tape.layers[i] = None        # free this layer's activations
-            if after_layer is not None:
-                after_layer(i)
+            tape.layers[i] = None        # this layer's activations: the deferred weight-gradient jobs keep what they still need
+            layer_done(i)
         type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
         dtype0 = self.g("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
         ops.embed_ln_bwd(g, tape.ids.view(-1), self.w("embeddings.word_embeddings.weight"),
@@ -660,8 +669,7 @@ class HipEncoder(nn.Module):
                          tape.mean0, tape.rstd0, self.g("embeddings.word_embeddings.weight"),
                          self.g("embeddings.position_embeddings.weight"), dtype0, self.g("embeddings.LayerNorm.weight"),
                          self.g("embeddings.LayerNorm.bias"), partial, T, L, tape.p_embed, tape.seed, accumulate=self._acc)
-        if after_layer is not None:
-            after_layer(-1)
+        layer_done(-1, force=True)
 
     # ------------------------------------------------------------------ HF-style call surface
     def forward(self, input_ids=None, attention_mask=None, **_):

@@ -38,7 +38,8 @@ def _chk(t, dtype, name, dim=None):
 
 
 def pad_rows(rows: int) -> int:
-    """Activation / gradient buffers feeding cldrd_wgrad_bf16 are allocated with rows rounded up to 64 (zero tail)."""
+    """Activation / gradient buffers are allocated with rows rounded up to 64 (allocation granularity only: no kernel reads the
+    rows past M any more - the weight-gradient kernel fetches them from a zero page)."""
     return (rows + 63) // 64 * 64
 
 
@@ -75,19 +76,57 @@ def wgrad_workspace_elems(M, N1, N2) -> int:
 
 
 def wgrad(dY, X, dW, M, workspace, accumulate=False, dbias=None):
-    """dW[N1,N2] (+)= dY[:M]^T @ X[:M] (and dbias[N1] (+)= column sums of dY[:M]); dY, X bf16 with >= pad_rows(M)
-    rows (zero tail); dW, dbias fp32."""
+    """dW[N1,N2] (+)= dY[:M]^T @ X[:M] (and dbias[N1] (+)= column sums of dY[:M]); dY, X bf16 with >= M rows; dW, dbias fp32."""
     _chk(dY, BF16, "dY", 2), _chk(X, BF16, "X", 2), _chk(dW, F32, "dW", 2), _chk(workspace, F32, "workspace")
     N1, N2 = dW.shape
     if dY.shape[1] != N1 or X.shape[1] != N2 or not dW.is_contiguous():
         raise ValueError("wgrad: shape mismatch")
-    if dY.shape[0] < pad_rows(M) or X.shape[0] < pad_rows(M):
-        raise ValueError("wgrad: operands need ceil(M/64)*64 rows allocated")
+    if dY.shape[0] < M or X.shape[0] < M:
+        raise ValueError("wgrad: operands have fewer than M rows")
     if dbias is not None:
         _chk(dbias, F32, "dbias", 1)
     call("cldrd_wgrad_bf16", _p(dY), _p(X), _p(dW), _p(dbias), M, N1, N2, dY.stride(0), X.stride(0), _p(workspace),
          workspace.numel() * 4, 1 if accumulate else 0, _stream())
     return dW
+
+
+class WgradQueue:
+    """Deferred weight gradients of one tower: ``add`` records a problem (and keeps its operands alive), ``flush`` hands everything
+    recorded so far to ONE ``cldrd_wgrad_group`` launch on the current stream (include/cldrd_hip.h).  Only the data gradients are
+    on the critical path of the backward; grouping the weight gradients removes the token splits, the fp32 slabs and ~50 launches
+    per tower and step."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def add(self, dY, X, dW, M, dbias=None):
+        _chk(dY, BF16, "dY", 2), _chk(X, BF16, "X", 2), _chk(dW, F32, "dW", 2)
+        N1, N2 = dW.shape
+        if dY.shape[1] != N1 or X.shape[1] != N2 or not dW.is_contiguous() or dY.shape[0] < M or X.shape[0] < M:
+            raise ValueError("wgrad: shape mismatch")
+        if dbias is not None:
+            _chk(dbias, F32, "dbias", 1)
+        self.jobs.append((dY, X, dW, dbias, int(M)))
+
+    def __len__(self):
+        return len(self.jobs)
+
+    def flush(self, accumulate=False):
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        import ctypes as C
+        n = len(jobs)
+        VP, IN = C.c_void_p * n, C.c_int * n
+        A, B = VP(*[j[0].data_ptr() for j in jobs]), VP(*[j[1].data_ptr() for j in jobs])
+        W, Bi = VP(*[j[2].data_ptr() for j in jobs]), VP(*[(j[3].data_ptr() if j[3] is not None else None) for j in jobs])
+        Ms, N1s, N2s = IN(*[j[4] for j in jobs]), IN(*[j[2].shape[0] for j in jobs]), IN(*[j[2].shape[1] for j in jobs])
+        lda, ldb = IN(*[j[0].stride(0) for j in jobs]), IN(*[j[1].stride(0) for j in jobs])
+        need = _lib.load().cldrd_wgrad_group_workspace(Ms, N1s, N2s, n)
+        ws = torch.empty(need, dtype=F32, device=jobs[0][2].device) if need else None
+        call("cldrd_wgrad_group", A, B, W, Bi, Ms, N1s, N2s, lda, ldb, n, _p(ws), need * 4, 1 if accumulate else 0, _stream())
+        # `jobs` held the operands alive until here; they were allocated on the stream this launch is on, so releasing them now
+        # is ordered behind it by the caching allocator
 
 
 def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0):

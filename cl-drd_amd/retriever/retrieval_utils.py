@@ -244,12 +244,12 @@ class FlatIPIndex:
             raise ValueError("queries must be finite and inside the fp16 range (|x| <= 65504)")
         nb = (nq + QUERY_TILE - 1) // QUERY_TILE
         stats["scans"] = 0 if exhaustive else nb
-        c_all = counts.view(nb, QUERY_TILE + 1)[:, :QUERY_TILE].reshape(-1)[:nq] if nq % QUERY_TILE == 0 else None
         if self.profile:
+            # batch b keeps its list lengths at counts[129 b .. 129 b + m) and the dropped-hit counter right behind them
+            c_all = counts.view(nb, QUERY_TILE + 1)[:, :QUERY_TILE].reshape(-1)[:nq]
             stats["search_ms"] = e0.elapsed_time(e1)
             stats["rescored"] = int(n2.sum().item())
-            if c_all is not None:
-                stats["candidates"] = int(c_all.clamp(max=CAND_CAP).sum().item())
+            stats["candidates"] = int(c_all.clamp(max=CAND_CAP).sum().item())
         bad = np.nonzero(status)[0]
         stats["unproven_first_pass"] = int(bad.size)
         attempt = 0

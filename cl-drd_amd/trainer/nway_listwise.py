@@ -87,6 +87,10 @@ class NwayTrainer:
         self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.distributed else 1
         self.flat_p, self.flat_g = model.fuse_flat()
+        # deferred weight gradients: one group launch per tower at the end of the backward on one GPU; with RCCL every
+        # ceil(layers / 2) layers, so the first half of the buckets is all-reduced while the rest of the backward still runs
+        for t in model.towers():
+            t.wgrad_flush_layers = max(1, -(-t.cfg.n_layers // 2)) if self.distributed else 0
         dev = self.flat_p.device
         self._require_gpu(dev)
         n = self.flat_p.numel()

@@ -43,11 +43,19 @@ int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int 
 
 /* Weight gradient dW[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (A = dY, B = layer input; autograd's Linear backward), and,
  * when dbias != NULL, the bias gradient dbias[N1] (+)= column sums of A in the same pass.
- * N1, N2 multiples of 128.  A and B must have ceil(M/64)*64 rows allocated with rows >= M zero.
- * workspace: >= cldrd_wgrad_splits(M,N1,N2) * (N1 * N2 + N1) floats. */
+ * N1, N2 multiples of 128 (or N1 % 256 == 0 and N2 % 192 == 0); rows >= M are never read (no padding contract).
+ * cldrd_wgrad_group: n such problems in ONE launch (the pointer / shape arrays are HOST arrays).  The weight gradients are off the
+ * critical path of the backward, so the trainer defers them: with a tower's 20+ problems in one launch every workgroup sweeps all
+ * tokens of its output tile and writes dW once - no token split, no fp32 partial slabs, no reduction launches.
+ * workspace (floats): cldrd_wgrad_group_workspace(...) for a group (0 when no token split is chosen),
+ * cldrd_wgrad_splits(M,N1,N2) * (N1 * N2 + N1) for the single-problem form. */
 int cldrd_wgrad_splits(int M, int N1, int N2);
 int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, float* dbias, int M, int N1, int N2, int lda, int ldb,
                      float* workspace, size_t workspace_bytes, int accumulate, void* stream);
+size_t cldrd_wgrad_group_workspace(const int* M, const int* N1, const int* N2, int n);
+int cldrd_wgrad_group(const void* const* A, const void* const* B, float* const* dW, float* const* dbias, const int* M,
+                      const int* N1, const int* N2, const int* lda, const int* ldb, int n, float* workspace,
+                      size_t workspace_bytes, int accumulate, void* stream);
 
 /* ---- attention (HF DistilBertSelfAttention / BertSelfAttention, head dim 64, L <= 256) --------------------
  * qkv: bf16 [nseq*L, 3*H*64] = Q | K | V;  mask: int64 [nseq, L], 0 = padded key, or NULL;

@@ -109,10 +109,11 @@ def test_gemm_nt_dropout_is_deterministic_and_unbiased():
                                      (130, 256, 192), (4000, 512, 384), (777, 256, 768), (64, 1536, 768), (5000, 1536, 768)])
 def test_wgrad(M, N1, N2):
     Mp = ops.pad_rows(M)
-    dY, X = torch.zeros(Mp, N1), torch.zeros(Mp, N2)
+    # rows >= M hold garbage (NaN): the kernel must not read them (its last K tile takes them from a zero page)
+    dY, X = torch.full((Mp, N1), float("nan")), torch.full((Mp, N2), float("nan"))
     dY[:M], X[:M] = rnd(8, (M, N1)), rnd(9, (M, N2))
     dY, X = bf(dY), bf(X)
-    ref = dY.float().T @ X.float()
+    ref = dY[:M].float().T @ X[:M].float()
     dW = torch.full((N1, N2), 7.0, dtype=torch.float32, device=DEV)
     ws = torch.empty(ops.wgrad_workspace_elems(M, N1, N2), dtype=torch.float32, device=DEV)
     ops.wgrad(dY.to(DEV), X.to(DEV), dW, M, ws, accumulate=False)
@@ -120,7 +121,32 @@ def test_wgrad(M, N1, N2):
     db = torch.full((N1,), 3.0, dtype=torch.float32, device=DEV)
     ops.wgrad(dY.to(DEV), X.to(DEV), dW, M, ws, accumulate=True, dbias=db)
     close(dW, 2 * ref, 1e-4, 2e-4 * math.sqrt(M), "wgrad accumulate")
-    close(db, 3.0 + dY.double().sum(0), 1e-4, 1e-4 * math.sqrt(M), "wgrad fused bias gradient")
+    close(db, 3.0 + dY[:M].double().sum(0), 1e-4, 1e-4 * math.sqrt(M), "wgrad fused bias gradient")
+
+
+@pytest.mark.parametrize("accumulate", [False, True])
+@pytest.mark.parametrize("shapes", [
+    [(4096, 768, 768), (4096, 2304, 768), (4096, 3072, 768), (4096, 768, 3072), (30, 768, 768)],       # encoder layer + a short problem, 256 x 192 tiles
+    [(200, 128, 256), (200, 256, 128), (77, 128, 128)],                                                # tiny model: 128 x 128 tiles, token splits
+    [(1000, 256, 192)] * 40,                                                                            # more than 32 problems: two launches
+])
+def test_wgrad_group(shapes, accumulate):
+    """cldrd_wgrad_group: many problems, one launch; unpadded operands with token tails; bias gradients on some problems."""
+    q = ops.WgradQueue()
+    refs = []
+    for i, (M, N1, N2) in enumerate(shapes):
+        dY, X = bf(rnd(20 + i, (M, N1))), bf(rnd(60 + i, (M, N2)))
+        dW = torch.full((N1, N2), 2.0, dtype=torch.float32, device=DEV)
+        db = torch.full((N1,), -1.0, dtype=torch.float32, device=DEV) if i % 2 == 0 else None
+        q.add(dY.to(DEV), X.to(DEV), dW, M, dbias=db)
+        refs.append((dW, db, dY.float().T @ X.float(), dY.double().sum(0), M))
+    q.flush(accumulate=accumulate)
+    assert len(q) == 0
+    for dW, db, rW, rb, M in refs:
+        base = 2.0 if accumulate else 0.0
+        close(dW, base + rW, 1e-4, 1e-4 * math.sqrt(M), "wgrad_group dW")
+        if db is not None:
+            close(db, (-1.0 if accumulate else 0.0) + rb, 1e-4, 1e-4 * math.sqrt(M), "wgrad_group dbias")
 
 
 def test_wgrad_asymmetric():

@@ -254,7 +254,9 @@ def test_full_size_configs_match_reference_goldens(name):
         got = logits.cpu().numpy()
         err = np.abs(got - ref).max()
         ratio = err / amp_err
-        print(f"{name}/{loss_kind}: max|dlogit| {err:.4f} = {ratio:.2f} x the reference's autocast drift {amp_err:.4f} (max|logit| {np.abs(ref).max():.2f})")
+        rms, amp_rms = np.sqrt(np.mean((got - ref) ** 2)), np.sqrt(np.mean((g["logits_autocast_bf16"] - ref) ** 2))
+        print(f"{name}/{loss_kind}: max|dlogit| {err:.4f} = {ratio:.2f} x the reference's autocast drift {amp_err:.4f} (max|logit| {np.abs(ref).max():.2f}); "
+              f"rms {rms:.4f} = {rms / amp_rms:.2f} x its rms {amp_rms:.4f}")
         assert ratio <= 1.0, f"{name}: bf16 drift {err:.4f} exceeds the reference's own autocast drift {amp_err:.4f}"
         if "loss" in g.files:                                # cfg1 golden (round 1 layout)
             ref_loss, names, vals = float(g["loss"]), [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]

@@ -23,8 +23,9 @@ def r(t):
     return t.to(torch.bfloat16).float()
 
 
-def forward(w, cfg, ids, mask, mode):
-    """mode: dict(sum32=bool, res32=bool, grad-free).  Returns CLS fp32 [M, d]."""
+def forward(w, cfg, ids, mask, mode, hiddens=None):
+    """mode: dict(sum32=bool, res32=bool, grad-free).  Returns CLS fp32 [M, d]; `hiddens` (a list) receives the bf16 input of
+    every layer."""
     M, L = ids.shape
     d, H = cfg.dim, cfg.n_heads
     dh = d // H
@@ -37,6 +38,8 @@ def forward(w, cfg, ids, mask, mode):
         x32 = xb
     bias = torch.zeros(M, 1, 1, L).masked_fill(mask[:, None, None, :] == 0, torch.finfo(torch.float32).min)
     for i in range(cfg.n_layers):
+        if hiddens is not None:
+            hiddens.append(xb)
         q_n, k_n, v_n, o_n, ln1_n, f1_n, f2_n, ln2_n = E._layer_names(cfg, i)
         lin = lambda a, n: F.linear(a, r(w[n + ".weight"]), w[n + ".bias"])
         q = r(lin(xb, q_n)).view(M, L, H, dh).transpose(1, 2)
@@ -66,9 +69,10 @@ def forward(w, cfg, ids, mask, mode):
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "cfg1"
-    g = np.load(os.path.join(ROOT, "tests", "golden", f"full_distilbert_{name}.npz"))
+    bert = name == "cfg4"
+    g = np.load(os.path.join(ROOT, "tests", "golden", "full_bert_cfg4.npz" if bert else f"full_distilbert_{name}.npz"))
     B, N, Lq, Lp = int(g["B"]), int(g["N"]), int(g["Lq"]), int(g["Lp"])
-    cfg = E.RefConfig()
+    cfg = E.RefConfig(arch="bert", n_layers=12) if bert else E.RefConfig()
     shapes = E.param_shapes(cfg)
     qp = {k: syn.init_param(11, k, s, std=0.02, perturb=True) for k, s in shapes.items()}
     pp = {k: syn.init_param(12, k, s, std=0.02, perturb=True) for k, s in shapes.items()}
@@ -79,8 +83,11 @@ def main():
     print(f"{name}: max|logit| {np.abs(ref).max():.3f}; reference autocast drift {amp:.4f}")
     torch.set_num_threads(8)
     with torch.no_grad():
-        for label, mode in (("all bf16 (round 1)", dict(sum32=False, res32=False)), ("fp32 pre-LN sums", dict(sum32=True, res32=False)),
-                            ("fp32 sums + fp32 residual", dict(sum32=True, res32=True))):
+        variants = (("all bf16 (round 1)", dict(sum32=False, res32=False)), ("fp32 pre-LN sums", dict(sum32=True, res32=False)),
+                    ("fp32 sums + fp32 residual", dict(sum32=True, res32=True)))
+        if len(sys.argv) > 2:
+            variants = variants[2:]
+        for label, mode in variants:
             q = forward(qp, cfg, batch["query"]["input_ids"], batch["query"]["attention_mask"], mode)
             p = forward(pp, cfg, batch["nway_passages"]["input_ids"].reshape(B * N, Lp),
                         batch["nway_passages"]["attention_mask"].reshape(B * N, Lp), mode).view(B, N, -1)
