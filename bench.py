@@ -220,7 +220,7 @@ def main():
             qn *= (10.0 / qn.norm(dim=1, keepdim=True))
             flat_index.search_device(qn[:256], kq)             # warm-up
             sync_all()
-            nb = (nq_r + 127) // 128
+            nb = (nq_r + 127) // 128                          # reference batches of 128 queries (the unit of SURVEY.md section 8d)
             # (1) device-resident search: queries and results stay in HBM, one host sync (the proof flags)
             t2 = time.perf_counter()
             Dq, Iq, st = flat_index.search_device(qn, kq)
@@ -240,9 +240,12 @@ def main():
             from cldrd_amd import hip_ops as ops2
             qh16 = qn[:128].half().contiguous()
             thr = torch.full((128,), 11.5, device=dev)
-            counts = torch.zeros(129, dtype=torch.int32, device=dev)
-            cr = torch.empty(128, 8192, dtype=torch.int32, device=dev)
-            cs_ = torch.empty(128, 8192, dtype=torch.float32, device=dev)
+            QT = flat_index.query_tile                      # queries per pass over the index: 256 at d = 768 (two reference batches)
+            qh16 = qn[:QT].half().contiguous()
+            thr = torch.full((QT,), 11.9, device=dev)      # ~1000 hits per query, as in the search
+            counts = torch.zeros(QT + 1, dtype=torch.int32, device=dev)
+            cr = torch.empty(QT, 8192, dtype=torch.int32, device=dev)
+            cs_ = torch.empty(QT, 8192, dtype=torch.float32, device=dev)
             ops2.topk_scan_filter(qh16, flat_index._p16, thr, counts, cr, cs_)
             evs = []
             for _ in range(10):
@@ -253,12 +256,15 @@ def main():
                 e1.record()
                 evs.append((e0, e1))
             torch.cuda.synchronize()
-            scan_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            scan_pass_ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            scan_ms = scan_pass_ms * 128.0 / QT             # per 128-query reference batch
             scan_bytes = rows * D * 2 + 128 * D * 2            # bytes of one 128-query batch x one shard scan (16-bit rows)
             batch_ms = st["search_ms"] / nb
             retrieve = {"seconds": dr, "nq": nq_r, "rows_per_shard": rows, "rows_total": world * rows, "k": kq, "batch": 128,
                         "scans": st["scans"], "rescans": st["rescans"], "unproven_first_pass": st["unproven_first_pass"],
                         "candidates_per_query": round(st["candidates"] / nq_r, 1), "rescored_per_query": round(st["rescored"] / nq_r, 1),
+                        "queries_per_pass": QT, "scan_pass_ms": round(scan_pass_ms, 3),
+                        "scan_physical_hbm_gb_s": round((rows * D * 2 + QT * D * 2) / scan_pass_ms / 1e6, 1),
                         "scan_kernel_ms": round(scan_ms, 3), "scan_hbm_gb_s": round(scan_bytes / scan_ms / 1e6, 1),
                         "scan_hbm_frac": round(scan_bytes / scan_ms / 1e6 / 8000.0, 4),
                         "scan_tflops": round(2.0 * 128 * rows * D / scan_ms / 1e9, 1),

@@ -50,7 +50,7 @@ SIGNATURES = {
     "cldrd_topk_prep_queries": (ci, [vp, vp, vp, vp, ci, ci, vp, vp]),
     "cldrd_topk_thresholds": (ci, [vp, vp, cf, ci, vp, vp, ci, vp]),
     "cldrd_topk_select": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp]),
-    "cldrd_flatip_search": (ci, [vp, vp, vp, vp, vp, vp, C.c_longlong, ci, ci, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp]),
+    "cldrd_flatip_search": (ci, [vp, vp, vp, vp, vp, vp, C.c_longlong, ci, ci, ci, ci, vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp]),
     "cldrd_topk_kth_largest": (ci, [vp, ci, ci, ci, ci, vp, vp]),
     "cldrd_topk_rescore": (ci, [vp, vp, ci, vp, vp, vp, ci, ci, vp]),
     "cldrd_topk_sort": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),

@@ -338,20 +338,22 @@ static WgradTile wgrad_tile_group(const int* N1, const int* N2, int n) {
     return {128, 128};
 }
 
-// Token splits per output tile.  One workgroup occupies a CU (LDS), so items = tiles * splits workgroups run in
-// ceil(items / 256) rounds of ceil(ktotal / splits) K tiles each, plus a per-workgroup cost (pipeline fill, output write) of about
-// OVERHEAD K-tile times, plus - for splits > 1 - the fp32 slabs written and read back (bytes / ~5 TB/s, in units of the ~1.5 us a
-// K tile takes) and the reduction launch.  Smallest modelled time wins; ties go to fewer splits.
+// Token splits per output tile.  One workgroup occupies a CU (LDS).  With `sp` splits an item of problem p sweeps
+// ceil(ktotal_p / sp) K tiles plus a fixed cost (pipeline fill, output write) of about OVERHEAD K-tile times; the items are handed
+// out in order, so the launch takes about (total work / 256 CUs) rounded up to whole largest items.  Splits > 1 add the fp32 slabs
+// written and read back (bytes / ~5 TB/s, in units of the ~1.5 us a K tile takes) and the reduction launches.  Smallest modelled
+// time wins; ties go to fewer splits.  (Weighting every problem by its OWN token count matters: the 120 tiles of the CLS-only last
+// layer sweep 4 K tiles, the 744 of the full layers 512 - counting them alike chose 2 splits and paid 0.3 GB of slabs per step.)
 static int wgrad_splits_group(const int* M, const int* N1, const int* N2, int n, WgradTile t) {
-    long tiles = 0;
     int ktotal = 1;
     double out_bytes = 0.0;
+    long tiles_all = 0;
     for (int i = 0; i < n; ++i) {
-        tiles += (long)(N1[i] / t.t1) * (N2[i] / t.t2);
         ktotal = ktotal > (M[i] + BK - 1) / BK ? ktotal : (M[i] + BK - 1) / BK;
         out_bytes += 4.0 * N1[i] * N2[i];
+        tiles_all += (long)(N1[i] / t.t1) * (N2[i] / t.t2);
     }
-    if (tiles <= 0) return 1;
+    if (tiles_all <= 0) return 1;
     static int overhead = -1;
     if (overhead < 0) { const char* e = getenv("CLDRD_WGRAD_OVERHEAD"); overhead = e ? atoi(e) : 6; }
     static int force = -1;
@@ -360,8 +362,15 @@ static int wgrad_splits_group(const int* M, const int* N1, const int* N2, int n,
     int best = 1;
     double best_cost = -1.0;
     for (int sp = 1; sp <= 64 && sp <= ktotal; ++sp) {
-        const long rounds = (tiles * sp + 255) / 256;
-        double cost = (double)rounds * ((ktotal + sp - 1) / sp + overhead);
+        double work = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const long tiles = (long)(N1[i] / t.t1) * (N2[i] / t.t2);
+            const int kt = (M[i] + BK - 1) / BK;
+            work += (double)tiles * sp * ((kt + sp - 1) / sp + overhead);
+        }
+        const double item = (ktotal + sp - 1) / sp + overhead;
+        double cost = item * (double)(long)((work / 256.0 + item - 1e-9) / item);          // whole largest items
+        if (cost < item) cost = item;
         if (sp > 1) cost += 2.0 * sp * out_bytes / 5.0e12 / 1.5e-6 + 4.0;
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
     }

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restri
 
 // eps[q] >= |fp16 scan score - fp32 exact score| for every index row (pmax = largest row norm, both operands rounded to fp16):
 //   rounding of q and p (RNE, u = 2^-11 each, Cauchy-Schwarz)            |q| pmax (2^-10 + 2^-22)
-//   fp32 accumulation inside the MFMA chain and inside the re-score      |q| pmax d 2^-21      (2 ulp per add, both sums)
+//   fp32 accumulation: MFMA chain (d adds, 2^-23 each if the adder truncates) + re-score (d fmas, 2^-24 each):  |q| pmax d 2^-22
 //   values below the fp16 normal range (flushed or rounded, <= 2^-14)    2^-14 sqrt(d) (|q| + pmax) + d 2^-28
 // thr[q] = est[q] - 2 eps[q]: the scan keeps a row when its fp16 score reaches thr (cldrd_topk_select explains the 2).
 __global__ void thresholds_kernel(const float* __restrict__ est, const float* __restrict__ qnorm, float pmax, int d, float* __restrict__ thr,
@@ -201,7 +201,7 @@ __global__ void thresholds_kernel(const float* __restrict__ est, const float* __
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const double qn = qnorm[i], pm = pmax, dd = d;
-    double e = qn * pm * (0x1p-10 + 0x1p-22 + dd * 0x1p-21) + 0x1p-14 * sqrt(dd) * (qn + pm) + dd * 0x1p-28;
+    double e = qn * pm * (0x1p-10 + 0x1p-22 + dd * 0x1p-22) + 0x1p-14 * sqrt(dd) * (qn + pm) + dd * 0x1p-28;
     const float ef = (float)(e * (1.0 + 1e-6)) + 1e-30f;
     eps[i] = ef;
     if (est) thr[i] = est[i] - 2.0f * ef;
@@ -305,35 +305,66 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int KS, int ablate, bool F16>     // d = 32 * KS; ablate != 0: timing experiments only (tools/scan_bench.py); F16: fp16 shadow
-__global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q, int nq,
+// NW waves x NQS sets of 16 queries each = NQ queries per pass: <8, 1> = the reference's 128-query batch (2 waves per SIMD, 96 of
+// 256 VGPRs hold queries); <4, 4> = 256 queries per pass (one wave per SIMD, 384 of its 512 VGPRs hold queries): the index bytes are
+// read once per 256 queries instead of once per 128, and with 4 MFMAs per A fragment the pass is still HBM-bound at d = 768.
+// The same MFMA with the query fragment pinned in an AGPR quad.  With 384 query registers per lane hipcc keeps most of them in
+// AGPRs and copies each fragment to VGPRs before every use (416 v_accvgpr_read per tile: as much issue time as the MFMAs); MFMA
+// can read its B operand from AGPRs directly, which the "a" constraint forces.  Inline asm is opaque to hipcc's hazard
+// recognizer: the caller separates the last MFMA of a chain from the first VALU read of its result with mfma_result_fence().
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16_bq(bf16x8 a, bf16x8 bq_agpr, f32x4 c) {
+    if constexpr (F16) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(bq_agpr));
+    else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(bq_agpr));
+    return c;
+}
+__device__ __forceinline__ void mfma_result_fence() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory"); }
+
+template <int KS, int ablate, bool F16, int NW = 8, int NQS = 1>     // d = 32 * KS; ablate != 0: timing experiments only (tools/scan_bench.py); F16: fp16 shadow
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(const bf16_t* __restrict__ P, const bf16_t* __restrict__ Q, int nq,
                                                               long long rows, const float* __restrict__ thr,
                                                               int* __restrict__ counts, int* __restrict__ cand_rows,
                                                               float* __restrict__ cand_scores, int cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int R = 32, ROWB = KS * 64, TILEB = R * ROWB, PIECES = TILEB / 1024, NW = 8, PPW = PIECES / NW, NSLOT = 3;
-    constexpr int LCAP = (160 * 1024 - NSLOT * TILEB - 16 - 1024) / 12 < 4096 ? (160 * 1024 - NSLOT * TILEB - 16 - 1024) / 12 : 4096;   // LDS hit list
+    constexpr int R = 32, ROWB = KS * 64, TILEB = R * ROWB, PIECES = TILEB / 1024, PPW = PIECES / NW, NSLOT = 3;
+    constexpr int NQ = 16 * NQS * NW;          // queries per pass
+    constexpr int LCAP = (160 * 1024 - NSLOT * TILEB - 16 - 8 * NQ) / 12 < 4096 ? (160 * 1024 - NSLOT * TILEB - 16 - 8 * NQ) / 12 : 4096;   // LDS hit list
+    static_assert(PIECES % NW == 0 && NQ <= 256, "tile pieces must divide over the waves; the hit list packs the query in 8 bits");
     int* lcount = (int*)(smem + NSLOT * TILEB);
-    int* qcnt = lcount + 4;                    // [0,128) per-query hit counts, [128,256) global bases (flush scratch)
-    int* lq = qcnt + 256;
+    int* qcnt = lcount + 4;                    // [0,NQ) per-query hit counts, [NQ,2NQ) global bases (flush scratch)
+    int* lq = qcnt + 2 * NQ;
     int* lrow = lq + LCAP;
     float* lscore = (float*)(lrow + LCAP);
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long long ntiles = (rows + R - 1) / R;
 
-    // ---- this wave's 16 queries as B fragments for every k-step (registers, loaded once): 4*KS VGPRs
-    const int qn = wid * 16 + (lane & 15);
-    bf16x8 bq[KS];
-    {
+    // ---- this wave's 16 NQS queries as B fragments for every k-step (registers, loaded once): 4 KS NQS registers.
+    // Fragment f = s KS + ks lives in an AGPR quad for f < NA (all 256 AGPRs when NQS = 4: sets 0, 1 and two thirds of set 2) and in
+    // VGPRs otherwise; one wave per SIMD owns all 512 registers of its lanes then (see mfma16_bq for why the split is by hand).
+    constexpr int NA = NQS > 1 ? (NQS * KS < 64 ? NQS * KS : 64) : 0, NV = NQS * KS - NA;
+    const int qn0 = wid * 16 * NQS + (lane & 15);          // query of set s: qn0 + 16 s
+    bf16x8 bqa[NA > 0 ? NA : 1], bqv[NV > 0 ? NV : 1];
+    float thr_lane[NQS];
+#pragma unroll
+    for (int s = 0; s < NQS; ++s) {
+        const int qn = qn0 + 16 * s;
         const bf16_t* qp = Q + (size_t)min(qn, nq - 1) * (KS * 32) + 8 * (lane >> 4);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bq[ks] = *(const bf16x8*)(qp + ks * 32);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(bq[ks]));      // wait for the loads here, not inside the tile loop
+        for (int ks = 0; ks < KS; ++ks) {
+            const int f = s * KS + ks;
+            const bf16x8 v = *(const bf16x8*)(qp + ks * 32);
+            if (f < NA) bqa[f < NA ? f : 0] = v; else bqv[f >= NA ? f - NA : 0] = v;
+        }
+        thr_lane[s] = qn < nq ? thr[qn] : __builtin_inff();
     }
-    float thr_lane = qn < nq ? thr[qn] : __builtin_inff();
-    asm volatile("" : "+v"(thr_lane));       // consume the load HERE: otherwise hipcc waits vmcnt(0) at its first use inside the tile loop
+    // wait for the loads here, not inside the tile loop (and consume the thresholds: otherwise hipcc waits vmcnt(0) at their first use)
+#pragma unroll
+    for (int f = 0; f < NA; ++f) asm volatile("" : "+a"(bqa[f]));
+#pragma unroll
+    for (int f = 0; f < NV; ++f) asm volatile("" : "+v"(bqv[f]));
+#pragma unroll
+    for (int s = 0; s < NQS; ++s) asm volatile("" : "+v"(thr_lane[s]));
     const uint32_t lcount_off = (uint32_t)(uintptr_t)LDS_PTR(lcount), lq_off = (uint32_t)(uintptr_t)LDS_PTR(lq);
     static_assert(8 * LCAP < 65536, "ds_write offset field");
     if (threadIdx.x < 4) lcount[threadIdx.x] = 0;               // [0] list length, [1..3] its snapshots (see the flush check)
@@ -365,17 +396,18 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
     // Move the LDS hit list to the per-query candidate lists: one global atomic per (block, query) reserves the block's range in
     // that query's list (per-hit atomics on 128 addresses serialise in L2).  Called by the whole workgroup (barriers inside).
     auto flush = [&]() {
-        if (threadIdx.x < 256) qcnt[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < 2 * NQ; i += blockDim.x) qcnt[i] = 0;
         __syncthreads();
         const int nhits = *lcount;
         const int n = min(nhits, LCAP);
         for (int e = threadIdx.x; e < n; e += blockDim.x) lq[e] |= atomicAdd(qcnt + lq[e], 1) << 8;      // rank inside the block
         __syncthreads();
-        if (threadIdx.x < 128 && qcnt[threadIdx.x] > 0) qcnt[128 + threadIdx.x] = atomicAdd(counts + threadIdx.x, qcnt[threadIdx.x]);
+        for (int i = threadIdx.x; i < NQ; i += blockDim.x)
+            if (qcnt[i] > 0) qcnt[NQ + i] = atomicAdd(counts + i, qcnt[i]);
         __syncthreads();
         for (int e = threadIdx.x; e < n; e += blockDim.x) {
             const int q = lq[e] & 255;
-            const int pos = qcnt[128 + q] + (lq[e] >> 8);
+            const int pos = qcnt[NQ + q] + (lq[e] >> 8);
             if (pos < cap) { cand_rows[(size_t)q * cap + pos] = lrow[e]; cand_scores[(size_t)q * cap + pos] = lscore[e]; }
         }
         if (threadIdx.x == 0 && nhits > LCAP) atomicAdd(counts + nq, nhits - LCAP);      // counts[nq] = hits dropped (the caller rescans)
@@ -418,7 +450,8 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
         // Two half-row chunks of A fragments are kept in flight ahead of the MFMAs that consume them: with 2 waves per SIMD
         // nothing else hides the LDS latency (measured: reads alone and MFMAs alone both keep up with the DMA stream,
         // read -> wait -> MFMA in one chain does not).  sched_barrier pins the order, hipcc still counts the lgkmcnt waits.
-        constexpr int CH = KS % 3 == 0 ? KS / 3 : KS / 2, NCM = KS / CH, NC = 2 * NCM;      // chunk = CH k-steps of one 16-row half
+        // chunk = CH k-steps of one 16-row half (smaller chunks when most registers hold queries)
+        constexpr int CH = NQS > 1 ? (KS % 4 == 0 ? 4 : 2) : (KS % 3 == 0 ? KS / 3 : KS / 2), NCM = KS / CH, NC = 2 * NCM;
         bf16x8 ab[2][CH];
         // chunk position of k-step ks in row r: ((4 ks + (lane >> 4)) ^ (r & 15)) = 16 (ks >> 2) + (((ks & 3) << 2) ^ (r & 12) | (lane >> 4) ^ (r & 3)):
         // four lane-dependent bases, everything else is an immediate offset of the ds_read
@@ -432,12 +465,14 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
                 a[i] = *(const bf16x8*)(pk[ks & 3] + (c / NCM) * 16 * ROWB + (ks >> 2) * 256);
             }
         };
-        auto emit = [&](f32x4 acc, int mt) {        // acc[j] = <P[row], Q[qn]> with row = 32 t + 16 mt + 4 (lane >> 4) + j
+        auto emit = [&](f32x4 acc, int mt, int qn, float thr_q) {        // acc[j] = <P[row], Q[qn]> with row = 32 t + 16 mt + 4 (lane >> 4) + j
             if (ablate == 2) { asm volatile("" ::"v"(acc)); return; }
             const int row0 = (int)(t * R) + mt * 16 + 4 * (lane >> 4);
+            // one test for the four rows first: no hit in this lane is the common case (~0.2 % of the scores are hits)
+            if (!(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) >= thr_q)) return;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (acc[j] >= thr_lane && row0 + j < (int)rows) {
+                if (acc[j] >= thr_q && row0 + j < (int)rows) {
                     // LDS list append, hand-issued: through atomicAdd / plain stores hipcc orders these LDS accesses after
                     // the LDS-DMA in flight (s_waitcnt vmcnt(0) per hit), which stalls the stream
                     uint32_t e;
@@ -454,16 +489,34 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
         fetch(ab[1], 1);
         __builtin_amdgcn_sched_barrier(0);
         if (t + 2 * step < ntiles) stage(fs, t + 2 * step);                 // issued under the latency of the first fragment reads
-        f32x4 acc;
+        f32x4 acc[NQS];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             __builtin_amdgcn_sched_barrier(0);
-            if (c % NCM == 0) acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (c % NCM == 0) {
 #pragma unroll
-            for (int i = 0; i < CH; ++i) acc = mfma16<F16>(ab[c & 1][i], bq[(c % NCM) * CH + i], acc);
+                for (int s = 0; s < NQS; ++s) acc[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+#pragma unroll
+                for (int s = 0; s < NQS; ++s) {        // NQS independent chains
+                    const int f = s * KS + (c % NCM) * CH + i;
+                    if (f < NA) {
+                        acc[s] = mfma16_bq<F16>(ab[c & 1][i], bqa[f < NA ? f : 0], acc[s]);
+                    } else {
+                        // a chain that changes from the asm form to the builtin form: give the opaque MFMA's result its wait states
+                        if (NA > 0 && f == NA && f % KS != 0) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[s]));
+                        acc[s] = mfma16<F16>(ab[c & 1][i], bqv[f >= NA ? f - NA : 0], acc[s]);
+                    }
+                }
             __builtin_amdgcn_sched_barrier(0);
             if (c + 2 < NC) fetch(ab[c & 1], c + 2);
-            if (c % NCM == NCM - 1) emit(acc, c / NCM);
+            if (c % NCM == NCM - 1) {
+                if constexpr (NA > 0) mfma_result_fence();
+#pragma unroll
+                for (int s = 0; s < NQS; ++s) emit(acc[s], c / NCM, qn0 + 16 * s, thr_lane[s]);
+            }
         }
         if (ablate == 0 && wid == 0) {           // snapshot of the list level for the check two tiles on (hand-issued: see emit)
             uint32_t v;
@@ -478,20 +531,20 @@ __global__ __launch_bounds__(512, 2) void scan_stream_kernel(const bf16_t* __res
     flush();
 }
 
-template <int KS, int ABL, bool F16>
+template <int KS, int ABL, bool F16, int NW = 8, int NQS = 1>
 int launch_scan_stream_abl(const void* Q, const void* P, int nq, long long rows, const float* thr, int* counts, int* cand_rows,
                            float* cand_scores, int cap, hipStream_t st) {
-    constexpr int tb = 3 * 32 * KS * 64;
-    constexpr int lcap = (160 * 1024 - tb - 16 - 1024) / 12 < 4096 ? (160 * 1024 - tb - 16 - 1024) / 12 : 4096;
-    constexpr int lds = tb + 16 + 1024 + lcap * 12;
+    constexpr int tb = 3 * 32 * KS * 64, NQ = 16 * NQS * NW;
+    constexpr int lcap = (160 * 1024 - tb - 16 - 8 * NQ) / 12 < 4096 ? (160 * 1024 - tb - 16 - 8 * NQ) / 12 : 4096;
+    constexpr int lds = tb + 16 + 8 * NQ + lcap * 12;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)scan_stream_kernel<KS, ABL, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)scan_stream_kernel<KS, ABL, F16, NW, NQS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
     const long long ntiles = (rows + 31) / 32;
     const int grid = (int)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL((scan_stream_kernel<KS, ABL, F16>), dim3(grid), dim3(512), lds, st, (const bf16_t*)P, (const bf16_t*)Q, nq, rows, thr,
+    hipLaunchKernelGGL((scan_stream_kernel<KS, ABL, F16, NW, NQS>), dim3(grid), dim3(64 * NW), lds, st, (const bf16_t*)P, (const bf16_t*)Q, nq, rows, thr,
                        counts, cand_rows, cand_scores, cap);
     CLDRD_LAUNCH_CHECK();
     return 0;
@@ -507,6 +560,10 @@ int launch_scan_stream(const void* Q, const void* P, int nq, long long rows, con
             case 2: return launch_scan_stream_abl<24, 2, false>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
             default: break;
         }
+    }
+    if (nq > 128) {                                    // 129..256 queries: the 4-wave x 64-query instance (fp16 shadow, d = 768 only)
+        if (KS == 24 && f16) return launch_scan_stream_abl<24, 0, true, 4, 4>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+        return -1;
     }
     if (f16) return launch_scan_stream_abl<KS, 0, true>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
     return launch_scan_stream_abl<KS, 0, false>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
@@ -616,21 +673,24 @@ extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long
 // The whole search of one shard for nq queries (device resident, fp32 + fp16 copies), in batches of 128 as the reference searches
 // (retriever/retrieve_top_passages.py:88, retrieval_utils.py:131-153), enqueued back to back on `stream` with no host round trip:
 //   scan (fp16 MFMA, HBM-bound) -> select t^ and the 2 eps band -> exact fp32 re-score -> sort + cut -> D, I, status.
-// counts: int[nb * 129] zeroed by the caller (nb = ceil(nq / 128); per batch 128 list lengths + 1 dropped-hit counter);
-// cand_rows / cand_scores: [128, cap] scratch; rows2 / scores2: [128, cap2] scratch; n2, status, khat: [nq]; D, I: [nq, k].
+// qtile = 128: one pass over the index per reference batch; 256: two batches share a pass (the index bytes are read once per 256
+// queries; d = 768 keeps 256 queries in the registers of a CU).  counts: int[nb * (qtile + 1)] zeroed by the caller
+// (nb = ceil(nq / qtile); per pass qtile list lengths + 1 dropped-hit counter); cand_rows / cand_scores: [qtile, cap] scratch;
+// rows2 / scores2: [qtile, cap2] scratch; n2, status, khat: [nq]; D, I: [nq, k].
 // exhaustive != 0 (rows <= cap): no scan, every row is re-scored.  The caller reads `status` once at the end and redoes the
 // (rare) unproven queries with thresholds of its choice through this same entry point.
 extern "C" int cldrd_flatip_search(const float* q32, const void* qh, const float* thr, const float* eps, const void* Ph, const float* P32,
-                                   long long rows, int d, int nq, int k, int* counts, int* cand_rows, float* cand_scores, int cap,
+                                   long long rows, int d, int nq, int k, int qtile, int* counts, int* cand_rows, float* cand_scores, int cap,
                                    int* rows2, float* scores2, int cap2, int* n2, int* status, float* khat, float* D, int* I,
                                    int exhaustive, void* stream) {
     CLDRD_CHECK(nq > 0 && rows > 0 && k > 0 && cap > 0 && cap <= 8192 && cap2 > 0 && cap2 <= 8192 && d % 4 == 0, "flatip_search: bad arguments");
+    CLDRD_CHECK(qtile == 128 || qtile == 256, "flatip_search: the query tile is 128 (the reference's batch) or 256 (two batches per pass over the index)");
     CLDRD_CHECK(!exhaustive || rows <= cap, "flatip_search: exhaustive mode needs rows <= cap");
     hipStream_t st = (hipStream_t)stream;
     const int kk = (int)(k < rows ? k : rows);
-    for (int lo = 0, b = 0; lo < nq; lo += 128, ++b) {
-        const int m = nq - lo < 128 ? nq - lo : 128;
-        int* cb = counts + (size_t)b * 129;
+    for (int lo = 0, b = 0; lo < nq; lo += qtile, ++b) {
+        const int m = nq - lo < qtile ? nq - lo : qtile;
+        int* cb = counts + (size_t)b * (qtile + 1);
         int rc;
         if (exhaustive) {
             hipLaunchKernelGGL(all_candidates_kernel, dim3((unsigned)((rows + 255) / 256), m), dim3(256), 0, st, cb, cand_rows, cand_scores, (int)rows, cap);
@@ -652,7 +712,7 @@ extern "C" int cldrd_flatip_search(const float* q32, const void* qh, const float
 // Streaming form of cldrd_topk_scan_filter for d in {128, 256, 768} and nq <= 128 (returns -1 when it does not apply).
 int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts, int* cand_rows,
                            float* cand_scores, int cap, int f16, hipStream_t st) {
-    if (nq > 128 || rows < 64 || rows >= 2147483647LL / 32) return -1;
+    if (nq > 256 || rows < 64 || rows >= 2147483647LL / 32) return -1;
     switch (d) {
         case 128: return launch_scan_stream<4>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, f16 != 0, st);
         case 256: return launch_scan_stream<8>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, f16 != 0, st);

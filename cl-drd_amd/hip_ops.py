@@ -374,7 +374,8 @@ def topk_select(counts, cand_rows, cand_scores, kk, thr, eps, rows2, n2, status,
          rows2.shape[1], _p(n2), _p(status), _p(khat), 1 if exhaustive else 0, _stream())
 
 
-def flatip_search(q32, qh, thr, eps, P16, P32, k, counts, cand_rows, cand_scores, rows2, scores2, n2, status, khat, D, I, exhaustive=False):
+def flatip_search(q32, qh, thr, eps, P16, P32, k, counts, cand_rows, cand_scores, rows2, scores2, n2, status, khat, D, I, exhaustive=False,
+                  qtile=128):
     """The whole search of one shard (include/cldrd_hip.h: cldrd_flatip_search); everything device resident, no host sync."""
     _chk(q32, F32, "q32", 2), _chk(P32, F32, "P32", 2), _chk(thr, F32, "thr", 1), _chk(eps, F32, "eps", 1)
     _chk(D, F32, "D", 2), _chk(I, torch.int32, "I", 2)
@@ -382,11 +383,13 @@ def flatip_search(q32, qh, thr, eps, P16, P32, k, counts, cand_rows, cand_scores
     rows = P32.shape[0]
     if not exhaustive:
         _chk(qh, F16, "qh", 2), _chk(P16, F16, "P16", 2)
-    if counts.numel() < ((nq + 127) // 128) * 129 or n2.numel() < nq or status.numel() < nq or khat.numel() < nq or D.shape != (nq, k) or I.shape != (nq, k):
+    if cand_rows.shape[0] < qtile or rows2.shape[0] < qtile:
+        raise ValueError("flatip_search: the candidate buffers need qtile rows")
+    if counts.numel() < ((nq + qtile - 1) // qtile) * (qtile + 1) or n2.numel() < nq or status.numel() < nq or khat.numel() < nq or D.shape != (nq, k) or I.shape != (nq, k):
         raise ValueError("flatip_search: buffer sizes do not match nq / k")
     if not (q32.is_contiguous() and P32.is_contiguous() and D.is_contiguous() and I.is_contiguous()):
         raise ValueError("flatip_search: operands must be contiguous")
-    call("cldrd_flatip_search", _p(q32), _p(qh), _p(thr), _p(eps), _p(P16), _p(P32), rows, d, nq, int(k), _p(counts), _p(cand_rows),
+    call("cldrd_flatip_search", _p(q32), _p(qh), _p(thr), _p(eps), _p(P16), _p(P32), rows, d, nq, int(k), int(qtile), _p(counts), _p(cand_rows),
          _p(cand_scores), cand_rows.shape[1], _p(rows2), _p(scores2), rows2.shape[1], _p(n2), _p(status), _p(khat), _p(D), _p(I),
          1 if exhaustive else 0, _stream())
 

@@ -38,9 +38,11 @@ import torch
 
 from .. import hip_ops as ops
 
-SAMPLE_ROWS = 65536          # rows scored for the threshold estimate
+SAMPLE_ROWS = 16384          # rows scored for the threshold estimate (a heuristic: 4x fewer rows cost ~20 % more candidates, which
+                             # only the cheap select sees, and make the estimate 4x cheaper)
 CAND_CAP = 8192              # candidate slots per query (LDS limit of cldrd_topk_select / cldrd_topk_sort)
-QUERY_TILE = 128             # queries per scan (one MFMA tile row; the reference also searches in batches of 128)
+QUERY_TILE = 128             # the reference searches in batches of 128 (retrieve_top_passages.py:88); at d = 768 two such batches
+                             # share one pass over the index (FlatIPIndex.query_tile = 256: the index bytes are read once per 256 queries)
 EST_CHUNK = 1024             # queries per threshold-estimate GEMM
 MAX_ATTEMPTS = 12
 
@@ -157,6 +159,10 @@ class FlatIPIndex:
             self._sample = torch.zeros((self._s_rows + 7) // 8 * 8, d, dtype=torch.bfloat16, device=device)
             ops.gather_cast_rows(self._p32, self._sample, self._s_rows, self._s_stride)
             self._max_norm = math.sqrt(ops.row_sqnorm_max(self._p32))
+            qt = os.environ.get("CLDRD_QUERY_TILE", "")
+            self.query_tile = int(qt) if qt in ("128", "256") else (256 if d == 768 else 128)      # 256: only the d = 768 streaming scan
+            if self.query_tile == 256 and d != 768:
+                self.query_tile = 128
             if int(flag.item()) or not math.isfinite(self._max_norm):
                 raise ValueError("FlatIPIndex: embeddings must be finite and inside the fp16 range (|x| <= 65504) for the scan shadow")
 
@@ -242,11 +248,13 @@ class FlatIPIndex:
         status = st.cpu().numpy()                       # the one synchronisation of a search
         if int(flag.item()):
             raise ValueError("queries must be finite and inside the fp16 range (|x| <= 65504)")
-        nb = (nq + QUERY_TILE - 1) // QUERY_TILE
+        QT = self.query_tile
+        nb = (nq + QT - 1) // QT
         stats["scans"] = 0 if exhaustive else nb
+        stats["query_tile"] = QT
         if self.profile:
-            # batch b keeps its list lengths at counts[129 b .. 129 b + m) and the dropped-hit counter right behind them
-            c_all = counts.view(nb, QUERY_TILE + 1)[:, :QUERY_TILE].reshape(-1)[:nq]
+            # pass b keeps its list lengths at counts[(QT + 1) b .. (QT + 1) b + m) and the dropped-hit counter right behind them
+            c_all = counts.view(nb, QT + 1)[:, :QT].reshape(-1)[:nq]
             stats["search_ms"] = e0.elapsed_time(e1)
             stats["rescored"] = int(n2.sum().item())
             stats["candidates"] = int(c_all.clamp(max=CAND_CAP).sum().item())
@@ -291,7 +299,7 @@ class FlatIPIndex:
             thr_h[bad] = t_b
             khat.index_copy_(0, idx, khat2)
             status[bad] = status_b
-            nbad = (bad.size + QUERY_TILE - 1) // QUERY_TILE
+            nbad = (bad.size + QT - 1) // QT
             stats["scans"] += nbad
             stats["rescans"] += nbad
             bad = bad[~good]
@@ -304,23 +312,23 @@ class FlatIPIndex:
         if ws is None:
             ws = self._ws = {}
         if key not in ws:
-            dev = self.device
-            ws[key] = dict(cand_rows=torch.empty(QUERY_TILE, CAND_CAP, dtype=torch.int32, device=dev),
-                           cand_scores=torch.empty(QUERY_TILE, CAND_CAP, dtype=torch.float32, device=dev),
-                           rows2=torch.empty(QUERY_TILE, cap2, dtype=torch.int32, device=dev),
-                           scores2=torch.empty(QUERY_TILE, cap2, dtype=torch.float32, device=dev))
+            dev, QT = self.device, self.query_tile
+            ws[key] = dict(cand_rows=torch.empty(QT, CAND_CAP, dtype=torch.int32, device=dev),
+                           cand_scores=torch.empty(QT, CAND_CAP, dtype=torch.float32, device=dev),
+                           rows2=torch.empty(QT, cap2, dtype=torch.int32, device=dev),
+                           scores2=torch.empty(QT, cap2, dtype=torch.float32, device=dev))
         return ws[key]
 
     def _run(self, q32, qh, thr, eps, k, ws, D, I, exhaustive):
         dev = self.device
-        nq = q32.shape[0]
-        nb = (nq + QUERY_TILE - 1) // QUERY_TILE
-        counts = torch.zeros(nb * (QUERY_TILE + 1), dtype=torch.int32, device=dev)
+        nq, QT = q32.shape[0], self.query_tile
+        nb = (nq + QT - 1) // QT
+        counts = torch.zeros(nb * (QT + 1), dtype=torch.int32, device=dev)
         n2 = torch.empty(nq, dtype=torch.int32, device=dev)
         status = torch.empty(nq, dtype=torch.int32, device=dev)
         khat = torch.empty(nq, dtype=torch.float32, device=dev)
         ops.flatip_search(q32, qh, thr, eps, self._p16, self._p32, k, counts, ws["cand_rows"], ws["cand_scores"], ws["rows2"], ws["scores2"],
-                          n2, status, khat, D, I, exhaustive=exhaustive)
+                          n2, status, khat, D, I, exhaustive=exhaustive, qtile=QT)
         return status, counts, n2, khat
 
     # -- persistence (own format; faiss' binary layout is not reproduced) ----------------

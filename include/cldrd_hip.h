@@ -146,10 +146,11 @@ int cldrd_transpose_bf16_batched(const void* src, void* dst, const long long* de
  * The shard lives in HBM twice: fp32 rows (exact scores) and a 16-bit shadow the scan streams (fp16 by default: 11-bit
  * significand, so |scan - exact| <= eps is 8x tighter than with bf16; `f16` selects the MFMA type of the scan entry points).
  *
- * cldrd_flatip_search is the whole search of nq device-resident queries in batches of 128 (the reference's batching,
- * retrieve_top_passages.py:88), enqueued back to back with no host round trip; per batch:
- *   scan:    16-bit MFMA scores Q[128,d] . P[rows,d]^T; (query, row) pairs with score >= thr[query] are appended to the query's
- *            candidate list (cand_rows / cand_scores: [128, cap]).  counts = 128 list lengths + 1 counter of hits the
+ * cldrd_flatip_search is the whole search of nq device-resident queries in passes of qtile = 128 queries (the reference's
+ * batching, retrieve_top_passages.py:88) or 256 (two reference batches share one pass over the index bytes), enqueued back to
+ * back with no host round trip; per pass:
+ *   scan:    16-bit MFMA scores Q[qtile,d] . P[rows,d]^T; (query, row) pairs with score >= thr[query] are appended to the query's
+ *            candidate list (cand_rows / cand_scores: [qtile, cap]).  counts = qtile list lengths + 1 counter of hits the
  *            streaming kernel had to drop (its on-chip list overflowed within one tile), zeroed by the caller;
  *   select:  t^ = kk-th largest scan score of the list; rows with scan score >= t^ - 2 eps[query] are kept (rows2, n2) - no other
  *            row can be in the exact top-kk (proof in csrc/topk.hip); status[query] = 0 when that proof holds, else a bit mask
@@ -164,7 +165,7 @@ int cldrd_cast_f16(const float* src, void* dst, size_t n, unsigned int* flag, vo
 int cldrd_topk_prep_queries(const float* q, void* q_f16, void* q_bf16, float* qnorm, int nq, int d, unsigned int* flag, void* stream);
 int cldrd_topk_thresholds(const float* est, const float* qnorm, float pmax, int d, float* thr, float* eps, int nq, void* stream);
 int cldrd_flatip_search(const float* q32, const void* q16, const float* thr, const float* eps, const void* P16, const float* P32,
-                        long long rows, int d, int nq, int k, int* counts, int* cand_rows, float* cand_scores, int cap,
+                        long long rows, int d, int nq, int k, int qtile, int* counts, int* cand_rows, float* cand_scores, int cap,
                         int* rows2, float* scores2, int cap2, int* n2, int* status, float* khat, float* D, int* I,
                         int exhaustive, void* stream);
 int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
