@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
     // ---- this wave's 16 NQS queries as B fragments for every k-step (registers, loaded once): 4 KS NQS registers.
     // Fragment f = s KS + ks lives in an AGPR quad for f < NA (all 256 AGPRs when NQS = 4: sets 0, 1 and two thirds of set 2) and in
     // VGPRs otherwise; one wave per SIMD owns all 512 registers of its lanes then (see mfma16_bq for why the split is by hand).
-    constexpr int NA = NQS > 1 ? (NQS * KS < 64 ? NQS * KS : 64) : 0, NV = NQS * KS - NA;
+    constexpr int NA = (NQS > 1 && NW == 4) ? (NQS * KS < 64 ? NQS * KS : 64) : 0, NV = NQS * KS - NA;
     const int qn0 = wid * 16 * NQS + (lane & 15);          // query of set s: qn0 + 16 s
     bf16x8 bqa[NA > 0 ? NA : 1], bqv[NV > 0 ? NV : 1];
     float thr_lane[NQS];
@@ -369,6 +369,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
     static_assert(8 * LCAP < 65536, "ds_write offset field");
     if (threadIdx.x < 4) lcount[threadIdx.x] = 0;               // [0] list length, [1..3] its snapshots (see the flush check)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing but LDS-DMA is in flight from here on
+    __syncthreads();                                            // the first snapshot read comes BEFORE the first barrier of the tile loop
 
     // ---- DMA addressing: piece p = wid*PPW + j covers LDS bytes [1024 p, 1024 p + 1024) of the tile image
     uint32_t soff[PPW];
@@ -423,19 +424,15 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
         // Level of the hit list for the flush decision below.  The decision must be workgroup-uniform (flush() has barriers) but
         // lcount moves as soon as a fast wave emits hits of the current tile, so everybody reads a SNAPSHOT wave 0 took at the end
         // of tile it-2 (three rotating slots; that write is ordered by the barrier of tile it-1, and wave 0 cannot overwrite the slot
-        // before the end of tile it+1, i.e. after every wave has passed the next barrier).  Issued here, consumed after the waits
-        // below: no extra LDS round trip on the critical path.
-        uint32_t snap = 0;
-        if (ablate == 0) {
-            const int sl = (it + 1) % 3;
-            if (sl == 0) asm volatile("ds_read_b32 %0, %1 offset:4" : "=v"(snap) : "v"(lcount_off) : "memory");
-            else if (sl == 1) asm volatile("ds_read_b32 %0, %1 offset:8" : "=v"(snap) : "v"(lcount_off) : "memory");
-            else asm volatile("ds_read_b32 %0, %1 offset:12" : "=v"(snap) : "v"(lcount_off) : "memory");
-        }
+        // before the end of tile it+1, i.e. after every wave has passed the next barrier).  The read sits in the SAME asm statement
+        // as the wait that lands it: issued separately, hipcc copied the destination register before the wait (stale value in the
+        // last tile -> waves disagreeing on the flush -> mismatched barriers; caught by tools/scan_debug.py on 625-tile shards).
         // tile t must have landed; tile t+step may stay in flight.  NO global memory operation other than the DMA may appear
         // inside this loop: hipcc would put s_waitcnt vmcnt(0) next to it and drain the two tiles in flight (measured: ~1 us per hit)
-        if (t + step < ntiles) asm volatile("s_waitcnt vmcnt(%1) lgkmcnt(0)" : "+v"(snap) : "n"(PPW) : "memory");     // (also lands the snapshot read)
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(snap) :: "memory");
+        uint32_t snap = 0;
+        const uint32_t snap_addr = lcount_off + 4u * (1u + (uint32_t)((it + 1) % 3));
+        if (t + step < ntiles) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt vmcnt(%2) lgkmcnt(0)" : "=&v"(snap) : "v"(snap_addr), "n"(PPW) : "memory");
+        else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=&v"(snap) : "v"(snap_addr) : "memory");
         __builtin_amdgcn_s_barrier();                                       // ... for every wave; slot of tile t-step is free
         asm volatile("" ::: "memory");
         // Hit-list level check: `snap` was read at the top of this iteration (see there); the decision is workgroup-uniform.
@@ -451,7 +448,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
         // nothing else hides the LDS latency (measured: reads alone and MFMAs alone both keep up with the DMA stream,
         // read -> wait -> MFMA in one chain does not).  sched_barrier pins the order, hipcc still counts the lgkmcnt waits.
         // chunk = CH k-steps of one 16-row half (smaller chunks when most registers hold queries)
-        constexpr int CH = NQS > 1 ? (KS % 4 == 0 ? 4 : 2) : (KS % 3 == 0 ? KS / 3 : KS / 2), NCM = KS / CH, NC = 2 * NCM;
+        constexpr int CH = NQS > 1 ? (NW == 8 ? 2 : (KS % 4 == 0 ? 4 : 2)) : (KS % 3 == 0 ? KS / 3 : KS / 2), NCM = KS / CH, NC = 2 * NCM;
         bf16x8 ab[2][CH];
         // chunk position of k-step ks in row r: ((4 ks + (lane >> 4)) ^ (r & 15)) = 16 (ks >> 2) + (((ks & 3) << 2) ^ (r & 12) | (lane >> 4) ^ (r & 3)):
         // four lane-dependent bases, everything else is an immediate offset of the ds_read
@@ -562,7 +559,7 @@ int launch_scan_stream(const void* Q, const void* P, int nq, long long rows, con
         }
     }
     if (nq > 128) {                                    // 129..256 queries: the 4-wave x 64-query instance (fp16 shadow, d = 768 only)
-        if (KS == 24 && f16) return launch_scan_stream_abl<24, 0, true, 4, 4>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+        if (KS == 24 && f16) return launch_scan_stream_abl<24, 0, true, 8, 2>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
         return -1;
     }
     if (f16) return launch_scan_stream_abl<KS, 0, true>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);

@@ -224,7 +224,10 @@ def test_scan_stream_flushes_its_hit_list(nq):
     Q = torch.from_numpy(syn.normal(31, nq * d).reshape(nq, d).astype(np.float32)).to(DEV).half()
     P = torch.from_numpy(syn.normal(32, rows * d).reshape(rows, d).astype(np.float32)).to(DEV).half()
     S = Q.float() @ P.float().T
-    thr = torch.quantile(S[:, :8000], 1.0 - 0.05, dim=1).contiguous()          # ~2000 hits per query
+    # ~2000 hits per query at 128 queries, ~800 at 256 (same hits per workgroup; the list level is checked with a lag of two tiles,
+    # so a rate far beyond anything a search produces overflows the list between two checks - which is reported, not lost)
+    frac = 0.05 if nq == 128 else 0.02
+    thr = torch.quantile(S[:, :8000], 1.0 - frac, dim=1).contiguous()
     got = []
     for tiled in (False, True):
         counts = torch.zeros(nq + 1, dtype=torch.int32, device=DEV)
@@ -232,7 +235,7 @@ def test_scan_stream_flushes_its_hit_list(nq):
         cs = torch.zeros(nq, cap, device=DEV)
         ops.topk_scan_filter(Q, P, thr, counts, cr, cs, tiled=tiled)
         c = counts.cpu().numpy()
-        assert c[nq] == 0 and (c[:nq] <= cap).all() and c[:nq].mean() > 1200
+        assert c[nq] == 0 and (c[:nq] <= cap).all() and c[:nq].mean() > 0.6 * frac * rows
         crh = cr.cpu().numpy()
         got.append([np.sort(crh[q, :c[q]]) for q in range(nq)])
     for q in range(nq):

@@ -20,6 +20,9 @@ def run(tag, Q, P, thr_val, env=None, reps=30):
     for k in ("CLDRD_SCAN_ABLATE", "CLDRD_SCAN"):
         os.environ.pop(k, None)
     os.environ.update(env or {})
+    nq = Q.shape[0]
+    counts = torch.zeros(nq + 1, dtype=torch.int32, device=dev)
+    cr = torch.empty(nq, cap, dtype=torch.int32, device=dev); cs = torch.empty(nq, cap, device=dev)
     thr = torch.full((nq,), thr_val, device=dev)
     for _ in range(3): counts.zero_(); ops.topk_scan_filter(Q, P, thr, counts, cr, cs)
     torch.cuda.synchronize()
@@ -28,7 +31,7 @@ def run(tag, Q, P, thr_val, env=None, reps=30):
     for _ in range(reps): counts.zero_(); ops.topk_scan_filter(Q, P, thr, counts, cr, cs)
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / reps
-    print(f"{tag:34s} {t*1e3:7.1f} us  {rows*d*2/t/1e9:.2f} TB/s  hits/query {counts[:nq].float().mean().item():.0f} dropped {int(counts[nq])}", flush=True)
+    print(f"{tag:34s} nq {nq:3d} {t*1e3:7.1f} us  {rows*d*2/t/1e9:.2f} TB/s physical, {rows*d*2*(nq/128)/t/1e9:.2f} TB/s per 128-query unit  hits/query {counts[:nq].float().mean().item():.0f} dropped {int(counts[nq])}", flush=True)
 
 
 Ph, Pb, Qh, Qb = P32.half(), P32.bfloat16(), Q32.half(), Q32.bfloat16()
@@ -38,6 +41,12 @@ for rnd in range(2):
     run("fp16 thr 11.5 (~1300 hits/query)", Qh, Ph, 11.5)
     run("bf16 thr 11.5", Qb, Pb, 11.5)
     run("fp16 thr 12.3 (~600 hits/query)", Qh, Ph, 12.3)
+Q256 = torch.randn(256, d, device=dev, generator=gen)
+Q256 *= 10.0 / Q256.norm(dim=1, keepdim=True)
+Q256h = Q256.half()
+for rnd in range(2):
+    run("fp16 256 queries no hits", Q256h, Ph, 1e9)
+    run("fp16 256 queries thr 11.9", Q256h, Ph, 11.9)
 run("bf16 DMA only (ablate 1)", Qb, Pb, 11.5, {"CLDRD_SCAN_ABLATE": "1"})
 run("bf16 no hit handling (ablate 2)", Qb, Pb, 11.5, {"CLDRD_SCAN_ABLATE": "2"})
 run("bf16 tiled GEMM scan", Qb, Pb, 11.5, {"CLDRD_SCAN": "gemm"}, reps=10)
