@@ -313,6 +313,28 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
     }
 }
 
+// the same for every problem of a group in one launch: blockIdx.y = problem
+__global__ void reduce_slabs_group_kernel(TnGroupArgs ga) {
+    const TnProblem& P = ga.p[blockIdx.y];
+    const size_t n_main4 = (size_t)P.N1 * P.N2 / 4, n_all4 = n_main4 + (P.dbias ? (size_t)P.N1 / 4 : 0);
+    const size_t stride4 = ((size_t)P.N1 * P.N2 + (size_t)P.N1) / 4;
+    const float4* slabs = (const float4*)(ga.slabs + P.slab_off);
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all4; i += step) {
+        float4 s = slabs[i];
+        for (int k = 1; k < ga.splits; ++k) {
+            const float4 t = slabs[i + k * stride4];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float4* dst = i < n_main4 ? (float4*)P.dW + i : (float4*)P.dbias + (i - n_main4);
+        if (ga.accumulate) {
+            const float4 o = *dst;
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+        *dst = s;
+    }
+}
+
 }  // namespace
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -359,9 +381,16 @@ static int wgrad_splits_group(const int* M, const int* N1, const int* N2, int n,
     static int force = -1;
     if (force < 0) { const char* e = getenv("CLDRD_WGRAD_SPLITS"); force = e ? atoi(e) : 0; }
     if (force > 0) return force < ktotal ? force : ktotal;
-    int best = 1;
+    // Workgroups of one XCD share A / B panels through its 4-MiB L2 only while they sweep the same token range at about the same
+    // time; nothing synchronises them, so over a long sweep they drift apart and every one of them streams its operands from HBM
+    // (measured at cfg2: 512 K tiles per item, no split: 3.2 ms for the passage tower's group; 2 splits of 256: 2.9 ms + 0.1 ms of
+    // slabs).  Items are therefore capped at MAXK K tiles.
+    static int maxk = -1;
+    if (maxk < 0) { const char* e = getenv("CLDRD_WGRAD_MAXK"); maxk = e ? atoi(e) : 256; if (maxk < 1) maxk = 256; }
+    const int sp_min = (ktotal + maxk - 1) / maxk;
+    int best = sp_min;
     double best_cost = -1.0;
-    for (int sp = 1; sp <= 64 && sp <= ktotal; ++sp) {
+    for (int sp = sp_min; sp <= 64 && sp <= ktotal; ++sp) {
         double work = 0.0;
         for (int i = 0; i < n; ++i) {
             const long tiles = (long)(N1[i] / t.t1) * (N2[i] / t.t2);
@@ -461,15 +490,11 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
         else rc = launch_tn_group<128, 128, 4>(g, items, st);
         if (rc) return rc;
         if (splits > 1) {
-            for (int i = 0; i < m; ++i) {
-                const TnProblem& P = g.p[i];
-                const size_t n_main4 = (size_t)P.N1 * P.N2 / 4, n_all4 = n_main4 + (P.dbias ? (size_t)P.N1 / 4 : 0);
-                const size_t stride = (size_t)P.N1 * P.N2 + (size_t)P.N1;
-                const int rb = (int)((n_all4 + 255) / 256 < 2048 ? (n_all4 + 255) / 256 : 2048);
-                hipLaunchKernelGGL(reduce_slabs_kernel, dim3(rb), dim3(256), 0, st, (const float*)workspace + P.slab_off, P.dW, P.dbias, n_main4,
-                                   n_all4, splits, stride / 4, accumulate);
-                CLDRD_LAUNCH_CHECK();
-            }
+            size_t biggest = 0;
+            for (int i = 0; i < m; ++i) biggest = biggest > (size_t)g.p[i].N1 * g.p[i].N2 / 4 ? biggest : (size_t)g.p[i].N1 * g.p[i].N2 / 4;
+            const int rb = (int)((biggest + 255) / 256 < 256 ? (biggest + 255) / 256 : 256);
+            hipLaunchKernelGGL(reduce_slabs_group_kernel, dim3(rb, m), dim3(256), 0, st, g);       // one reduction launch for the group
+            CLDRD_LAUNCH_CHECK();
         }
     }
     return 0;
