@@ -16,20 +16,20 @@ SIGNATURES = {
     "cldrd_last_error": (C.c_char_p, []),
     "cldrd_version": (ci, []),
     "cldrd_device_ok": (ci, []),
-    "cldrd_gemm_nt_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, vp]),
+    "cldrd_gemm_nt_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp]),
     "cldrd_wgrad_splits": (ci, [ci, ci, ci]),
     "cldrd_wgrad_bf16": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, csz, ci, vp]),
     "cldrd_wgrad_group_workspace": (csz, [vp, vp, vp, ci]),
     "cldrd_wgrad_group": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, csz, ci, vp]),
-    "cldrd_attention_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
+    "cldrd_attention_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
     "cldrd_attention_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
-    "cldrd_attention_cls_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
+    "cldrd_attention_cls_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
     "cldrd_attention_cls_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
     "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, vp]),
     "cldrd_ln_partial_blocks": (ci, [ci]),
-    "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, vp]),
+    "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, ci, vp]),
     "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp]),
-    "cldrd_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, ci, ci, vp, vp]),
+    "cldrd_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, ci, ci, vp, ci, vp]),
     "cldrd_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cull, ci, ci, vp]),
     "cldrd_colsum_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_scatter_cls_grad": (ci, [vp, vp, ci, ci, ci, ci, vp]),

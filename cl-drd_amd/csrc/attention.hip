@@ -40,6 +40,26 @@ __device__ __forceinline__ bf16x8 pack8(const float* v) {
     return r;
 }
 
+// 16-bit activation format of the FORWARD kernels: bf16 (default), or fp16 for the high-precision forward of the query tower
+// (encoder.py: 11-bit significand operands, same MFMA rate; the backward always runs on the bf16 tape).
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16_t f2h(float f) { const _Float16 h = (_Float16)f; return __builtin_bit_cast(bf16_t, h); }
+__device__ __forceinline__ float h2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+template <bool F16> __device__ __forceinline__ bf16_t f2x(float f) { if constexpr (F16) return f2h(f); else return f2bf(f); }
+template <bool F16> __device__ __forceinline__ float x2f(bf16_t v) { if constexpr (F16) return h2f(v); else return bf2f(v); }
+template <bool F16>
+__device__ __forceinline__ bf16x8 pack8x(const float* v) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (short)f2x<F16>(v[j]);
+    return r;
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // copy a [L, 64] bf16 head slice (row stride ld elements) into an LDS tile of Lp rows, zero-filling rows >= L
 __device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld, int L, int Lp) {
     for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
@@ -55,7 +75,7 @@ __device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld,
 //
 // Forward with all the scores of a query block in registers (16 NKB accumulators): for L <= 128 this is ~7 % faster than the
 // streaming form below (16 score MFMAs back to back, one softmax pass, 16 P.V MFMAs) and is what the train step uses.
-template <int NKB, bool DROP>
+template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
@@ -87,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
             S[kb] = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                S[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], S[kb], 0, 0, 0);
+                S[kb] = mfma32<F16>(row_frag(sK, kb * 32 + r, s, h), qf[s], S[kb]);
         }
         // S[kb][t] = <K[key], Q[q]> with key = 32 kb + rowmap(t, h), q = 32 qb + r
         // softmax in the log2 domain (v_exp_f32 is 2^x): scores * scale * log2(e) + bias, bias read 4 keys at a time
@@ -139,10 +159,10 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pa = pack8(pv + 8 * s2);
+                const bf16x8 pa = pack8x<F16>(pv + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pa, tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), O[dt], 0, 0, 0);
+                    O[dt] = mfma32<F16>(pa, tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), O[dt]);
             }
         }
         // O[dt][t] = ctx[q = 32 qb + rowmap(t, h)][d = 32 dt + r]
@@ -151,7 +171,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int qq = qb * 32 + rowmap(t, h);
-                if (qq < L) ctx[((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r] = f2bf(O[dt][t]);
+                if (qq < L) ctx[((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r] = f2x<F16>(O[dt][t]);
             }
     }
 }
@@ -444,6 +464,23 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 }
 
 template <int NKB, bool DROP>
+int launch_fwd_f16(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
+                   unsigned long long seed, hipStream_t st) {
+    const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP, true>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+template <int NKB>
+int launch_fwd_h(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
+                 unsigned long long seed, hipStream_t st) {
+    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_f16<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, st)
+                                              : launch_fwd_f16<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, st);
+}
+
+template <int NKB, bool DROP>
 int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
                  unsigned long long seed, hipStream_t st) {
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
@@ -489,11 +526,20 @@ int launch_bwd(const void* qkv, const long long* mask, const void* ctx, const vo
 // qkv: bf16 [nseq*L, 3*H*64] (Q | K | V, heads contiguous inside each); mask: int64 [nseq, L] (0 = padded key) or null;
 // ctx: bf16 [nseq*L, H*64]; lse: fp32 [nseq, H, L] (may be null for inference).
 extern "C" int cldrd_attention_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
-                                   float dropout_p, unsigned long long seed, void* stream) {
+                                   float dropout_p, unsigned long long seed, int io_f16, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_fwd: need 0 < L <= 256");
     const float scale = 0.125f;   // 1 / sqrt(64)
     const int nkb = (L + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    if (io_f16) {                 // fp16 activations: the all-scores-in-registers kernel only (L <= 128)
+        CLDRD_CHECK(L <= 128, "attention_fwd: the fp16 forward handles L <= 128");
+        switch (nkb) {
+            case 1: return launch_fwd_h<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+            case 2: return launch_fwd_h<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+            case 3: return launch_fwd_h<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+            default: return launch_fwd_h<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+        }
+    }
     switch (nkb) {
         case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
         case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
@@ -532,6 +578,7 @@ extern "C" int cldrd_attention_bwd(const void* qkv, const long long* mask, const
 // everything after attention runs on one row per sequence.  One wavefront per (sequence, head).
 namespace {
 
+template <bool F16>
 __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
                                                            const int64_t* __restrict__ mask, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ probs, int L, int H, float scale,
@@ -540,7 +587,7 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
     __shared__ float sq[64];
     const int seq = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x;
     const int dm = H * 64;
-    sq[lane] = bf2f(qc[(size_t)seq * dm + hd * 64 + lane]);
+    sq[lane] = x2f<F16>(qc[(size_t)seq * dm + hd * 64 + lane]);
     __syncthreads();
     const bf16_t* kb = kv + (size_t)seq * L * 2 * dm + hd * 64;
     const bf16_t* vb = kb + dm;
@@ -559,7 +606,7 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
                 const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    a += __uint_as_float(w[j] << 16) * sq[c * 8 + 2 * j] + __uint_as_float(w[j] & 0xFFFF0000u) * sq[c * 8 + 2 * j + 1];
+                    a += x2f<F16>((bf16_t)(w[j] & 0xFFFFu)) * sq[c * 8 + 2 * j] + x2f<F16>((bf16_t)(w[j] >> 16)) * sq[c * 8 + 2 * j + 1];
             }
             s = a * scale;
         }
@@ -585,8 +632,8 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
     }
     __syncthreads();
     float o = 0.f;
-    for (int key = 0; key < L; ++key) o += sp[key] * bf2f(vb[(size_t)key * 2 * dm + lane]);
-    ctx[(size_t)seq * dm + hd * 64 + lane] = f2bf(o);
+    for (int key = 0; key < L; ++key) o += sp[key] * x2f<F16>(vb[(size_t)key * 2 * dm + lane]);
+    ctx[(size_t)seq * dm + hd * 64 + lane] = f2x<F16>(o);
 }
 
 __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
@@ -662,11 +709,15 @@ __global__ __launch_bounds__(256) void add_rows_strided_kernel(bf16_t* __restric
 
 // qc: bf16 [nseq, H*64] (CLS queries); kv: bf16 [nseq*L, 2*H*64] = K | V; ctx: bf16 [nseq, H*64]; probs: fp32 [nseq, H, L]
 extern "C" int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L,
-                                       int H, float dropout_p, unsigned long long seed, void* stream) {
+                                       int H, float dropout_p, unsigned long long seed, int io_f16, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0 && probs != nullptr, "attention_cls_fwd: need 0 < L <= 256 and a probs buffer");
-    hipLaunchKernelGGL(attn_cls_fwd_kernel, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
-                       (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u,
-                       1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
+    if (io_f16)
+        hipLaunchKernelGGL(attn_cls_fwd_kernel<true>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
+                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+    else
+        hipLaunchKernelGGL(attn_cls_fwd_kernel<false>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
+                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

@@ -29,7 +29,8 @@ struct GemmNtArgs {
 enum : int {
     EPI_BIAS = 1, EPI_PREACT = 2, EPI_GELU = 4, EPI_GELUGRAD = 8, EPI_DROPOUT = 16, EPI_RESIDUAL = 32, EPI_F32 = 64, EPI_FILTER = 128,
     EPI_RES32 = 256,              // the residual operand is fp32 (only with EPI_RESIDUAL)
-    EPI_F16IN = 512,              // A and B hold fp16, not bf16 (top-k scan over the fp16 index shadow; only with EPI_FILTER)
+    EPI_F16IN = 512,              // A, B (and a 16-bit C) hold fp16, not bf16: the top-k scan over the fp16 index shadow (with EPI_FILTER)
+                                  // and the high-precision forward of the query tower (small-M kernel; not with preact / gelu_pre)
     EPI_GENERIC = 1 << 20
 };
 
@@ -56,7 +57,7 @@ template <int EPI> struct EpiFlags {
 };
 
 static inline int epi_flavour(const GemmNtArgs& a) {
-    return (a.bias ? EPI_BIAS : 0) | (a.preact ? EPI_PREACT : 0) | (a.act == 1 ? EPI_GELU : 0) | (a.gelu_pre ? EPI_GELUGRAD : 0) |
+    return (a.in_f16 ? EPI_F16IN : 0) | (a.bias ? EPI_BIAS : 0) | (a.preact ? EPI_PREACT : 0) | (a.act == 1 ? EPI_GELU : 0) | (a.gelu_pre ? EPI_GELUGRAD : 0) |
            (a.drop_thresh ? EPI_DROPOUT : 0) | (a.residual ? EPI_RESIDUAL : 0) | (a.out_f32 ? EPI_F32 : 0) |
            ((a.residual && a.res_f32) ? EPI_RES32 : 0);
 }
@@ -70,6 +71,15 @@ __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
 __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     uint4 o;
     o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+    return o;
+}
+__device__ __forceinline__ uint32_t pack2half(float lo, float hi) {
+    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+__device__ __forceinline__ uint4 pack8h(const float (&v)[8]) {
+    uint4 o;
+    o.x = pack2half(v[0], v[1]); o.y = pack2half(v[2], v[3]); o.z = pack2half(v[4], v[5]); o.w = pack2half(v[6], v[7]);
     return o;
 }
 
@@ -121,7 +131,8 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         *(float4*)C = make_float4(v[0], v[1], v[2], v[3]);
         *(float4*)(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        *(uint4*)((bf16_t*)p.C + crow) = pack8(v);
+        if constexpr (EPI != EPI_GENERIC && (EPI & EPI_F16IN) != 0) *(uint4*)((bf16_t*)p.C + crow) = pack8h(v);
+        else *(uint4*)((bf16_t*)p.C + crow) = pack8(v);
     }
 }
 

@@ -125,7 +125,7 @@ int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows,
 extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                   int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
-                                  void* stream) {
+                                  int io_f16, void* stream) {
     CLDRD_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
     CLDRD_CHECK(K % 32 == 0, "gemm_nt: K must be a multiple of 32");
     CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && N % 8 == 0 && (residual == nullptr || ldr % 8 == 0),
@@ -143,6 +143,21 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
     a.drop_scale = 1.0f / (1.0f - dropout_p);
     a.seed = seed; a.out_f32 = out_f32;
     a.thr = nullptr; a.counts = nullptr; a.cand_rows = nullptr; a.cand_scores = nullptr; a.cap = 0;
+    a.in_f16 = io_f16 ? 1 : 0;
+    if (io_f16) {
+        // fp16 operands / 16-bit output (the high-precision forward of the query tower): small-M kernel, forward flavours only
+        CLDRD_CHECK(K % BK == 0, "gemm_nt: K must be a multiple of 64");
+        CLDRD_CHECK(preact == nullptr && gelu_pre == nullptr, "gemm_nt: the fp16 format has no preact / gelu_pre epilogue (forward without a tape)");
+        switch (epi_flavour(a)) {
+            case EPI_F16IN | EPI_BIAS: return launch_nt<EPI_F16IN | EPI_BIAS>(a, (hipStream_t)stream);
+            case EPI_F16IN | EPI_BIAS | EPI_GELU: return launch_nt<EPI_F16IN | EPI_BIAS | EPI_GELU>(a, (hipStream_t)stream);
+            case EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
+                return launch_nt<EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
+            case EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
+                return launch_nt<EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
+            default: return cldrd_set_error("gemm_nt: this epilogue combination is not built for the fp16 format");
+        }
+    }
     // large-M shapes go to the 256-row ring kernel; CLDRD_GEMM_TILE=128|192|256 forces a variant (experiments)
     const char* env_tile = getenv("CLDRD_GEMM_TILE");
     const int force = env_tile ? atoi(env_tile) : 0;

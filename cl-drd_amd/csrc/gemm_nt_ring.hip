@@ -280,7 +280,7 @@ int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_
     static int gn_env = -2;
     if (gn_env == -2) { const char* e = getenv("CLDRD_GEMM_GN"); gn_env = e ? atoi(e) : -1; }
     gn_force = gn_env;
-    if (a.K % BK != 0) return -1;
+    if (a.K % BK != 0 || a.in_f16) return -1;
     if ((double)a.M * a.lda * 2.0 >= 4.0e9 || (double)a.N * a.ldb * 2.0 >= 4.0e9) return -1;   // 32-bit DMA offsets
     int bn = force_bn;
     if (bn == 0) {

@@ -52,6 +52,20 @@ __device__ __forceinline__ void store_row_bf16(bf16_t* row, int d, int lane, con
         }
     }
 }
+// fp16 instead of bf16 (the high-precision forward of the query tower)
+__device__ __forceinline__ void store_row_f16(bf16_t* row, int d, int lane, const RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            const _Float16 h0 = (_Float16)r.v[it][0], h1 = (_Float16)r.v[it][1], h2 = (_Float16)r.v[it][2], h3 = (_Float16)r.v[it][3];
+            uint2 u;
+            u.x = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+            u.y = (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16);
+            *(uint2*)(row + c) = u;
+        }
+    }
+}
 __device__ __forceinline__ void store_row_f32(float* row, int d, int lane, const RowF& r) {
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
@@ -84,7 +98,7 @@ template <int DC, bool X32>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ out, float* __restrict__ out32,
                                                       float* __restrict__ mean_o, float* __restrict__ rstd_o, int T, int d_rt,
-                                                      float eps, float* __restrict__ cls_out, int cls_stride) {
+                                                      float eps, float* __restrict__ cls_out, int cls_stride, int out_f16) {
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -105,7 +119,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
             if (cls) *(float4*)(cls_out + (size_t)(row / cls_stride) * d + c) = make_float4(r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
         }
     }
-    store_row_bf16(out + (size_t)row * d, d, lane, r);
+    if (out_f16) store_row_f16(out + (size_t)row * d, d, lane, r);
+    else store_row_bf16(out + (size_t)row * d, d, lane, r);
     if (X32 && out32) store_row_f32(out32 + (size_t)row * d, d, lane, r);
     if (lane == 0) { if (mean_o) mean_o[row] = mean; if (rstd_o) rstd_o[row] = rstd; }
 }
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             bf16_t* __restrict__ out, float* __restrict__ out32, float* __restrict__ mean_o,
                                                             float* __restrict__ rstd_o, int T, int L, int d_rt, int vocab, float eps,
-                                                            uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+                                                            uint32_t drop_thresh, float drop_scale, uint64_t seed, int out_f16) {
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -158,7 +173,8 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
             }
         }
     }
-    store_row_bf16(out + (size_t)row * d, d, lane, r);
+    if (out_f16) store_row_f16(out + (size_t)row * d, d, lane, r);
+    else store_row_bf16(out + (size_t)row * d, d, lane, r);
     if (out32) store_row_f32(out32 + (size_t)row * d, d, lane, r);
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
@@ -440,12 +456,12 @@ static inline int ln_bwd_blocks(int T) {
 extern "C" int cldrd_ln_partial_blocks(int T) { return ln_bwd_blocks(T); }
 
 extern "C" int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
-                                   int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, void* stream) {
+                                   int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, int out_f16, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_fwd: need 0 < d <= 1024, d % 4 == 0");
     CLDRD_CHECK(x_f32 || out32 == nullptr, "layernorm_fwd: an fp32 output copy goes with an fp32 input (the fp32 residual stream)");
     ln_dispatch(d, x_f32 != 0, [&](auto dc, auto x32) {
         hipLaunchKernelGGL((ln_fwd_kernel<decltype(dc)::value, decltype(x32)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                           (bf16_t*)out, out32, mean, rstd, T, d, eps, cls_out, cls_stride > 0 ? cls_stride : 1);
+                           (bf16_t*)out, out32, mean, rstd, T, d, eps, cls_out, cls_stride > 0 ? cls_stride : 1, out_f16);
     });
     CLDRD_LAUNCH_CHECK();
     return 0;
@@ -453,13 +469,13 @@ extern "C" int cldrd_layernorm_fwd(const void* x, const float* gamma, const floa
 
 extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
                                   const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
-                                  int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, void* stream) {
+                                  int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, int out_f16, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_fwd: bad shape");
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
         hipLaunchKernelGGL((embed_ln_fwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                            (const int64_t*)ids, word, pos, type0, gamma, beta, (bf16_t*)out, out32, mean, rstd, T, L, d, vocab, eps, th,
-                           1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                           1.0f / (1.0f - dropout_p), (uint64_t)seed, out_f16);
     });
     CLDRD_LAUNCH_CHECK();
     return 0;

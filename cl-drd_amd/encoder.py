@@ -222,6 +222,8 @@ class HipEncoder(nn.Module):
         self.flat_p = torch.zeros(self.layout.total, dtype=torch.float32)
         self.flat_g = None
         self.flat_h = None          # bf16 shadow (same layout)
+        self.flat_h16 = None        # fp16 shadow (same layout): only towers that run the high-precision forward keep one
+        self.hp_forward = False     # set by NwayDualEncoder on the query tower (see encode)
         self.flat_t = None          # transposed bf16 shadows
         self._t_desc = None
         self._shadow_version = -1
@@ -284,7 +286,7 @@ class HipEncoder(nn.Module):
                 flat[off:off + _numel(shape)].view(shape).copy_(params[n].data.to(torch.float32))
             self._rebind(flat)
             self.flat_g = None
-            self.flat_h = self.flat_t = self._t_desc = None
+            self.flat_h = self.flat_h16 = self.flat_t = self._t_desc = None
             self._shadow_version = -1
 
     def adopt_flat(self, flat_p: torch.Tensor, flat_g: torch.Tensor | None = None):
@@ -378,6 +380,10 @@ class HipEncoder(nn.Module):
             self.flat_h = torch.empty(self.layout.total, dtype=torch.bfloat16, device=self.flat_p.device)
         if cast:
             ops.cast_bf16(self.flat_p, self.flat_h)
+        if self.hp_forward:
+            if self.flat_h16 is None or self.flat_h16.device != self.flat_p.device:
+                self.flat_h16 = torch.empty(self.layout.total, dtype=torch.float16, device=self.flat_p.device)
+            ops.cast_f16(self.flat_p, self.flat_h16)
         if need_transposed and self.cfg.n_layers:
             if self.flat_t is None:
                 self.flat_t = torch.empty(self.layout.t_total, dtype=torch.bfloat16, device=self.flat_p.device)
@@ -394,7 +400,7 @@ class HipEncoder(nn.Module):
         self._shadow_version = self.flat_p._version
 
     def _shadows_ok(self, need_t):
-        return (self.flat_h is not None and self._shadow_version == self.flat_p._version and
+        return (self.flat_h is not None and self._shadow_version == self.flat_p._version and (not self.hp_forward or self.flat_h16 is not None) and
                 (not need_t or (self.flat_t is not None and getattr(self, "_t_fresh", False))))
 
     def ht(self, layer, key):
@@ -402,16 +408,21 @@ class HipEncoder(nn.Module):
         return self.flat_t[off:off + shp[0] * shp[1]].view(shp)
 
     # ------------------------------------------------------------------ forward
-    def _layer_weights(self, i):
+    def _layer_weights(self, i, fp16=False):
         cfg, n = self.cfg, layer_param_names(self.cfg, i)
         d = cfg.dim
         oq = self.layout.entries[n["q"] + ".weight"][0]
         ob = self.layout.entries[n["q"] + ".bias"][0]
-        return dict(Wqkv=self.flat_h[oq:oq + 3 * d * d].view(3 * d, d), bqkv=self.flat_p[ob:ob + 3 * d],
-                    Wo=self.h(n["o"] + ".weight"), bo=self.w(n["o"] + ".bias"),
+        sh = self.flat_h16 if fp16 else self.flat_h
+
+        def h(name):
+            off, shape = self.layout.entries[name]
+            return sh[off:off + _numel(shape)].view(shape)
+        return dict(Wqkv=sh[oq:oq + 3 * d * d].view(3 * d, d), bqkv=self.flat_p[ob:ob + 3 * d],
+                    Wo=h(n["o"] + ".weight"), bo=self.w(n["o"] + ".bias"),
                     g1=self.w(n["ln1"] + ".weight"), b1=self.w(n["ln1"] + ".bias"),
-                    W1=self.h(n["f1"] + ".weight"), bf1=self.w(n["f1"] + ".bias"),
-                    W2=self.h(n["f2"] + ".weight"), bf2=self.w(n["f2"] + ".bias"),
+                    W1=h(n["f1"] + ".weight"), bf1=self.w(n["f1"] + ".bias"),
+                    W2=h(n["f2"] + ".weight"), bf2=self.w(n["f2"] + ".bias"),
                     g2=self.w(n["ln2"] + ".weight"), b2=self.w(n["ln2"] + ".bias"))
 
     def _layer_grads(self, i):
@@ -433,8 +444,29 @@ class HipEncoder(nn.Module):
         return torch.empty(ops.pad_rows(rows), cols, dtype=dtype, device=dev)
 
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None, *, train: bool | None = None,
-               save: bool = False, seed: int | None = None):
-        """CLS embeddings fp32 [M, d] (== HF ``model(**enc)[0][:, 0, :]``).  With ``save`` also returns the tape."""
+               save: bool = False, seed: int | None = None, fp16: bool | None = None):
+        """CLS embeddings fp32 [M, d] (== HF ``model(**enc)[0][:, 0, :]``).  With ``save`` also returns the tape.
+
+        ``fp16`` (default: ``self.hp_forward``, which NwayDualEncoder sets on the QUERY tower): high-precision forward - the same
+        kernels with fp16 instead of bf16 MFMA operands (11-bit significands, same rate; forward activations of a BERT encoder are
+        far inside the fp16 range, and the reference itself runs fp16 autocast on its GPUs).  Why the query tower: a logit error is
+        dq.p + q.dp, there are N passages per query, and with CLS vectors that share a large common component every logit of a row
+        inherits the SAME dq.p term - B draws dominate max|dlogit| - while the query tower is ~1 % of the FLOPs and runs on a side
+        stream.  The backward needs bf16 operands, so with ``save`` the bf16 forward runs as well (it fills the tape; same dropout
+        masks: same seed) and only the returned CLS comes from the fp16 pass."""
+        fp16 = self.hp_forward if fp16 is None else fp16
+        if seed is None:
+            self.step_seed += 1
+            seed = (self.step_seed * 0x9E3779B1) & 0x7FFFFFFFFFFF
+        if fp16 and self.stream32 and self.hp_forward and input_ids.dim() == 2 and input_ids.shape[1] <= 128:
+            tape = None
+            if save:
+                _, tape = self._encode(input_ids, attention_mask, train=train, save=True, seed=seed, fp16=False)
+            cls = self._encode(input_ids, attention_mask, train=train, save=False, seed=seed, fp16=True)
+            return (cls, tape) if save else cls
+        return self._encode(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=False)
+
+    def _encode(self, input_ids, attention_mask, *, train, save, seed, fp16):
         cfg = self.cfg
         train = self.training if train is None else train
         if input_ids.dim() != 2:
@@ -450,9 +482,7 @@ class HipEncoder(nn.Module):
         T, d, f, H = M * L, cfg.dim, cfg.hidden_dim, cfg.n_heads
         p_h = cfg.dropout if train else 0.0
         p_a = cfg.attention_dropout if train else 0.0
-        if seed is None:
-            self.step_seed += 1
-            seed = (self.step_seed * 0x9E3779B1) & 0x7FFFFFFFFFFF
+        dt16 = torch.float16 if fp16 else torch.bfloat16         # 16-bit activation format of this pass
         tape = None
         if save:
             tape = _Tape()
@@ -461,7 +491,7 @@ class HipEncoder(nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         S32 = self.stream32
         sdt = torch.float32 if S32 else torch.bfloat16         # storage type of the pre-LN sums
-        x = self._buf(T, d, dev)
+        x = self._buf(T, d, dev, dt16)
         x32 = self._buf(T, d, dev, torch.float32) if S32 else None      # fp32 copy of the layer input: the residual operand
         mean0, rstd0 = torch.empty(T, **f32), torch.empty(T, **f32)
         type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
@@ -473,28 +503,28 @@ class HipEncoder(nn.Module):
         cls = torch.empty(M, d, **f32)
         p_out = p_h if cfg.arch == "bert" else 0.0          # DistilBERT has no dropout after out_lin
         for i in range(cfg.n_layers):
-            W = self._layer_weights(i)
+            W = self._layer_weights(i, fp16)
             s_l = seed + 7919 * (i + 1)
             if i == cfg.n_layers - 1 and self.cls_only_last:
-                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls)
+                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16)
                 break
-            qkv = self._buf(T, 3 * d, dev)
+            qkv = self._buf(T, 3 * d, dev, dt16)
             ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
-            ctx = self._buf(T, d, dev)
+            ctx = self._buf(T, d, dev, dt16)
             lse = torch.empty(M, H, L, **f32) if save else None
             ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1)
             s1 = self._buf(T, d, dev, sdt)
             ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out, seed=s_l + 2)
-            x1 = self._buf(T, d, dev)
+            x1 = self._buf(T, d, dev, dt16)
             x1_32 = self._buf(T, d, dev, torch.float32) if S32 else None
             mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if save else (None, None)
             ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps, out32=x1_32)
-            hbuf = self._buf(T, f, dev)
-            pre = self._buf(T, f, dev) if save else None
+            hbuf = self._buf(T, f, dev, dt16)
+            pre = self._buf(T, f, dev, dt16) if save else None
             ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=1)
             s2 = self._buf(T, d, dev, sdt)
             ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
-            xo = self._buf(T, d, dev)
+            xo = self._buf(T, d, dev, dt16)
             last = i == cfg.n_layers - 1
             xo32 = self._buf(T, d, dev, torch.float32) if (S32 and not last) else None
             mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if save else (None, None)
@@ -508,7 +538,7 @@ class HipEncoder(nn.Module):
         return (cls, tape) if save else cls
 
     # ------------------------------------------------------------------ last layer, CLS row only
-    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls):
+    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16=torch.bfloat16):
         """Only ``last_hidden_state[:, 0, :]`` is consumed (reference models/nway_dual_encoder.py:52,56,64), so the last
         layer projects K and V for every token but Q, attention, out-proj, FFN and both LayerNorms for token 0 only:
         identical CLS output, ~1/6 of the layer's FLOPs."""
@@ -516,33 +546,33 @@ class HipEncoder(nn.Module):
         d, f, H = cfg.dim, cfg.hidden_dim, cfg.n_heads
         dev = x.device
         f32 = dict(dtype=torch.float32, device=dev)
-        kv = self._buf(T, 2 * d, dev)
+        kv = self._buf(T, 2 * d, dev, dt16)
         ops.gemm_nt(x, W["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
         S32 = x32 is not None
         sdt = torch.float32 if S32 else torch.bfloat16
-        xc = self._buf(M, d, dev)
+        xc = self._buf(M, d, dev, dt16)
         xc[:M].copy_(x[:T].view(M, L, d)[:, 0, :])                 # gather the CLS rows (a copy, no arithmetic)
         xc32 = None
         if S32:
             xc32 = self._buf(M, d, dev, torch.float32)
             xc32[:M].copy_(x32[:T].view(M, L, d)[:, 0, :])
-        qc = self._buf(M, d, dev)
+        qc = self._buf(M, d, dev, dt16)
         ops.gemm_nt(xc, W["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
-        ctxc = self._buf(M, d, dev)
+        ctxc = self._buf(M, d, dev, dt16)
         probs = torch.empty(M, H, L, **f32)
         ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1)
         s1 = self._buf(M, d, dev, sdt)
         ops.gemm_nt(ctxc, W["Wo"], s1, M, bias=W["bo"], residual=xc32 if S32 else xc, dropout_p=p_out, seed=s_l + 2)
-        x1 = self._buf(M, d, dev)
+        x1 = self._buf(M, d, dev, dt16)
         x1_32 = self._buf(M, d, dev, torch.float32) if S32 else None
         mean1, rstd1 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
         ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, M, cfg.eps, out32=x1_32)
-        hbuf = self._buf(M, f, dev)
-        pre = self._buf(M, f, dev) if save else None
+        hbuf = self._buf(M, f, dev, dt16)
+        pre = self._buf(M, f, dev, dt16) if save else None
         ops.gemm_nt(x1, W["W1"], hbuf, M, bias=W["bf1"], preact=pre, act=1)
         s2 = self._buf(M, d, dev, sdt)
         ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
-        xo = self._buf(M, d, dev)
+        xo = self._buf(M, d, dev, dt16)
         mean2, rstd2 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
         ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, M, cfg.eps, cls, 1)
         if save:
@@ -755,8 +785,8 @@ class _EncodeFn(torch.autograd.Function):
     when the CLS gradient arrives; parameter gradients are accumulated straight into ``flat_g`` / ``param.grad``."""
 
     @staticmethod
-    def forward(ctx, anchor, enc, ids, mask):
-        cls, tape = enc.encode(ids, mask, save=True)
+    def forward(ctx, anchor, enc, ids, mask, fp16):
+        cls, tape = enc.encode(ids, mask, save=True, fp16=fp16)
         ctx.enc, ctx.tape = enc, tape
         return cls
 
@@ -764,12 +794,12 @@ class _EncodeFn(torch.autograd.Function):
     def backward(ctx, dcls):
         ctx.enc.backward_from_cls(ctx.tape, dcls.contiguous().float(), check_grads=True)
         ctx.tape = None
-        return None, None, None, None
+        return None, None, None, None, None
 
 
-def encode_autograd(enc: HipEncoder, ids, mask):
+def encode_autograd(enc: HipEncoder, ids, mask, fp16=None):
     if torch.is_grad_enabled() and any(p.requires_grad for p in enc.parameters()):
         if getattr(enc, "_anchor", None) is None or enc._anchor.device != enc.flat_p.device:
             enc._anchor = torch.zeros(1, device=enc.flat_p.device, requires_grad=True)
-        return _EncodeFn.apply(enc._anchor, enc, ids, mask)
-    return enc.encode(ids, mask, save=False)
+        return _EncodeFn.apply(enc._anchor, enc, ids, mask, fp16)
+    return enc.encode(ids, mask, save=False, fp16=fp16)

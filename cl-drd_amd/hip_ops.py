@@ -13,6 +13,14 @@ from ._lib import call
 
 BF16 = torch.bfloat16
 F32 = torch.float32
+F16 = torch.float16
+
+
+def _fmt16(t, name):
+    """16-bit activation format of a forward operand: bf16 (default) or fp16 (high-precision forward of the query tower)."""
+    if t.dtype not in (BF16, F16):
+        raise TypeError(f"{name}: expected bf16 or fp16, got {t.dtype}")
+    return 1 if t.dtype == F16 else 0
 
 
 def _stream():
@@ -45,15 +53,17 @@ def pad_rows(rows: int) -> int:
 
 def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pre=None, act=0, alpha=1.0,
             dropout_p=0.0, seed=0):
-    """out[M,N] = epilogue(alpha * A[M,K] @ B[N,K]^T); A, B bf16; out bf16 or fp32."""
-    _chk(A, BF16, "A", 2), _chk(B, BF16, "B", 2)
+    """out[M,N] = epilogue(alpha * A[M,K] @ B[N,K]^T); A, B bf16 (or both fp16: forward flavours, M < 1024); out 16-bit like A, or fp32."""
+    io_f16 = _fmt16(A, "A")
+    dt16 = F16 if io_f16 else BF16
+    _chk(A, dt16, "A", 2), _chk(B, dt16, "B", 2)
     M = A.shape[0] if M is None else M
     N, K = B.shape
     if A.shape[1] != K or out.shape[1] != N or out.shape[0] < M or A.shape[0] < M:
         raise ValueError(f"gemm_nt: shape mismatch A{tuple(A.shape)} B{tuple(B.shape)} out{tuple(out.shape)} M={M}")
     out_f32 = 1 if out.dtype == F32 else 0
     if not out_f32:
-        _chk(out, BF16, "out", 2)
+        _chk(out, dt16, "out", 2)
     if bias is not None:
         _chk(bias, F32, "bias", 1)
     for t, n in ((preact, "preact"), (gelu_pre, "gelu_pre")):
@@ -67,7 +77,7 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
             raise ValueError("gemm_nt: residual must be [>= M, N]")
     call("cldrd_gemm_nt_bf16", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
          _p(residual), residual.stride(0) if residual is not None else 0, _p(preact), _p(gelu_pre), act, alpha,
-         dropout_p, seed, out_f32, res_f32, _stream())
+         dropout_p, seed, out_f32, res_f32, io_f16, _stream())
     return out
 
 
@@ -130,7 +140,8 @@ class WgradQueue:
 
 
 def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0):
-    _chk(qkv, BF16, "qkv", 2), _chk(ctx, BF16, "ctx", 2)
+    io_f16 = _fmt16(qkv, "qkv")
+    _chk(qkv, F16 if io_f16 else BF16, "qkv", 2), _chk(ctx, F16 if io_f16 else BF16, "ctx", 2)
     if mask is not None:
         _chk(mask, torch.int64, "mask", 2)
         if not mask.is_contiguous() or tuple(mask.shape) != (nseq, L):
@@ -139,7 +150,7 @@ def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0):
         raise ValueError("attention: qkv must be [T, 3*H*64], ctx [T, H*64], contiguous")
     if lse is not None:
         _chk(lse, F32, "lse")
-    call("cldrd_attention_fwd", _p(qkv), _p(mask), _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, _stream())
+    call("cldrd_attention_fwd", _p(qkv), _p(mask), _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _stream())
     return ctx
 
 
@@ -155,10 +166,12 @@ def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, se
 
 
 def attention_cls_fwd(qc, kv, mask, ctx, probs, nseq, L, H, dropout_p=0.0, seed=0):
-    _chk(qc, BF16, "qc", 2), _chk(kv, BF16, "kv", 2), _chk(ctx, BF16, "ctx", 2), _chk(probs, F32, "probs")
+    io_f16 = _fmt16(qc, "qc")
+    dt16 = F16 if io_f16 else BF16
+    _chk(qc, dt16, "qc", 2), _chk(kv, dt16, "kv", 2), _chk(ctx, dt16, "ctx", 2), _chk(probs, F32, "probs")
     if kv.shape[1] != 2 * H * 64 or not kv.is_contiguous() or not qc.is_contiguous() or not ctx.is_contiguous():
         raise ValueError("attention_cls: kv must be contiguous [T, 2*H*64]")
-    call("cldrd_attention_cls_fwd", _p(qc), _p(kv), _p(mask), _p(ctx), _p(probs), nseq, L, H, dropout_p, seed, _stream())
+    call("cldrd_attention_cls_fwd", _p(qc), _p(kv), _p(mask), _p(ctx), _p(probs), nseq, L, H, dropout_p, seed, io_f16, _stream())
 
 
 def attention_cls_bwd(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p=0.0, seed=0):
@@ -184,7 +197,7 @@ def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps,
     if out32 is not None:
         _chk(out32, F32, "out32", 2)
     call("cldrd_embed_ln_fwd", _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd),
-         T, L, d, word.shape[0], eps, dropout_p, seed, _p(out32), _stream())
+         T, L, d, word.shape[0], eps, dropout_p, seed, _p(out32), _fmt16(out, "out"), _stream())
     return out
 
 
@@ -199,12 +212,13 @@ def embed_ln_bwd(dy, ids, word, pos, type0, gamma, mean, rstd, dword, dpos, dtyp
 def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_stride=0, out32=None):
     """x bf16, or fp32 (pre-LN sum of the fp32 residual stream; then out32, optional, receives the fp32 output as well)."""
     x_f32 = 1 if x.dtype == F32 else 0
-    _chk(x, F32 if x_f32 else BF16, "x", 2), _chk(out, BF16, "out", 2), _chk(gamma, F32, "gamma", 1), _chk(beta, F32, "beta", 1)
+    out_f16 = _fmt16(out, "out")
+    _chk(x, F32 if x_f32 else BF16, "x", 2), _chk(out, F16 if out_f16 else BF16, "out", 2), _chk(gamma, F32, "gamma", 1), _chk(beta, F32, "beta", 1)
     if out32 is not None:
         _chk(out32, F32, "out32", 2)
     d = x.shape[1]
     call("cldrd_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), T, d, eps, _p(cls_out),
-         cls_stride, x_f32, _p(out32), _stream())
+         cls_stride, x_f32, _p(out32), out_f16, _stream())
     return out
 
 
@@ -330,8 +344,6 @@ def transpose_bf16_batched(src, dst, desc, tile_prefix, ndesc, total_tiles):
 
 
 # ---------------------------------------------------------------------------------------------------- top-k search
-F16 = torch.float16
-
 
 def topk_scan_filter(Q, P, thr, counts, cand_rows, cand_scores, tiled=False):
     """Q, P: both fp16 or both bf16 (the MFMA type follows)."""

@@ -52,6 +52,12 @@ class NwayDualEncoder(nn.Module):
             self.passage_encoder = self.query_encoder
         else:
             self.passage_encoder = HipEncoder.from_pretrained(model_name_or_path)
+        # The query side runs its FORWARD with fp16 MFMA operands (HipEncoder.encode: 8x finer operand rounding at no cost - the
+        # query tower is ~1 % of the FLOPs - and it removes the dq.p term that every logit of a row shares).  CLDRD_QUERY_FP16=0
+        # keeps it in bf16.  With shared weights the one tower keeps an fp16 shadow too and only query calls use it.
+        import os
+        self.query_fp16 = os.environ.get("CLDRD_QUERY_FP16", "1") != "0"
+        self.query_encoder.hp_forward = self.query_fp16
 
     # -- reference call surface -------------------------------------------------------------------------------
     def forward(self, queries, nway_passages):
@@ -64,16 +70,16 @@ class NwayDualEncoder(nn.Module):
         return _ScoreFn.apply(query_reps, nway_passage_reps.reshape(bz * nway, D), bz, nway, mode)
 
     def query_embs(self, queries):
-        return encode_autograd(self.query_encoder, queries["input_ids"], queries.get("attention_mask"))
+        return encode_autograd(self.query_encoder, queries["input_ids"], queries.get("attention_mask"), fp16=self.query_fp16)
 
     def passage_embs(self, passages):
-        return encode_autograd(self.passage_encoder, passages["input_ids"], passages.get("attention_mask"))
+        return encode_autograd(self.passage_encoder, passages["input_ids"], passages.get("attention_mask"), fp16=False)
 
     def nway_passage_embs(self, nway_passages):
         input_ids, attention_mask = nway_passages["input_ids"], nway_passages["attention_mask"]
         bz, nway, seq_len = input_ids.shape
         input_ids, attention_mask = input_ids.reshape(bz * nway, seq_len), attention_mask.reshape(bz * nway, seq_len)
-        passage_reps = encode_autograd(self.passage_encoder, input_ids, attention_mask)
+        passage_reps = encode_autograd(self.passage_encoder, input_ids, attention_mask, fp16=False)
         return passage_reps.view(bz, nway, -1)
 
     # -- MI355X-specific ----------------------------------------------------------------------------------------

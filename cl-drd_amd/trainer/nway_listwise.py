@@ -171,9 +171,9 @@ class NwayTrainer:
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
-            q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True)
+            q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True, fp16=model.query_fp16)
         p_cls, p_tape = pe.encode(nw["input_ids"].reshape(bz * nway, L), nw["attention_mask"].reshape(bz * nway, L),
-                                  train=True, save=True)
+                                  train=True, save=True, fp16=False)
         if side is not main:
             main.wait_stream(side)
             q_cls.record_stream(main)

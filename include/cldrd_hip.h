@@ -36,10 +36,14 @@ int cldrd_device_ok(void);            /* 1 if device 0 is a gfx950 */
  *   epilogue order: + bias[N] -> (store preact) -> act (1 = erf-GELU) -> * gelu'(gelu_pre) -> dropout -> + residual
  *   K % 64 == 0; A/B/C 16-byte aligned; out_f32 != 0 stores fp32 instead of bf16; res_f32 != 0: `residual` is fp32
  *   (the fp32 residual stream: out-projection / FFN2 add the fp32 LayerNorm output and store the fp32 pre-LN sum, as the
- *   reference's autocast does - trainer/multistep-curriculum/nway_listwise_1.py:334). */
+ *   reference's autocast does - trainer/multistep-curriculum/nway_listwise_1.py:334).
+ *   io_f16 != 0: A, B and a 16-bit C are fp16 instead of bf16 (same MFMA rate, 11-bit significands): the forward kernels
+ *   (this one for M < 1024, attention_fwd for L <= 128, attention_cls_fwd, layernorm_fwd, embed_ln_fwd) take this format for the
+ *   high-precision forward of the query tower; the backward entry points are bf16 only. */
 int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                        const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
-                       int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, void* stream);
+                       int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int io_f16,
+                       void* stream);
 
 /* Weight gradient dW[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (A = dY, B = layer input; autograd's Linear backward), and,
  * when dbias != NULL, the bias gradient dbias[N1] (+)= column sums of A in the same pass.
@@ -61,7 +65,7 @@ int cldrd_wgrad_group(const void* const* A, const void* const* B, float* const* 
  * qkv: bf16 [nseq*L, 3*H*64] = Q | K | V;  mask: int64 [nseq, L], 0 = padded key, or NULL;
  * ctx: bf16 [nseq*L, H*64];  lse: fp32 [nseq, H, L] (NULL allowed in forward-only use). */
 int cldrd_attention_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
-                        float dropout_p, unsigned long long seed, void* stream);
+                        float dropout_p, unsigned long long seed, int io_f16, void* stream);
 int cldrd_attention_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                         void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
 
@@ -70,7 +74,7 @@ int cldrd_attention_bwd(const void* qkv, const long long* mask, const void* ctx,
  * probs: fp32 [nseq, H, L] (softmax row, saved for the backward); dkv: bf16 [nseq*L, 2*H*64] (every row written).
  * cldrd_add_rows_strided: dst[m * stride_rows] += src[m] for bf16 rows of d elements (puts the CLS-row gradients back). */
 int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L,
-                            int H, float dropout_p, unsigned long long seed, void* stream);
+                            int H, float dropout_p, unsigned long long seed, int io_f16, void* stream);
 int cldrd_attention_cls_bwd(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
                             int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
 int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, void* stream);
@@ -80,7 +84,7 @@ int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_
 int cldrd_ln_partial_blocks(int T);
 int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
-                       int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, void* stream);
+                       int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, int out_f16, void* stream);
 int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
                        float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,
@@ -90,7 +94,7 @@ int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, 
  * x_f32 != 0: x is fp32 (the pre-LN sum of the fp32 residual stream) and out32 (optional) receives the fp32 output next to
  * the bf16 copy the GEMMs read; cldrd_embed_ln_fwd has the same optional out32. */
 int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
-                        int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, void* stream);
+                        int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, int out_f16, void* stream);
 /* dx = LN backward of dy; dx_dropped (optional) = dropout-masked dx for the branch that passed through dropout;
  * dgamma/dbeta/dbias (each optional) receive sum(dy*xhat), sum(dy), sum(dx_dropped or dx). */
 int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,

@@ -544,3 +544,57 @@ def test_transpose_bf16_batched_matches_torch():
     for r, c in shapes:
         assert torch.equal(dst[off:off + r * c].view(c, r), src[off:off + r * c].view(r, c).T), (r, c)
         off += r * c
+
+
+# ------------------------------------------------------------------------------------------------ fp16 forward format
+def test_forward_kernels_in_the_fp16_format():
+    """The high-precision forward of the query tower runs the same kernels on fp16 operands (encoder.py): small-M GEMM with the
+    forward epilogues, attention (all-scores-in-registers kernel and the CLS-only one), LayerNorm / embedding outputs.  fp16 keeps
+    11 significant bits: the tolerances are 8x tighter than for the bf16 format."""
+    M, N, K = 240, 768, 768
+    A, B = rnd(41, (M, K)).half(), rnd(42, (N, K), 0.05).half()
+    bias, res32 = rnd(43, (N,)), rnd(44, (M, N))
+    ref = A.double() @ B.double().T + bias.double()
+    out = torch.empty(M, N, dtype=torch.float16, device=DEV)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV))
+    close(out, ref, 1.0 / 1024, 1e-3, "fp16 gemm + bias")
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), act=1)
+    close(out, torch.nn.functional.gelu(ref), 1.0 / 1024, 1e-3, "fp16 gemm + bias + gelu")
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out32, bias=bias.to(DEV), residual=res32.to(DEV))
+    close(out32, ref + res32.double(), 1e-4, 2e-4 * math.sqrt(K), "fp16 gemm + bias + fp32 residual -> fp32")
+    with pytest.raises(Exception):      # no tape in this format: the backward runs on the bf16 pass
+        ops.gemm_nt(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), preact=torch.empty_like(out), act=1)
+    # attention
+    for nseq, L, H in ((3, 30, 2), (2, 128, 3)):
+        d, T = H * 64, nseq * L
+        qkv = rnd(45, (T, 3 * d)).half()
+        lens = np.clip(syn.msmarco_lengths(46, nseq, L), 2, L)
+        mask = torch.from_numpy((np.arange(L)[None, :] < lens[:, None]).astype(np.int64))
+        ref_ctx, ref_lse = attn_ref(qkv.double(), mask, nseq, L, H)
+        ctx = torch.empty(T, d, dtype=torch.float16, device=DEV)
+        lse = torch.empty(nseq, H, L, dtype=torch.float32, device=DEV)
+        ops.attention_fwd(qkv.to(DEV), mask.to(DEV), ctx, lse, nseq, L, H)
+        close(ctx, ref_ctx, 1 / 512, 3e-3, f"fp16 attention L={L}")
+        close(lse, ref_lse, 1e-4, 1e-3, "fp16 attention lse")
+        # CLS-only form: queries of token 0 against K | V of every token
+        kv = qkv[:, d:].contiguous()
+        qc = qkv.view(nseq, L, 3 * d)[:, 0, :d].contiguous()
+        ctxc = torch.empty(nseq, d, dtype=torch.float16, device=DEV)
+        probs = torch.empty(nseq, H, L, dtype=torch.float32, device=DEV)
+        ops.attention_cls_fwd(qc.to(DEV), kv.to(DEV), mask.to(DEV), ctxc, probs, nseq, L, H)
+        close(ctxc, ref_ctx.view(nseq, L, d)[:, 0], 1 / 1024, 2e-3, f"fp16 CLS attention L={L}")
+    with pytest.raises(Exception):
+        ops.attention_fwd(torch.zeros(256, 192, dtype=torch.float16, device=DEV), None, torch.zeros(256, 64, dtype=torch.float16, device=DEV), None, 1, 256, 1)
+    # LayerNorm: fp32 sum in, fp16 + fp32 out
+    T, d = 77, 768
+    x = rnd(47, (T, d), 2.0)
+    g_, b_ = 1.0 + rnd(48, (d,), 0.1), rnd(49, (d,), 0.1)
+    ref_ln = torch.nn.functional.layer_norm(x.double(), (d,), g_.double(), b_.double(), 1e-12)
+    o16 = torch.empty(ops.pad_rows(T), d, dtype=torch.float16, device=DEV)
+    o32 = torch.empty(ops.pad_rows(T), d, dtype=torch.float32, device=DEV)
+    xs = torch.zeros(ops.pad_rows(T), d)
+    xs[:T] = x
+    ops.layernorm_fwd(xs.to(DEV), g_.to(DEV), b_.to(DEV), o16, None, None, T, 1e-12, out32=o32)
+    close(o16[:T], ref_ln, 1 / 1024, 1e-3, "LayerNorm fp16 out")
+    close(o32[:T], ref_ln, 1e-5, 1e-5, "LayerNorm fp32 out")
