@@ -11,28 +11,9 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .. import hip_ops as ops
+from .. import hip_ops as ops  # noqa: F401
+from .. import torch_ops  # noqa: F401  (registers torch.ops.cldrd.*)
 from ..encoder import HipEncoder, encode_autograd
-
-
-class _ScoreFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, q, p, B, N, mode):
-        q, p = q.contiguous(), p.contiguous()
-        Np = N if mode == 0 else (B * N if mode == 1 else 2 * N)
-        logits = torch.empty(B, Np, dtype=torch.float32, device=q.device)
-        ops.score_fwd(q, p, logits, B, N, mode)
-        ctx.save_for_backward(q, p)
-        ctx.dims = (B, N, mode)
-        return logits
-
-    @staticmethod
-    def backward(ctx, dlogits):
-        q, p = ctx.saved_tensors
-        B, N, mode = ctx.dims
-        dq, dp = torch.empty_like(q), torch.empty_like(p)
-        ops.score_bwd(dlogits.contiguous().float(), q, p, dq, dp, B, N, mode)
-        return dq, dp, None, None, None
 
 
 def score_mode(in_batch_loss: bool, all_in_batch_neg: bool) -> int:
@@ -67,7 +48,7 @@ class NwayDualEncoder(nn.Module):
         assert query_reps.dim() == 2 and nway_passage_reps.dim() == 3
         bz, nway, D = nway_passage_reps.shape
         mode = score_mode(self.in_batch_loss, self.all_in_batch_neg)
-        return _ScoreFn.apply(query_reps, nway_passage_reps.reshape(bz * nway, D), bz, nway, mode)
+        return torch.ops.cldrd.nway_score(query_reps, nway_passage_reps.reshape(bz * nway, D), bz, nway, mode)
 
     def query_embs(self, queries):
         return encode_autograd(self.query_encoder, queries["input_ids"], queries.get("attention_mask"), fp16=self.query_fp16)

@@ -103,3 +103,25 @@ def test_lr_schedule_matches_golden():
         warm, total = int(g[name + "/warmup"]), int(g[name + "/total"])
         for s, f in zip(g[name + "/steps"], g[name + "/factor"]):
             assert linear_schedule_factor(int(s), warm, total) == pytest.approx(float(f), abs=1e-12)
+
+
+def test_torch_library_ops_are_registered_with_fake_kernels():
+    """torch.ops.cldrd.* (cl-drd_amd/torch_ops.py): every op is known to the dispatcher, has a schema and a fake (meta) kernel so
+    shapes can be inferred without a GPU; a CPU tensor finds no kernel (no CPU fallback)."""
+    import cldrd_amd.torch_ops as T
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    for name in T.OPS:
+        assert hasattr(torch.ops.cldrd, name), name
+        assert "cldrd::" + name in str(getattr(torch.ops.cldrd, name).default._schema)
+    with FakeTensorMode():
+        q, p = torch.empty(4, 768), torch.empty(32, 768)
+        assert torch.ops.cldrd.nway_score(q, p, 4, 8, 0).shape == (4, 8)
+        assert torch.ops.cldrd.nway_score(q, p, 4, 8, 1).shape == (4, 32)
+        assert torch.ops.cldrd.nway_score(q, p, 4, 8, 2).shape == (4, 16)
+        out, grad = torch.ops.cldrd.listwise_loss(torch.empty(4, 8), torch.empty(4, 8), 0, None, 1.0, -1.0, True)
+        assert out.shape == (2,) and grad.shape == (4, 8)
+        y = torch.ops.cldrd.linear(torch.empty(64, 128, dtype=torch.bfloat16), torch.empty(256, 128, dtype=torch.bfloat16), None, None, True, False)
+        assert y.shape == (64, 256) and y.dtype == torch.bfloat16
+        assert torch.ops.cldrd.self_attention(torch.empty(60, 384, dtype=torch.bfloat16), None, 2, 30, 2).shape == (60, 128)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.cldrd.nway_score(torch.zeros(2, 8), torch.zeros(4, 8), 2, 2, 0)

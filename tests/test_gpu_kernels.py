@@ -598,3 +598,33 @@ def test_forward_kernels_in_the_fp16_format():
     ops.layernorm_fwd(xs.to(DEV), g_.to(DEV), b_.to(DEV), o16, None, None, T, 1e-12, out32=o32)
     close(o16[:T], ref_ln, 1 / 1024, 1e-3, "LayerNorm fp16 out")
     close(o32[:T], ref_ln, 1e-5, 1e-5, "LayerNorm fp32 out")
+
+
+def test_torch_library_ops_on_the_gpu():
+    """torch.ops.cldrd.* run the HIP kernels, carry autograd formulas, and pass torch.library.opcheck (schema, fake kernel,
+    autograd registration consistent with the real kernel)."""
+    import cldrd_amd.torch_ops  # noqa: F401
+    q = torch.randn(4, 768, device=DEV, requires_grad=True)
+    p = torch.randn(32, 768, device=DEV, requires_grad=True)
+    for mode in (0, 1, 2):
+        logits = torch.ops.cldrd.nway_score(q, p, 4, 8, mode)
+        ref = (q.detach().double() @ p.detach().double().T)
+        if mode == 0:
+            ref = torch.stack([ref[b, b * 8:(b + 1) * 8] for b in range(4)])
+            close(logits, ref, 1e-5, 1e-4, "nway_score")
+        logits.sum().backward()
+    torch.library.opcheck(torch.ops.cldrd.nway_score, (q.detach(), p.detach(), 4, 8, 0), test_utils=("test_schema", "test_faketensor"))
+    yp = torch.randn(4, 8, device=DEV, requires_grad=True)
+    yt = torch.randn(4, 8, device=DEV)
+    out, grad = torch.ops.cldrd.listwise_loss(yp, yt, 1, None, 1.0, -1.0, True)
+    out[0].backward()
+    assert torch.allclose(yp.grad, grad)
+    torch.library.opcheck(torch.ops.cldrd.listwise_loss, (yp.detach(), yt, 1, None, 1.0, -1.0, True), test_utils=("test_schema", "test_faketensor"))
+    x = torch.randn(64, 128, device=DEV).bfloat16()
+    w = torch.randn(256, 128, device=DEV).bfloat16()
+    y = torch.ops.cldrd.linear(x, w, None, None, False, True)
+    close(y, x.double() @ w.double().T, 1e-4, 1e-3, "cldrd::linear")
+    ln = torch.ops.cldrd.layer_norm(y, torch.ones(256, device=DEV), torch.zeros(256, device=DEV), 1e-12)
+    close(ln, torch.nn.functional.layer_norm(y.double(), (256,)), 1 / 128, 1e-2, "cldrd::layer_norm")
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        torch.ops.cldrd.nway_score(q.detach().cpu(), p.detach().cpu(), 4, 8, 0)
