@@ -270,6 +270,8 @@ int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st) {
     return a.in_f16 ? launch_ring_epi<128, EPI_FILTER | EPI_F16IN>(a, st) : launch_ring_epi<128, EPI_FILTER>(a, st);
 }
 
+int cldrd_gemm_nt_pers_dispatch(const GemmNtArgs& a, int bn, hipStream_t st);    // gemm_nt_pers.hip
+
 // Returns -1 if this variant does not apply (caller falls back to the 128x128 kernel), else the launch status.
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_t st) {
     GemmNtArgs a = a_in;
@@ -302,6 +304,15 @@ int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_
     // group pass would re-read the A panels - PMC: 436 MB instead of 293 MB for N = 768, K = 2304 / 3072)
     a.gn = gn_force >= 0 ? gn_force : (a.K <= 1024 ? (int)(2.0e6 / ((double)bn * a.K * 2.0) + 0.5) : 0);
     if (a.gn < 0) a.gn = 0;
+    // Persistent form (gemm_nt_pers.hip: one workgroup per CU walks its tiles, register epilogue, stores left in flight), opt-in with
+    // CLDRD_GEMM_PERSIST=1: measured equal to this kernel within 1 % on the encoder shapes and in the training step
+    // (profiles/r02_microbench.txt) - the K loop sits at the CU's L2 -> LDS rate either way and the epilogues that hurt are VALU-
+    // bound (GELU) or HBM-bound (fp32 residual stream), which a tile walk does not change.  Read per call: tests flip it in-process.
+    const char* pe = getenv("CLDRD_GEMM_PERSIST");
+    if (pe && atoi(pe) != 0) {
+        const int rc = cldrd_gemm_nt_pers_dispatch(a, bn, st);
+        if (rc >= 0) return rc;
+    }
     if (bn == 256 && a.N % 256 == 0) return launch_ring<256>(a, st);
     if (bn == 192 && a.N % 192 == 0) return launch_ring<192>(a, st);
     return -1;

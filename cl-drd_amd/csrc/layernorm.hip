@@ -42,6 +42,23 @@ __device__ __forceinline__ void load_row_f32(const float* row, int d, int lane, 
         }
     }
 }
+// INTERLEAVED column map for kernels that scatter a row with float atomics: element (it, j) of a lane is column
+// it*256 + j*64 + lane, so one wave-instruction touches 64 consecutive floats = 256 contiguous bytes.  With the vector map above
+// (4 consecutive columns per lane) an atomic instruction spreads its 64 dwords over 1 KiB - four times the 64-B requests at the
+// memory side, where float atomics execute (MI355X_MICROARCH.md, Global float atomics): the embedding backward ran 380 us, not 130.
+__device__ __forceinline__ int icol(int it, int j, int lane) { return it * 256 + j * 64 + lane; }
+__device__ __forceinline__ void load_row_bf16_i(const bf16_t* row, int d, int lane, RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int c = icol(it, j, lane); r.v[it][j] = c < d ? bf2f(row[c]) : 0.f; }
+}
+__device__ __forceinline__ void load_row_f32_i(const float* row, int d, int lane, RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int c = icol(it, j, lane); r.v[it][j] = c < d ? row[c] : 0.f; }
+}
 __device__ __forceinline__ void store_row_bf16(bf16_t* row, int d, int lane, const RowF& r) {
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
@@ -183,6 +200,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
 // Binary tree over the waves through LDS with plain 16-byte stores / loads (fixed order: bitwise reproducible; LDS float
 // atomics from 8 waves onto the same 3*d addresses cost more than the row streaming itself).
 // LDS: (waves / 2) * 3 * MAX_IT * 64 float4 = 6 KiB per wave pair.
+template <bool INTERLEAVED = false>
 __device__ __forceinline__ void block_partials(float* smem, RowF& a, RowF& b, RowF& c3, int d, int lane, float* __restrict__ partial) {
     const int w = threadIdx.x >> 6;
     float4* s4 = (float4*)smem;
@@ -212,9 +230,17 @@ __device__ __forceinline__ void block_partials(float* smem, RowF& a, RowF& b, Ro
         for (int k = 0; k < 3; ++k)
 #pragma unroll
             for (int it = 0; it < MAX_IT; ++it) {
-                const int c = it * 256 + lane * 4;
-                if (c < d)
-                    *(float4*)(partial + (size_t)blockIdx.x * 3 * d + k * d + c) = make_float4(acc[k]->v[it][0], acc[k]->v[it][1], acc[k]->v[it][2], acc[k]->v[it][3]);
+                if (INTERLEAVED) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = icol(it, j, lane);
+                        if (c < d) partial[(size_t)blockIdx.x * 3 * d + k * d + c] = acc[k]->v[it][j];
+                    }
+                } else {
+                    const int c = it * 256 + lane * 4;
+                    if (c < d)
+                        *(float4*)(partial + (size_t)blockIdx.x * 3 * d + k * d + c) = make_float4(acc[k]->v[it][0], acc[k]->v[it][1], acc[k]->v[it][2], acc[k]->v[it][3]);
+                }
             }
     }
 }
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const int l = row % L;
         RowF g, xr, p;
-        load_row_bf16(dy + (size_t)row * d, d, lane, g);
+        load_row_bf16_i(dy + (size_t)row * d, d, lane, g);
         {   // a row whose incoming gradient is exactly zero (padded positions: nothing attends to them) contributes exactly
             // zero to every sum below: skip it, and with it the atomics of all pad tokens onto the one [PAD] table row
             float amax = 0.f;
@@ -322,14 +348,14 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
                 for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(g.v[it][j]));
             if (wave_max(amax) == 0.f) continue;
         }
-        load_row_f32(word + (size_t)id * d, d, lane, xr);
-        load_row_f32(pos + (size_t)l * d, d, lane, p);
+        load_row_f32_i(word + (size_t)id * d, d, lane, xr);
+        load_row_f32_i(pos + (size_t)l * d, d, lane, p);
 #pragma unroll
         for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
             for (int j = 0; j < 4; ++j) xr.v[it][j] += p.v[it][j];
         if (type0) {
-            load_row_f32(type0, d, lane, p);
+            load_row_f32_i(type0, d, lane, p);
 #pragma unroll
             for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
@@ -339,53 +365,46 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
         const uint32_t rk = drop_rowkey(seed, (uint32_t)row);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int it = 0; it < MAX_IT; ++it) {
-            const int c = it * 256 + lane * 4;
-            if (c < d) {
-                const float4 gm = *(const float4*)(gamma + c);
-                const float gg[4] = {gm.x, gm.y, gm.z, gm.w};
-                const uint32_t h0 = drop_pair(rk, c), h1 = drop_pair(rk, c + 2);
-                const bool keep[4] = {drop_keep_lo(h0, drop_thresh), drop_keep_hi(h0, drop_thresh), drop_keep_lo(h1, drop_thresh), drop_keep_hi(h1, drop_thresh)};
+        for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {
+                const int c = icol(it, j, lane);
+                if (c < d) {
                     float dyv = g.v[it][j];
-                    if (DROP) dyv = keep[j] ? dyv * drop_scale : 0.f;
+                    if (DROP) dyv = dropout_keep(rk, (uint32_t)c, drop_thresh) ? dyv * drop_scale : 0.f;
                     const float xh = (xr.v[it][j] - mean) * rstd;
                     dg.v[it][j] += dyv * xh; db.v[it][j] += dyv;
-                    const float t = dyv * gg[j];
+                    const float t = dyv * gamma[c];
                     s1 += t; s2 += t * xh;
                     xr.v[it][j] = xh; g.v[it][j] = t;
                 }
             }
-        }
         s1 = wave_sum(s1) / (float)d; s2 = wave_sum(s2) / (float)d;
 #pragma unroll
-        for (int it = 0; it < MAX_IT; ++it) {
-            const int c = it * 256 + lane * 4;
-            if (c < d) {
+        for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 4; ++j) {
+                const int c = icol(it, j, lane);
+                if (c < d) {
                     const float v = rstd * (g.v[it][j] - s1 - xr.v[it][j] * s2);
                     dt.v[it][j] += v;
-                    atomicAdd(dword + (size_t)id * d + c + j, v);
+                    atomicAdd(dword + (size_t)id * d + c, v);          // 64 lanes x 4 B contiguous per instruction
                     if (pos_uniform) dp.v[it][j] += v;
-                    else atomicAdd(dpos + (size_t)l * d + c + j, v);
+                    else atomicAdd(dpos + (size_t)l * d + c, v);
                 }
             }
-        }
     }
     if (pos_uniform) {
         const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) % L;
 #pragma unroll
-        for (int it = 0; it < MAX_IT; ++it) {
-            const int c = it * 256 + lane * 4;
-            if (c < d) {
+        for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) atomicAdd(dpos + (size_t)l * d + c + j, dp.v[it][j]);
+            for (int j = 0; j < 4; ++j) {
+                const int c = icol(it, j, lane);
+                if (c < d) atomicAdd(dpos + (size_t)l * d + c, dp.v[it][j]);
             }
-        }
     }
-    block_partials(lsm, dg, db, dt, d, lane, partial);
+    block_partials<true>(lsm, dg, db, dt, d, lane, partial);
 }
 
 // out[c] (+)= sum_b partial[b][c].  Block = 64 columns x 16 row groups (coalesced 256-B row reads, 16 short load chains

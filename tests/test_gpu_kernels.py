@@ -102,6 +102,99 @@ def test_gemm_nt_dropout_is_deterministic_and_unbiased():
     assert not torch.equal(out1, out2)
 
 
+# The persistent large-M kernel (gemm_nt_pers.hip): every compiled epilogue flavour, BN = 192 and 256, more tiles than CUs (a
+# workgroup walks 2-3 tiles: next-tile DMA issued before the epilogue, stores left in flight under a counted vmcnt), a partial
+# last M tile (predicated epilogue + drain), against torch fp32 on the same bf16 inputs; the one-tile-per-workgroup ring kernel
+# (CLDRD_GEMM_PERSIST=0) must give the same bits for 16-bit outputs.
+_PERS_FLAVOURS = ["plain", "bias", "bias_gelu_pre", "bias_gelu", "bias_res16", "bias_drop_res16", "gelugrad", "res16", "f32",
+                  "bias_res32_f32", "bias_drop_res32_f32"]
+
+
+@pytest.mark.parametrize("M,N,K", [(16640, 768, 256), (20000, 1024, 192), (9000, 2304, 128)])
+@pytest.mark.parametrize("flavour", _PERS_FLAVOURS)
+def test_gemm_nt_persistent_flavours(flavour, M, N, K):
+    import oracle.dropout_ref as DRo
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
+    B = (torch.randn(N, K, device=DEV, generator=g) * 0.5).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    res16 = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    res32 = torch.randn(M, N, device=DEV, generator=g)
+    gp = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    base = A.float() @ B.float().T
+    p_drop, seed = 0.1, (5 << 32) | 77
+    kw, ref, out_dtype = {}, base, torch.bfloat16
+    if flavour in ("f32", "bias_res32_f32", "bias_drop_res32_f32"):
+        out_dtype = torch.float32
+    if flavour.startswith("bias"):
+        kw["bias"] = bias
+        ref = ref + bias
+    pre = None
+    if flavour == "bias_gelu_pre":
+        pre = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        kw.update(preact=pre, act=1)
+    if flavour == "bias_gelu":
+        kw.update(act=1)
+    if "gelu" in flavour and flavour != "gelugrad":
+        pre_ref = ref
+        ref = torch.nn.functional.gelu(ref)
+    if flavour == "gelugrad":
+        x = gp.float()
+        ref = ref * (0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi))
+        kw["gelu_pre"] = gp
+    if "drop" in flavour:
+        keep = torch.from_numpy(DRo.keep_mask(seed, p_drop, M, N)).to(DEV)
+        ref = torch.where(keep, ref / (1 - p_drop), torch.zeros((), device=DEV))
+        kw.update(dropout_p=p_drop, seed=seed)
+    if "res16" in flavour:
+        kw["residual"] = res16
+        ref = ref + res16.float()
+    if "res32" in flavour:
+        kw["residual"] = res32
+        ref = ref + res32
+    out = torch.full((M + 8, N), float("nan"), dtype=out_dtype, device=DEV)
+    os.environ["CLDRD_GEMM_PERSIST"] = "1"
+    try:
+        ops.gemm_nt(A, B, out, M, **kw)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("CLDRD_GEMM_PERSIST", None)
+    assert torch.isnan(out[M:].float()).all(), "rows past M were written"
+    if out_dtype == torch.float32:
+        close(out[:M], ref, 2e-5, 2e-4 * math.sqrt(K), flavour)
+    else:
+        close(out[:M], ref, 1 / 128, 2e-2, flavour)
+    if pre is not None:
+        close(pre, pre_ref, 1 / 128, 2e-2, "preact")
+    # same numbers from the one-tile-per-workgroup kernel (same MFMA order; the epilogue arithmetic is the same fp32 sequence)
+    out2 = torch.full((M + 8, N), float("nan"), dtype=out_dtype, device=DEV)
+    ops.gemm_nt(A, B, out2, M, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out[:M], out2[:M]), f"{flavour}: persistent and ring kernels differ"
+
+
+def test_gemm_nt_persistent_repeated_launches_are_stable():
+    """Race screen for the counted-vmcnt hand-off between tiles: 30 launches of a 3-tiles-per-workgroup problem must agree bit for bit."""
+    M, N, K = 256 * 200, 768, 768
+    g = torch.Generator(device=DEV).manual_seed(3)
+    A = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    B = (torch.randn(N, K, device=DEV, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N, device=DEV, generator=g)
+    res = torch.randn(M, N, device=DEV, generator=g)
+    first = torch.empty(M, N, device=DEV)
+    os.environ["CLDRD_GEMM_PERSIST"] = "1"
+    try:
+        ops.gemm_nt(A, B, first, bias=bias, residual=res)
+        ref = A.float() @ B.float().T + bias + res
+        close(first, ref, 2e-5, 2e-4 * math.sqrt(K), "pers 200 row panels")
+        for _ in range(30):
+            out = torch.empty(M, N, device=DEV)
+            ops.gemm_nt(A, B, out, bias=bias, residual=res)
+            assert torch.equal(out, first)
+    finally:
+        os.environ.pop("CLDRD_GEMM_PERSIST", None)
+
+
 # ------------------------------------------------------------------------------------------------ weight gradient
 @pytest.mark.parametrize("M,N1,N2", [(64, 128, 128), (200, 128, 256), (1024, 384, 128), (4096, 768, 768), (3000, 256, 768),
                                      (8192, 2304, 768), (2048, 768, 3072), (130, 512, 128),
@@ -247,8 +340,8 @@ def test_layernorm_fwd_bwd(T, d):
     close(dbias, dx.float().sum(0), 2e-2, 2e-2 * dx.float().sum(0).abs().max().item() + 1e-2, "ln dbias")
 
 
-def test_embed_ln_fwd_bwd():
-    V, P, d, M, L = 300, 40, 256, 6, 20
+@pytest.mark.parametrize("V,P,d,M,L", [(300, 40, 256, 6, 20), (2000, 128, 768, 5, 128), (500, 64, 1024, 3, 50)])
+def test_embed_ln_fwd_bwd(V, P, d, M, L):
     T = M * L
     word, pos, typ = rnd(20, (V, d)), rnd(21, (P, d)), rnd(22, (2, d))
     gamma, beta = 1 + rnd(23, (d,), 0.1), rnd(24, (d,), 0.1)

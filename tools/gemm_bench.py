@@ -8,38 +8,48 @@ from cldrd_amd import hip_ops as ops
 def main():
     dev = "cuda"
     T = int(os.environ.get("T", 32768))
-    shapes = [("qkv", T, 2304, 768, {}), ("out", T, 768, 768, {"res": 1}), ("ffn1", T, 3072, 768, {"pre": 1, "act": 1}),
-              ("ffn2", T, 768, 3072, {"res": 1}), ("dgrad_ffn2", T, 3072, 768, {"gp": 1}), ("dgrad_qkv", T, 768, 2304, {"res": 1})]
+    # the eight Linear GEMMs of one encoder layer (forward + data gradients) with the epilogues the trainer uses (fp32 residual stream)
+    shapes = [("qkv", T, 2304, 768, {"bias": 1}), ("out", T, 768, 768, {"bias": 1, "res32": 1}),
+              ("ffn1", T, 3072, 768, {"bias": 1, "pre": 1, "act": 1}), ("ffn2", T, 768, 3072, {"bias": 1, "res32": 1, "drop": 1}),
+              ("dgrad_ffn2", T, 3072, 768, {"gp": 1}), ("dgrad_ffn1", T, 768, 3072, {"res": 1}),
+              ("dgrad_out", T, 768, 768, {}), ("dgrad_qkv", T, 768, 2304, {"res": 1})]
+    variants = os.environ.get("VARIANTS", "pers,ring").split(",")      # pers | ring | ring128 | ring192 | ring256
     torch.manual_seed(0)
+    tot = {v: 0.0 for v in variants}
     for name, M, N, K, ep in shapes:
         A = torch.randn(M, K, device=dev).bfloat16()
         B = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
-        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        bias = torch.randn(N, device=dev)
-        kw = dict(bias=bias)
+        out = torch.empty(M, N, device=dev, dtype=torch.float32 if ep.get("res32") else torch.bfloat16)
+        kw = {}
+        if ep.get("bias"): kw["bias"] = torch.randn(N, device=dev)
         if ep.get("res"): kw["residual"] = torch.randn(M, N, device=dev).bfloat16()
+        if ep.get("res32"): kw["residual"] = torch.randn(M, N, device=dev)
         if ep.get("pre"): kw["preact"] = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         if ep.get("act"): kw["act"] = 1
         if ep.get("gp"): kw["gelu_pre"] = torch.randn(M, N, device=dev).bfloat16()
+        if ep.get("drop"): kw.update(dropout_p=0.1, seed=1234)
         res = {}
         for rnd in range(3):
-            for tile in ("128", "192", "256"):
-                if tile == "256" and N % 256: continue
-                os.environ["CLDRD_GEMM_TILE"] = tile
+            for v in variants:
+                os.environ["CLDRD_GEMM_PERSIST"] = "1" if v == "pers" else ("2" if v == "pers1" else "0")
+                if v.startswith("ring") and len(v) > 4: os.environ["CLDRD_GEMM_TILE"] = v[4:]
+                else: os.environ.pop("CLDRD_GEMM_TILE", None)
                 for _ in range(2): ops.gemm_nt(A, B, out, **kw)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(10): ops.gemm_nt(A, B, out, **kw)
                 e1.record(); torch.cuda.synchronize()
-                res.setdefault(tile, []).append(e0.elapsed_time(e1) / 10)
+                res.setdefault(v, []).append(e0.elapsed_time(e1) / 10)
         fl = 2.0 * M * N * K
-        # plain (no epilogue extras) for the best tile
         line = f"{name:11s} M={M} N={N} K={K}: "
-        for tile, ts in res.items():
+        for v, ts in res.items():
             t = min(ts)
-            line += f" tile{tile}: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF/s |"
+            tot[v] += t
+            line += f" {v}: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF/s |"
         print(line, flush=True)
+    print("layer total (8 GEMMs): " + " | ".join(f"{v}: {t*1e3:7.1f} us" for v, t in tot.items()), flush=True)
+    os.environ.pop("CLDRD_GEMM_PERSIST", None)
     os.environ.pop("CLDRD_GEMM_TILE", None)
     # weight gradients: dW[N1,N2] = dY[T,N1]^T X[T,N2] (+ bias gradient), split-K slabs + reduction included
     for name, N1, N2 in [("w_qkv", 2304, 768), ("w_out", 768, 768), ("w_ffn1", 3072, 768), ("w_ffn2", 768, 3072)]:
