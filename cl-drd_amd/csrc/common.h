@@ -23,8 +23,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return __builtin_bit_cast(bf16_t, b);
 }
 
+// two floats -> one dword of bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32.  (f2bf(lo) | f2bf(hi) << 16 compiled to two converts, a
+// shift and an or: 4 VALU per pair in epilogues that are VALU-bound.)
+typedef __bf16 cldrd_bf16v2 __attribute__((ext_vector_type(2)));
+typedef float cldrd_f32v2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const cldrd_f32v2 f = {lo, hi};
+    const cldrd_bf16v2 b = __builtin_convertvector(f, cldrd_bf16v2);
+    return __builtin_bit_cast(uint32_t, b);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -11,7 +11,8 @@ struct GemmNtArgs {
     int res_f32 = 0;
     bf16_t* preact;               // [M, ldc] or null: (alpha*acc + bias) before the activation
     const bf16_t* gelu_pre;       // [M, ldc] or null: multiply by gelu'(gelu_pre)
-    int act;                      // 0 none, 1 erf-GELU
+    int act;                      // bit 0: erf-GELU; bit 1 (derivative form): `preact` receives gelu'(pre-activation) instead of the
+                                  // pre-activation, and `gelu_pre` already holds that derivative (the epilogue multiplies, nothing else)
     float alpha;
     uint32_t drop_thresh;         // 0 = no dropout
     float drop_scale;
@@ -29,6 +30,7 @@ struct GemmNtArgs {
 enum : int {
     EPI_BIAS = 1, EPI_PREACT = 2, EPI_GELU = 4, EPI_GELUGRAD = 8, EPI_DROPOUT = 16, EPI_RESIDUAL = 32, EPI_F32 = 64, EPI_FILTER = 128,
     EPI_RES32 = 256,              // the residual operand is fp32 (only with EPI_RESIDUAL)
+    EPI_DGELU = 1024,             // derivative form of the saved activation input (act bit 1): with EPI_PREACT / EPI_GELUGRAD
     EPI_F16IN = 512,              // A, B (and a 16-bit C) hold fp16, not bf16: the top-k scan over the fp16 index shadow (with EPI_FILTER)
                                   // and the high-precision forward of the query tower (small-M kernel; not with preact / gelu_pre)
     EPI_GENERIC = 1 << 20
@@ -44,20 +46,22 @@ __device__ __forceinline__ f32x4 gemm_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 
 template <int EPI> struct EpiFlags {
-    const bool bias, preact, gelu, gelugrad, dropout, residual, f32, res32;
+    const bool bias, preact, gelu, gelugrad, dropout, residual, f32, res32, dgelu;
     __device__ __forceinline__ explicit EpiFlags(const GemmNtArgs& p)
         : bias(EPI == EPI_GENERIC ? p.bias != nullptr : (EPI & EPI_BIAS) != 0),
           preact(EPI == EPI_GENERIC ? p.preact != nullptr : (EPI & EPI_PREACT) != 0),
-          gelu(EPI == EPI_GENERIC ? p.act == 1 : (EPI & EPI_GELU) != 0),
+          gelu(EPI == EPI_GENERIC ? (p.act & 1) != 0 : (EPI & EPI_GELU) != 0),
           gelugrad(EPI == EPI_GENERIC ? p.gelu_pre != nullptr : (EPI & EPI_GELUGRAD) != 0),
           dropout(EPI == EPI_GENERIC ? p.drop_thresh != 0 : (EPI & EPI_DROPOUT) != 0),
           residual(EPI == EPI_GENERIC ? p.residual != nullptr : (EPI & EPI_RESIDUAL) != 0),
           f32(EPI == EPI_GENERIC ? p.out_f32 != 0 : (EPI & EPI_F32) != 0),
-          res32(EPI == EPI_GENERIC ? (p.residual != nullptr && p.res_f32 != 0) : (EPI & EPI_RES32) != 0) {}
+          res32(EPI == EPI_GENERIC ? (p.residual != nullptr && p.res_f32 != 0) : (EPI & EPI_RES32) != 0),
+          dgelu(EPI == EPI_GENERIC ? (p.act & 2) != 0 : (EPI & EPI_DGELU) != 0) {}
 };
 
 static inline int epi_flavour(const GemmNtArgs& a) {
-    return (a.in_f16 ? EPI_F16IN : 0) | (a.bias ? EPI_BIAS : 0) | (a.preact ? EPI_PREACT : 0) | (a.act == 1 ? EPI_GELU : 0) | (a.gelu_pre ? EPI_GELUGRAD : 0) |
+    return (a.in_f16 ? EPI_F16IN : 0) | (a.bias ? EPI_BIAS : 0) | (a.preact ? EPI_PREACT : 0) | ((a.act & 1) ? EPI_GELU : 0) | (a.gelu_pre ? EPI_GELUGRAD : 0) |
+           (((a.act & 2) && (a.preact || a.gelu_pre)) ? EPI_DGELU : 0) |
            (a.drop_thresh ? EPI_DROPOUT : 0) | (a.residual ? EPI_RESIDUAL : 0) | (a.out_f32 ? EPI_F32 : 0) |
            ((a.residual && a.res_f32) ? EPI_RES32 : 0);
 }
@@ -84,7 +88,8 @@ __device__ __forceinline__ uint4 pack8h(const float (&v)[8]) {
 }
 
 // Fused epilogue for 8 consecutive output columns (m, n..n+7); v[] = raw accumulators, bias8/res/gp already loaded.
-// order: alpha*acc + bias -> (store preact) -> GELU -> * gelu'(gelu_pre) -> dropout -> + residual -> store
+// order: alpha*acc + bias -> (store preact, or gelu'(preact) in the derivative form) -> GELU -> * gelu'(gelu_pre) (derivative form:
+// * gelu_pre) -> dropout -> + residual -> store
 template <int EPI>
 __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFlags<EPI>& fl, float (&v)[8], int m, int n,
                                                const float (&bias8)[8], const uint4& res, const uint4& res_hi, const uint4& gp) {
@@ -95,16 +100,40 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         for (int j = 0; j < 8; ++j) v[j] += bias8[j];
     }
     const size_t crow = (size_t)m * p.ldc + n;
-    if (fl.preact) *(uint4*)(p.preact + crow) = pack8(v);
-    if (fl.gelu) {
+    if (fl.preact && fl.gelu && fl.dgelu) {
+        // forward of a GELU layer with a tape: the backward only ever needs gelu'(x), so that is what is saved (one exp and one rcp
+        // serve both the value and the derivative here; the data-gradient GEMM's epilogue then multiplies instead of evaluating
+        // erf and exp again - that epilogue was VALU-bound: 12 us of a 31-us tile round with the MFMA pipe idle)
+        float dv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        for (int j = 0; j < 8; ++j) {
+            float c, e;
+            gelu_parts(v[j], c, e);
+            dv[j] = fmaf(v[j] * 0.39894228040143268f, e, c);
+            v[j] *= c;
+        }
+        *(uint4*)(p.preact + crow) = pack8(dv);
+    } else {
+        if (fl.preact) {
+            if (fl.dgelu) {
+                float dv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dv[j] = gelu_grad_f(v[j]);
+                *(uint4*)(p.preact + crow) = pack8(dv);
+            } else {
+                *(uint4*)(p.preact + crow) = pack8(v);
+            }
+        }
+        if (fl.gelu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        }
     }
     if (fl.gelugrad) {
         float g[8];
         unpack8(gp, g);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(g[j]);
+        for (int j = 0; j < 8; ++j) v[j] *= fl.dgelu ? g[j] : gelu_grad_f(g[j]);
     }
     if (fl.dropout) {
         const uint32_t rk = drop_rowkey(p.seed, (uint32_t)m);      // n is a multiple of 8: four column pairs

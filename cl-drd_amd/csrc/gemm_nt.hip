@@ -133,6 +133,7 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
     CLDRD_CHECK(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)residual % 16 == 0),
                 "gemm_nt: operands must be 16-byte aligned");
     CLDRD_CHECK(dropout_p >= 0.f && dropout_p < 1.f, "gemm_nt: dropout_p out of range");
+    CLDRD_CHECK(act >= 0 && act <= 3, "gemm_nt: act must be 0..3 (bit 0 erf-GELU, bit 1 derivative form of preact / gelu_pre)");
     GemmNtArgs a;
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -170,6 +171,8 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
         case 0: return launch_nt<0>(a, (hipStream_t)stream);
         case EPI_BIAS: return launch_nt<EPI_BIAS>(a, (hipStream_t)stream);
         case EPI_BIAS | EPI_PREACT | EPI_GELU: return launch_nt<EPI_BIAS | EPI_PREACT | EPI_GELU>(a, (hipStream_t)stream);
+        case EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU: return launch_nt<EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU>(a, (hipStream_t)stream);
+        case EPI_GELUGRAD | EPI_DGELU: return launch_nt<EPI_GELUGRAD | EPI_DGELU>(a, (hipStream_t)stream);
         case EPI_BIAS | EPI_RESIDUAL: return launch_nt<EPI_BIAS | EPI_RESIDUAL>(a, (hipStream_t)stream);
         case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL: return launch_nt<EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL>(a, (hipStream_t)stream);
         case EPI_GELUGRAD: return launch_nt<EPI_GELUGRAD>(a, (hipStream_t)stream);

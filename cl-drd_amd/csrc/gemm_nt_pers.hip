@@ -71,7 +71,7 @@ __device__ __forceinline__ void pers_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
     constexpr int MTG = PM::MTG, NG = PM::NG, PPG = PM::PPG;
     constexpr bool BIAS = (EPI & EPI_BIAS) != 0, PREACT = (EPI & EPI_PREACT) != 0, GELU = (EPI & EPI_GELU) != 0,
                    GGRAD = (EPI & EPI_GELUGRAD) != 0, DROP = (EPI & EPI_DROPOUT) != 0, RES = (EPI & EPI_RESIDUAL) != 0,
-                   F32 = (EPI & EPI_F32) != 0, RES32 = (EPI & EPI_RES32) != 0;
+                   F32 = (EPI & EPI_F32) != 0, RES32 = (EPI & EPI_RES32) != 0, DGELU = (EPI & EPI_DGELU) != 0;
     constexpr bool RES16 = RES && !RES32;
     constexpr bool IN16 = GGRAD || RES16;
     static_assert(!(GGRAD && RES16), "one 16-bit input stream per epilogue");
@@ -145,14 +145,43 @@ __device__ __forceinline__ void pers_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
                     v[t][nt][j] = acc[g * MTG + t][nt][j] * p.alpha;
                     if constexpr (BIAS) v[t][nt][j] += bias4[nt][j];
                 }
-        if constexpr (PREACT) store16(p.preact, g, v);
-        if constexpr (GELU) {
+        if constexpr (PREACT && GELU && DGELU) {         // save gelu'(x) (derivative form, gemm_epilogue.h): one exp + rcp for value and derivative
+            float dv[MTG][NT][4];
 #pragma unroll
             for (int t = 0; t < MTG; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[t][nt][j] = gelu_f(v[t][nt][j]);
+                    for (int j = 0; j < 4; ++j) {
+                        float c, e;
+                        gelu_parts(v[t][nt][j], c, e);
+                        dv[t][nt][j] = fmaf(v[t][nt][j] * 0.39894228040143268f, e, c);
+                        v[t][nt][j] *= c;
+                    }
+            store16(p.preact, g, dv);
+        } else {
+            if constexpr (PREACT) {
+                if constexpr (DGELU) {
+                    float dv[MTG][NT][4];
+#pragma unroll
+                    for (int t = 0; t < MTG; ++t)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) dv[t][nt][j] = gelu_grad_f(v[t][nt][j]);
+                    store16(p.preact, g, dv);
+                } else {
+                    store16(p.preact, g, v);
+                }
+            }
+            if constexpr (GELU) {
+#pragma unroll
+                for (int t = 0; t < MTG; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[t][nt][j] = gelu_f(v[t][nt][j]);
+            }
         }
         float w[MTG][NT][4];
         if constexpr (IN16) {           // back from the 8-columns-per-lane layout to the accumulator layout
@@ -175,7 +204,7 @@ __device__ __forceinline__ void pers_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[t][nt][j] *= gelu_grad_f(w[t][nt][j]);
+                    for (int j = 0; j < 4; ++j) v[t][nt][j] *= DGELU ? w[t][nt][j] : gelu_grad_f(w[t][nt][j]);
         }
         if constexpr (DROP) {
 #pragma unroll
@@ -446,6 +475,8 @@ int launch_pers(const GemmNtArgs& a, hipStream_t st) {
         case 0: return launch_pers_epi<BN, 0>(a, st);
         case EPI_BIAS: return launch_pers_epi<BN, EPI_BIAS>(a, st);
         case EPI_BIAS | EPI_PREACT | EPI_GELU: return launch_pers_epi<BN, EPI_BIAS | EPI_PREACT | EPI_GELU>(a, st);
+        case EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU: return launch_pers_epi<BN, EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU>(a, st);
+        case EPI_GELUGRAD | EPI_DGELU: return launch_pers_epi<BN, EPI_GELUGRAD | EPI_DGELU>(a, st);
         case EPI_BIAS | EPI_GELU: return launch_pers_epi<BN, EPI_BIAS | EPI_GELU>(a, st);
         case EPI_BIAS | EPI_RESIDUAL: return launch_pers_epi<BN, EPI_BIAS | EPI_RESIDUAL>(a, st);
         case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL: return launch_pers_epi<BN, EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL>(a, st);

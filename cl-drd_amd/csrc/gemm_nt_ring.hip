@@ -250,6 +250,8 @@ int launch_ring(const GemmNtArgs& a, hipStream_t st) {
         case 0: return launch_ring_epi<BN, 0>(a, st);
         case EPI_BIAS: return launch_ring_epi<BN, EPI_BIAS>(a, st);
         case EPI_BIAS | EPI_PREACT | EPI_GELU: return launch_ring_epi<BN, EPI_BIAS | EPI_PREACT | EPI_GELU>(a, st);
+        case EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU: return launch_ring_epi<BN, EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU>(a, st);
+        case EPI_GELUGRAD | EPI_DGELU: return launch_ring_epi<BN, EPI_GELUGRAD | EPI_DGELU>(a, st);
         case EPI_BIAS | EPI_GELU: return launch_ring_epi<BN, EPI_BIAS | EPI_GELU>(a, st);
         case EPI_BIAS | EPI_RESIDUAL: return launch_ring_epi<BN, EPI_BIAS | EPI_RESIDUAL>(a, st);
         case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL: return launch_ring_epi<BN, EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL>(a, st);

@@ -521,7 +521,7 @@ class HipEncoder(nn.Module):
             ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps, out32=x1_32)
             hbuf = self._buf(T, f, dev, dt16)
             pre = self._buf(T, f, dev, dt16) if save else None
-            ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=1)
+            ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=3 if save else 1)     # the tape keeps gelu'(pre-activation)
             s2 = self._buf(T, d, dev, sdt)
             ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
             xo = self._buf(T, d, dev, dt16)
@@ -569,7 +569,7 @@ class HipEncoder(nn.Module):
         ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, M, cfg.eps, out32=x1_32)
         hbuf = self._buf(M, f, dev, dt16)
         pre = self._buf(M, f, dev, dt16) if save else None
-        ops.gemm_nt(x1, W["W1"], hbuf, M, bias=W["bf1"], preact=pre, act=1)
+        ops.gemm_nt(x1, W["W1"], hbuf, M, bias=W["bf1"], preact=pre, act=3 if save else 1)
         s2 = self._buf(M, d, dev, sdt)
         ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
         xo = self._buf(M, d, dev, dt16)
@@ -596,7 +596,7 @@ class HipEncoder(nn.Module):
         dF = ds2m if ds2m is not None else ds2
         self._wq.add(dF, a["h"], G["W2"], M)
         dpre = self._buf(M, f, dev)
-        ops.gemm_nt(dF, self.ht(i, "f2"), dpre, M, gelu_pre=a["pre"])
+        ops.gemm_nt(dF, self.ht(i, "f2"), dpre, M, gelu_pre=a["pre"], act=2)
         self._wq.add(dpre, a["x1"], G["W1"], M, dbias=G["bf1"])
         dx1 = self._buf(M, d, dev)
         ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, M, residual=ds2)
@@ -672,7 +672,7 @@ class HipEncoder(nn.Module):
             dF = ds2m if ds2m is not None else ds2
             self._wq.add(dF, a["h"], G["W2"], T)
             dpre = self._buf(T, f, dev)
-            ops.gemm_nt(dF, self.ht(i, "f2"), dpre, T, gelu_pre=a["pre"])
+            ops.gemm_nt(dF, self.ht(i, "f2"), dpre, T, gelu_pre=a["pre"], act=2)
             self._wq.add(dpre, a["x1"], G["W1"], T, dbias=G["bf1"])
             dx1 = self._buf(T, d, dev)
             ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T, residual=ds2)

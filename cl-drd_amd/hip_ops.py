@@ -53,7 +53,9 @@ def pad_rows(rows: int) -> int:
 
 def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pre=None, act=0, alpha=1.0,
             dropout_p=0.0, seed=0):
-    """out[M,N] = epilogue(alpha * A[M,K] @ B[N,K]^T); A, B bf16 (or both fp16: forward flavours, M < 1024); out 16-bit like A, or fp32."""
+    """out[M,N] = epilogue(alpha * A[M,K] @ B[N,K]^T); A, B bf16 (or both fp16: forward flavours, M < 1024); out 16-bit like A, or fp32.
+
+    ``act``: bit 0 = erf-GELU; bit 1 = derivative form: ``preact`` receives gelu'(pre-activation) (act=3), ``gelu_pre`` holds it (act=2)."""
     io_f16 = _fmt16(A, "A")
     dt16 = F16 if io_f16 else BF16
     _chk(A, dt16, "A", 2), _chk(B, dt16, "B", 2)

@@ -33,7 +33,11 @@ int cldrd_device_ok(void);            /* 1 if device 0 is a gfx950 */
  * Replaces torch.nn.Linear inside the HF encoder (reference models/nway_dual_encoder.py:52,56,64 ->
  * transformers DistilBERT q_lin/k_lin/v_lin/out_lin/ffn.lin1/ffn.lin2, BERT query/key/value/dense).
  *   C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T)
- *   epilogue order: + bias[N] -> (store preact) -> act (1 = erf-GELU) -> * gelu'(gelu_pre) -> dropout -> + residual
+ *   epilogue order: + bias[N] -> (store preact) -> act (bit 0 = erf-GELU) -> * gelu'(gelu_pre) -> dropout -> + residual
+ *   act bit 1 = derivative form of the saved activation input: `preact` receives gelu'(pre-activation) instead of the
+ *   pre-activation (forward, act = 3), and `gelu_pre` is taken to hold that derivative already (backward, act = 2: the epilogue
+ *   multiplies by it and evaluates nothing) - what torch saves for GELU's backward is its input; saving the derivative moves the
+ *   erf / exp out of the data-gradient GEMM's epilogue, which was VALU-bound.
  *   K % 64 == 0; A/B/C 16-byte aligned; out_f32 != 0 stores fp32 instead of bf16; res_f32 != 0: `residual` is fp32
  *   (the fp32 residual stream: out-projection / FFN2 add the fp32 LayerNorm output and store the fp32 pre-LN sum, as the
  *   reference's autocast does - trainer/multistep-curriculum/nway_listwise_1.py:334).

@@ -84,6 +84,14 @@ def test_gemm_nt_epilogues(M, N, K):
     gelu_grad = 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
     ops.gemm_nt(Ad, Bd, out, gelu_pre=gp.to(DEV), residual=res.to(DEV), alpha=0.5)
     close(out, 0.5 * (A.float() @ B.float().T) * gelu_grad + res.float(), 1 / 128, 2e-2, "gelu_grad")
+    # derivative form (what the encoder's tape uses): the forward saves gelu'(pre-activation), the backward multiplies by it
+    dsave = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_nt(Ad, Bd, out, bias=bias.to(DEV), preact=dsave, act=3)
+    close(out, torch.nn.functional.gelu(base), 1 / 128, 2e-2, "gelu (derivative form)")
+    close(dsave, 0.5 * (1 + torch.erf(base / math.sqrt(2))) + base * torch.exp(-0.5 * base * base) / math.sqrt(2 * math.pi), 1 / 128, 1e-3,
+          "saved gelu'")
+    ops.gemm_nt(Ad, Bd, out, gelu_pre=dsave, act=2)
+    close(out, (A.float() @ B.float().T) * dsave.float().cpu(), 1 / 128, 2e-2, "multiply by the saved derivative")
 
 
 def test_gemm_nt_dropout_is_deterministic_and_unbiased():
@@ -106,8 +114,8 @@ def test_gemm_nt_dropout_is_deterministic_and_unbiased():
 # workgroup walks 2-3 tiles: next-tile DMA issued before the epilogue, stores left in flight under a counted vmcnt), a partial
 # last M tile (predicated epilogue + drain), against torch fp32 on the same bf16 inputs; the one-tile-per-workgroup ring kernel
 # (CLDRD_GEMM_PERSIST=0) must give the same bits for 16-bit outputs.
-_PERS_FLAVOURS = ["plain", "bias", "bias_gelu_pre", "bias_gelu", "bias_res16", "bias_drop_res16", "gelugrad", "res16", "f32",
-                  "bias_res32_f32", "bias_drop_res32_f32"]
+_PERS_FLAVOURS = ["plain", "bias", "bias_gelu_pre", "bias_gelu_dpre", "bias_gelu", "bias_res16", "bias_drop_res16", "gelugrad",
+                  "gelugrad_d", "res16", "f32", "bias_res32_f32", "bias_drop_res32_f32"]
 
 
 @pytest.mark.parametrize("M,N,K", [(16640, 768, 256), (20000, 1024, 192), (9000, 2304, 128)])
@@ -133,11 +141,19 @@ def test_gemm_nt_persistent_flavours(flavour, M, N, K):
     if flavour == "bias_gelu_pre":
         pre = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
         kw.update(preact=pre, act=1)
+    if flavour == "bias_gelu_dpre":
+        pre = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        kw.update(preact=pre, act=3)
     if flavour == "bias_gelu":
         kw.update(act=1)
-    if "gelu" in flavour and flavour != "gelugrad":
+    if "gelu" in flavour and not flavour.startswith("gelugrad"):
         pre_ref = ref
+        if flavour == "bias_gelu_dpre":
+            pre_ref = 0.5 * (1 + torch.erf(ref / math.sqrt(2))) + ref * torch.exp(-0.5 * ref * ref) / math.sqrt(2 * math.pi)
         ref = torch.nn.functional.gelu(ref)
+    if flavour == "gelugrad_d":
+        ref = ref * gp.float()
+        kw.update(gelu_pre=gp, act=2)
     if flavour == "gelugrad":
         x = gp.float()
         ref = ref * (0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi))
