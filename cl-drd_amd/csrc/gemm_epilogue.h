@@ -9,6 +9,10 @@ struct GemmNtArgs {
     const void* residual;         // [M, ldr] or null, added last; bf16, or fp32 when res_f32 (the fp32 residual stream)
     int ldr;
     int res_f32 = 0;
+    // fp32 residual given as a LayerNorm still to be applied: residual[m][n] holds the pre-LN sum s and the value added is
+    // (s - ln_mean[m]) * ln_rstd[m] * ln_gamma[n] + ln_beta[n] - the LayerNorm kernel then need not write its fp32 output copy at all
+    // (100 MB per LayerNorm at cfg2; same bytes read here).  All four or none; only with res_f32.
+    const float* ln_mean = nullptr; const float* ln_rstd = nullptr; const float* ln_gamma = nullptr; const float* ln_beta = nullptr;
     bf16_t* preact;               // [M, ldc] or null: (alpha*acc + bias) before the activation
     const bf16_t* gelu_pre;       // [M, ldc] or null: multiply by gelu'(gelu_pre)
     int act;                      // bit 0: erf-GELU; bit 1 (derivative form): `preact` receives gelu'(pre-activation) instead of the
@@ -30,6 +34,7 @@ struct GemmNtArgs {
 enum : int {
     EPI_BIAS = 1, EPI_PREACT = 2, EPI_GELU = 4, EPI_GELUGRAD = 8, EPI_DROPOUT = 16, EPI_RESIDUAL = 32, EPI_F32 = 64, EPI_FILTER = 128,
     EPI_RES32 = 256,              // the residual operand is fp32 (only with EPI_RESIDUAL)
+    EPI_RESLN = 2048,             // the fp32 residual is a pre-LN sum: apply the LayerNorm (ln_* of GemmNtArgs) on the fly (with EPI_RES32)
     EPI_DGELU = 1024,             // derivative form of the saved activation input (act bit 1): with EPI_PREACT / EPI_GELUGRAD
     EPI_F16IN = 512,              // A, B (and a 16-bit C) hold fp16, not bf16: the top-k scan over the fp16 index shadow (with EPI_FILTER)
                                   // and the high-precision forward of the query tower (small-M kernel; not with preact / gelu_pre)
@@ -46,7 +51,7 @@ __device__ __forceinline__ f32x4 gemm_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 
 template <int EPI> struct EpiFlags {
-    const bool bias, preact, gelu, gelugrad, dropout, residual, f32, res32, dgelu;
+    const bool bias, preact, gelu, gelugrad, dropout, residual, f32, res32, dgelu, resln;
     __device__ __forceinline__ explicit EpiFlags(const GemmNtArgs& p)
         : bias(EPI == EPI_GENERIC ? p.bias != nullptr : (EPI & EPI_BIAS) != 0),
           preact(EPI == EPI_GENERIC ? p.preact != nullptr : (EPI & EPI_PREACT) != 0),
@@ -56,14 +61,15 @@ template <int EPI> struct EpiFlags {
           residual(EPI == EPI_GENERIC ? p.residual != nullptr : (EPI & EPI_RESIDUAL) != 0),
           f32(EPI == EPI_GENERIC ? p.out_f32 != 0 : (EPI & EPI_F32) != 0),
           res32(EPI == EPI_GENERIC ? (p.residual != nullptr && p.res_f32 != 0) : (EPI & EPI_RES32) != 0),
-          dgelu(EPI == EPI_GENERIC ? (p.act & 2) != 0 : (EPI & EPI_DGELU) != 0) {}
+          dgelu(EPI == EPI_GENERIC ? (p.act & 2) != 0 : (EPI & EPI_DGELU) != 0),
+          resln(EPI == EPI_GENERIC ? (p.residual != nullptr && p.res_f32 != 0 && p.ln_mean != nullptr) : (EPI & EPI_RESLN) != 0) {}
 };
 
 static inline int epi_flavour(const GemmNtArgs& a) {
     return (a.in_f16 ? EPI_F16IN : 0) | (a.bias ? EPI_BIAS : 0) | (a.preact ? EPI_PREACT : 0) | ((a.act & 1) ? EPI_GELU : 0) | (a.gelu_pre ? EPI_GELUGRAD : 0) |
            (((a.act & 2) && (a.preact || a.gelu_pre)) ? EPI_DGELU : 0) |
            (a.drop_thresh ? EPI_DROPOUT : 0) | (a.residual ? EPI_RESIDUAL : 0) | (a.out_f32 ? EPI_F32 : 0) |
-           ((a.residual && a.res_f32) ? EPI_RES32 : 0);
+           ((a.residual && a.res_f32) ? EPI_RES32 : 0) | ((a.residual && a.res_f32 && a.ln_mean) ? EPI_RESLN : 0);
 }
 
 __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
@@ -193,7 +199,15 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
         bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
         bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
     }
+    float lng[8], lnb[8];
+    if (fl.resln && lane_ok) {
+        const float4 g0 = *(const float4*)(p.ln_gamma + n), g1 = *(const float4*)(p.ln_gamma + n + 4);
+        const float4 b0 = *(const float4*)(p.ln_beta + n), b1 = *(const float4*)(p.ln_beta + n + 4);
+        lng[0] = g0.x; lng[1] = g0.y; lng[2] = g0.z; lng[3] = g0.w; lng[4] = g1.x; lng[5] = g1.y; lng[6] = g1.z; lng[7] = g1.w;
+        lnb[0] = b0.x; lnb[1] = b0.y; lnb[2] = b0.z; lnb[3] = b0.w; lnb[4] = b1.x; lnb[5] = b1.y; lnb[6] = b1.z; lnb[7] = b1.w;
+    }
     uint4 res[NPASS], resh[NPASS], gp[NPASS];
+    float lmu[NPASS], lrs[NPASS];
     auto prefetch = [&](int mh) {
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
@@ -208,6 +222,7 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
                         const uint4* rp = (const uint4*)((const float*)p.residual + (size_t)m * p.ldr + n);
                         res[pass] = rp[0];
                         resh[pass] = rp[1];
+                        if (fl.resln) { lmu[pass] = p.ln_mean[m]; lrs[pass] = p.ln_rstd[m]; }
                     } else {
                         res[pass] = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + n);
                     }
@@ -227,6 +242,19 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
         uint4 cres[NPASS], cresh[NPASS], cgp[NPASS];
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) { cres[pass] = res[pass]; cresh[pass] = resh[pass]; cgp[pass] = gp[pass]; }
+        if (fl.resln) {       // the residual is LayerNorm(pre-LN sum): same expression as ln_fwd_kernel's fp32 output
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const float mu = lmu[pass], rs = lrs[pass];
+                uint32_t* lo = (uint32_t*)&cres[pass];
+                uint32_t* hi = (uint32_t*)&cresh[pass];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lo[j] = __float_as_uint((__uint_as_float(lo[j]) - mu) * rs * lng[j] + lnb[j]);
+                    hi[j] = __float_as_uint((__uint_as_float(hi[j]) - mu) * rs * lng[4 + j] + lnb[4 + j]);
+                }
+            }
+        }
         if ((fl.residual || fl.gelugrad) && mh + 1 < MT / 2) prefetch(mh + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         float v[NPASS][8];

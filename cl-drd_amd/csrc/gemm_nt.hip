@@ -122,10 +122,32 @@ int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st);               
 int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts, int* cand_rows,
                            float* cand_scores, int cap, int f16, hipStream_t st);   // topk.hip
 
+extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                     const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
+                                     int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
+                                     int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
+                                     const float* ln_beta, void* stream);
+
 extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                   int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                   int io_f16, void* stream) {
+    return cldrd_gemm_nt_bf16_ln(A, B, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, preact, gelu_pre, act, alpha, dropout_p, seed,
+                                 out_f32, res_f32, io_f16, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// The same with the fp32 residual given as a LayerNorm still to be applied (GemmNtArgs::ln_*): all four pointers or none.
+extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                     const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
+                                     int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
+                                     int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
+                                     const float* ln_beta, void* stream) {
+    {
+        const int nln = (ln_mean != nullptr) + (ln_rstd != nullptr) + (ln_gamma != nullptr) + (ln_beta != nullptr);
+        CLDRD_CHECK(nln == 0 || nln == 4, "gemm_nt: ln_mean / ln_rstd / ln_gamma / ln_beta go together");
+        CLDRD_CHECK(nln == 0 || (residual != nullptr && res_f32 != 0), "gemm_nt: the LayerNorm-on-the-fly residual needs an fp32 residual");
+        CLDRD_CHECK(nln == 0 || (((uintptr_t)ln_gamma % 16 == 0) && ((uintptr_t)ln_beta % 16 == 0)), "gemm_nt: ln_gamma / ln_beta must be 16-byte aligned");
+    }
     CLDRD_CHECK(M > 0 && N > 0 && K > 0, "gemm_nt: empty problem");
     CLDRD_CHECK(K % 32 == 0, "gemm_nt: K must be a multiple of 32");
     CLDRD_CHECK(lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 && N % 8 == 0 && (residual == nullptr || ldr % 8 == 0),
@@ -138,6 +160,7 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
     a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
     a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.bias = bias; a.residual = residual; a.ldr = ldr; a.res_f32 = (residual != nullptr && res_f32) ? 1 : 0;
+    a.ln_mean = ln_mean; a.ln_rstd = ln_rstd; a.ln_gamma = ln_gamma; a.ln_beta = ln_beta;
     a.preact = (bf16_t*)preact; a.gelu_pre = (const bf16_t*)gelu_pre;
     a.act = act; a.alpha = alpha;
     a.drop_thresh = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
@@ -156,6 +179,10 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
                 return launch_nt<EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
             case EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
                 return launch_nt<EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
+            case EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN:
+                return launch_nt<EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN>(a, (hipStream_t)stream);
+            case EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN:
+                return launch_nt<EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN>(a, (hipStream_t)stream);
             default: return cldrd_set_error("gemm_nt: this epilogue combination is not built for the fp16 format");
         }
     }
@@ -181,6 +208,10 @@ extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, 
         case EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32: return launch_nt<EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
         case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
             return launch_nt<EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
+        case EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN:
+            return launch_nt<EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN>(a, (hipStream_t)stream);
+        case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN:
+            return launch_nt<EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN>(a, (hipStream_t)stream);
         default: return launch_nt<EPI_GENERIC>(a, (hipStream_t)stream);
     }
 }

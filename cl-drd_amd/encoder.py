@@ -502,6 +502,11 @@ class HipEncoder(nn.Module):
             tape.mean0, tape.rstd0 = mean0, rstd0
         cls = torch.empty(M, d, **f32)
         p_out = p_h if cfg.arch == "bert" else 0.0          # DistilBERT has no dropout after out_lin
+        # fp32 residual stream: a LayerNorm's fp32 output is consumed exactly once, as the residual operand of the next out-projection /
+        # FFN2 epilogue.  It is not stored: that epilogue reads the pre-LN sum (which the backward keeps anyway) and applies mean / rstd /
+        # gamma / beta on the fly (`residual_ln`) - 100 MB less written per LayerNorm at cfg2, the same bytes read.
+        res_ln = None                                        # LayerNorm still to be applied to x32 (None: x32 is the value itself)
+        LNF = S32 and os.environ.get("CLDRD_LN_ON_THE_FLY", "1") != "0"          # "0": store every fp32 LayerNorm output (A/B runs)
         for i in range(cfg.n_layers):
             W = self._layer_weights(i, fp16)
             s_l = seed + 7919 * (i + 1)
@@ -514,25 +519,30 @@ class HipEncoder(nn.Module):
             lse = torch.empty(M, H, L, **f32) if save else None
             ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1)
             s1 = self._buf(T, d, dev, sdt)
-            ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out, seed=s_l + 2)
+            ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out, seed=s_l + 2, residual_ln=res_ln)
             x1 = self._buf(T, d, dev, dt16)
-            x1_32 = self._buf(T, d, dev, torch.float32) if S32 else None
-            mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if save else (None, None)
+            mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
+            x1_32 = self._buf(T, d, dev, torch.float32) if (S32 and not LNF) else None
             ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps, out32=x1_32)
             hbuf = self._buf(T, f, dev, dt16)
             pre = self._buf(T, f, dev, dt16) if save else None
             ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=3 if save else 1)     # the tape keeps gelu'(pre-activation)
             s2 = self._buf(T, d, dev, sdt)
-            ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
+            ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=(s1 if LNF else x1_32) if S32 else x1, dropout_p=p_h, seed=s_l + 3,
+                        residual_ln=(mean1, rstd1, W["g1"], W["b1"]) if LNF else None)
             xo = self._buf(T, d, dev, dt16)
             last = i == cfg.n_layers - 1
-            xo32 = self._buf(T, d, dev, torch.float32) if (S32 and not last) else None
-            mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if save else (None, None)
+            # the CLS-only last layer gathers its fp32 residual rows from a stored copy: the layer before it still writes one
+            need32 = S32 and not last and ((i + 1 == cfg.n_layers - 1 and self.cls_only_last) or not LNF)
+            xo32 = self._buf(T, d, dev, torch.float32) if need32 else None
+            mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
             ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32)
             if save:
                 tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
                                         h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h, p_a=p_a, p_out=p_out))
-            x, x32 = xo, xo32
+            x = xo
+            if S32:
+                x32, res_ln = (xo32, None) if need32 else (s2, (mean2, rstd2, W["g2"], W["b2"]))
         if cfg.n_layers == 0:
             cls.copy_(x.view(ops.pad_rows(T), d)[:T].view(M, L, d)[:, 0].float())
         return (cls, tape) if save else cls

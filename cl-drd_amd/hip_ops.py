@@ -52,10 +52,11 @@ def pad_rows(rows: int) -> int:
 
 
 def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pre=None, act=0, alpha=1.0,
-            dropout_p=0.0, seed=0):
+            dropout_p=0.0, seed=0, residual_ln=None):
     """out[M,N] = epilogue(alpha * A[M,K] @ B[N,K]^T); A, B bf16 (or both fp16: forward flavours, M < 1024); out 16-bit like A, or fp32.
 
-    ``act``: bit 0 = erf-GELU; bit 1 = derivative form: ``preact`` receives gelu'(pre-activation) (act=3), ``gelu_pre`` holds it (act=2)."""
+    ``act``: bit 0 = erf-GELU; bit 1 = derivative form: ``preact`` receives gelu'(pre-activation) (act=3), ``gelu_pre`` holds it (act=2).
+    ``residual_ln`` = (mean[M], rstd[M], gamma[N], beta[N]): the fp32 ``residual`` is a pre-LN sum and LayerNorm(residual) is what is added."""
     io_f16 = _fmt16(A, "A")
     dt16 = F16 if io_f16 else BF16
     _chk(A, dt16, "A", 2), _chk(B, dt16, "B", 2)
@@ -77,6 +78,17 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
         _chk(residual, F32 if res_f32 else BF16, "residual", 2)
         if residual.shape[0] < M or residual.shape[1] != N:
             raise ValueError("gemm_nt: residual must be [>= M, N]")
+    if residual_ln is not None:
+        mean, rstd, gamma, beta = residual_ln
+        if not res_f32:
+            raise ValueError("gemm_nt: residual_ln needs an fp32 residual (the pre-LN sum)")
+        _chk(mean, F32, "ln mean", 1), _chk(rstd, F32, "ln rstd", 1), _chk(gamma, F32, "ln gamma", 1), _chk(beta, F32, "ln beta", 1)
+        if mean.numel() < M or rstd.numel() < M or gamma.numel() != N or beta.numel() != N:
+            raise ValueError("gemm_nt: residual_ln = (mean[>= M], rstd[>= M], gamma[N], beta[N])")
+        call("cldrd_gemm_nt_bf16_ln", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
+             _p(residual), residual.stride(0), _p(preact), _p(gelu_pre), act, alpha, dropout_p, seed, out_f32, res_f32, io_f16,
+             _p(mean), _p(rstd), _p(gamma), _p(beta), _stream())
+        return out
     call("cldrd_gemm_nt_bf16", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
          _p(residual), residual.stride(0) if residual is not None else 0, _p(preact), _p(gelu_pre), act, alpha,
          dropout_p, seed, out_f32, res_f32, io_f16, _stream())

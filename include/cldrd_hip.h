@@ -49,6 +49,14 @@ int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int 
                        int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int io_f16,
                        void* stream);
 
+/* The same GEMM with the fp32 residual given as a LayerNorm still to be applied: `residual` holds the pre-LN sum s (fp32, res_f32 = 1) and
+ * the epilogue adds (s - ln_mean[m]) * ln_rstd[m] * ln_gamma[n] + ln_beta[n] - exactly what cldrd_layernorm_fwd would have written
+ * as its fp32 output, which it then need not write (HF: hidden = LayerNorm(...); out = dense(x) + hidden).  All four ln_* or none. */
+int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                          const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
+                          int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int io_f16,
+                          const float* ln_mean, const float* ln_rstd, const float* ln_gamma, const float* ln_beta, void* stream);
+
 /* Weight gradient dW[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (A = dY, B = layer input; autograd's Linear backward), and,
  * when dbias != NULL, the bias gradient dbias[N1] (+)= column sums of A in the same pass.
  * N1, N2 multiples of 128 (or N1 % 256 == 0 and N2 % 192 == 0); rows >= M are never read (no padding contract).

