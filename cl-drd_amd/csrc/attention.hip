@@ -346,6 +346,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
         const int key = kb * 32 + r;
         const float bias_k = sBias[key];
         f32x16 dK[2] = {(f32x16){0.f}, (f32x16){0.f}}, dV[2] = {(f32x16){0.f}, (f32x16){0.f}};
+#pragma unroll
         for (int qb = 0; qb < NKB; ++qb) {
             f32x16 S = (f32x16){0.f}, dP = (f32x16){0.f};
 #pragma unroll
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
         const float lse_q = sLse[q], delta_q = sDelta[q];
         const uint32_t rk_q = sRk[q];
         f32x16 dQ[2] = {(f32x16){0.f}, (f32x16){0.f}};
+#pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
             f32x16 ST = (f32x16){0.f}, dPT = (f32x16){0.f};
 #pragma unroll

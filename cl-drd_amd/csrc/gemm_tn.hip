@@ -63,6 +63,15 @@ __device__ __forceinline__ int chunk_pos(int c, int m) {
 // by hand: hipcc models the ds_read_tr builtin as an LDS access that may alias the LDS-DMA in flight and puts
 // s_waitcnt vmcnt(0) in front of it, which drains the two K tiles being prefetched on every k-step (the kernel then runs at
 // DMA latency, not at MFMA rate).  The price is that the lgkmcnt waits are ours too, see kstep().
+// One LDS-DMA piece (1 KiB per wave), saddr form: LDS destination = m0 + lane*16, source = uniform 64-bit base + per-lane 32-bit offset
+// (hipcc turned `base + kt*stride + zext(off)` into two 64-bit VALU adds per piece and kept every offset as a register pair: 245 -> 225
+// VGPRs for the 256 x 192 tile, +1..2 %).  Tried on the way and dropped: the bias gradient by v_dot2c_f32_bf16 instead of the all-ones
+// MFMA (frees 24 VGPRs, but the launch ran 15 % slower even without a bias problem in it) and a 256 x 256 tile (spills only outside
+// the K loop, 1018 TF/s at 4096^3 against 877 for 256 x 128, but no better than 256 x 192 on the encoder shapes once the tile counts
+// are rounded to whole rounds of CUs).
+__device__ __forceinline__ void tn_dma16(uint32_t lds_addr, uint32_t voff, const void* sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
 struct Frag { bf16x4 lo, hi; };
 template <int OFF, int HI>
 __device__ __forceinline__ void tr_issue(Frag& f, uint32_t addr) {
@@ -138,12 +147,11 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
             }
             return;
         }
+        const uint32_t lbase = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * SLOT;
 #pragma unroll
-        for (int i = 0; i < APW; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + oa[i]), LDS_PTR(base + (APW * wid + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < APW; ++i) tn_dma16(lbase + (APW * wid + i) * 1024, oa[i], pa);
 #pragma unroll
-        for (int i = 0; i < BPW; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb + ob[i]), LDS_PTR(base + A_BYTES + (BPW * wid + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < BPW; ++i) tn_dma16(lbase + A_BYTES + (BPW * wid + i) * 1024, ob[i], pb);
     };
 
     // ---- transposed-read addressing: 16-lane group g reads token rows 8g+q (+4); lane (4q+pp) supplies cols 4pp..4pp+3.
