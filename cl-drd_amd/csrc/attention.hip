@@ -465,6 +465,237 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
     }
 }
 
+// Backward, persistent two-role form for L <= 128 and many (sequence, head) items.
+//
+// Measured on the kernel above at cfg2 (3072 items, two 4-wave workgroups per CU): loading an item's tiles takes 50 us of the
+// 158 when every CU does it at once (HBM-bound: 252 MB), sweep A 3.2 us and sweep B 4.2 us per item at ONE wave per SIMD - and a
+// workgroup does the three one after the other, so a CU overlaps them only across its two resident workgroups (LDS and the VGPRs
+// allow no third).  Here one 8-wave workgroup per CU walks its items:
+//   * waves 0..3 run sweep A while waves 4..7 run sweep B on the same tiles (two waves per SIMD, different work);
+//   * waves 4..7 first issue the global loads of the NEXT item into registers (Q, K, V, dO, O: 80 VGPRs), run their sweep, then
+//     write them to the other LDS buffer (with delta, mask bias, LSE, dropout row keys): issue-early / write-late, the HBM latency
+//     sits under the sweep;  one __syncthreads per item.
+// The sweeps are the code of attn_bwd_kernel with the block loops rolled (the prefetch registers need the room).
+template <int NKB, bool DROP>
+__global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                         const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
+                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
+                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed, int nitems) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Lp = 32 * NKB;
+    constexpr int TILE = Lp * RSB;
+    constexpr int BUF = 4 * TILE + 4 * Lp * (int)sizeof(float);
+    constexpr int NCH = NKB;                            // 16-byte chunks per thread and tile: Lp * 8 / 256
+    const int tid = threadIdx.x, wid = tid >> 6;
+    const bool role_b = wid >= 4;
+    const int rw = wid & 3;
+    const int dm = H * 64, ld = 3 * dm;
+    const float scale2 = scale * LOG2E;
+    // per-lane indices are re-derived from an OPAQUE copy of the thread id in every iteration: hipcc otherwise hoists the loop-
+    // invariant halves of ~40 64-bit load / store addresses out of the item loop and spills them (76 VGPRs of scratch at L = 128)
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
+    int tb = tid & 255;
+    uint4 pq[NCH], pk[NCH], pv[NCH], pdo[NCH], po[NCH];
+    float p_bias = 0.f, p_lse = 0.f;
+    auto issue = [&](int item) {
+        const int seq = item / H, hd = item % H;
+        const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
+        const bf16_t* dob = dctx + (size_t)seq * L * dm + hd * 64;
+        const bf16_t* ob = ctx + (size_t)seq * L * dm + hd * 64;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tb + 256 * j, row = idx >> 3, ch = idx & 7;
+            pq[j] = pk[j] = pv[j] = pdo[j] = po[j] = make_uint4(0, 0, 0, 0);
+            if (row < L) {
+                const bf16_t* rp = base + (size_t)row * ld + ch * 8;
+                pq[j] = *(const uint4*)rp;
+                pk[j] = *(const uint4*)(rp + dm);
+                pv[j] = *(const uint4*)(rp + 2 * dm);
+                pdo[j] = *(const uint4*)(dob + (size_t)row * dm + ch * 8);
+                po[j] = *(const uint4*)(ob + (size_t)row * dm + ch * 8);
+            }
+        }
+        if (tb < Lp) {
+            p_bias = (tb < L && (!mask || mask[(size_t)seq * L + tb] != 0)) ? 0.f : NEG_BIG;
+            p_lse = tb < L ? lse[((size_t)seq * H + hd) * L + tb] * LOG2E : 1.0e30f;
+        }
+    };
+    auto commit = [&](int b, int item) {
+        const int seq = item / H, hd = item % H;
+        char* base = smem + b * BUF;
+        float* fl = (float*)(base + 4 * TILE);
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tb + 256 * j, row = idx >> 3, ch = idx & 7;
+            const int off = row * RSB + ch * 16;
+            *(uint4*)(base + off) = pq[j];
+            *(uint4*)(base + TILE + off) = pk[j];
+            *(uint4*)(base + 2 * TILE + off) = pv[j];
+            *(uint4*)(base + 3 * TILE + off) = pdo[j];
+            const uint32_t vv[4] = {pdo[j].x, pdo[j].y, pdo[j].z, pdo[j].w}, oo[4] = {po[j].x, po[j].y, po[j].z, po[j].w};
+            float dsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dsum += __uint_as_float(vv[e] << 16) * __uint_as_float(oo[e] << 16) +
+                        __uint_as_float(vv[e] & 0xFFFF0000u) * __uint_as_float(oo[e] & 0xFFFF0000u);
+            dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64);
+            if (ch == 0) fl[2 * Lp + row] = dsum;
+        }
+        if (tb < Lp) {
+            fl[tb] = p_bias;
+            fl[Lp + tb] = p_lse;
+            ((uint32_t*)fl)[3 * Lp + tb] = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + tb));
+        }
+    };
+    int item = blockIdx.x;
+    if (role_b && item < nitems) { issue(item); commit(0, item); }
+    __syncthreads();
+    int cur = 0;
+    for (; item < nitems; item += gridDim.x) {
+        const int next = item + gridDim.x;
+        const bool has_next = next < nitems;
+        const char* sQ = smem + cur * BUF;
+        const char* sK = sQ + TILE;
+        const char* sV = sK + TILE;
+        const char* sdO = sV + TILE;
+        const float* sBias = (const float*)(sdO + TILE);
+        const float* sLse = sBias + Lp;
+        const float* sDelta = sLse + Lp;
+        const uint32_t* sRk = (const uint32_t*)(sDelta + Lp);
+        const int seq = item / H, hd = item % H;
+        const int t_ = opaque(tid);
+        const int lane = t_ & 63, r = lane & 31, h = lane >> 5;
+        tb = t_ & 255;
+        if (role_b) {
+            if (has_next) issue(next);
+            if (rw < NKB) {       // ---- sweep B: query on lane; dQ for 32 queries accumulates over all key blocks
+                const int qb = rw;
+        bf16x8 qf[4], dof[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { qf[s] = row_frag(sQ, qb * 32 + r, s, h); dof[s] = row_frag(sdO, qb * 32 + r, s, h); }
+        const int q = qb * 32 + r;
+        const float lse_q = sLse[q], delta_q = sDelta[q];
+        const uint32_t rk_q = sRk[q];
+        f32x16 dQ[2] = {(f32x16){0.f}, (f32x16){0.f}};
+        for (int kb = 0; kb < NKB; ++kb) {
+            f32x16 ST = (f32x16){0.f}, dPT = (f32x16){0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                ST = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], ST, 0, 0, 0);
+                dPT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, kb * 32 + r, s, h), dof[s], dPT, 0, 0, 0);
+            }
+            float ds[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int key4 = kb * 32 + 8 * u + 4 * h;
+                const float4 b4 = *(const float4*)(sBias + key4);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const int t = 4 * u + j;
+                    const float p0 = __builtin_amdgcn_exp2f(fmaf(ST[t], scale2, bb[j]) - lse_q);
+                    const float p1 = __builtin_amdgcn_exp2f(fmaf(ST[t + 1], scale2, bb[j + 1]) - lse_q);
+                    float dp0 = dPT[t], dp1 = dPT[t + 1];
+                    if (DROP) {
+                        const uint32_t hh = drop_pair(rk_q, (uint32_t)(key4 + j));
+                        dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 * drop_scale : 0.f;
+                        dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 * drop_scale : 0.f;
+                    }
+                    ds[t] = p0 * (dp0 - delta_q);
+                    ds[t + 1] = p1 * (dp1 - delta_q);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 sa = pack8(ds + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa, tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), dQ[dt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int qq = qb * 32 + rowmap(t, h);
+                if (qq < L) dqkv[((size_t)seq * L + qq) * ld + hd * 64 + dt * 32 + r] = f2bf(dQ[dt][t] * scale);
+            }
+                }
+            if (has_next) commit(cur ^ 1, next);
+        } else if (rw < NKB) {    // ---- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks
+            const int kb = rw;
+        bf16x8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { kf[s] = row_frag(sK, kb * 32 + r, s, h); vf[s] = row_frag(sV, kb * 32 + r, s, h); }
+        const int key = kb * 32 + r;
+        const float bias_k = sBias[key];
+        f32x16 dK[2] = {(f32x16){0.f}, (f32x16){0.f}}, dV[2] = {(f32x16){0.f}, (f32x16){0.f}};
+        for (int qb = 0; qb < NKB; ++qb) {
+            f32x16 S = (f32x16){0.f}, dP = (f32x16){0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, qb * 32 + r, s, h), kf[s], S, 0, 0, 0);
+                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sdO, qb * 32 + r, s, h), vf[s], dP, 0, 0, 0);
+            }
+            // S[t], dP[t]: query q = 32 qb + rowmap(t, h), key = 32 kb + r
+            float pd[16], ds[16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // queries rowmap(4u .. 4u+3, h) are consecutive: their LSE / delta / dropout row keys come as 16-byte LDS reads
+                const int q4 = qb * 32 + 8 * u + 4 * h;
+                const float4 l4 = *(const float4*)(sLse + q4), d4 = *(const float4*)(sDelta + q4);
+                const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+                uint4 k4 = make_uint4(0, 0, 0, 0);
+                if (DROP) k4 = *(const uint4*)(sRk + q4);
+                const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = 4 * u + j;
+                    const float p = __builtin_amdgcn_exp2f(fmaf(S[t], scale2, bias_k) - ll[j]);
+                    float pdv = p, dp = dP[t];
+                    if (DROP) {
+                        const bool keep = dropout_keep(kk[j], (uint32_t)key, drop_thresh);
+                        pdv = keep ? p * drop_scale : 0.f;
+                        dp = keep ? dp * drop_scale : 0.f;
+                    }
+                    pd[t] = pdv;
+                    ds[t] = p * (dp - dd[j]);
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pb = pack8(pd + 8 * s2), sb = pack8(ds + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sdO, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, dV[dt], 0, 0, 0);
+                    dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sb, dK[dt], 0, 0, 0);
+                }
+            }
+        }
+        // dV[dt][t] = dV[key][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
+        if (key < L) {
+            bf16_t* ok = dqkv + ((size_t)seq * L + key) * ld + dm + hd * 64;
+            bf16_t* ov = ok + dm;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int d0 = dt * 32 + 8 * u + 4 * h;
+                    uint2 a, b;
+                    a.x = pack2bf(dK[dt][4 * u] * scale, dK[dt][4 * u + 1] * scale);
+                    a.y = pack2bf(dK[dt][4 * u + 2] * scale, dK[dt][4 * u + 3] * scale);
+                    b.x = pack2bf(dV[dt][4 * u], dV[dt][4 * u + 1]);
+                    b.y = pack2bf(dV[dt][4 * u + 2], dV[dt][4 * u + 3]);
+                    *(uint2*)(ok + d0) = a;
+                    *(uint2*)(ov + d0) = b;
+                }
+        }
+            }
+        __syncthreads();          // the other buffer is complete, and nobody reads this one any more
+        cur ^= 1;
+    }
+}
+
 template <int NKB, bool DROP>
 int launch_fwd_f16(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
                    unsigned long long seed, hipStream_t st) {
@@ -504,9 +735,33 @@ int launch_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, in
     return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, st)
                                               : launch_fwd_d<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, st);
 }
+int attn_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
 template <int NKB, bool DROP>
 int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
                  int L, int H, float scale, float p, unsigned long long seed, hipStream_t st) {
+    if constexpr (NKB <= 4) {
+        // many items: the persistent two-role kernel (CLDRD_ATTN_BWD2=0 keeps the one-item-per-workgroup kernel: A/B runs and tests)
+        const char* e = getenv("CLDRD_ATTN_BWD2");
+        const int nitems = nseq * H, cus = attn_num_cus();
+        if (nitems >= 2 * cus && !(e && atoi(e) == 0)) {
+            const size_t lds2 = 2 * (4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float));
+            (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                               (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
+                               DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed, nitems);
+            CLDRD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const size_t lds = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,

@@ -329,6 +329,42 @@ def test_attention_fwd_bwd(nseq, L, H, masked):
     close(dqkv, g, 1 / 32, 2e-2 * scale, f"attention bwd L={L}")
 
 
+@pytest.mark.parametrize("nseq,L,H,p", [(48, 128, 12, 0.0), (48, 128, 12, 0.1), (90, 100, 6, 0.1), (200, 30, 3, 0.0), (70, 64, 8, 0.1),
+                                         (43, 96, 12, 0.0)])
+def test_attention_bwd_persistent_two_role_kernel(nseq, L, H, p):
+    """>= 2 items per CU and L <= 128: the persistent kernel (sweep A and sweep B on different waves, next item prefetched through
+    registers into the second LDS buffer).  Same arithmetic in the same order as the one-item-per-workgroup kernel, which the
+    reference tests above pin: the two must agree bit for bit, masked and ragged, with and without dropout, over several items per
+    workgroup (a stale or half-written LDS buffer would show up here)."""
+    d, T = H * 64, nseq * L
+    g = torch.Generator(device=DEV).manual_seed(nseq * L + H)
+    qkv = torch.randn(T, 3 * d, device=DEV, generator=g).bfloat16()
+    dctx = torch.randn(T, d, device=DEV, generator=g).bfloat16()
+    lens = torch.randint(2, L + 1, (nseq,), device=DEV, generator=g)
+    lens[0] = L
+    mask = (torch.arange(L, device=DEV)[None, :] < lens[:, None]).to(torch.int64).contiguous()
+    ctx = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(nseq, H, L, dtype=torch.float32, device=DEV)
+    ops.attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=p, seed=99)
+    outs = []
+    for env in ("0", None, None):
+        if env is None:
+            os.environ.pop("CLDRD_ATTN_BWD2", None)
+        else:
+            os.environ["CLDRD_ATTN_BWD2"] = env
+        dqkv = torch.full((T, 3 * d), float("nan"), dtype=torch.bfloat16, device=DEV)
+        try:
+            ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=p, seed=99)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("CLDRD_ATTN_BWD2", None)
+        outs.append(dqkv)
+    valid = mask.bool().reshape(-1)
+    assert not torch.isnan(outs[1][valid].float()).any()
+    assert torch.equal(outs[0][valid], outs[1][valid]), "persistent kernel differs from the one-item-per-workgroup kernel"
+    assert torch.equal(outs[1], outs[2]), "two launches of the persistent kernel differ"
+
+
 def test_attention_dropout_statistics():
     nseq, L, H = 2, 64, 2
     T, d = nseq * L, H * 64
