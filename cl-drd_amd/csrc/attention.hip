@@ -165,7 +165,8 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
                     O[dt] = mfma32<F16>(pa, tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), O[dt]);
             }
         }
-        // O[dt][t] = ctx[q = 32 qb + rowmap(t, h)][d = 32 dt + r]
+        // O[dt][t] = ctx[q = 32 qb + rowmap(t, h)][d = 32 dt + r]     (the transposed form - lane = query, 8-byte stores - was tried:
+        // 8 % SLOWER here, 70 -> 79 us with dropout; it is what the streaming kernel below and the backward's dQ use)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -452,16 +453,23 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
                 const bf16x8 sa = pack8(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa, tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), dQ[dt], 0, 0, 0);
+                    // operands swapped: D[d][q], so a lane (= query) ends up with 4 consecutive head dimensions per register quad and dQ
+                    // leaves in 8-byte stores (the other order gave 32 two-byte stores per lane)
+                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sa, dQ[dt], 0, 0, 0);
             }
         }
+        if (q < L) {      // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
+            bf16_t* oq = dqkv + ((size_t)seq * L + q) * ld + hd * 64;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int qq = qb * 32 + rowmap(t, h);
-                if (qq < L) dqkv[((size_t)seq * L + qq) * ld + hd * 64 + dt * 32 + r] = f2bf(dQ[dt][t] * scale);
-            }
+                for (int u = 0; u < 4; ++u) {
+                    uint2 a;
+                    a.x = pack2bf(dQ[dt][4 * u] * scale, dQ[dt][4 * u + 1] * scale);
+                    a.y = pack2bf(dQ[dt][4 * u + 2] * scale, dQ[dt][4 * u + 3] * scale);
+                    *(uint2*)(oq + dt * 32 + 8 * u + 4 * h) = a;
+                }
+        }
     }
 }
 
@@ -610,16 +618,23 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                 const bf16x8 sa = pack8(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(sa, tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), dQ[dt], 0, 0, 0);
+                    // operands swapped: D[d][q], so a lane (= query) ends up with 4 consecutive head dimensions per register quad and dQ
+                    // leaves in 8-byte stores (the other order gave 32 two-byte stores per lane)
+                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sa, dQ[dt], 0, 0, 0);
             }
         }
+        if (q < L) {      // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
+            bf16_t* oq = dqkv + ((size_t)seq * L + q) * ld + hd * 64;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int qq = qb * 32 + rowmap(t, h);
-                if (qq < L) dqkv[((size_t)seq * L + qq) * ld + hd * 64 + dt * 32 + r] = f2bf(dQ[dt][t] * scale);
-            }
+                for (int u = 0; u < 4; ++u) {
+                    uint2 a;
+                    a.x = pack2bf(dQ[dt][4 * u] * scale, dQ[dt][4 * u + 1] * scale);
+                    a.y = pack2bf(dQ[dt][4 * u + 2] * scale, dQ[dt][4 * u + 3] * scale);
+                    *(uint2*)(oq + dt * 32 + 8 * u + 4 * h) = a;
+                }
+        }
                 }
             if (has_next) commit(cur ^ 1, next);
         } else if (rw < NKB) {    // ---- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks
