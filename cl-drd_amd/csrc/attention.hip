@@ -60,6 +60,11 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// dropout by keep BITS: value * (bit `pos` of w ? 1 : 0) as one v_bfe_i32 (0 / all ones) and one v_and
+__device__ __forceinline__ float keep_bit(float v, uint32_t w, int pos) {
+    return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)w, pos, 1));
+}
+
 // copy a [L, 64] bf16 head slice (row stride ld elements) into an LDS tile of Lp rows, zero-filling rows >= L
 __device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld, int L, int Lp) {
     for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
@@ -177,6 +182,181 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
     }
 }
 
+
+// Forward for L <= 128 and many (sequence, head) items: one persistent 8-wave workgroup per CU.  Waves 0..3 compute (the body of
+// attn_fwd_full_kernel, one query block each), waves 4..7 only move data: they issue the global loads of the NEXT item's Q, K, V into
+// registers, wait, and write them to the second LDS buffer - so an item's HBM latency sits under the previous item's arithmetic instead
+// of in front of its own (the kernel above does load -> barrier -> compute per workgroup and overlaps only across the two workgroups
+// a CU can hold).  One __syncthreads per item.
+template <int NKB, bool DROP, bool F16 = false>
+__global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
+                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed, int nitems,
+                                                         uint32_t* __restrict__ bits_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Lp = 32 * NKB;
+    constexpr int TILE = Lp * RSB;
+    constexpr int NBITS = DROP ? Lp * NKB : 0;          // dropout keep bits of an item: dword [kb][q] = keys 32 kb .. 32 kb + 31 of query q
+    constexpr int BUF = 3 * TILE + (Lp + NBITS) * (int)sizeof(float);
+    constexpr int NCH = NKB;                            // 16-byte chunks per loader thread and tile: Lp * 8 / 256
+    const int tid = threadIdx.x, wid = tid >> 6;
+    const bool loader = wid >= 4;
+    const int rw = wid & 3;
+    const int dm = H * 64, ld = 3 * dm;
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };      // see attn_bwd2_kernel
+    int tb = tid & 255;
+    uint4 pq[NCH], pk[NCH], pv[NCH];
+    float p_bias = 0.f;
+    auto issue = [&](int item) {
+        const int seq = item / H, hd = item % H;
+        const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tb + 256 * j, row = idx >> 3, ch = idx & 7;
+            pq[j] = pk[j] = pv[j] = make_uint4(0, 0, 0, 0);
+            if (row < L) {
+                const bf16_t* rp = base + (size_t)row * ld + ch * 8;
+                pq[j] = *(const uint4*)rp;
+                pk[j] = *(const uint4*)(rp + dm);
+                pv[j] = *(const uint4*)(rp + 2 * dm);
+            }
+        }
+        if (tb < Lp) p_bias = (tb < L && (!mask || mask[(size_t)seq * L + tb] != 0)) ? 0.f : NEG_BIG;
+    };
+    auto commit = [&](int b) {
+        char* base = smem + b * BUF;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tb + 256 * j, row = idx >> 3, ch = idx & 7;
+            const int off = row * RSB + ch * 16;
+            *(uint4*)(base + off) = pq[j];
+            *(uint4*)(base + TILE + off) = pk[j];
+            *(uint4*)(base + 2 * TILE + off) = pv[j];
+        }
+        if (tb < Lp) ((float*)(base + 3 * TILE))[tb] = p_bias;
+    };
+    // The loader waves have time to spare: they also evaluate the dropout hash of the next item (one mix32 per key PAIR, common.h) and
+    // leave the keep decisions as bits in LDS - and in `bits_out` for the backward, which then hashes nothing.  With the hash in the
+    // compute waves (one per SIMD here) dropout cost 23 us of 70 per layer.
+    auto make_bits = [&](int b, int item) {
+        if constexpr (DROP) {
+            const int seq = item / H, hd = item % H;
+            uint32_t* sb = (uint32_t*)(smem + b * BUF + 3 * TILE) + Lp;
+            for (int idx = tb; idx < NBITS; idx += 256) {
+                const int q = idx % Lp, kb = idx / Lp;
+                const uint32_t rk = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + q));
+                uint32_t w = 0;
+#pragma unroll
+                for (int pp = 0; pp < 16; ++pp) {
+                    const uint32_t hh = drop_pair(rk, (uint32_t)(kb * 32 + 2 * pp));
+                    w |= (drop_keep_lo(hh, drop_thresh) ? 1u : 0u) << (2 * pp);
+                    w |= (drop_keep_hi(hh, drop_thresh) ? 1u : 0u) << (2 * pp + 1);
+                }
+                sb[idx] = w;
+                if (bits_out) bits_out[(size_t)item * NBITS + idx] = w;
+            }
+        }
+    };
+    int item = blockIdx.x;
+    if (loader && item < nitems) { issue(item); commit(0); make_bits(0, item); }
+    __syncthreads();
+    int cur = 0;
+    for (; item < nitems; item += gridDim.x) {
+        const int next = item + gridDim.x;
+        const char* sQ = smem + cur * BUF;
+        const char* sK = sQ + TILE;
+        const char* sV = sK + TILE;
+        const float* sBias = (const float*)(sV + TILE);
+        const uint32_t* sBits = (const uint32_t*)(sBias + Lp);
+        const int seq = item / H, hd = item % H;
+        const int t_ = opaque(tid);
+        const int lane = t_ & 63, r = lane & 31, h = lane >> 5;
+        tb = t_ & 255;
+        if (loader) {
+            if (next < nitems) { issue(next); commit(cur ^ 1); make_bits(cur ^ 1, next); }
+        } else if (rw < NKB) {
+            const int qb = rw;
+        bf16x8 qf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = row_frag(sQ, qb * 32 + r, s, h);
+        f32x16 S[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            S[kb] = (f32x16){0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                S[kb] = mfma32<F16>(row_frag(sK, kb * 32 + r, s, h), qf[s], S[kb]);
+        }
+        // S[kb][t] = <K[key], Q[q]> with key = 32 kb + rowmap(t, h), q = 32 qb + r
+        // softmax in the log2 domain (v_exp_f32 is 2^x): scores * scale * log2(e) + bias, bias read 4 keys at a time
+        // (keys rowmap(4u .. 4u+3, h) = 8u + 4h + 0..3 are consecutive)
+        const float scale2 = scale * LOG2E;
+        float mx = NEG_BIG * 4.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
+                const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = fmaf(S[kb][4 * u + j], scale2, bb[j]);
+                    S[kb][4 * u + j] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float e = __builtin_amdgcn_exp2f(S[kb][t] - mx);
+                S[kb][t] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const int q = qb * 32 + r;
+        if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (mx + __log2f(sum)) * LN2;
+        const float inv = 1.0f / sum;
+        // dropout mask element (row, col) = ((seq*H + hd)*L + q, key); keys rowmap(t, h), t even / odd, are a column pair
+        const uint32_t rk = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + q));
+        f32x16 O[2] = {(f32x16){0.f}, (f32x16){0.f}};
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+            float pv[16];
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
+                float p0 = S[kb][t] * inv, p1 = S[kb][t + 1] * inv;
+                if (DROP) {       // keys rowmap(t, h), rowmap(t, h) + 1 of block kb: two adjacent bits of the loader's dword
+                    const uint32_t w = sBits[kb * Lp + q] >> (4 * h);
+                    p0 = keep_bit(p0 * drop_scale, w, rowmap(t, 0));
+                    p1 = keep_bit(p1 * drop_scale, w, rowmap(t, 0) + 1);
+                }
+                pv[t] = p0; pv[t + 1] = p1;
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 pa = pack8x<F16>(pv + 8 * s2);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    O[dt] = mfma32<F16>(pa, tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), O[dt]);
+            }
+        }
+        // O[dt][t] = ctx[q = 32 qb + rowmap(t, h)][d = 32 dt + r]     (the transposed form - lane = query, 8-byte stores - was tried:
+        // 8 % SLOWER here, 70 -> 79 us with dropout; it is what the streaming kernel below and the backward's dQ use)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int qq = qb * 32 + rowmap(t, h);
+                if (qq < L) ctx[((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r] = f2x<F16>(O[dt][t]);
+            }
+            }
+        __syncthreads();          // the other buffer is complete, and nobody reads this one any more
+        cur ^= 1;
+    }
+}
 
 // Forward, streaming over the key blocks with a running maximum (one pass, "flash" form): per 32-key block
 //   S^T = K_kb . Q^T (lane = query column)  ->  m' = max(m, colmax)  ->  O^T *= 2^(m - m'),  l = l 2^(m - m') + sum p,
@@ -484,15 +664,18 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 //     write them to the other LDS buffer (with delta, mask bias, LSE, dropout row keys): issue-early / write-late, the HBM latency
 //     sits under the sweep;  one __syncthreads per item.
 // The sweeps are the code of attn_bwd_kernel with the block loops rolled (the prefetch registers need the room).
-template <int NKB, bool DROP>
+template <int NKB, bool DROP, bool BITS>
 __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                          const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
-                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed, int nitems) {
+                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed, int nitems,
+                                                         const uint32_t* __restrict__ drop_bits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
     constexpr int TILE = Lp * RSB;
-    constexpr int BUF = 4 * TILE + 4 * Lp * (int)sizeof(float);
+    constexpr int NBITS = BITS ? Lp * NKB : 0;          // the forward's dropout keep bits (attn_fwd2_kernel): dword [kb][q]
+    constexpr int NBW = (NBITS + 255) / 256;
+    constexpr int BUF = 4 * TILE + (4 * Lp + NBITS) * (int)sizeof(float);
     constexpr int NCH = NKB;                            // 16-byte chunks per thread and tile: Lp * 8 / 256
     const int tid = threadIdx.x, wid = tid >> 6;
     const bool role_b = wid >= 4;
@@ -505,6 +688,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
     int tb = tid & 255;
     uint4 pq[NCH], pk[NCH], pv[NCH], pdo[NCH], po[NCH];
     float p_bias = 0.f, p_lse = 0.f;
+    uint32_t pbits[NBW > 0 ? NBW : 1];
     auto issue = [&](int item) {
         const int seq = item / H, hd = item % H;
         const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
@@ -526,6 +710,10 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         if (tb < Lp) {
             p_bias = (tb < L && (!mask || mask[(size_t)seq * L + tb] != 0)) ? 0.f : NEG_BIG;
             p_lse = tb < L ? lse[((size_t)seq * H + hd) * L + tb] * LOG2E : 1.0e30f;
+        }
+        if constexpr (BITS) {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j) pbits[j] = tb + 256 * j < NBITS ? drop_bits[(size_t)item * NBITS + tb + 256 * j] : 0u;
         }
     };
     auto commit = [&](int b, int item) {
@@ -554,6 +742,11 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             fl[Lp + tb] = p_lse;
             ((uint32_t*)fl)[3 * Lp + tb] = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + tb));
         }
+        if constexpr (BITS) {
+#pragma unroll
+            for (int j = 0; j < NBW; ++j)
+                if (tb + 256 * j < NBITS) ((uint32_t*)fl)[4 * Lp + tb + 256 * j] = pbits[j];
+        }
     };
     int item = blockIdx.x;
     if (role_b && item < nitems) { issue(item); commit(0, item); }
@@ -570,6 +763,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         const float* sLse = sBias + Lp;
         const float* sDelta = sLse + Lp;
         const uint32_t* sRk = (const uint32_t*)(sDelta + Lp);
+        const uint32_t* sBits = sRk + Lp;
         const int seq = item / H, hd = item % H;
         const int t_ = opaque(tid);
         const int lane = t_ & 63, r = lane & 31, h = lane >> 5;
@@ -587,6 +781,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         f32x16 dQ[2] = {(f32x16){0.f}, (f32x16){0.f}};
         for (int kb = 0; kb < NKB; ++kb) {
             f32x16 ST = (f32x16){0.f}, dPT = (f32x16){0.f};
+            uint32_t wbits = 0;
+            if constexpr (BITS) wbits = sBits[kb * Lp + q] >> (4 * h);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 ST = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], ST, 0, 0, 0);
@@ -605,9 +801,14 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                     const float p1 = __builtin_amdgcn_exp2f(fmaf(ST[t + 1], scale2, bb[j + 1]) - lse_q);
                     float dp0 = dPT[t], dp1 = dPT[t + 1];
                     if (DROP) {
-                        const uint32_t hh = drop_pair(rk_q, (uint32_t)(key4 + j));
-                        dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 * drop_scale : 0.f;
-                        dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 * drop_scale : 0.f;
+                        if constexpr (BITS) {       // keys key4 + j, key4 + j + 1: adjacent bits of the forward's dword [kb][q]
+                            dp0 = keep_bit(dp0 * drop_scale, wbits, 8 * u + j);
+                            dp1 = keep_bit(dp1 * drop_scale, wbits, 8 * u + j + 1);
+                        } else {
+                            const uint32_t hh = drop_pair(rk_q, (uint32_t)(key4 + j));
+                            dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 * drop_scale : 0.f;
+                            dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 * drop_scale : 0.f;
+                        }
                     }
                     ds[t] = p0 * (dp0 - delta_q);
                     ds[t + 1] = p1 * (dp1 - delta_q);
@@ -661,7 +862,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                 const float4 l4 = *(const float4*)(sLse + q4), d4 = *(const float4*)(sDelta + q4);
                 const float ll[4] = {l4.x, l4.y, l4.z, l4.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
                 uint4 k4 = make_uint4(0, 0, 0, 0);
-                if (DROP) k4 = *(const uint4*)(sRk + q4);
+                if (DROP) k4 = BITS ? *(const uint4*)(sBits + kb * Lp + q4) : *(const uint4*)(sRk + q4);      // BITS: dwords [kb][q4 .. q4+3], bit = key
                 const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -669,9 +870,14 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                     const float p = __builtin_amdgcn_exp2f(fmaf(S[t], scale2, bias_k) - ll[j]);
                     float pdv = p, dp = dP[t];
                     if (DROP) {
-                        const bool keep = dropout_keep(kk[j], (uint32_t)key, drop_thresh);
-                        pdv = keep ? p * drop_scale : 0.f;
-                        dp = keep ? dp * drop_scale : 0.f;
+                        if constexpr (BITS) {
+                            pdv = keep_bit(p * drop_scale, kk[j], r);
+                            dp = keep_bit(dp * drop_scale, kk[j], r);
+                        } else {
+                            const bool keep = dropout_keep(kk[j], (uint32_t)key, drop_thresh);
+                            pdv = keep ? p * drop_scale : 0.f;
+                            dp = keep ? dp * drop_scale : 0.f;
+                        }
                     }
                     pd[t] = pdv;
                     ds[t] = p * (dp - dd[j]);
@@ -711,6 +917,9 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
     }
 }
 
+int attn_num_cus();
+bool attn_fwd2_enabled(int nseq, int L, int H);
+
 template <int NKB, bool DROP>
 int launch_fwd_f16(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
                    unsigned long long seed, hipStream_t st) {
@@ -730,9 +939,20 @@ int launch_fwd_h(const void* qkv, const long long* mask, void* ctx, float* lse, 
 
 template <int NKB, bool DROP>
 int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-                 unsigned long long seed, hipStream_t st) {
+                 unsigned long long seed, uint32_t* bits_out, hipStream_t st) {
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
     if constexpr (NKB <= 4) {
+        // many items: the persistent loader / compute kernel (CLDRD_ATTN_FWD2=0 keeps the one-item-per-workgroup kernel: A/B runs and tests)
+        const int nitems = nseq * H, cus = attn_num_cus();
+        if (attn_fwd2_enabled(nseq, L, H)) {
+            const size_t lds2 = 2 * (lds + (DROP ? 32 * NKB * NKB * sizeof(uint32_t) : 0));
+            (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            hipLaunchKernelGGL((attn_fwd2_kernel<NKB, DROP>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                               (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed, nitems,
+                               bits_out);
+            CLDRD_LAUNCH_CHECK();
+            return 0;
+        }
         (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                            (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
@@ -746,9 +966,9 @@ int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, 
 }
 template <int NKB>
 int launch_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-               unsigned long long seed, hipStream_t st) {
-    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, st)
-                                              : launch_fwd_d<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, st);
+               unsigned long long seed, uint32_t* bits_out, hipStream_t st) {
+    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, bits_out, st)
+                                              : launch_fwd_d<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, nullptr, st);
 }
 int attn_num_cus() {
     static int n = 0;
@@ -760,19 +980,32 @@ int attn_num_cus() {
     return n;
 }
 
+bool attn_fwd2_enabled(int nseq, int L, int H) {
+    const char* e = getenv("CLDRD_ATTN_FWD2");
+    return L <= 128 && nseq * H >= 2 * attn_num_cus() && !(e && atoi(e) == 0);
+}
+
 template <int NKB, bool DROP>
 int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
-                 int L, int H, float scale, float p, unsigned long long seed, hipStream_t st) {
+                 int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st) {
     if constexpr (NKB <= 4) {
         // many items: the persistent two-role kernel (CLDRD_ATTN_BWD2=0 keeps the one-item-per-workgroup kernel: A/B runs and tests)
         const char* e = getenv("CLDRD_ATTN_BWD2");
         const int nitems = nseq * H, cus = attn_num_cus();
         if (nitems >= 2 * cus && !(e && atoi(e) == 0)) {
-            const size_t lds2 = 2 * (4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float));
-            (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                               (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                               DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed, nitems);
+            const size_t lds1 = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
+            if (DROP && drop_bits) {
+                const size_t lds2 = 2 * (lds1 + 32 * NKB * NKB * sizeof(uint32_t));
+                (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, DROP>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                                   (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
+                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed, nitems, drop_bits);
+            } else {
+                (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
+                hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, false>), dim3(cus), dim3(512), 2 * lds1, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                                   (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
+                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed, nitems, (const uint32_t*)nullptr);
+            }
             CLDRD_LAUNCH_CHECK();
             return 0;
         }
@@ -787,18 +1020,33 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
 }
 template <int NKB>
 int launch_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
-               int L, int H, float scale, float p, unsigned long long seed, hipStream_t st) {
+               int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st) {
     return p > 0.f && dropout_thresh16(p) > 0
-               ? launch_bwd_d<NKB, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, p, seed, st)
-               : launch_bwd_d<NKB, false>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, 0.f, seed, st);
+               ? launch_bwd_d<NKB, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, p, seed, drop_bits, st)
+               : launch_bwd_d<NKB, false>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, 0.f, seed, nullptr, st);
 }
 
 }  // namespace
 
 // qkv: bf16 [nseq*L, 3*H*64] (Q | K | V, heads contiguous inside each); mask: int64 [nseq, L] (0 = padded key) or null;
 // ctx: bf16 [nseq*L, H*64]; lse: fp32 [nseq, H, L] (may be null for inference).
+// Does the forward for this shape run the persistent kernel that leaves the dropout keep bits behind?  Returns the number of 32-bit
+// words of the bit array (nseq*H items x [key block][query]), 0 when the bits are not produced (the backward then hashes itself).
+extern "C" long long cldrd_attention_bits_words(int nseq, int L, int H, float dropout_p) {
+    if (!(dropout_p > 0.f && dropout_thresh16(dropout_p) > 0) || nseq <= 0 || L <= 0 || H <= 0 || !attn_fwd2_enabled(nseq, L, H)) return 0;
+    const long long nkb = (L + 31) / 32;
+    return (long long)nseq * H * 32 * nkb * nkb;
+}
+
+extern "C" int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
+                                        float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* stream);
 extern "C" int cldrd_attention_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
                                    float dropout_p, unsigned long long seed, int io_f16, void* stream) {
+    return cldrd_attention_fwd_bits(qkv, mask, ctx, lse, nseq, L, H, dropout_p, seed, io_f16, nullptr, stream);
+}
+// drop_bits_out (optional, cldrd_attention_bits_words() words): receives the dropout keep bits for cldrd_attention_bwd_bits.
+extern "C" int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
+                                        float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_fwd: need 0 < L <= 256");
     const float scale = 0.125f;   // 1 / sqrt(64)
     const int nkb = (L + 31) / 32;
@@ -813,33 +1061,42 @@ extern "C" int cldrd_attention_fwd(const void* qkv, const long long* mask, void*
         }
     }
     switch (nkb) {
-        case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-        case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-        case 3: return launch_fwd<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-        case 4: return launch_fwd<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-        case 5: return launch_fwd<5>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-        case 6: return launch_fwd<6>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-        case 7: return launch_fwd<7>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-        default: return launch_fwd<8>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+        case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
+        case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
+        case 3: return launch_fwd<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
+        case 4: return launch_fwd<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
+        case 5: return launch_fwd<5>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
+        case 6: return launch_fwd<6>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
+        case 7: return launch_fwd<7>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
+        default: return launch_fwd<8>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
     }
 }
 
+extern "C" int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
+                                        void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
+                                        void* stream);
 extern "C" int cldrd_attention_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                                    void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream) {
+    return cldrd_attention_bwd_bits(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p, seed, nullptr, stream);
+}
+// drop_bits (optional): what cldrd_attention_fwd_bits left for the same (nseq, L, H, dropout_p, seed); null: the mask is re-hashed.
+extern "C" int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
+                                        void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
+                                        void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_bwd: need 0 < L <= 256");
     CLDRD_CHECK(lse != nullptr, "attention_bwd: lse is required");
     const float scale = 0.125f;
     const int nkb = (L + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     switch (nkb) {
-        case 1: return launch_bwd<1>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
-        case 2: return launch_bwd<2>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
-        case 3: return launch_bwd<3>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
-        case 4: return launch_bwd<4>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
-        case 5: return launch_bwd<5>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
-        case 6: return launch_bwd<6>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
-        case 7: return launch_bwd<7>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
-        default: return launch_bwd<8>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, st);
+        case 1: return launch_bwd<1>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+        case 2: return launch_bwd<2>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+        case 3: return launch_bwd<3>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+        case 4: return launch_bwd<4>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+        case 5: return launch_bwd<5>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+        case 6: return launch_bwd<6>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+        case 7: return launch_bwd<7>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+        default: return launch_bwd<8>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
     }
 }
 

@@ -517,7 +517,8 @@ class HipEncoder(nn.Module):
             ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
             ctx = self._buf(T, d, dev, dt16)
             lse = torch.empty(M, H, L, **f32) if save else None
-            ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1)
+            dbits = ops.attention_drop_bits(M, L, H, p_a, dev) if (save and dt16 == torch.bfloat16) else None      # dropout keep bits for the backward
+            ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits)
             s1 = self._buf(T, d, dev, sdt)
             ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out, seed=s_l + 2, residual_ln=res_ln)
             x1 = self._buf(T, d, dev, dt16)
@@ -538,7 +539,7 @@ class HipEncoder(nn.Module):
             mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
             ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32)
             if save:
-                tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, lse=lse, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
+                tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, lse=lse, dbits=dbits, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
                                         h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h, p_a=p_a, p_out=p_out))
             x = xo
             if S32:
@@ -696,7 +697,7 @@ class HipEncoder(nn.Module):
             dctx = self._buf(T, d, dev)
             ops.gemm_nt(dA, self.ht(i, "o"), dctx, T)
             dqkv = self._buf(T, 3 * d, dev)
-            ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1)
+            ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1, drop_bits=a.get("dbits"))
             self._wq.add(dqkv, a["x_in"], G["Wqkv"], T, dbias=G["bqkv"])
             g = self._buf(T, d, dev)
             ops.gemm_nt(dqkv, self.ht(i, "qkv"), g, T, residual=ds1)

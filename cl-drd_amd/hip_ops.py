@@ -153,7 +153,13 @@ class WgradQueue:
         # is ordered behind it by the caching allocator
 
 
-def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0):
+def attention_drop_bits(nseq, L, H, dropout_p, device):
+    """int32 buffer for the dropout keep bits the forward leaves for the backward at this shape, or None (the backward re-hashes)."""
+    n = _lib.load().cldrd_attention_bits_words(nseq, L, H, dropout_p)
+    return torch.empty(n, dtype=torch.int32, device=device) if n > 0 else None
+
+
+def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None):
     io_f16 = _fmt16(qkv, "qkv")
     _chk(qkv, F16 if io_f16 else BF16, "qkv", 2), _chk(ctx, F16 if io_f16 else BF16, "ctx", 2)
     if mask is not None:
@@ -164,18 +170,24 @@ def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0):
         raise ValueError("attention: qkv must be [T, 3*H*64], ctx [T, H*64], contiguous")
     if lse is not None:
         _chk(lse, F32, "lse")
-    call("cldrd_attention_fwd", _p(qkv), _p(mask), _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _stream())
+    if drop_bits is not None:
+        _chk(drop_bits, torch.int32, "drop_bits", 1)
+        if drop_bits.numel() != _lib.load().cldrd_attention_bits_words(nseq, L, H, dropout_p):
+            raise ValueError("attention_fwd: drop_bits must come from attention_drop_bits() for the same shape")
+    call("cldrd_attention_fwd_bits", _p(qkv), _p(mask), _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _p(drop_bits), _stream())
     return ctx
 
 
-def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, seed=0):
+def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None):
     for t, n in ((qkv, "qkv"), (ctx, "ctx"), (dctx, "dctx"), (dqkv, "dqkv")):
         _chk(t, BF16, n, 2)
         if not t.is_contiguous():
             raise ValueError(f"attention_bwd: {n} must be contiguous")
     _chk(lse, F32, "lse")
-    call("cldrd_attention_bwd", _p(qkv), _p(mask), _p(ctx), _p(dctx), _p(lse), _p(dqkv), nseq, L, H, dropout_p, seed,
-         _stream())
+    if drop_bits is not None:
+        _chk(drop_bits, torch.int32, "drop_bits", 1)
+    call("cldrd_attention_bwd_bits", _p(qkv), _p(mask), _p(ctx), _p(dctx), _p(lse), _p(dqkv), nseq, L, H, dropout_p, seed,
+         _p(drop_bits), _stream())
     return dqkv
 
 

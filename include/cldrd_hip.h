@@ -81,6 +81,17 @@ int cldrd_attention_fwd(const void* qkv, const long long* mask, void* ctx, float
 int cldrd_attention_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                         void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
 
+/* Dropout keep bits.  For L <= 128 and at least two (sequence, head) items per CU the forward runs as a persistent loader / compute
+ * kernel whose loader waves evaluate the dropout hash and leave the keep decisions behind as bits ([item][key block][query] dwords);
+ * the backward for the same (nseq, L, H, dropout_p, seed) then reads them instead of hashing again.  cldrd_attention_bits_words()
+ * says how many 32-bit words that is for a shape (0: this shape does not produce bits - pass null and the backward re-hashes). */
+long long cldrd_attention_bits_words(int nseq, int L, int H, float dropout_p);
+int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
+                             float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* stream);
+int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
+                             void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
+                             void* stream);
+
 /* CLS-only attention of the LAST layer (the reference pools last_hidden_state[:, 0, :], models/nway_dual_encoder.py:52,56,64):
  * qc: bf16 [nseq, H*64] = queries of token 0; kv: bf16 [nseq*L, 2*H*64] = K | V of every token; ctx/dctx/dqc: bf16 [nseq, H*64];
  * probs: fp32 [nseq, H, L] (softmax row, saved for the backward); dkv: bf16 [nseq*L, 2*H*64] (every row written).

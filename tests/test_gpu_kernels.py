@@ -345,16 +345,20 @@ def test_attention_bwd_persistent_two_role_kernel(nseq, L, H, p):
     mask = (torch.arange(L, device=DEV)[None, :] < lens[:, None]).to(torch.int64).contiguous()
     ctx = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
     lse = torch.empty(nseq, H, L, dtype=torch.float32, device=DEV)
-    ops.attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=p, seed=99)
+    bits = ops.attention_drop_bits(nseq, L, H, p, DEV)          # the forward's dropout keep bits (None without dropout)
+    assert (bits is not None) == (p > 0)
+    if bits is not None:
+        bits.fill_(-1)
+    ops.attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=p, seed=99, drop_bits=bits)
     outs = []
-    for env in ("0", None, None):
+    for env, b in (("0", None), (None, None), (None, None), (None, bits)):
         if env is None:
             os.environ.pop("CLDRD_ATTN_BWD2", None)
         else:
             os.environ["CLDRD_ATTN_BWD2"] = env
         dqkv = torch.full((T, 3 * d), float("nan"), dtype=torch.bfloat16, device=DEV)
         try:
-            ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=p, seed=99)
+            ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=p, seed=99, drop_bits=b)
             torch.cuda.synchronize()
         finally:
             os.environ.pop("CLDRD_ATTN_BWD2", None)
@@ -363,6 +367,37 @@ def test_attention_bwd_persistent_two_role_kernel(nseq, L, H, p):
     assert not torch.isnan(outs[1][valid].float()).any()
     assert torch.equal(outs[0][valid], outs[1][valid]), "persistent kernel differs from the one-item-per-workgroup kernel"
     assert torch.equal(outs[1], outs[2]), "two launches of the persistent kernel differ"
+    assert torch.equal(outs[1], outs[3]), "the forward's keep bits give a different mask than the hash"
+
+
+@pytest.mark.parametrize("nseq,L,H,p", [(48, 128, 12, 0.0), (48, 128, 12, 0.1), (90, 100, 6, 0.1), (200, 30, 3, 0.0), (70, 64, 8, 0.1)])
+def test_attention_fwd_persistent_loader_kernel(nseq, L, H, p):
+    """>= 2 items per CU and L <= 128: the persistent forward (4 compute waves + 4 loader waves, double-buffered LDS) must reproduce the
+    one-item-per-workgroup kernel bit for bit (context and LSE), which the reference tests above pin."""
+    d, T = H * 64, nseq * L
+    g = torch.Generator(device=DEV).manual_seed(nseq * L + H + 1)
+    qkv = torch.randn(T, 3 * d, device=DEV, generator=g).bfloat16()
+    lens = torch.randint(2, L + 1, (nseq,), device=DEV, generator=g)
+    lens[0] = L
+    mask = (torch.arange(L, device=DEV)[None, :] < lens[:, None]).to(torch.int64).contiguous()
+    outs = []
+    for env in ("0", None, "bits"):
+        if env == "0":
+            os.environ["CLDRD_ATTN_FWD2"] = env
+        else:
+            os.environ.pop("CLDRD_ATTN_FWD2", None)
+        ctx = torch.full((T, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+        lse = torch.full((nseq, H, L), float("nan"), dtype=torch.float32, device=DEV)
+        try:
+            bits = ops.attention_drop_bits(nseq, L, H, p, DEV) if env == "bits" else None
+            ops.attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=p, seed=1234, drop_bits=bits)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("CLDRD_ATTN_FWD2", None)
+        outs.append((ctx, lse))
+    assert not torch.isnan(outs[1][0].float()).any() and not torch.isnan(outs[1][1]).any()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "persistent forward differs from the one-item kernel"
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
 
 
 def test_attention_dropout_statistics():

@@ -16,8 +16,9 @@ ctx = torch.empty(T, d, device=dev, dtype=torch.bfloat16)
 lse = torch.empty(nseq, H, L, device=dev)
 dqkv = torch.empty(T, 3 * d, device=dev, dtype=torch.bfloat16)
 for p in (0.0, 0.1):
-    f = lambda: ops.attention_fwd(qkv, None, ctx, lse, nseq, L, H, dropout_p=p, seed=5)
-    b = lambda: ops.attention_bwd(qkv, None, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=p, seed=5)
+    bits = ops.attention_drop_bits(nseq, L, H, p, dev) if os.environ.get("ATTN_BITS", "1") != "0" else None
+    f = lambda: ops.attention_fwd(qkv, None, ctx, lse, nseq, L, H, dropout_p=p, seed=5, drop_bits=bits)
+    b = lambda: ops.attention_bwd(qkv, None, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=p, seed=5, drop_bits=bits)
     for name, fn, nbytes in (("fwd", f, T * d * 2 * 4), ("bwd", b, T * d * 2 * 9)):
         for _ in range(2): fn()
         torch.cuda.synchronize()
