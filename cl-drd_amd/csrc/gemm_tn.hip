@@ -78,6 +78,8 @@ __device__ __forceinline__ void tr_issue(Frag& f, uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
                  : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr), "n"(OFF), "n"(OFF + HI) : "memory");
 }
+template <int N>
+__device__ __forceinline__ void tn_wait_frag(Frag& f) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N)); }
 __device__ __forceinline__ bf16x8 frag8(const Frag& f) { return (bf16x8){f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]}; }
 
 template <int T1, int T2, int NW>
@@ -243,6 +245,107 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
     using KS0 = std::integral_constant<int, 0>;
     using KS1 = std::integral_constant<int, 1>;
 
+    // FA = 8 (the 256-row tiles): A fragments are refilled FOUR rows after their last use instead of at once.
+    // lgkmcnt is a 4-bit counter.  With the schedule above a k-step keeps 2 FA + 2 NBF = 22 reads in flight and row t1 waits with
+    // lgkmcnt(15) where 20 were meant: it also waits for reads issued only ~2 rows (100 cycles) earlier, i.e. for LDS latency - halving
+    // the reads (a wrong-result experiment) gave +5..16 %.  Here fragment f of k-step s+1 is requested after row f + 4 (rows 0..3
+    // request fragments 4..7 of the SAME k-step, rows 4..7 fragments 0..3 and B of the next one): every request is 4 rows old when
+    // it is waited for and at most 6 (rows 0..4) or 6 + 2 NBF (rows 5..7) younger ones exist - exact counts, all <= 14.
+    // Consequences: a k-step starts with A0..A3 and B in registers only; the slot of K tile kt is free (barrier + DMA of K tile kt+2)
+    // after row 3 of its second k-step, not after row 0; the very last k-step still issues its (unused) requests so that the counts
+    // hold, and they are drained before the epilogue touches the registers.
+    constexpr int WLO = 6, WHI = 6 + 2 * NBF;
+    static_assert(FA != 8 || NSLOT == 2, "the 256-row tiles use two LDS slots");
+    auto wait_row0_lag = [&](Frag (&bc)[NBF]) {
+        if constexpr (NBF == 4)
+            asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo),
+                         "+v"(bc[1].hi), "+v"(bc[2].lo), "+v"(bc[2].hi), "+v"(bc[3].lo), "+v"(bc[3].hi) : "n"(WLO));
+        else
+            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo),
+                         "+v"(bc[1].hi), "+v"(bc[2].lo), "+v"(bc[2].hi) : "n"(WLO));
+    };
+    // one 32-token k-step; current fragments at slot offset coff / k-step CKS, the next k-step's at noff / NKS
+    auto kstep8 = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t coff, auto cks_tag, uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
+        constexpr int CKS = decltype(cks_tag)::value, NKS = decltype(nks_tag)::value;
+        constexpr int COA = CKS * 32 * T1 * 2, NOA = NKS * 32 * T1 * 2, NOB = NKS * 32 * T2 * 2;
+        wait_row0_lag(bc);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(0, bc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!sync && late_wave && slot >= 0 && kt + NSLOT < nk) {
+            stage(slot, kt + NSLOT);                       // postponed from the previous K tile's barrier (see gemm_nt_ring.hip)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        tr_issue<COA, 4 * T1 * 2>(af[4], ra[4] + coff);
+#pragma unroll
+        for (int t1 = 1; t1 < 4; ++t1) {
+            __builtin_amdgcn_sched_barrier(0);
+            tn_wait_frag<WLO>(af[t1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(t1, bc);
+            __builtin_amdgcn_sched_barrier(0);
+            tr_issue<COA, 4 * T1 * 2>(af[t1 + 4], ra[t1 + 4] + coff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        tn_wait_frag<WLO>(af[4]);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(4, bc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sync) {
+            // every read of this K tile's slot has been issued (and is waited for here); K tile kt+1 must have landed
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (!late_wave && kt + NSLOT < nk) stage(slot, kt + NSLOT);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int t = 0; t < NBF; ++t) tr_issue<NOB, 4 * T2 * 2>(bn[t], rb[t] + noff);
+        tr_issue<NOA, 4 * T1 * 2>(af[0], ra[0] + noff);
+#pragma unroll
+        for (int t1 = 5; t1 < 8; ++t1) {
+            __builtin_amdgcn_sched_barrier(0);
+            tn_wait_frag<WHI>(af[t1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_row(t1, bc);
+            __builtin_amdgcn_sched_barrier(0);
+            tr_issue<NOA, 4 * T1 * 2>(af[t1 - 4], ra[t1 - 4] + noff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    if constexpr (FA == 8) {
+        if (nk > 0) {
+            stage(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (nk > 1) stage(1, 1);
+#pragma unroll
+            for (int t = 0; t < NBF; ++t) tr_issue<0, 4 * T2 * 2>(b0[t], rb[t]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) tr_issue<0, 4 * T1 * 2>(af[t], ra[t]);
+            int cs = 0, ps = -1;                               // slots of K tiles kt and kt-1
+            for (int kt = 0; kt + 1 < nk; ++kt) {
+                const int ns = cs ^ 1;
+                kstep8(b0, b1, (uint32_t)(cs * SLOT), KS0{}, (uint32_t)(cs * SLOT), KS1{}, false, ps, kt - 1);
+                kstep8(b1, b0, (uint32_t)(cs * SLOT), KS1{}, (uint32_t)(ns * SLOT), KS0{}, true, cs, kt);
+                ps = cs;
+                cs = ns;
+            }
+            kstep8(b0, b1, (uint32_t)(cs * SLOT), KS0{}, (uint32_t)(cs * SLOT), KS1{}, false, ps, nk - 2);
+            kstep8(b1, b0, (uint32_t)(cs * SLOT), KS1{}, (uint32_t)(cs * SLOT), KS0{}, false, -1, nk);      // its next-k-step requests read stale LDS: unused
+            // drain them: an outstanding read lands in its destination register whatever the register holds by then
+            if constexpr (NBF == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(af[1].lo), "+v"(af[1].hi), "+v"(af[2].lo), "+v"(af[2].hi),
+                             "+v"(af[3].lo), "+v"(af[3].hi), "+v"(b0[0].lo), "+v"(b0[0].hi), "+v"(b0[1].lo), "+v"(b0[1].hi), "+v"(b0[2].lo),
+                             "+v"(b0[2].hi), "+v"(b0[3].lo), "+v"(b0[3].hi));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(af[1].lo), "+v"(af[1].hi), "+v"(af[2].lo), "+v"(af[2].hi),
+                             "+v"(af[3].lo), "+v"(af[3].hi), "+v"(b0[0].lo), "+v"(b0[0].hi), "+v"(b0[1].lo), "+v"(b0[1].hi), "+v"(b0[2].lo),
+                             "+v"(b0[2].hi));
+        }
+    } else
     if (nk > 0) {
         stage(0, 0);
         if (NSLOT == 3 && nk > 1) {
