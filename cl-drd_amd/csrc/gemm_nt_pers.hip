@@ -442,180 +442,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_pers_kernel(GemmNtArgs p, int 
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// "Duo" form: TWO 4-wave workgroups per CU, each with a 256 x 128 tile (waves 2 x 2 of 128 x 64: the same wave tile, hence the same
-// register epilogue), 32-deep K slices in three 24-KiB LDS slots (72 KiB per workgroup).  Why: with one 8-wave workgroup per CU the
-// epilogue of a tile (VALU-bound GELU, or HBM-bound fp32 residual in / out) leaves the MFMA pipe idle - 35-50 % of a tile round at
-// K = 768 - and nothing else lives on the CU to use it.  Two independent workgroups drift apart: one's K loop (MFMA + LDS-DMA) runs
-// under the other's epilogue (VALU + global loads / stores).  The price is the smaller tile: 85 instead of 128 FLOP per byte moved into
-// LDS, i.e. 1.5 x the L2 -> LDS bytes - which two workgroups per CU can pull (the 128 x 128 kernel, also two per CU, takes in 58 GB/s per
-// CU where every one-workgroup kernel here saturates at 40-42).
-// LDS rows are 64 bytes (one 32-deep slice of a row = half a 128-B line); 16-B chunk c of row r sits at c ^ (((r >> 2) & 1) << 1):
-// conflict-free for ds_read_b128's lane groups (brute-forced over the XOR maps, tools/lds_bank_sim.py has the lane groups).
-constexpr int DBM = 256, DBN = 128, DBK = 32, DSLOTS = 3;
-constexpr int DA_BYTES = DBM * DBK * 2, DB_BYTES = DBN * DBK * 2, DSLOT = DA_BYTES + DB_BYTES;
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_duo_kernel(GemmNtArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = 4;                    // 16-col MFMA tiles per wave (wave tile 128 x 64)
-    constexpr int G = 6;                     // LDS-DMA instructions per wave per K slice: 4 of A, 2 of B
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int ntn = p.N / DBN;
-    const int ntm = (p.M + DBM - 1) / DBM;
-    const int wm = wid >> 1, wn = wid & 1;
-    const int nk_ = p.K / DBK;
-    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-    int m0, n0;
-    {
-        const int tile = xcd_remap(blockIdx.x, gridDim.x);
-        int mt_, nt_;
-        if (p.gn > 0 && p.gn < ntn) {
-            const int mc = (ntm + 7) / 8;
-            const int c = tile / (mc * ntn), r = tile % (mc * ntn);
-            const int mrows = min(mc, ntm - c * mc);
-            const int g = r / (mrows * p.gn);
-            const int r2 = r - g * mrows * p.gn;
-            const int gw = min(p.gn, ntn - g * p.gn);
-            mt_ = c * mc + r2 / gw;
-            nt_ = g * p.gn + r2 % gw;
-        } else {
-            mt_ = tile / ntn;
-            nt_ = tile % ntn;
-        }
-        m0 = mt_ * DBM;
-        n0 = nt_ * DBN;
-    }
-    // ---- LDS-DMA: piece = 16 rows x 64 B; lane -> row (lane >> 2), LDS chunk (lane & 3), source chunk swizzled ----
-    const int prow = lane >> 2;
-    const int schunk = (lane & 3) ^ (((prow >> 2) & 1) << 1);
-    uint32_t oa[4], ob[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        oa[i] = (uint32_t)min(m0 + (4 * wid + i) * 16 + prow, p.M - 1) * (uint32_t)(p.lda * 2) + schunk * 16;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        ob[i] = (uint32_t)(n0 + (2 * wid + i) * 16 + prow) * (uint32_t)(p.ldb * 2) + schunk * 16;
-    auto stage = [&](int slot, int kt) {
-        const uint32_t base = lds0 + slot * DSLOT;
-        const char* pa = (const char*)p.A + kt * (DBK * 2);
-        const char* pb = (const char*)p.B + kt * (DBK * 2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma16(base + (4 * wid + i) * 1024, oa[i], pa);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) dma16(base + DA_BYTES + (2 * wid + i) * 1024, ob[i], pb);
-    };
-    // ---- fragment addressing: row (lane & 15) of a 16-row tile, 16-B chunk lane >> 4 (swizzled) ----
-    const int frow = lane & 15;
-    const int fch = ((lane >> 4) ^ (((frow >> 2) & 1) << 1)) * 16;
-    const int a_off = (wm * 128 + frow) * 64 + fch;
-    const int b_off = DA_BYTES + (wn * 64 + frow) * 64 + fch;
-
-    f32x4 acc[8][NT];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[8], b0[NT], b1[NT];
-    auto mfma_row = [&](int mt, bf16x8 (&bc)[NT]) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = gemm_mfma<EPI>(bc[nt], af[mt], acc[mt][nt]);
-    };
-    // one 32-deep slice kt (fragments in af / bc); the next slice's fragments are read from slot `ns` between the MFMAs
-    auto kstep = [&](bf16x8 (&bc)[NT], bf16x8 (&bn)[NT], int kt, int cslot, int ns) {
-        mfma_row(0, bc);
-        mfma_row(1, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        // slice kt+1 must have landed (slice kt+2, issued one step ago, may stay in flight); every fragment of slice kt is in registers
-        // everywhere once the barrier is passed: its slot takes slice kt+3
-        if (kt + 2 < nk_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (kt + DSLOTS < nk_) stage(cslot, kt + DSLOTS);
-        __builtin_amdgcn_sched_barrier(0);
-        const char* na = smem + ns * DSLOT + a_off;
-        const char* nb = smem + ns * DSLOT + b_off;
-        af[0] = *(const bf16x8*)(na);
-        af[1] = *(const bf16x8*)(na + 16 * 64);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) bn[t] = *(const bf16x8*)(nb + t * 16 * 64);
-#pragma unroll
-        for (int mt = 2; mt < 8; ++mt) {
-            mfma_row(mt, bc);
-            af[mt] = *(const bf16x8*)(na + mt * 16 * 64);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
-#pragma unroll
-        for (int mt = 2; mt < 8; ++mt) {
-            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    stage(0, 0);
-    if (nk_ > 1) stage(1, 1);
-    if (nk_ > 2) stage(2, 2);
-    if (nk_ > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G) : "memory");
-    else if (nk_ > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < NT; ++t) b0[t] = *(const bf16x8*)(smem + b_off + t * 16 * 64);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) af[t] = *(const bf16x8*)(smem + a_off + t * 16 * 64);
-    // ONE uniform loop, two slices per trip (the B fragment buffers swap roles; nk is even: K % 64 == 0).  The last step's prefetch
-    // reads a slot nothing was staged into - unused; a separate tail would be straight-line code in which hipcc renames the
-    // accumulators and spills 100+ registers.
-    int cs = 0;
-    for (int kt = 0; kt < nk_; kt += 2) {
-        const int s1 = cs == DSLOTS - 1 ? 0 : cs + 1;
-        const int s2 = s1 == DSLOTS - 1 ? 0 : s1 + 1;
-        kstep(b0, b1, kt, cs, s1);
-        kstep(b1, b0, kt + 1, s1, s2);
-        cs = s2;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (m0 + DBM <= p.M) pers_epilogue<NT, EPI, true>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
-    else pers_epilogue<NT, EPI, false>(p, acc, m0 + wm * 128, n0 + wn * 64, lane);
-}
-
-template <int EPI>
-int launch_duo_epi(const GemmNtArgs& a, hipStream_t st) {
-    constexpr int lds = DSLOTS * DSLOT;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_duo_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_set = true;
-    }
-    const int ntiles = ((a.M + DBM - 1) / DBM) * (a.N / DBN);
-    hipLaunchKernelGGL((gemm_nt_duo_kernel<EPI>), dim3(ntiles), dim3(256), lds, st, a);
-    CLDRD_LAUNCH_CHECK();
-    return 0;
-}
-
-int launch_duo(const GemmNtArgs& a, hipStream_t st) {
-    switch (epi_flavour(a)) {
-        case 0: return launch_duo_epi<0>(a, st);
-        case EPI_BIAS: return launch_duo_epi<EPI_BIAS>(a, st);
-        case EPI_BIAS | EPI_PREACT | EPI_GELU: return launch_duo_epi<EPI_BIAS | EPI_PREACT | EPI_GELU>(a, st);
-        case EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU: return launch_duo_epi<EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU>(a, st);
-        case EPI_GELUGRAD | EPI_DGELU: return launch_duo_epi<EPI_GELUGRAD | EPI_DGELU>(a, st);
-        case EPI_BIAS | EPI_GELU: return launch_duo_epi<EPI_BIAS | EPI_GELU>(a, st);
-        case EPI_GELUGRAD: return launch_duo_epi<EPI_GELUGRAD>(a, st);
-        case EPI_RESIDUAL: return launch_duo_epi<EPI_RESIDUAL>(a, st);
-        case EPI_BIAS | EPI_RESIDUAL: return launch_duo_epi<EPI_BIAS | EPI_RESIDUAL>(a, st);
-        case EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32: return launch_duo_epi<EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, st);
-        case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
-            return launch_duo_epi<EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, st);
-        default: return -1;
-    }
-}
-
 int pers_num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -665,12 +491,6 @@ int launch_pers(const GemmNtArgs& a, hipStream_t st) {
 }
 
 }  // namespace
-
-// The duo form (two 256 x 128 workgroups per CU); `a.gn` counts 128-column tiles here.  -1: does not apply.
-int cldrd_gemm_nt_duo_dispatch(const GemmNtArgs& a, hipStream_t st) {
-    if (a.in_f16 || a.K % (2 * DBK) != 0 || a.N % DBN != 0 || a.thr != nullptr || a.M < 1024) return -1;
-    return launch_duo(a, st);
-}
 
 // Returns -1 when this variant does not apply (the caller goes on to the ring kernel), else the launch status.
 // `a.gn` / `a.stagger` are set by the caller (cldrd_gemm_nt_ring_dispatch).

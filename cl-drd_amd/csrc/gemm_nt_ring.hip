@@ -277,7 +277,6 @@ int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st) {
 }
 
 int cldrd_gemm_nt_pers_dispatch(const GemmNtArgs& a, int bn, hipStream_t st);    // gemm_nt_pers.hip
-int cldrd_gemm_nt_duo_dispatch(const GemmNtArgs& a, hipStream_t st);             // gemm_nt_pers.hip
 
 // Returns -1 if this variant does not apply (caller falls back to the 128x128 kernel), else the launch status.
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_t st) {
@@ -291,15 +290,6 @@ int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_
     gn_force = gn_env;
     if (a.K % BK != 0 || a.in_f16) return -1;
     if ((double)a.M * a.lda * 2.0 >= 4.0e9 || (double)a.N * a.ldb * 2.0 >= 4.0e9) return -1;   // 32-bit DMA offsets
-    {   // duo form (two 256 x 128 workgroups per CU): experiments, CLDRD_GEMM_DUO=1
-        const char* de = getenv("CLDRD_GEMM_DUO");
-        if (de && atoi(de) != 0 && force_bn == 0) {
-            GemmNtArgs b = a;
-            b.gn = gn_env >= 0 ? gn_env : (a.K <= 1024 ? (int)(2.0e6 / (128.0 * a.K * 2.0) + 0.5) : 0);
-            const int rc = cldrd_gemm_nt_duo_dispatch(b, st);
-            if (rc >= 0) return rc;
-        }
-    }
     int bn = force_bn;
     if (bn == 0) {
         if (a.M < 1024) return -1;

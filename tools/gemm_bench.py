@@ -32,7 +32,6 @@ def main():
         for rnd in range(3):
             for v in variants:
                 os.environ["CLDRD_GEMM_PERSIST"] = "1" if v == "pers" else ("2" if v == "pers1" else "0")
-                os.environ["CLDRD_GEMM_DUO"] = "1" if v == "duo" else "0"
                 if v.startswith("ring") and len(v) > 4: os.environ["CLDRD_GEMM_TILE"] = v[4:]
                 else: os.environ.pop("CLDRD_GEMM_TILE", None)
                 for _ in range(2): ops.gemm_nt(A, B, out, **kw)
