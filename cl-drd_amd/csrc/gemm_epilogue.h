@@ -25,6 +25,8 @@ struct GemmNtArgs {
     // EPI_FILTER (top-k scan): keep C[m][n] >= thr[m] as candidate (n, score) of query m
     const float* thr; int* counts; int* cand_rows; float* cand_scores; int cap;
     int in_f16 = 0;               // top-k scan only: the operands are fp16 (EPI_F16IN instances), not bf16
+    int ksplit = 1;               // small-M kernel: K range split over ksplit workgroups per tile, fp32 partials in `slabs` ([ksplit][M][N]),
+    float* slabs = nullptr;       //   summed in a fixed order and finished (epilogue) by splitk_finish_kernel
     int gn = 0;                   // ring kernel: N tiles are walked in groups of gn inside an XCD's range (0: row-major)
     int stagger = 1;              // ring kernel: waves 4..7 issue their LDS-DMA one k-step after waves 0..3 (0: A/B runs)
 };
@@ -34,6 +36,7 @@ struct GemmNtArgs {
 enum : int {
     EPI_BIAS = 1, EPI_PREACT = 2, EPI_GELU = 4, EPI_GELUGRAD = 8, EPI_DROPOUT = 16, EPI_RESIDUAL = 32, EPI_F32 = 64, EPI_FILTER = 128,
     EPI_RES32 = 256,              // the residual operand is fp32 (only with EPI_RESIDUAL)
+    EPI_SPLITK = 4096,            // small-M kernel: write raw fp32 partial sums of this workgroup's K range to GemmNtArgs::slabs (no epilogue)
     EPI_RESLN = 2048,             // the fp32 residual is a pre-LN sum: apply the LayerNorm (ln_* of GemmNtArgs) on the fly (with EPI_RES32)
     EPI_DGELU = 1024,             // derivative form of the saved activation input (act bit 1): with EPI_PREACT / EPI_GELUGRAD
     EPI_F16IN = 512,              // A, B (and a 16-bit C) hold fp16, not bf16: the top-k scan over the fp16 index shadow (with EPI_FILTER)

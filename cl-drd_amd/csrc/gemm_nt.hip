@@ -28,8 +28,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntn = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    const int tile = xcd_remap(blockIdx.x, nwg);
+    constexpr bool SPLITK = EPI != EPI_GENERIC && (EPI & EPI_SPLITK) != 0;
+    const int ntiles = SPLITK ? (int)gridDim.x / p.ksplit : (int)gridDim.x;
+    const int split = SPLITK ? (int)blockIdx.x / ntiles : 0;
+    const int tile = SPLITK ? (int)blockIdx.x % ntiles : xcd_remap(blockIdx.x, gridDim.x);
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
     const int wm = wid >> 1, wn = wid & 1;
 
@@ -70,12 +72,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = p.K / BK;
-    stage(0, 0);
+    // K range of this workgroup (split-K: a contiguous share of the K tiles; the others: everything)
+    const int nk_all = p.K / BK;
+    const int kper = SPLITK ? (nk_all + p.ksplit - 1) / p.ksplit : nk_all;
+    const int kbeg = split * kper;
+    const int nk = min(nk_all, kbeg + kper) - kbeg;
+    if (nk > 0) stage(0, kbeg * BK);
     for (int kt = 0; kt < nk; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kbeg + kt + 1) * BK);
         const char* sb = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -94,12 +100,99 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
         }
     }
 
-    if constexpr ((EPI & EPI_FILTER) != 0 && EPI != EPI_GENERIC) {
+    if constexpr (SPLITK) {
+        // raw partial sums of this K range, accumulator layout: lane holds 4 consecutive columns of row (lane & 15) of each 16 x 16 tile
+        float* out = p.slabs + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 64 + mt * 16 + (lane & 15);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + wn * 64 + nt * 16 + 4 * (lane >> 4);
+                if (m < p.M && n < p.N) *(f32x4*)(out + (size_t)m * p.N + n) = acc[mt][nt];
+            }
+        }
+    } else if constexpr ((EPI & EPI_FILTER) != 0 && EPI != EPI_GENERIC) {
         gemm_nt_filter_epilogue<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
     } else {
         __syncthreads();      // all fragment reads of the last K tile are done: the staging buffers become epilogue scratch
         gemm_nt_epilogue<4, 4, EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, (float*)smem + wid * (32 * 68));
     }
+}
+
+// Split-K, second half: every thread owns 8 consecutive columns of a row, sums the ksplit partials in a fixed order and runs the
+// same fused epilogue (run-time flags) as the one-pass kernels.  F16OUT: a 16-bit C is fp16 (the fp16 format of the forward kernels).
+template <bool F16OUT>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(GemmNtArgs p) {
+    const int n8 = p.N / 8;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)p.M * n8) return;
+    const int m = (int)(idx / n8), n = (int)(idx % n8) * 8;
+    const EpiFlags<EPI_GENERIC> fl(p);
+    float v[8];
+    {
+        const float* s0 = p.slabs + (size_t)m * p.N + n;
+        const f32x4 a = *(const f32x4*)s0, b = *(const f32x4*)(s0 + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        for (int k = 1; k < p.ksplit; ++k) {
+            const float* sk = s0 + (size_t)k * p.M * p.N;
+            const f32x4 c = *(const f32x4*)sk, d = *(const f32x4*)(sk + 4);
+            v[0] += c[0]; v[1] += c[1]; v[2] += c[2]; v[3] += c[3]; v[4] += d[0]; v[5] += d[1]; v[6] += d[2]; v[7] += d[3];
+        }
+    }
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (fl.bias) {
+        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+    uint4 res = make_uint4(0, 0, 0, 0), resh = make_uint4(0, 0, 0, 0), gp = make_uint4(0, 0, 0, 0);
+    if (fl.residual) {
+        if (fl.res32) {
+            const uint4* rp = (const uint4*)((const float*)p.residual + (size_t)m * p.ldr + n);
+            res = rp[0];
+            resh = rp[1];
+            if (fl.resln) {       // residual = LayerNorm(pre-LN sum): the expression of ln_fwd_kernel / gemm_nt_epilogue
+                const float mu = p.ln_mean[m], rs = p.ln_rstd[m];
+                uint32_t* lo = (uint32_t*)&res;
+                uint32_t* hi = (uint32_t*)&resh;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lo[j] = __float_as_uint((__uint_as_float(lo[j]) - mu) * rs * p.ln_gamma[n + j] + p.ln_beta[n + j]);
+                    hi[j] = __float_as_uint((__uint_as_float(hi[j]) - mu) * rs * p.ln_gamma[n + 4 + j] + p.ln_beta[n + 4 + j]);
+                }
+            }
+        } else {
+            res = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + n);
+        }
+    }
+    if (fl.gelugrad) gp = *(const uint4*)(p.gelu_pre + (size_t)m * p.ldc + n);
+    if constexpr (F16OUT) {
+        if (!fl.f32) {            // fp16 C: apply8's generic store is bf16, so finish in fp32 registers and pack here
+            GemmNtArgs q = p;
+            float tmp[8];
+            q.C = tmp - n; q.ldc = 0; q.out_f32 = 1;      // the store of apply8 lands in tmp; (m, n) stay real: the dropout mask is keyed on them
+            const EpiFlags<EPI_GENERIC> fq(q);
+            // preact / gelu_pre are indexed with ldc: the fp16 format has neither (checked by the launcher)
+            gemm_nt_apply8<EPI_GENERIC>(q, fq, v, m, n, bias8, res, resh, gp);
+            *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = pack8h(tmp);
+            return;
+        }
+    }
+    gemm_nt_apply8<EPI_GENERIC>(p, fl, v, m, n, bias8, res, resh, gp);
+}
+
+// K splits of the small-M kernel for a shape (1: one pass).  The 128 x 128 kernel holds two workgroups per CU: aim at ~1.5 per CU with
+// at least 4 K tiles each, only where the one-pass grid leaves most of the chip idle.
+static int splitk_choice(int M, int N, int K) {
+    const char* e = getenv("CLDRD_GEMM_SPLITK");        // 1: never split, n > 1: n splits (read per call: tests flip it in-process)
+    const int force = e ? atoi(e) : 0;
+    if (force == 1) return 1;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = K / BK;
+    if (M >= 1024 || tiles >= 128 || nk < 8) return 1;
+    int ks = 384 / tiles;
+    if (ks > nk / 4) ks = nk / 4;
+    if (force > 1) ks = force < nk ? force : nk;
+    return ks < 2 ? 1 : ks;
 }
 
 template <int EPI>
@@ -122,11 +215,23 @@ int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st);               
 int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts, int* cand_rows,
                            float* cand_scores, int cap, int f16, hipStream_t st);   // topk.hip
 
+extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                     const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
+                                     int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
+                                     int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
+                                     const float* ln_beta, float* workspace, size_t workspace_bytes, void* stream);
 extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                      const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
                                      const float* ln_beta, void* stream);
+
+// Bytes of workspace with which cldrd_gemm_nt_bf16_ws splits the K range of this shape over several workgroups (0: it does not)
+extern "C" size_t cldrd_gemm_nt_splitk_workspace(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 8 != 0) return 0;
+    const int ks = splitk_choice(M, N, K);
+    return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
+}
 
 extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
@@ -142,6 +247,18 @@ extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int 
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
                                      const float* ln_beta, void* stream) {
+    return cldrd_gemm_nt_bf16_ws(A, B, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, preact, gelu_pre, act, alpha, dropout_p, seed, out_f32,
+                                 res_f32, io_f16, ln_mean, ln_rstd, ln_gamma, ln_beta, nullptr, 0, stream);
+}
+
+// The same with a workspace: small-M problems whose one-pass grid would leave most CUs idle (the CLS-only last layer, the query
+// tower: M = 256 rows, K up to 3072 -> 12 workgroups walking 48 K tiles each) are split along K over cldrd_gemm_nt_splitk_workspace()
+// bytes of fp32 partials and finished by a second launch (fixed summation order; same epilogue).  workspace = null: one pass.
+extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                                     const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
+                                     int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
+                                     int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
+                                     const float* ln_beta, float* workspace, size_t workspace_bytes, void* stream) {
     {
         const int nln = (ln_mean != nullptr) + (ln_rstd != nullptr) + (ln_gamma != nullptr) + (ln_beta != nullptr);
         CLDRD_CHECK(nln == 0 || nln == 4, "gemm_nt: ln_mean / ln_rstd / ln_gamma / ln_beta go together");
@@ -168,6 +285,30 @@ extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int 
     a.seed = seed; a.out_f32 = out_f32;
     a.thr = nullptr; a.counts = nullptr; a.cand_rows = nullptr; a.cand_scores = nullptr; a.cap = 0;
     a.in_f16 = io_f16 ? 1 : 0;
+    if (workspace != nullptr && K % BK == 0 && N % 8 == 0 && !(io_f16 && (preact || gelu_pre))) {
+        const int ks = splitk_choice(M, N, K);
+        if (ks > 1 && workspace_bytes >= (size_t)ks * M * N * sizeof(float) && (uintptr_t)workspace % 16 == 0) {
+            a.ksplit = ks;
+            a.slabs = workspace;
+            const int nblk = ((M + BM - 1) / BM) * ((N + BN - 1) / BN) * ks;
+            hipStream_t st = (hipStream_t)stream;
+            if (io_f16) {
+                static bool set16 = false;
+                if (!set16) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SPLITK | EPI_F16IN>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); set16 = true; }
+                hipLaunchKernelGGL((gemm_nt_kernel<EPI_SPLITK | EPI_F16IN>), dim3(nblk), dim3(256), 2 * STAGE_BYTES, st, a);
+            } else {
+                static bool set = false;
+                if (!set) { (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI_SPLITK>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES); set = true; }
+                hipLaunchKernelGGL((gemm_nt_kernel<EPI_SPLITK>), dim3(nblk), dim3(256), 2 * STAGE_BYTES, st, a);
+            }
+            CLDRD_LAUNCH_CHECK();
+            const size_t nthr = (size_t)M * (N / 8);
+            if (io_f16) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, a);
+            CLDRD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (io_f16) {
         // fp16 operands / 16-bit output (the high-precision forward of the query tower): small-M kernel, forward flavours only
         CLDRD_CHECK(K % BK == 0, "gemm_nt: K must be a multiple of 64");

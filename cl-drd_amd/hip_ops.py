@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import torch
 
+import os
+
 from . import _lib
 from ._lib import call
 
@@ -78,6 +80,7 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
         _chk(residual, F32 if res_f32 else BF16, "residual", 2)
         if residual.shape[0] < M or residual.shape[1] != N:
             raise ValueError("gemm_nt: residual must be [>= M, N]")
+    mean = rstd = gamma = beta = None
     if residual_ln is not None:
         mean, rstd, gamma, beta = residual_ln
         if not res_f32:
@@ -85,14 +88,22 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
         _chk(mean, F32, "ln mean", 1), _chk(rstd, F32, "ln rstd", 1), _chk(gamma, F32, "ln gamma", 1), _chk(beta, F32, "ln beta", 1)
         if mean.numel() < M or rstd.numel() < M or gamma.numel() != N or beta.numel() != N:
             raise ValueError("gemm_nt: residual_ln = (mean[>= M], rstd[>= M], gamma[N], beta[N])")
-        call("cldrd_gemm_nt_bf16_ln", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
-             _p(residual), residual.stride(0), _p(preact), _p(gelu_pre), act, alpha, dropout_p, seed, out_f32, res_f32, io_f16,
-             _p(mean), _p(rstd), _p(gamma), _p(beta), _stream())
-        return out
-    call("cldrd_gemm_nt_bf16", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
-         _p(residual), residual.stride(0) if residual is not None else 0, _p(preact), _p(gelu_pre), act, alpha,
-         dropout_p, seed, out_f32, res_f32, io_f16, _stream())
+    # small-M problems (CLS-only last layer, query tower) are split along K when that fills the chip: fp32 partials in a scratch tensor
+    ws, ws_bytes = None, 0
+    if M < 1024:
+        key = (M, N, K, os.environ.get("CLDRD_GEMM_SPLITK"))
+        ws_bytes = _SPLITK_WS.get(key)
+        if ws_bytes is None:
+            ws_bytes = _SPLITK_WS[key] = int(_lib.load().cldrd_gemm_nt_splitk_workspace(M, N, K))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes // 4, dtype=F32, device=A.device)
+    call("cldrd_gemm_nt_bf16_ws", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
+         _p(residual), residual.stride(0) if residual is not None else 0, _p(preact), _p(gelu_pre), act, alpha, dropout_p, seed,
+         out_f32, res_f32, io_f16, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(ws), ws_bytes, _stream())
     return out
+
+
+_SPLITK_WS = {}
 
 
 def wgrad_workspace_elems(M, N1, N2) -> int:

@@ -57,6 +57,16 @@ int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, i
                           int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int io_f16,
                           const float* ln_mean, const float* ln_rstd, const float* ln_gamma, const float* ln_beta, void* stream);
 
+/* The same with a workspace: problems of fewer than 1024 rows whose one-pass grid would leave most CUs idle (CLS-only last layer, query
+ * tower) are split along K: fp32 partials in `workspace` (cldrd_gemm_nt_splitk_workspace() bytes; 0 = this shape is not split), summed in
+ * a fixed order and finished with the same epilogue by a second launch.  workspace = NULL: cldrd_gemm_nt_bf16_ln. */
+size_t cldrd_gemm_nt_splitk_workspace(int M, int N, int K);
+int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+                          const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
+                          int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int io_f16,
+                          const float* ln_mean, const float* ln_rstd, const float* ln_gamma, const float* ln_beta,
+                          float* workspace, size_t workspace_bytes, void* stream);
+
 /* Weight gradient dW[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (A = dY, B = layer input; autograd's Linear backward), and,
  * when dbias != NULL, the bias gradient dbias[N1] (+)= column sums of A in the same pass.
  * N1, N2 multiples of 128 (or N1 % 256 == 0 and N2 % 192 == 0); rows >= M are never read (no padding contract).

@@ -108,6 +108,72 @@ def test_gemm_nt_epilogues(M, N, K):
     close(out32, torch.where(keep, base / 0.9, torch.zeros(())) + ln, 1e-5, 1e-4 * math.sqrt(K), "dropout + LayerNorm residual")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (240, 3072, 768), (130, 384, 1024), (512, 768, 768)])
+@pytest.mark.parametrize("flavour", ["bias", "bias_gelu_dpre", "gelugrad_d", "res16", "bias_drop_res32_f32", "ln_res32_f32", "f16_bias_gelu", "f16_res32_f32"])
+def test_gemm_nt_small_m_split_k(flavour, M, N, K):
+    """Small-M problems are split along K (fp32 partials + a finishing launch with the same epilogue): against the one-pass kernel
+    (CLDRD_GEMM_SPLITK=1) on the same inputs - 16-bit outputs agree to one rounding of the last place (the partial sums are added in a
+    different order), fp32 outputs to 1e-5 of the row scale - and with an odd split count forced."""
+    import oracle.dropout_ref as DRo
+    f16 = flavour.startswith("f16")
+    dt = torch.float16 if f16 else torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).to(dt)
+    B = (torch.randn(N, K, device=DEV, generator=g) * 0.5).to(dt)
+    bias = torch.randn(N, device=DEV, generator=g)
+    kw, out_dtype = {}, dt
+    if "bias" in flavour:
+        kw["bias"] = bias
+    if flavour == "bias_gelu_dpre":
+        kw.update(preact=torch.empty(M, N, dtype=torch.bfloat16, device=DEV), act=3)
+    if flavour == "f16_bias_gelu":
+        kw.update(act=1)
+    if flavour == "gelugrad_d":
+        kw.update(gelu_pre=torch.rand(M, N, device=DEV, generator=g).bfloat16(), act=2)
+    if flavour == "res16":
+        kw["residual"] = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    if "res32" in flavour:
+        kw["residual"] = torch.randn(M, N, device=DEV, generator=g)
+        out_dtype = torch.float32
+        if flavour == "f16_res32_f32":
+            kw["bias"] = bias
+    if flavour == "bias_drop_res32_f32":
+        kw.update(dropout_p=0.1, seed=(3 << 32) | 5)
+    if flavour == "ln_res32_f32":
+        s32 = kw["residual"]
+        kw["bias"] = bias
+        kw["residual_ln"] = (s32.mean(1).contiguous(), (1.0 / torch.sqrt(s32.var(1, unbiased=False) + 1e-12)).contiguous(),
+                             1 + 0.1 * torch.randn(N, device=DEV, generator=g), 0.1 * torch.randn(N, device=DEV, generator=g))
+    outs, pres = [], []
+    for env in ("1", None, "5"):
+        if env is None:
+            os.environ.pop("CLDRD_GEMM_SPLITK", None)
+        else:
+            os.environ["CLDRD_GEMM_SPLITK"] = env
+        out = torch.full((M, N), float("nan"), dtype=out_dtype, device=DEV)
+        if "preact" in kw:
+            kw["preact"] = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        try:
+            ops.gemm_nt(A, B, out, **kw)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("CLDRD_GEMM_SPLITK", None)
+        outs.append(out.float())
+        pres.append(kw["preact"].float() if "preact" in kw else None)
+    ref = outs[0]
+    assert not torch.isnan(ref).any()
+    scale = ref.abs().max().item()
+    for o, pr in zip(outs[1:], pres[1:]):
+        if out_dtype == torch.float32:
+            close(o, ref, 1e-5, 2e-5 * scale, f"split-K {flavour}")
+        else:
+            close(o, ref, 1 / 128, 1e-5 * scale, f"split-K {flavour}")          # one 16-bit rounding where the fp32 sums straddle a boundary
+        if pr is not None:
+            close(pr, pres[0], 1 / 128, 1e-4, "split-K saved derivative")
+    if "drop" in flavour:          # the mask is keyed on (row, col) of the output: zeros in the same places
+        assert torch.equal(outs[1] == kw["residual"], ref == kw["residual"])
+
+
 def test_gemm_nt_dropout_is_deterministic_and_unbiased():
     M, N, K = 512, 256, 64
     A, B = bf(torch.ones(M, K)), bf(torch.ones(N, K) / K)
