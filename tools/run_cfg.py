@@ -8,7 +8,8 @@ from cldrd_amd.encoder import EncoderConfig
 from cldrd_amd.models import NwayDualEncoder
 from cldrd_amd.trainer import NwayTrainer
 
-CFG = {2: dict(arch="distilbert", layers=6, B=8, N=32, L=128, loss="kl_div"),
+CFG = {1: dict(arch="distilbert", layers=6, B=4, N=8, L=128, loss="margin_mse"),
+       2: dict(arch="distilbert", layers=6, B=8, N=32, L=128, loss="kl_div"),
        3: dict(arch="distilbert", layers=6, B=4, N=200, L=128, loss="margin_mse"),
        4: dict(arch="bert", layers=12, B=4, N=64, L=256, loss="lambda_mrr")}
 ap = argparse.ArgumentParser(); ap.add_argument("--cfg", type=int, default=4); ap.add_argument("--steps", type=int, default=5)
