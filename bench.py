@@ -43,6 +43,9 @@ def pmc_traffic(kernel_substr, timeout_s=150):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    # this process itself runs under a profiler (rocprofv3 preloads its tool library): no nested profiler, the outer one has the counters
+    if any(k.startswith(("ROCPROF", "ROCP_")) or k == "HSA_TOOLS_LIB" for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "skipped: this process is being profiled (nested rocprofv3 not attempted)"
     here = os.path.abspath(__file__)
     tot = {}
     tmp = tempfile.mkdtemp(prefix="cldrd_pmc_", dir="/tmp")
