@@ -25,35 +25,77 @@ __device__ __forceinline__ float from_orderable(uint32_t o) {
     return __uint_as_float(u);
 }
 
+// One digit of the MSB-first radix select: hist[0..256) holds the counts of the current digit among the values that match the
+// prefix so far; pick the largest digit b whose suffix count (digits >= b) reaches `remaining`, append it to the prefix and keep
+// the rank inside that bin.  Threads 0..255 own one bin each (thread i -> digit 255 - i, so an inclusive scan in thread order is
+// the suffix sum from the top); a single thread walking the bins serially cost ~10 us per digit (256 dependent LDS reads).
+// Called by the whole block between two of the caller's barriers; has one barrier inside.
+__device__ __forceinline__ void radix_pick_digit(const unsigned int* hist, unsigned int* wsum, unsigned int prefix, int shift,
+                                                 unsigned int* sel_prefix, unsigned int* sel_remaining) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const unsigned int rem = *sel_remaining;            // read by everybody BEFORE the barrier, written by one thread after it
+    unsigned int c = 0, incl = 0;
+    if (threadIdx.x < 256) {
+        c = hist[255 - threadIdx.x];
+        incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wsum[wid] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        for (int w = 0; w < wid; ++w) incl += wsum[w];
+        const unsigned int excl = incl - c;
+        const bool here = excl < rem && rem <= incl;
+        const bool bottom = threadIdx.x == 255 && incl < rem;       // fewer matching values than the rank asked for: lowest digit
+        if (here || bottom) {
+            *sel_prefix = prefix | ((unsigned int)(255 - threadIdx.x) << shift);
+            *sel_remaining = rem - excl;
+        }
+    }
+}
+
 // thr[q] = kth-largest value of scores[q][0..S) (kth is 1-based, clamped to S).  One block per query, MSB-first radix
-// select with 8-bit digits: 4 passes over the row (L2 resident), 256-bin LDS histogram per pass.
+// select with 8-bit digits, 256-bin LDS histogram per pass.  NR > 0 (S <= NR * 1024: the threshold sample): the row is read ONCE
+// into NR registers per thread (independent loads, one L2 latency) and the four passes run on registers; NR = 0: every pass re-reads
+// the row (a dependent-latency loop: ~4 us per pass at S = 16384).
+template <int NR>
 __global__ __launch_bounds__(1024) void kth_largest_kernel(const float* __restrict__ scores, int ld, int S, int kth,
                                                            float* __restrict__ thr) {
-    __shared__ unsigned int hist[256];
+    __shared__ unsigned int hist[256], wsum[4];
     __shared__ unsigned int sel_prefix, sel_remaining;
     const float* row = scores + (size_t)blockIdx.x * ld;
     if (threadIdx.x == 0) { sel_prefix = 0; sel_remaining = (unsigned)min(kth, S); }
+    constexpr bool REG = NR > 0;
+    uint32_t own[REG ? NR : 1];
+    if constexpr (REG) {
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            const int i = threadIdx.x + 1024 * j;
+            own[j] = orderable(row[i < S ? i : 0]);
+        }
+    }
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
         const unsigned int prefix = sel_prefix;
         const unsigned int pmask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int i = threadIdx.x; i < S; i += blockDim.x) {
-            const uint32_t o = orderable(row[i]);
-            if ((o & pmask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
+        if constexpr (REG) {
+#pragma unroll
+            for (int j = 0; j < NR; ++j)
+                if ((int)threadIdx.x + 1024 * j < S && (own[j] & pmask) == prefix) atomicAdd(&hist[(own[j] >> shift) & 255u], 1u);
+        } else {
+            for (int i = threadIdx.x; i < S; i += blockDim.x) {
+                const uint32_t o = orderable(row[i]);
+                if ((o & pmask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned int rem = sel_remaining, b = 255;
-            for (;; --b) {                       // walk from the largest digit down
-                const unsigned int c = hist[b];
-                if (c >= rem || b == 0) break;
-                rem -= c;
-            }
-            sel_prefix = prefix | (b << shift);
-            sel_remaining = rem;
-        }
+        radix_pick_digit(hist, wsum, prefix, shift, &sel_prefix, &sel_remaining);
         __syncthreads();
     }
     if (threadIdx.x == 0) thr[blockIdx.x] = from_orderable(sel_prefix);
@@ -96,17 +138,26 @@ __global__ __launch_bounds__(1024) void topk_sort_kernel(const int* __restrict__
         keys[i] = key;
     }
     __syncthreads();
+    // Bitonic network.  Pair t exchanges keys (t / stride) 2 stride + t % stride and + stride: the 64 pairs of one wave (t = 64 w ..
+    // 64 w + 63, then + blockDim.x) stay inside ONE 128-key chunk while stride <= 64, so those steps (56 of the 66 at NP = 2048) only
+    // need the wave's own LDS accesses in order - a compiler fence, no workgroup barrier.  The barrier comes back around every step
+    // with stride >= 128.
+    bool wide_before = true;
     for (int size = 2; size <= NP; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const bool wide = stride >= 128;
+            if (wide || wide_before) __syncthreads();
+            else { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+            wide_before = wide;
             for (int t = threadIdx.x; t < NP / 2; t += blockDim.x) {
-                const int lo = (t / stride) * 2 * stride + (t % stride), hi = lo + stride;
+                const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1)), hi = lo + stride;      // stride is a power of two
                 const bool up = ((lo & size) == 0);
                 const unsigned long long a = keys[lo], b = keys[hi];
                 if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
             }
-            __syncthreads();
         }
     }
+    __syncthreads();
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         const unsigned long long key = i < NP ? keys[i] : ~0ull;
         const bool ok = i < n;
@@ -231,7 +282,7 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(const int* __restr
                                                                int* __restrict__ rows2, int cap2, int* __restrict__ n2, int* __restrict__ status,
                                                                float* __restrict__ khat, int exhaustive) {
     extern __shared__ __attribute__((aligned(16))) unsigned int sc[];      // cap orderable scores
-    __shared__ unsigned int hist[256];
+    __shared__ unsigned int hist[256], wsum[4];
     __shared__ unsigned int sel_prefix, sel_remaining, nkeep;
     const int q = blockIdx.x;
     const int c = counts[q];
@@ -257,16 +308,7 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(const int* __restr
                     if ((o & pmask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
                 }
                 __syncthreads();
-                if (threadIdx.x == 0) {
-                    unsigned int rem = sel_remaining, b = 255;
-                    for (;; --b) {
-                        const unsigned int cnt = hist[b];
-                        if (cnt >= rem || b == 0) break;
-                        rem -= cnt;
-                    }
-                    sel_prefix = prefix | (b << shift);
-                    sel_remaining = rem;
-                }
+                radix_pick_digit(hist, wsum, prefix, shift, &sel_prefix, &sel_remaining);
                 __syncthreads();
             }
             t_hat = from_orderable(sel_prefix);
@@ -570,7 +612,9 @@ int launch_scan_stream(const void* Q, const void* P, int nq, long long rows, con
 
 extern "C" int cldrd_topk_kth_largest(const float* scores, int ld, int nq, int S, int kth, float* thr, void* stream) {
     CLDRD_CHECK(nq > 0 && S > 0 && kth >= 1, "topk_kth_largest: bad arguments");
-    hipLaunchKernelGGL(kth_largest_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, ld, S, kth, thr);
+    if (S <= 8 * 1024) hipLaunchKernelGGL(kth_largest_kernel<8>, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, ld, S, kth, thr);
+    else if (S <= 32 * 1024) hipLaunchKernelGGL(kth_largest_kernel<32>, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, ld, S, kth, thr);
+    else hipLaunchKernelGGL(kth_largest_kernel<0>, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, ld, S, kth, thr);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

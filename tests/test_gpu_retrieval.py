@@ -28,6 +28,46 @@ def test_kth_largest_matches_numpy():
         assert np.array_equal(thr.cpu().numpy(), ref), kth
 
 
+@pytest.mark.parametrize("S", [1024, 8192, 8193, 16496, 32768, 32769, 40000])
+def test_kth_largest_register_and_streaming_forms(S):
+    """S <= 32768 keeps the row in registers (8 or 32 per thread), larger rows are re-read per radix digit; both against numpy, with ties, negative
+    values, infinities and a leading dimension larger than S."""
+    nq = 5
+    x = (syn.normal(11, nq * (S + 8)).reshape(nq, S + 8) * 5).astype(np.float32)
+    x[1, : S // 2] = -2.25
+    x[2, :3] = [np.inf, -np.inf, 0.0]
+    x[3] = np.abs(x[3]) * 1e-30
+    xd = torch.from_numpy(x).to(DEV)
+    thr = torch.empty(nq, device=DEV)
+    for kth in (1, 34, 257, S // 2, S - 1, S):
+        ops.topk_kth_largest(xd, S, kth, thr)
+        ref = -np.sort(-x[:, :S], axis=1)[:, kth - 1]
+        assert np.array_equal(thr.cpu().numpy(), ref), (S, kth)
+
+
+@pytest.mark.parametrize("cap,k", [(2, 1), (100, 10), (128, 128), (1000, 1000), (2048, 1000), (3000, 100), (8192, 1000)])
+def test_topk_sort_orders_by_score_then_row(cap, k):
+    """The bitonic sort runs its narrow steps without workgroup barriers: every list length around the 128-key chunk size and the
+    power-of-two padding, ties broken by the lower row, short lists padded with (-inf, -1)."""
+    rng = np.random.default_rng(cap)
+    nq = 9
+    counts = rng.integers(0, cap + 1, size=nq).astype(np.int32)
+    counts[0], counts[1], counts[2] = cap, 0, min(cap, 129)
+    rows = np.stack([rng.permutation(50000)[:cap] for _ in range(nq)]).astype(np.int32)
+    scores = rng.standard_normal((nq, cap)).astype(np.float32)
+    scores[:, ::3] = np.round(scores[:, ::3]) + 0.0      # plenty of ties (+ 0.0: no -0.0, which the key order puts below 0.0)
+    D = torch.empty(nq, k, device=DEV)
+    I = torch.empty(nq, k, dtype=torch.int32, device=DEV)
+    ops.topk_sort(torch.from_numpy(counts).to(DEV), torch.from_numpy(rows).to(DEV), torch.from_numpy(scores).to(DEV), k, D, I)
+    D, I = D.cpu().numpy(), I.cpu().numpy()
+    for q in range(nq):
+        n = int(counts[q])
+        order = np.lexsort((rows[q, :n], -scores[q, :n].astype(np.float64)))[:k]
+        m = len(order)
+        assert np.array_equal(I[q, :m], rows[q, order]) and np.array_equal(D[q, :m], scores[q, order]), (cap, q)
+        assert np.all(I[q, m:] == -1) and np.all(np.isneginf(D[q, m:]))
+
+
 def same_ranking(D, I, Dr, Ir, rel=1e-5):
     """Identical ids and ranks wherever adjacent reference scores differ by more than rel * |score|; scores within rel.
     Inside a run of near-equal reference scores (adjacent gaps <= rel * |score| + 1e-6) the order may differ but the id SET of
