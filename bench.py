@@ -258,7 +258,8 @@ def main():
             flat_index = FlatIPIndex.from_device_rows(P, id_offset=rank * rows)
             qn = torch.randn(nq_r, D, device=dev, generator=gen)
             qn *= (10.0 / qn.norm(dim=1, keepdim=True))
-            flat_index.search_device(qn[:256], kq)             # warm-up
+            flat_index.search_device(qn, kq)                   # warm-up: one full search (workspaces, and the clocks settle: the first
+                                                               # ~10 passes after an idle gap run 20-30 % slower than the steady state)
             sync_all()
             nb = (nq_r + 127) // 128                          # reference batches of 128 queries (the unit of SURVEY.md section 8d)
             # (1) device-resident search: queries and results stay in HBM, one host sync (the proof flags)
@@ -286,9 +287,10 @@ def main():
             counts = torch.zeros(QT + 1, dtype=torch.int32, device=dev)
             cr = torch.empty(QT, 8192, dtype=torch.int32, device=dev)
             cs_ = torch.empty(QT, 8192, dtype=torch.float32, device=dev)
-            ops2.topk_scan_filter(qh16, flat_index._p16, thr, counts, cr, cs_)
+            for _ in range(40):                               # same settling as above before the timed launches
+                ops2.topk_scan_filter(qh16, flat_index._p16, thr, counts, cr, cs_)
             evs = []
-            for _ in range(10):
+            for _ in range(20):
                 counts.zero_()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()

@@ -338,8 +338,11 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(const int* __restr
 // ring in tiles of 32 whole rows = 32*d*2 bytes of CONTIGUOUS memory per tile (full-page DRAM bursts; the tiled GEMM
 // fetched 128-B slivers of 256 different rows per step and topped out at ~2.3 TB/s).  Persistent: one workgroup per
 // CU walks tiles b, b+grid, ...; two tiles (96 KiB at d = 768) stay in flight per CU behind a counted vmcnt.
-// Hits (score >= thr[query], ~0.2 % of the scores) go to a small LDS list and are flushed to the per-query candidate
-// lists with global atomics only when the list fills up or at the end, so the DMA queue is never drained in the loop.
+// Hits (score >= thr[query], ~0.2 % of the scores) go to small LDS lists, ONE PER WAVE: the list length is a wave-uniform
+// register and a hit's slot comes from ballot + mbcnt, so an append is three ds_writes and no LDS atomic (a shared list cost
+// one ds_add_rtn round trip per hit row: ~400 cycles per 16 x 16 score block with a hit, 17 % of the pass at ~3000 candidates
+// per query).  The lists are flushed to the per-query candidate lists with global atomics only when one of them fills up or
+// at the end, so the DMA queue is never drained in the loop.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <bool F16>
 __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -370,10 +373,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int R = 32, ROWB = KS * 64, TILEB = R * ROWB, PIECES = TILEB / 1024, PPW = PIECES / NW, NSLOT = 3;
     constexpr int NQ = 16 * NQS * NW;          // queries per pass
-    constexpr int LCAP = (160 * 1024 - NSLOT * TILEB - 16 - 8 * NQ) / 12 < 4096 ? (160 * 1024 - NSLOT * TILEB - 16 - 8 * NQ) / 12 : 4096;   // LDS hit list
-    static_assert(PIECES % NW == 0 && NQ <= 256, "tile pieces must divide over the waves; the hit list packs the query in 8 bits");
-    int* lcount = (int*)(smem + NSLOT * TILEB);
-    int* qcnt = lcount + 4;                    // [0,NQ) per-query hit counts, [NQ,2NQ) global bases (flush scratch)
+    constexpr int LCAP = (160 * 1024 - NSLOT * TILEB - 128 - 8 * NQ) / 12 < 4096 ? (160 * 1024 - NSLOT * TILEB - 128 - 8 * NQ) / 12 : 4096;   // LDS hit lists
+    constexpr int WCAP = LCAP / NW;            // slots of one wave's list: entries [wid WCAP, (wid + 1) WCAP) of lq / lrow / lscore
+    static_assert(PIECES % NW == 0 && NQ <= 256 && NW <= 8, "tile pieces must divide over the waves; the hit list packs the query in 8 bits");
+    int* lcount = (int*)(smem + NSLOT * TILEB);   // [0,8) list lengths at the last flush call, [8,32) three rotating snapshots of them
+    int* qcnt = lcount + 32;                   // [0,NQ) per-query hit counts, [NQ,2NQ) global bases (flush scratch)
     int* lq = qcnt + 2 * NQ;
     int* lrow = lq + LCAP;
     float* lscore = (float*)(lrow + LCAP);
@@ -409,7 +413,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
     for (int s = 0; s < NQS; ++s) asm volatile("" : "+v"(thr_lane[s]));
     const uint32_t lcount_off = (uint32_t)(uintptr_t)LDS_PTR(lcount), lq_off = (uint32_t)(uintptr_t)LDS_PTR(lq);
     static_assert(8 * LCAP < 65536, "ds_write offset field");
-    if (threadIdx.x < 4) lcount[threadIdx.x] = 0;               // [0] list length, [1..3] its snapshots (see the flush check)
+    if (threadIdx.x < 32) lcount[threadIdx.x] = 0;
+    int wcnt = 0;                                               // hits this wave has appended since the last flush (wave-uniform)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // nothing but LDS-DMA is in flight from here on
     __syncthreads();                                            // the first snapshot read comes BEFORE the first barrier of the tile loop
 
@@ -421,15 +426,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
         const int row = byte / ROWB, cl = (byte % ROWB) / 16;
         soff[j] = (uint32_t)(row * ROWB + ((cl ^ (row & 15)) * 16));      // XOR on the source side, LDS stays linear
     }
+    // saddr form, hand-issued: scalar 64-bit tile base + one 32-bit lane offset per piece (through the builtin every piece cost a
+    // 64-bit VALU add and a register pair, and the <8 waves x 32 queries> instance spilled inside the tile loop).  hipcc does not
+    // count these in its vmcnt bookkeeping; the waits below are written by hand anyway.
     const long long last = rows * ROWB - 16;                              // clamp the tail tile inside the allocation
+    const uint32_t smem_off = (uint32_t)(uintptr_t)LDS_PTR(smem);
     auto stage = [&](int slot, long long tile) {
-        char* dst = smem + slot * TILEB + wid * PPW * 1024;
+        const uint32_t dst = smem_off + (uint32_t)(slot * TILEB + wid * PPW * 1024);
+        const char* sbase = (const char*)P + tile * (long long)TILEB;
+        const long long room = last - tile * (long long)TILEB;
+        const uint32_t lim = room < (long long)TILEB ? (uint32_t)room : 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            long long off = tile * (long long)TILEB + soff[j];
-            off = off > last ? last : off;
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR((const char*)P + off), LDS_PTR(dst + j * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < PPW; ++j)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + j * 1024), "v"(min(soff[j], lim)), "s"(sbase) : "memory");
     };
 
     uint32_t rd_off[4];
@@ -439,24 +448,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
     // Move the LDS hit list to the per-query candidate lists: one global atomic per (block, query) reserves the block's range in
     // that query's list (per-hit atomics on 128 addresses serialise in L2).  Called by the whole workgroup (barriers inside).
     auto flush = [&]() {
+        if (ablate == 4) { wcnt = 0; return; }                                                          // timing experiment: hits vanish
         for (int i = threadIdx.x; i < 2 * NQ; i += blockDim.x) qcnt[i] = 0;
+        if (lane == 0) lcount[wid] = wcnt;
         __syncthreads();
-        const int nhits = *lcount;
-        const int n = min(nhits, LCAP);
-        for (int e = threadIdx.x; e < n; e += blockDim.x) lq[e] |= atomicAdd(qcnt + lq[e], 1) << 8;      // rank inside the block
+        auto live = [&](int e) { const int w = e / WCAP; return w < NW && e - w * WCAP < min(lcount[w], WCAP); };
+        for (int e = threadIdx.x; e < NW * WCAP; e += blockDim.x)
+            if (live(e)) lq[e] |= atomicAdd(qcnt + lq[e], 1) << 8;                                      // rank inside the block
         __syncthreads();
         for (int i = threadIdx.x; i < NQ; i += blockDim.x)
-            if (qcnt[i] > 0) qcnt[NQ + i] = atomicAdd(counts + i, qcnt[i]);
+            if (qcnt[i] > 0) qcnt[NQ + i] = ablate == 3 ? 0 : atomicAdd(counts + i, qcnt[i]);         // ablate 3: no global atomics (timing only)
         __syncthreads();
-        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        for (int e = threadIdx.x; e < NW * WCAP; e += blockDim.x) {
+            if (!live(e)) continue;
             const int q = lq[e] & 255;
             const int pos = qcnt[NQ + q] + (lq[e] >> 8);
             if (pos < cap) { cand_rows[(size_t)q * cap + pos] = lrow[e]; cand_scores[(size_t)q * cap + pos] = lscore[e]; }
         }
-        if (threadIdx.x == 0 && nhits > LCAP) atomicAdd(counts + nq, nhits - LCAP);      // counts[nq] = hits dropped (the caller rescans)
+        if (threadIdx.x < NW && lcount[threadIdx.x] > WCAP) atomicAdd(counts + nq, lcount[threadIdx.x] - WCAP);   // counts[nq] = hits dropped (the caller rescans)
+        if (threadIdx.x >= 64 && threadIdx.x < 64 + 24) lcount[8 + threadIdx.x - 64] = 0;      // the snapshots in flight describe the lists just emptied
         __syncthreads();
-        if (threadIdx.x == 0) *lcount = 0;
-        __syncthreads();
+        wcnt = 0;
     };
     const long long t0 = blockIdx.x, step = gridDim.x;
     if (t0 < ntiles) stage(0, t0);
@@ -472,13 +484,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
         // tile t must have landed; tile t+step may stay in flight.  NO global memory operation other than the DMA may appear
         // inside this loop: hipcc would put s_waitcnt vmcnt(0) next to it and drain the two tiles in flight (measured: ~1 us per hit)
         uint32_t snap = 0;
-        const uint32_t snap_addr = lcount_off + 4u * (1u + (uint32_t)((it + 1) % 3));
+        const uint32_t snap_addr = lcount_off + 4u * (8u + 8u * (uint32_t)((it + 1) % 3) + (uint32_t)(lane & 7));      // lane l: wave l & 7
         if (t + step < ntiles) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt vmcnt(%2) lgkmcnt(0)" : "=&v"(snap) : "v"(snap_addr), "n"(PPW) : "memory");
         else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" : "=&v"(snap) : "v"(snap_addr) : "memory");
         __builtin_amdgcn_s_barrier();                                       // ... for every wave; slot of tile t-step is free
         asm volatile("" ::: "memory");
         // Hit-list level check: `snap` was read at the top of this iteration (see there); the decision is workgroup-uniform.
-        if (ablate == 0 && __builtin_amdgcn_readfirstlane(snap) > (uint32_t)(LCAP / 2)) flush();      // rare: about once per launch and workgroup
+        if ((ablate == 0 || ablate >= 3) && __builtin_amdgcn_ballot_w64(snap > (uint32_t)(WCAP / 2)) != 0) flush();      // some wave's list is half full (rare)
         const int fs = cs == 0 ? NSLOT - 1 : cs - 1;                        // slot of tile t-step
         const char* sb = smem + cs * TILEB;
         cs = cs == NSLOT - 1 ? 0 : cs + 1;
@@ -507,21 +519,23 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
         auto emit = [&](f32x4 acc, int mt, int qn, float thr_q) {        // acc[j] = <P[row], Q[qn]> with row = 32 t + 16 mt + 4 (lane >> 4) + j
             if (ablate == 2) { asm volatile("" ::"v"(acc)); return; }
             const int row0 = (int)(t * R) + mt * 16 + 4 * (lane >> 4);
-            // one test for the four rows first: no hit in this lane is the common case (~0.2 % of the scores are hits)
-            if (!(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) >= thr_q)) return;
+            // one test for the four rows of every lane first: no hit in the whole 16 x 16 block is the common case.  Everything
+            // below branches on ballots only, so the control flow - and with it wcnt - stays wave-uniform.
+            if (__builtin_amdgcn_ballot_w64(fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3])) >= thr_q) == 0) return;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (acc[j] >= thr_q && row0 + j < (int)rows) {
-                    // LDS list append, hand-issued: through atomicAdd / plain stores hipcc orders these LDS accesses after
-                    // the LDS-DMA in flight (s_waitcnt vmcnt(0) per hit), which stalls the stream
-                    uint32_t e;
-                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(e) : "v"(lcount_off), "v"(1u) : "memory");
-                    if (e < (uint32_t)LCAP) {
-                        const uint32_t a = lq_off + 4u * e;
-                        asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"
-                                     ::"v"(a), "v"(qn), "v"(row0 + j), "v"(acc[j]), "n"(4 * LCAP), "n"(8 * LCAP) : "memory");
-                    }
+                const bool hit = acc[j] >= thr_q && row0 + j < (int)rows;
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (m == 0) continue;
+                const int pos = wcnt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (hit && pos < WCAP) {
+                    // hand-issued LDS stores: through plain stores hipcc orders these LDS accesses after the LDS-DMA in flight
+                    // (s_waitcnt vmcnt(0) per hit), which stalls the stream
+                    const uint32_t a = lq_off + 4u * (uint32_t)(wid * WCAP + pos);
+                    asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"
+                                 ::"v"(a), "v"(qn), "v"(row0 + j), "v"(acc[j]), "n"(4 * LCAP), "n"(8 * LCAP) : "memory");
                 }
+                wcnt += __builtin_popcountll(m);
             }
         };
         fetch(ab[0], 0);
@@ -557,12 +571,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
                 for (int s = 0; s < NQS; ++s) emit(acc[s], c / NCM, qn0 + 16 * s, thr_lane[s]);
             }
         }
-        if (ablate == 0 && wid == 0) {           // snapshot of the list level for the check two tiles on (hand-issued: see emit)
-            uint32_t v;
-            const int sl = it % 3;
-            if (sl == 0) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:4" : "=&v"(v) : "v"(lcount_off) : "memory");
-            else if (sl == 1) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:8" : "=&v"(v) : "v"(lcount_off) : "memory");
-            else asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %1, %0 offset:12" : "=&v"(v) : "v"(lcount_off) : "memory");
+        if (ablate == 0 || ablate >= 3) {           // snapshot of this wave's list length for the check two tiles on (hand-issued: see emit)
+            const uint32_t a = lcount_off + 4u * (8u + 8u * (uint32_t)(it % 3) + (uint32_t)wid);
+            if (lane == 0) asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(wcnt) : "memory");
         }
     }
     // ---- what is left in the list
@@ -574,8 +585,8 @@ template <int KS, int ABL, bool F16, int NW = 8, int NQS = 1>
 int launch_scan_stream_abl(const void* Q, const void* P, int nq, long long rows, const float* thr, int* counts, int* cand_rows,
                            float* cand_scores, int cap, hipStream_t st) {
     constexpr int tb = 3 * 32 * KS * 64, NQ = 16 * NQS * NW;
-    constexpr int lcap = (160 * 1024 - tb - 16 - 8 * NQ) / 12 < 4096 ? (160 * 1024 - tb - 16 - 8 * NQ) / 12 : 4096;
-    constexpr int lds = tb + 16 + 8 * NQ + lcap * 12;
+    constexpr int lcap = (160 * 1024 - tb - 128 - 8 * NQ) / 12 < 4096 ? (160 * 1024 - tb - 128 - 8 * NQ) / 12 : 4096;
+    constexpr int lds = tb + 128 + 8 * NQ + lcap * 12;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)scan_stream_kernel<KS, ABL, F16, NW, NQS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -600,7 +611,15 @@ int launch_scan_stream(const void* Q, const void* P, int nq, long long rows, con
             default: break;
         }
     }
-    if (nq > 128) {                                    // 129..256 queries: the 4-wave x 64-query instance (fp16 shadow, d = 768 only)
+    if (nq > 128) {                                    // 129..256 queries: the 8-wave x 32-query instance (fp16 shadow, d = 768 only)
+        if (KS == 24 && f16) {
+            const char* ab = getenv("CLDRD_SCAN_ABLATE");
+            switch (ab ? atoi(ab) : 0) {
+                case 3: return launch_scan_stream_abl<24, 3, true, 8, 2>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+                case 4: return launch_scan_stream_abl<24, 4, true, 8, 2>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
+                default: break;
+            }
+        }
         if (KS == 24 && f16) return launch_scan_stream_abl<24, 0, true, 8, 2>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
         return -1;
     }

@@ -47,6 +47,11 @@ Q256h = Q256.half()
 for rnd in range(2):
     run("fp16 256 queries no hits", Q256h, Ph, 1e9)
     run("fp16 256 queries thr 11.9", Q256h, Ph, 11.9)
+# thr 11.1 ~ 3000 hits per query, what a k = 1000 search emits; ablate 3 = flush without the global atomics, 4 = flush drops the hits
+for thr_v in (11.9, 11.1):
+    run(f"fp16 256 queries thr {thr_v}", Q256h, Ph, thr_v)
+    run(f"fp16 256 q thr {thr_v} no atomics (3)", Q256h, Ph, thr_v, {"CLDRD_SCAN_ABLATE": "3"})
+    run(f"fp16 256 q thr {thr_v} no flush (4)", Q256h, Ph, thr_v, {"CLDRD_SCAN_ABLATE": "4"})
 run("bf16 DMA only (ablate 1)", Qb, Pb, 11.5, {"CLDRD_SCAN_ABLATE": "1"})
 run("bf16 no hit handling (ablate 2)", Qb, Pb, 11.5, {"CLDRD_SCAN_ABLATE": "2"})
 run("bf16 tiled GEMM scan", Qb, Pb, 11.5, {"CLDRD_SCAN": "gemm"}, reps=10)
