@@ -37,6 +37,7 @@ SIGNATURES = {
     "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp]),
     "cldrd_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, ci, ci, vp, ci, vp]),
     "cldrd_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cull, ci, ci, vp]),
+    "cldrd_ln_reduce_group": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "cldrd_colsum_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_scatter_cls_grad": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_score_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
@@ -47,6 +48,7 @@ SIGNATURES = {
     "cldrd_sqnorm_blocks": (ci, []),
     "cldrd_grad_clip_coef": (ci, [vp, csz, cf, vp, vp, vp]),
     "cldrd_adamw_step": (ci, [vp, vp, vp, vp, vp, vp, csz, cf, cf, cf, cf, cf, ci, vp, vp]),
+    "cldrd_adamw_step_h16": (ci, [vp, vp, vp, vp, vp, vp, csz, cf, cf, cf, cf, cf, ci, vp, vp, csz, csz, vp]),
     "cldrd_cast_bf16": (ci, [vp, vp, csz, vp]),
     "cldrd_transpose_cast_batched": (ci, [vp, vp, vp, vp, ci, ci, vp]),
     "cldrd_transpose_bf16_batched": (ci, [vp, vp, vp, vp, ci, ci, vp]),

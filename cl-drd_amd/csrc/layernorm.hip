@@ -500,13 +500,48 @@ extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const
     return 0;
 }
 
+// The same reduction for up to LN_GROUP_MAX LayerNorms in one launch (blockIdx.y = job): the parameter gradients of a LayerNorm are
+// not on the backward's critical path, so the trainer parks the per-block partials of every cldrd_layernorm_bwd call of a tower
+// and reduces them together (one launch instead of one 7-us launch per LayerNorm behind every ln_bwd_kernel).
+constexpr int LN_GROUP_MAX = 32;
+struct LnReduceGroup {
+    const float* partial[LN_GROUP_MAX];
+    float* out[LN_GROUP_MAX][3];
+    int nblk[LN_GROUP_MAX];
+};
+__global__ __launch_bounds__(1024) void reduce_partials_group_kernel(LnReduceGroup g, int n, int seg, int accumulate) {
+    constexpr int RG = 16;
+    __shared__ float red[RG][64];
+    const float* __restrict__ partial = g.partial[blockIdx.y];
+    const int nblk = g.nblk[blockIdx.y];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < n) {                                 // same summation order as reduce_partials_kernel: identical bits
+        int b = rg;
+        for (; b + RG < nblk; b += 2 * RG) { s0 += partial[(size_t)b * n + c]; s1 += partial[(size_t)(b + RG) * n + c]; }
+        if (b < nblk) s0 += partial[(size_t)b * n + c];
+    }
+    red[rg][threadIdx.x & 63] = s0 + s1;
+    __syncthreads();
+    if (rg != 0 || c >= n) return;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < RG; i += 4) s += (red[i][threadIdx.x] + red[i + 1][threadIdx.x]) + (red[i + 2][threadIdx.x] + red[i + 3][threadIdx.x]);
+    float* out = g.out[blockIdx.y][c < seg ? 0 : (c < 2 * seg ? 1 : 2)];
+    if (!out) return;
+    const int i = c % seg;
+    out[i] = accumulate ? out[i] + s : s;
+}
+
 static int launch_reduce(const float* partial, int nblk, int d, float* o0, float* o1, float* o2, int accumulate, hipStream_t st) {
+    if (!o0 && !o1 && !o2) return 0;             // deferred: the caller reduces `partial` later (cldrd_ln_reduce_group)
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((3 * d + 63) / 64), dim3(1024), 0, st, partial, nblk, 3 * d, o0, o1, o2, d, accumulate);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 
 // partial must hold cldrd_ln_partial_blocks(T) * 3 * d floats.  dgamma/dbeta/dbias are accumulated (+=) when accumulate != 0.
+// All three null: the reduction is deferred - `partial` keeps the per-block sums for a later cldrd_ln_reduce_group call.
 extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                    void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
                                    int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, void* stream) {
@@ -526,6 +561,26 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
     });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dbias, accumulate, (hipStream_t)stream);
+}
+
+// dgamma[i] / dbeta[i] / dbias[i] (each may be null) (+)= column sums of partial[i] = the scratch a cldrd_layernorm_bwd call with all
+// three outputs null left behind (T[i] rows went into it).  Bit-identical to the reduction that call would have run itself.
+extern "C" int cldrd_ln_reduce_group(const float* const* partial, const int* T, float* const* dgamma, float* const* dbeta,
+                                     float* const* dbias, int n, int d, int accumulate, void* stream) {
+    CLDRD_CHECK(n > 0 && d > 0 && d <= 1024 && d % 4 == 0, "ln_reduce_group: bad arguments");
+    for (int lo = 0; lo < n; lo += LN_GROUP_MAX) {
+        const int m = n - lo < LN_GROUP_MAX ? n - lo : LN_GROUP_MAX;
+        LnReduceGroup g;
+        for (int i = 0; i < m; ++i) {
+            CLDRD_CHECK(partial[lo + i] != nullptr && T[lo + i] > 0, "ln_reduce_group: empty job");
+            g.partial[i] = partial[lo + i];
+            g.nblk[i] = ln_bwd_blocks(T[lo + i]);
+            g.out[i][0] = dgamma[lo + i]; g.out[i][1] = dbeta[lo + i]; g.out[i][2] = dbias[lo + i];
+        }
+        hipLaunchKernelGGL(reduce_partials_group_kernel, dim3((3 * d + 63) / 64, m), dim3(1024), 0, (hipStream_t)stream, g, 3 * d, d, accumulate);
+        CLDRD_LAUNCH_CHECK();
+    }
+    return 0;
 }
 
 extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,

@@ -48,6 +48,7 @@ __global__ void clip_coef_kernel(const float* __restrict__ partial, int nblk, fl
 struct AdamArgs {
     float* p; const float* g; float* m; float* v; const uint8_t* decay; bf16_t* shadow;
     size_t n4; float lr, beta1, beta2, eps, wd, step_size; const float* coef;
+    uint16_t* shadow16; size_t h_lo4, h_hi4;      // fp16 copy of parameters [4 h_lo4, 4 h_hi4) (shadow16[0] = parameter 4 h_lo4), or null
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -89,6 +90,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
         if (a.shadow) {
             uint2 o; o.x = pack2bf(p.x, p.y); o.y = pack2bf(p.z, p.w);
             ((uint2*)a.shadow)[i] = o;
+        }
+        if (a.shadow16 && i >= a.h_lo4 && i < a.h_hi4) {
+            const _Float16 h0 = (_Float16)p.x, h1 = (_Float16)p.y, h2 = (_Float16)p.z, h3 = (_Float16)p.w;
+            uint2 o;
+            o.x = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+            o.y = (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16);
+            ((uint2*)a.shadow16)[i - a.h_lo4] = o;
         }
     }
 }
@@ -180,12 +188,25 @@ extern "C" int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, fl
 
 // Legacy transformers.AdamW (correct_bias=True), step is 1-based.  decay_flags: one byte per 64 parameters.
 // clip: device float[3] from cldrd_grad_clip_coef or null.  shadow: bf16 copy of the updated parameters or null.
+// shadow16 (optional): fp16 copy (RNE, as cldrd_cast_f16) of the updated parameters [h16_begin, h16_end) - the high-precision forward
+// of the query tower reads it; both bounds multiples of 4, shadow16[0] = parameter h16_begin.
+extern "C" int cldrd_adamw_step_h16(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,
+                                    size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                    const float* clip, void* shadow16, size_t h16_begin, size_t h16_end, void* stream);
 extern "C" int cldrd_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,
                                 size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                 const float* clip, void* stream) {
+    return cldrd_adamw_step_h16(p, g, m, v, decay_flags, shadow, n, lr, beta1, beta2, eps, weight_decay, step, clip, nullptr, 0, 0, stream);
+}
+extern "C" int cldrd_adamw_step_h16(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,
+                                    size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                    const float* clip, void* shadow16, size_t h16_begin, size_t h16_end, void* stream) {
     CLDRD_CHECK(n > 0 && n % 64 == 0, "adamw_step: n must be a multiple of 64");
     CLDRD_CHECK(step >= 1, "adamw_step: step is 1-based");
+    CLDRD_CHECK(shadow16 == nullptr || (h16_begin % 4 == 0 && h16_end % 4 == 0 && h16_begin <= h16_end && h16_end <= n && (uintptr_t)shadow16 % 8 == 0),
+                "adamw_step: fp16 shadow range must be 4-aligned and inside the buffer");
     AdamArgs a;
+    a.shadow16 = (uint16_t*)shadow16; a.h_lo4 = h16_begin / 4; a.h_hi4 = h16_end / 4;
     a.p = p; a.g = g; a.m = m; a.v = v; a.decay = decay_flags; a.shadow = (bf16_t*)shadow; a.n4 = n / 4;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.coef = clip;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);

@@ -372,18 +372,25 @@ class HipEncoder(nn.Module):
                 p64.append(t64)
             self._t_desc64 = (torch.tensor(p64, dtype=torch.int32, device=dev), t64)
 
-    def refresh_shadows(self, need_transposed: bool = True, cast: bool = True):
-        """bf16 copies of the weights for the MFMA GEMMs (+ transposed copies for the data-gradient GEMMs)."""
+    def h16_buffer(self):
+        """The fp16 weight shadow of a tower that runs the high-precision forward (allocated on first use), else None."""
+        if not self.hp_forward:
+            return None
+        if self.flat_h16 is None or self.flat_h16.device != self.flat_p.device:
+            self.flat_h16 = torch.empty(self.layout.total, dtype=torch.float16, device=self.flat_p.device)
+        return self.flat_h16
+
+    def refresh_shadows(self, need_transposed: bool = True, cast: bool = True, cast16: bool | None = None):
+        """bf16 copies of the weights for the MFMA GEMMs (+ transposed copies for the data-gradient GEMMs).  ``cast`` / ``cast16`` False:
+        the optimizer step has already written the bf16 / fp16 shadow (``cast16`` None = cast the fp16 shadow whenever the tower has one)."""
         if not self.flat_p.is_cuda:
             raise RuntimeError("HipEncoder runs on the GPU only: move the model with .cuda() first (no CPU path)")
         if self.flat_h is None:
             self.flat_h = torch.empty(self.layout.total, dtype=torch.bfloat16, device=self.flat_p.device)
         if cast:
             ops.cast_bf16(self.flat_p, self.flat_h)
-        if self.hp_forward:
-            if self.flat_h16 is None or self.flat_h16.device != self.flat_p.device:
-                self.flat_h16 = torch.empty(self.layout.total, dtype=torch.float16, device=self.flat_p.device)
-            ops.cast_f16(self.flat_p, self.flat_h16)
+        if self.hp_forward and (cast16 is None or cast16):
+            ops.cast_f16(self.flat_p, self.h16_buffer())
         if need_transposed and self.cfg.n_layers:
             if self.flat_t is None:
                 self.flat_t = torch.empty(self.layout.t_total, dtype=torch.bfloat16, device=self.flat_p.device)
@@ -603,7 +610,11 @@ class HipEncoder(nn.Module):
         ops.scatter_cls_grad(dcls.contiguous(), gc, M, 1, M)
         ds2 = self._buf(M, d, dev)
         ds2m = self._buf(M, d, dev) if p_h > 0 else None
-        ops.layernorm_bwd(gc, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], partial, M, p_h, s_l + 3, accumulate=self._acc)
+        lnq = getattr(self, "_lnq", None)
+        f32 = dict(dtype=torch.float32, device=dev)
+        own = (lambda: torch.empty(ops.ln_partial_elems(M, d), **f32)) if lnq is not None else (lambda: partial)
+        ops.layernorm_bwd(gc, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], own(), M, p_h, s_l + 3,
+                          accumulate=self._acc, defer=lnq)
         dF = ds2m if ds2m is not None else ds2
         self._wq.add(dF, a["h"], G["W2"], M)
         dpre = self._buf(M, f, dev)
@@ -613,7 +624,8 @@ class HipEncoder(nn.Module):
         ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, M, residual=ds2)
         ds1 = self._buf(M, d, dev)
         ds1m = self._buf(M, d, dev) if p_out > 0 else None
-        ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], partial, M, p_out, s_l + 2, accumulate=self._acc)
+        ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), M, p_out, s_l + 2,
+                          accumulate=self._acc, defer=lnq)
         dA = ds1m if ds1m is not None else ds1
         self._wq.add(dA, a["ctx"], G["Wo"], M)
         dctx = self._buf(M, d, dev)
@@ -647,12 +659,17 @@ class HipEncoder(nn.Module):
         # as one group at the end of the backward, or every `wgrad_flush_layers` layers when somebody (the trainer's all-reduce
         # hooks) wants layers to complete early; `after_layer(i)` is only called once layer i's weight gradients have been launched.
         self._wq = ops.WgradQueue()
+        # LayerNorm gamma / beta (and the preceding Linear's bias) gradients likewise: each full-size layernorm_bwd leaves its
+        # per-block sums in a scratch buffer of its own and they are all reduced by one launch next to the weight-gradient group
+        self._lnq = ops.LnReduceQueue() if os.environ.get("CLDRD_LN_DEFER", "1") != "0" else None
         flush_every = int(getattr(self, "wgrad_flush_layers", 0) or 0)
         waiting = []
 
         def layer_done(i, force=False):
             waiting.append(i)
             if force or (flush_every > 0 and len(waiting) >= flush_every):
+                if self._lnq is not None:
+                    self._lnq.flush(accumulate=self._acc)
                 self._wq.flush(accumulate=self._acc)
                 if after_layer is not None:
                     for j in waiting:
@@ -678,8 +695,10 @@ class HipEncoder(nn.Module):
             # --- output LayerNorm + FFN ---
             ds2 = self._buf(T, d, dev)
             ds2m = self._buf(T, d, dev) if p_h > 0 else None
-            ops.layernorm_bwd(g, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], partial, T,
-                              p_h, s_l + 3, accumulate=self._acc)
+            lnq = self._lnq
+            own = (lambda: torch.empty(ops.ln_partial_elems(T, d), **f32)) if lnq is not None else (lambda: partial)
+            ops.layernorm_bwd(g, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], own(), T,
+                              p_h, s_l + 3, accumulate=self._acc, defer=lnq)
             dF = ds2m if ds2m is not None else ds2
             self._wq.add(dF, a["h"], G["W2"], T)
             dpre = self._buf(T, f, dev)
@@ -690,8 +709,8 @@ class HipEncoder(nn.Module):
             # --- attention-output LayerNorm + attention ---
             ds1 = self._buf(T, d, dev)
             ds1m = self._buf(T, d, dev) if p_out > 0 else None
-            ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], partial, T,
-                              p_out, s_l + 2, accumulate=self._acc)
+            ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), T,
+                              p_out, s_l + 2, accumulate=self._acc, defer=lnq)
             dA = ds1m if ds1m is not None else ds1
             self._wq.add(dA, a["ctx"], G["Wo"], T)
             dctx = self._buf(T, d, dev)

@@ -259,11 +259,50 @@ def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_str
     return out
 
 
+class LnReduceQueue:
+    """Deferred LayerNorm parameter gradients of one tower: ``layernorm_bwd(..., defer=queue)`` leaves its per-block sums in a
+    scratch buffer of its own and records where they go; ``flush`` reduces everything recorded so far in ONE launch
+    (include/cldrd_hip.h: cldrd_ln_reduce_group) - bit-identical to the immediate form, one launch instead of one per LayerNorm."""
+
+    def __init__(self):
+        self.jobs = []
+
+    def __len__(self):
+        return len(self.jobs)
+
+    def flush(self, accumulate=False):
+        jobs, self.jobs = self.jobs, []
+        if not jobs:
+            return
+        import ctypes as C
+        n = len(jobs)
+        VP, IN = C.c_void_p * n, C.c_int * n
+        d = jobs[0][5]
+        if any(j[5] != d for j in jobs):
+            raise ValueError("LnReduceQueue: one width per queue")
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        call("cldrd_ln_reduce_group", VP(*[j[0].data_ptr() for j in jobs]), IN(*[j[4] for j in jobs]), VP(*[ptr(j[1]) for j in jobs]),
+             VP(*[ptr(j[2]) for j in jobs]), VP(*[ptr(j[3]) for j in jobs]), n, d, 1 if accumulate else 0, _stream())
+        # `jobs` kept the scratch buffers alive until here (same stream: releasing them now is ordered behind the launch)
+
+
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_dropped, dgamma, dbeta, dbias, partial, T, dropout_p=0.0, seed=0,
-                  accumulate=True):
+                  accumulate=True, defer=None):
+    """``defer`` (an LnReduceQueue): dgamma / dbeta / dbias are not produced by this call but by the queue's next ``flush``;
+    ``partial`` is then a buffer of this call's own (ln_partial_elems(T, d) floats) that the queue keeps alive."""
     x_f32 = 1 if x.dtype == F32 else 0
     _chk(dy, BF16, "dy", 2), _chk(x, F32 if x_f32 else BF16, "x", 2), _chk(dx, BF16, "dx", 2)
     d = x.shape[1]
+    if defer is not None:
+        for t, nme in ((dgamma, "dgamma"), (dbeta, "dbeta"), (dbias, "dbias")):
+            if t is not None:
+                _chk(t, F32, nme, 1)
+        if partial.numel() < ln_partial_elems(T, d):
+            raise ValueError("layernorm_bwd: deferred reduction needs a partial buffer of ln_partial_elems(T, d) floats")
+        call("cldrd_layernorm_bwd", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dx_dropped), None, None, None,
+             _p(partial), T, d, dropout_p, seed, 1 if accumulate else 0, x_f32, _stream())
+        defer.jobs.append((partial, dgamma, dbeta, dbias, int(T), int(d)))
+        return
     call("cldrd_layernorm_bwd", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dx_dropped), _p(dgamma),
          _p(dbeta), _p(dbias), _p(partial), T, d, dropout_p, seed, 1 if accumulate else 0, x_f32, _stream())
 
@@ -359,11 +398,20 @@ def grad_clip_coef(g, max_norm, partial, out):
     return out
 
 
-def adamw_step(p, g, m, v, decay_flags, shadow, *, lr, beta1, beta2, eps, weight_decay, step, clip=None):
+def adamw_step(p, g, m, v, decay_flags, shadow, *, lr, beta1, beta2, eps, weight_decay, step, clip=None, shadow16=None, h16_range=None):
+    """``shadow16`` (fp16, optional) receives the updated parameters ``[h16_range[0], h16_range[1])`` (``shadow16[0]`` = the first of them)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, F32, n, 1)
-    call("cldrd_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(decay_flags), _p(shadow), p.numel(), float(lr), float(beta1),
-         float(beta2), float(eps), float(weight_decay), int(step), _p(clip), _stream())
+    if shadow16 is None:
+        call("cldrd_adamw_step", _p(p), _p(g), _p(m), _p(v), _p(decay_flags), _p(shadow), p.numel(), float(lr), float(beta1),
+             float(beta2), float(eps), float(weight_decay), int(step), _p(clip), _stream())
+        return
+    _chk(shadow16, F16, "shadow16", 1)
+    lo, hi = int(h16_range[0]), int(h16_range[1])
+    if shadow16.numel() < hi - lo:
+        raise ValueError("adamw_step: shadow16 is smaller than its range")
+    call("cldrd_adamw_step_h16", _p(p), _p(g), _p(m), _p(v), _p(decay_flags), _p(shadow), p.numel(), float(lr), float(beta1),
+         float(beta2), float(eps), float(weight_decay), int(step), _p(clip), _p(shadow16), lo, hi, _stream())
 
 
 def cast_bf16(src, dst):

@@ -218,10 +218,15 @@ class NwayTrainer:
         towers = self.model.towers()
         # one AdamW launch over the joint buffer; it also writes the bf16 shadow of every tower
         shadow = self._joint_shadow()
+        # ... and the fp16 shadow of the (one) tower that runs the high-precision forward: the query tower
+        h16 = [(t, off) for t, off in zip(towers, self.model._tower_offsets) if t.hp_forward]
+        fused16 = len(h16) == 1 and os.environ.get("CLDRD_ADAM_H16", "1") != "0"
         ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, shadow, lr=lr, beta1=self.betas[0],
-                       beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=self.adam_step, clip=self.clip)
+                       beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=self.adam_step, clip=self.clip,
+                       shadow16=h16[0][0].h16_buffer() if fused16 else None,
+                       h16_range=(h16[0][1], h16[0][1] + h16[0][0].layout.total) if fused16 else None)
         for t in towers:
-            t.refresh_shadows(need_transposed=True, cast=False)
+            t.refresh_shadows(need_transposed=True, cast=False, cast16=not fused16)
         return lr
 
     def _joint_shadow(self):

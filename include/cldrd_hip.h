@@ -133,6 +133,11 @@ int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
 int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
                         int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, void* stream);
+/* Deferred form: call cldrd_layernorm_bwd with dgamma = dbeta = dbias = NULL (its `partial` then keeps the per-block sums and must
+ * stay untouched), and reduce the scratch buffers of n such calls in ONE launch afterwards.  T[i] = the T of call i; outputs as
+ * above, bit-identical to the immediate form.  (The parameter gradients of a LayerNorm are not on the backward's critical path.) */
+int cldrd_ln_reduce_group(const float* const* partial, const int* T, float* const* dgamma, float* const* dbeta,
+                          float* const* dbias, int n, int d, int accumulate, void* stream);
 /* out[N] (+)= column sums of bf16 x[T,N] (bias gradients).  partial: ceil(T/128) * N floats. */
 int cldrd_colsum_bf16(const void* x, float* out, float* partial, int T, int N, int ld, int accumulate, void* stream);
 /* g = zeros(bf16 [T,d]); g[r*stride] = dcls[r]  (gradient of the CLS pooling). */
@@ -172,6 +177,11 @@ int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, float* partia
 int cldrd_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,
                      size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                      const float* clip, void* stream);
+/* The same step that also leaves an fp16 copy (RNE, as cldrd_cast_f16) of the updated parameters [h16_begin, h16_end) in shadow16
+ * (shadow16[0] = parameter h16_begin; bounds multiples of 4): the query tower's high-precision forward reads fp16 weights. */
+int cldrd_adamw_step_h16(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,
+                         size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                         const float* clip, void* shadow16, size_t h16_begin, size_t h16_end, void* stream);
 int cldrd_cast_bf16(const float* src, void* dst, size_t n, void* stream);
 int cldrd_transpose_cast_batched(const float* src, void* dst, const long long* desc, const int* tile_prefix, int ndesc,
                                  int total_tiles, void* stream);

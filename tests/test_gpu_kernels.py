@@ -507,6 +507,38 @@ def test_layernorm_fwd_bwd(T, d):
     close(dbias, dx.float().sum(0), 2e-2, 2e-2 * dx.float().sum(0).abs().max().item() + 1e-2, "ln dbias")
 
 
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_layernorm_bwd_deferred_group_reduction_is_bit_identical(accumulate):
+    """Parameter gradients parked in per-call scratch buffers and reduced by ONE cldrd_ln_reduce_group launch (hip_ops.LnReduceQueue)
+    equal the immediate form bit for bit: different row counts, fp32 and bf16 inputs, absent outputs, with and without accumulation."""
+    d = 768
+    q = ops.LnReduceQueue()
+    want, got = [], []
+    for j, (T, x32, nones) in enumerate([(4096, True, ()), (240, False, ()), (37, True, (2,)), (8193, False, (0, 1))]):
+        x = rnd(60 + j, (T, d), 2.0)
+        x = (x if x32 else bf(x)).to(DEV)
+        dy = bf(rnd(70 + j, (T, d))).to(DEV)
+        gamma = (1 + rnd(80 + j, (d,), 0.1)).to(DEV)
+        mean = x.float().mean(1)
+        rstd = 1.0 / torch.sqrt(x.float().var(1, unbiased=False) + 1e-12)
+        outs = []
+        for form in range(2):
+            g3 = [None if k in nones else (torch.full((d,), 0.25 * (k + 1), device=DEV) if accumulate else torch.empty(d, device=DEV)) for k in range(3)]
+            dx, dx2 = torch.empty(T, d, dtype=torch.bfloat16, device=DEV), torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+            partial = torch.empty(ops.ln_partial_elems(T, d), device=DEV)
+            ops.layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx2, g3[0], g3[1], g3[2], partial, T, dropout_p=0.1, seed=5 + j,
+                              accumulate=accumulate, defer=q if form else None)
+            outs.append((g3, dx, dx2))
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+        want.append(outs[0][0]); got.append(outs[1][0])
+    assert len(q) == 4
+    q.flush(accumulate=accumulate)
+    assert len(q) == 0
+    for a3, b3 in zip(want, got):
+        for a, b in zip(a3, b3):
+            assert (a is None and b is None) or torch.equal(a, b)
+
+
 @pytest.mark.parametrize("V,P,d,M,L", [(300, 40, 256, 6, 20), (2000, 128, 768, 5, 128), (500, 64, 1024, 3, 50)])
 def test_embed_ln_fwd_bwd(V, P, d, M, L):
     T = M * L
@@ -646,6 +678,30 @@ def test_clip_and_adamw_match_oracle():
     before = pd.clone()
     ops.adamw_step(pd, gd, md, vd, flags.to(DEV), None, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=4, clip=clip)
     assert clip[2].item() == 1.0 and torch.equal(pd, before)
+
+
+def test_adamw_step_writes_the_fp16_shadow_of_a_sub_range():
+    """The fused step leaves the fp16 copy of parameters [lo, hi) (what cast_f16 of the updated parameters gives) and changes
+    nothing else: p, m, v and the bf16 shadow are bit-identical to the step without it; a skipped step still refreshes the copy."""
+    n, lo, hi = 64 * 500, 64 * 100 + 4, 64 * 300 - 8
+    p, g = rnd(50, (n,)), rnd(51, (n,), 0.01)
+    m, v = rnd(52, (n,), 0.001), rnd(53, (n,), 0.001).abs() * 1e-3
+    flags = torch.zeros(n // 64, dtype=torch.uint8); flags[1::3] = 1
+    res = []
+    for fused in (False, True):
+        pd, gd, md, vd = (a.to(DEV).clone() for a in (p, g, m, v))
+        shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+        h16 = torch.full((hi - lo + 8,), 7.0, dtype=torch.float16, device=DEV)
+        ops.adamw_step(pd, gd, md, vd, flags.to(DEV), shadow, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=2,
+                       shadow16=h16 if fused else None, h16_range=(lo, hi) if fused else None)
+        res.append((pd, md, vd, shadow, h16))
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b)
+    h16 = res[1][4]
+    assert torch.equal(h16[:hi - lo], res[1][0][lo:hi].half()) and (h16[hi - lo:] == 7.0).all()
+    with pytest.raises(Exception):
+        ops.adamw_step(pd, gd, md, vd, flags.to(DEV), shadow, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=2,
+                       shadow16=h16, h16_range=(lo + 1, hi))
 
 
 def test_transpose_cast_batched():
