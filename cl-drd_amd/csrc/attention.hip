@@ -700,11 +700,11 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             pq[j] = pk[j] = pv[j] = pdo[j] = po[j] = make_uint4(0, 0, 0, 0);
             if (row < L) {
                 const bf16_t* rp = base + (size_t)row * ld + ch * 8;
-                pq[j] = *(const uint4*)rp;
-                pk[j] = *(const uint4*)(rp + dm);
-                pv[j] = *(const uint4*)(rp + 2 * dm);
+                pq[j] = ld16_stream(rp);                          // q, k, v, o: the forward's tape, read once (common.h)
+                pk[j] = ld16_stream(rp + dm);
+                pv[j] = ld16_stream(rp + 2 * dm);
                 pdo[j] = *(const uint4*)(dob + (size_t)row * dm + ch * 8);
-                po[j] = *(const uint4*)(ob + (size_t)row * dm + ch * 8);
+                po[j] = ld16_stream(ob + (size_t)row * dm + ch * 8);
             }
         }
         if (tb < Lp) {

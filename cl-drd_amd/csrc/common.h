@@ -9,6 +9,28 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;    // MFMA A/B fragmen
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+// Streaming accesses for data touched once in a long while (the backward tape: written by the forward, read ~10 ms later): the
+// non-temporal hint keeps them from evicting what the NEXT kernel reads out of the 256-MB Infinity Cache.  CLDRD_TAPE_NT=0: A/B builds.
+#ifndef CLDRD_TAPE_NT
+#define CLDRD_TAPE_NT 1
+#endif
+__device__ __forceinline__ uint4 ld16_stream(const void* p) {
+#if CLDRD_TAPE_NT
+    const u32x4 t = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(t.x, t.y, t.z, t.w);
+#else
+    return *(const uint4*)p;
+#endif
+}
+__device__ __forceinline__ void st16_stream(void* p, const uint4& v) {
+#if CLDRD_TAPE_NT
+    const u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (u32x4*)p);
+#else
+    *(uint4*)p = v;
+#endif
+}
 
 #define CLDRD_WAVE 64
 

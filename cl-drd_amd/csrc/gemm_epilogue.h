@@ -121,16 +121,16 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
             dv[j] = fmaf(v[j] * 0.39894228040143268f, e, c);
             v[j] *= c;
         }
-        *(uint4*)(p.preact + crow) = pack8(dv);
+        st16_stream(p.preact + crow, pack8(dv));
     } else {
         if (fl.preact) {
             if (fl.dgelu) {
                 float dv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dv[j] = gelu_grad_f(v[j]);
-                *(uint4*)(p.preact + crow) = pack8(dv);
+                st16_stream(p.preact + crow, pack8(dv));
             } else {
-                *(uint4*)(p.preact + crow) = pack8(v);
+                st16_stream(p.preact + crow, pack8(v));
             }
         }
         if (fl.gelu) {
@@ -223,14 +223,14 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
                 if (fl.residual) {
                     if (fl.res32) {
                         const uint4* rp = (const uint4*)((const float*)p.residual + (size_t)m * p.ldr + n);
-                        res[pass] = rp[0];
-                        resh[pass] = rp[1];
+                        res[pass] = ld16_stream(rp);              // the fp32 stream's last reader before the backward
+                        resh[pass] = ld16_stream(rp + 1);
                         if (fl.resln) { lmu[pass] = p.ln_mean[m]; lrs[pass] = p.ln_rstd[m]; }
                     } else {
                         res[pass] = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + n);
                     }
                 }
-                if (fl.gelugrad) gp[pass] = *(const uint4*)(p.gelu_pre + (size_t)m * p.ldc + n);
+                if (fl.gelugrad) gp[pass] = ld16_stream(p.gelu_pre + (size_t)m * p.ldc + n);
             }
         }
     };

@@ -42,6 +42,19 @@ __device__ __forceinline__ void load_row_f32(const float* row, int d, int lane, 
         }
     }
 }
+// the same through the streaming path (common.h: ld16_stream): the backward's read of the pre-LN sums the forward left on the tape
+__device__ __forceinline__ void load_row_f32_stream(const float* row, int d, int lane, RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            const uint4 u = ld16_stream(row + c);
+            r.v[it][0] = __uint_as_float(u.x); r.v[it][1] = __uint_as_float(u.y); r.v[it][2] = __uint_as_float(u.z); r.v[it][3] = __uint_as_float(u.w);
+        } else {
+            r.v[it][0] = r.v[it][1] = r.v[it][2] = r.v[it][3] = 0.f;
+        }
+    }
+}
 // INTERLEAVED column map for kernels that scatter a row with float atomics: element (it, j) of a lane is column
 // it*256 + j*64 + lane, so one wave-instruction touches 64 consecutive floats = 256 contiguous bytes.  With the vector map above
 // (4 consecutive columns per lane) an atomic instruction spreads its 64 dwords over 1 KiB - four times the 64-B requests at the
@@ -267,7 +280,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < T; row += gridDim.x * wpb) {
         RowF g, xr;
         load_row_bf16(dy + (size_t)row * d, d, lane, g);
-        if (X32) load_row_f32((const float*)x + (size_t)row * d, d, lane, xr);
+        if (X32) load_row_f32_stream((const float*)x + (size_t)row * d, d, lane, xr);
         else load_row_bf16((const bf16_t*)x + (size_t)row * d, d, lane, xr);
         const float mean = mean_i[row], rstd = rstd_i[row];
         float s1 = 0.f, s2 = 0.f;

@@ -167,7 +167,7 @@ class NwayTrainer:
         main = torch.cuda.current_stream()
         # The query tower is ~1 % of the FLOPs but dozens of small, latency-bound launches: it runs on its own stream
         # next to the passage tower (forward and backward) instead of in front of it.
-        side = self.q_stream if not model.share_weights else main
+        side = self.q_stream if (not model.share_weights and os.environ.get("CLDRD_Q_SIDE", "1") != "0") else main      # "0": A/B runs
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
