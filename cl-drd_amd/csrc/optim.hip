@@ -48,6 +48,7 @@ __global__ void clip_coef_kernel(const float* __restrict__ partial, int nblk, fl
 struct AdamArgs {
     float* p; const float* g; float* m; float* v; const uint8_t* decay; bf16_t* shadow;
     size_t n4; float lr, beta1, beta2, eps, wd, step_size; const float* coef;
+    int reverse;
     uint16_t* shadow16; size_t h_lo4, h_hi4;      // fp16 copy of parameters [4 h_lo4, 4 h_hi4) (shadow16[0] = parameter 4 h_lo4), or null
 };
 
@@ -65,7 +66,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     const float coef = a.coef ? a.coef[1] : 1.0f;
     const bool skip = a.coef && a.coef[2] != 0.f;        // non-finite gradient norm: leave the weights untouched
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n4; i += stride) {
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < a.n4; i0 += stride) {
+        // the sweep runs from the END of the buffer: the norm pass in front of this kernel has just read g front to back, so its
+        // last ~256 MB are what the Infinity Cache still holds (elementwise: the order changes no result)
+        const size_t i = a.reverse ? a.n4 - 1 - i0 : i0;
         // p, g, m, v are streamed once per step (4 GB): non-temporal, so they do not push the bf16 shadows (read by the next
         // step's GEMMs) and the activations out of the Infinity Cache
         float4 p = ntload4((const float4*)a.p + i);
@@ -207,6 +211,7 @@ extern "C" int cldrd_adamw_step_h16(float* p, const float* g, float* m, float* v
                 "adamw_step: fp16 shadow range must be 4-aligned and inside the buffer");
     AdamArgs a;
     a.shadow16 = (uint16_t*)shadow16; a.h_lo4 = h16_begin / 4; a.h_hi4 = h16_end / 4;
+    { const char* e = getenv("CLDRD_ADAM_REVERSE"); a.reverse = !(e && e[0] == '0'); }      // "0": A/B runs
     a.p = p; a.g = g; a.m = m; a.v = v; a.decay = decay_flags; a.shadow = (bf16_t*)shadow; a.n4 = n / 4;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.coef = clip;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
