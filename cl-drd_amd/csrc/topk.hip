@@ -12,6 +12,9 @@
 // Kernels here: per-query k-th largest of the sample scores (threshold estimate, radix select), fp32 re-score,
 // bitonic sort + cut, max row norm.
 #include "common.h"
+#ifndef CLDRD_SCAN_NT
+#define CLDRD_SCAN_NT 1
+#endif
 #include <stdlib.h>
 
 namespace {
@@ -113,7 +116,13 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
         const float* pr = P + (size_t)cand_rows[(size_t)qi * cap + c] * d;
         float s = 0.f;
         for (int j = lane * 4; j < d; j += 256) {
-            const float4 a = *(const float4*)(qr + j), b = *(const float4*)(pr + j);
+            const float4 a = *(const float4*)(qr + j);
+#if CLDRD_SCAN_NT
+            const uint4 bu = ld16_stream(pr + j);              // an index row is read once per pass: keep it out of the caches
+            const float4 b = make_float4(__uint_as_float(bu.x), __uint_as_float(bu.y), __uint_as_float(bu.z), __uint_as_float(bu.w));
+#else
+            const float4 b = *(const float4*)(pr + j);
+#endif
             s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
         }
         s = wave_sum(s);
@@ -438,7 +447,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
         const uint32_t lim = room < (long long)TILEB ? (uint32_t)room : 0xFFFFFFFFu;
 #pragma unroll
         for (int j = 0; j < PPW; ++j)
+#if CLDRD_SCAN_NT
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst + j * 1024), "v"(min(soff[j], lim)), "s"(sbase) : "memory");
+#else
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + j * 1024), "v"(min(soff[j], lim)), "s"(sbase) : "memory");
+#endif
     };
 
     uint32_t rd_off[4];
