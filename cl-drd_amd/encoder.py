@@ -659,9 +659,11 @@ class HipEncoder(nn.Module):
         # as one group at the end of the backward, or every `wgrad_flush_layers` layers when somebody (the trainer's all-reduce
         # hooks) wants layers to complete early; `after_layer(i)` is only called once layer i's weight gradients have been launched.
         self._wq = ops.WgradQueue()
-        # LayerNorm gamma / beta (and the preceding Linear's bias) gradients likewise: each full-size layernorm_bwd leaves its
-        # per-block sums in a scratch buffer of its own and they are all reduced by one launch next to the weight-gradient group
-        self._lnq = ops.LnReduceQueue() if os.environ.get("CLDRD_LN_DEFER", "1") != "0" else None
+        # LayerNorm gamma / beta (and the preceding Linear's bias) gradients can be deferred likewise (CLDRD_LN_DEFER=1): each
+        # layernorm_bwd leaves its per-block sums in a scratch buffer of its own and one launch next to the weight-gradient group reduces
+        # them all.  Bit-identical and 22 launches fewer per step, but OFF by default: the step time does not move at cfg2 (the 7-us
+        # reductions cost nothing there) and the enqueue-bound cfg1 ran slower with it (profiles/r02_microbench.txt).
+        self._lnq = ops.LnReduceQueue() if os.environ.get("CLDRD_LN_DEFER", "0") == "1" else None
         flush_every = int(getattr(self, "wgrad_flush_layers", 0) or 0)
         waiting = []
 
