@@ -155,6 +155,17 @@ def _numel(shape):
     return n
 
 
+_ENV_FLAGS = {}
+
+
+def _env_flag(name, default):
+    """A/B switch read from the environment ONCE per process (the step looks several of them up per layer)."""
+    v = _ENV_FLAGS.get(name)
+    if v is None:
+        v = _ENV_FLAGS[name] = os.environ.get(name, default)
+    return v
+
+
 class FlatLayout:
     """Offsets of every parameter inside the flat buffer (each start aligned to 64 elements)."""
 
@@ -268,6 +279,7 @@ class HipEncoder(nn.Module):
         from a view shares the base tensor's version counter, so ``optimizer.step()`` / ``load_state_dict`` / any in-place
         write through a parameter bumps ``flat_p._version`` and the bf16 shadows are known to be stale.  (Rebinding with
         ``param.data = view`` would give each parameter a private counter: torch 2.10.)"""
+        self.__dict__.pop("_view_cache", None)         # cached parameter views belong to the buffers being replaced
         old = dict(self.named_parameters())
         for n in self._names:
             off, shape = self.layout.entries[n]
@@ -292,6 +304,7 @@ class HipEncoder(nn.Module):
     def adopt_flat(self, flat_p: torch.Tensor, flat_g: torch.Tensor | None = None):
         """Move this tower's parameters into a slice of a model-level flat buffer (same device)."""
         assert flat_p.numel() == self.layout.total and flat_p.dtype == torch.float32
+        self.__dict__.pop("_view_cache", None)
         flat_p.copy_(self.flat_p.to(flat_p.device))
         self._rebind(flat_p)
         self.flat_g = flat_g
@@ -334,17 +347,29 @@ class HipEncoder(nn.Module):
         if p0.grad is None or p0.grad.data_ptr() != self.flat_g.data_ptr():
             self._bind_grads()
 
-    def g(self, name):
+    # Views of one parameter inside the flat buffers.  They are looked up ~250 times per training step; slicing + reshaping a tensor
+    # costs ~2.5 us, so the views are cached per (buffer identity, name) - a flat buffer that is replaced (`.to()`, adopt_flat,
+    # a new shadow) has another data_ptr and simply misses.
+    def _view(self, flat, tag, name):
+        cache = self.__dict__.setdefault("_view_cache", {})
+        key = (tag, name)
+        hit = cache.get(key)
+        ptr = flat.data_ptr()
+        if hit is not None and hit[0] == ptr:
+            return hit[1]
         off, shape = self.layout.entries[name]
-        return self.flat_g[off:off + _numel(shape)].view(shape)
+        v = flat[off:off + _numel(shape)].view(shape)
+        cache[key] = (ptr, v)
+        return v
+
+    def g(self, name):
+        return self._view(self.flat_g, "g", name)
 
     def w(self, name):
-        off, shape = self.layout.entries[name]
-        return self.flat_p[off:off + _numel(shape)].view(shape)
+        return self._view(self.flat_p, "p", name)
 
     def h(self, name):
-        off, shape = self.layout.entries[name]
-        return self.flat_h[off:off + _numel(shape)].view(shape)
+        return self._view(self.flat_h, "h", name)
 
     # ------------------------------------------------------------------ bf16 shadows
     def _build_t_desc(self):
@@ -416,6 +441,17 @@ class HipEncoder(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def _layer_weights(self, i, fp16=False):
+        sh0 = self.flat_h16 if fp16 else self.flat_h
+        ck = ("W", i, bool(fp16))
+        cache = self.__dict__.setdefault("_view_cache", {})
+        hit = cache.get(ck)
+        if hit is not None and hit[0] == (sh0.data_ptr(), self.flat_p.data_ptr()):
+            return hit[1]
+        W = self._layer_weights_build(i, fp16)
+        cache[ck] = ((sh0.data_ptr(), self.flat_p.data_ptr()), W)
+        return W
+
+    def _layer_weights_build(self, i, fp16=False):
         cfg, n = self.cfg, layer_param_names(self.cfg, i)
         d = cfg.dim
         oq = self.layout.entries[n["q"] + ".weight"][0]
@@ -433,6 +469,16 @@ class HipEncoder(nn.Module):
                     g2=self.w(n["ln2"] + ".weight"), b2=self.w(n["ln2"] + ".bias"))
 
     def _layer_grads(self, i):
+        ck = ("G", i)
+        cache = self.__dict__.setdefault("_view_cache", {})
+        hit = cache.get(ck)
+        if hit is not None and hit[0] == self.flat_g.data_ptr():
+            return hit[1]
+        G = self._layer_grads_build(i)
+        cache[ck] = (self.flat_g.data_ptr(), G)
+        return G
+
+    def _layer_grads_build(self, i):
         cfg, n = self.cfg, layer_param_names(self.cfg, i)
         d = cfg.dim
         oq = self.layout.entries[n["q"] + ".weight"][0]
@@ -513,7 +559,7 @@ class HipEncoder(nn.Module):
         # FFN2 epilogue.  It is not stored: that epilogue reads the pre-LN sum (which the backward keeps anyway) and applies mean / rstd /
         # gamma / beta on the fly (`residual_ln`) - 100 MB less written per LayerNorm at cfg2, the same bytes read.
         res_ln = None                                        # LayerNorm still to be applied to x32 (None: x32 is the value itself)
-        LNF = S32 and os.environ.get("CLDRD_LN_ON_THE_FLY", "1") != "0"          # "0": store every fp32 LayerNorm output (A/B runs)
+        LNF = S32 and _env_flag("CLDRD_LN_ON_THE_FLY", "1") != "0"          # "0": store every fp32 LayerNorm output (A/B runs)
         for i in range(cfg.n_layers):
             W = self._layer_weights(i, fp16)
             s_l = seed + 7919 * (i + 1)
@@ -663,7 +709,7 @@ class HipEncoder(nn.Module):
         # layernorm_bwd leaves its per-block sums in a scratch buffer of its own and one launch next to the weight-gradient group reduces
         # them all.  Bit-identical and 22 launches fewer per step, but OFF by default: the step time does not move at cfg2 (the 7-us
         # reductions cost nothing there) and the enqueue-bound cfg1 ran slower with it (profiles/r02_microbench.txt).
-        self._lnq = ops.LnReduceQueue() if os.environ.get("CLDRD_LN_DEFER", "0") == "1" else None
+        self._lnq = ops.LnReduceQueue() if _env_flag("CLDRD_LN_DEFER", "0") == "1" else None
         flush_every = int(getattr(self, "wgrad_flush_layers", 0) or 0)
         waiting = []
 

@@ -22,6 +22,7 @@ import torch
 import torch.distributed as dist
 
 from .. import hip_ops as ops
+from ..encoder import _env_flag
 from ..models.nway_dual_encoder import NwayDualEncoder, score_mode
 
 LOSS_KINDS = ("lambda_mrr", "ranknet", "kl_div", "margin_mse")
@@ -155,7 +156,7 @@ class NwayTrainer:
         qe, pe = model.query_encoder, model.passage_encoder
         q, nw = batch["query"], batch["nway_passages"]
         bz, nway, L = nw["input_ids"].shape
-        write_once = not model.share_weights and os.environ.get("CLDRD_GRAD_ZERO", "") != "full"      # "full": A/B runs
+        write_once = not model.share_weights and _env_flag("CLDRD_GRAD_ZERO", "") != "full"      # "full": A/B runs
         if not write_once:
             self.flat_g.zero_()                 # two tapes accumulate into one tower's gradients
         else:
@@ -167,7 +168,7 @@ class NwayTrainer:
         main = torch.cuda.current_stream()
         # The query tower is ~1 % of the FLOPs but dozens of small, latency-bound launches: it runs on its own stream
         # next to the passage tower (forward and backward) instead of in front of it.
-        side = self.q_stream if (not model.share_weights and os.environ.get("CLDRD_Q_SIDE", "1") != "0") else main      # "0": A/B runs
+        side = self.q_stream if (not model.share_weights and _env_flag("CLDRD_Q_SIDE", "1") != "0") else main      # "0": A/B runs
         if side is not main:
             side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -220,7 +221,7 @@ class NwayTrainer:
         shadow = self._joint_shadow()
         # ... and the fp16 shadow of the (one) tower that runs the high-precision forward: the query tower
         h16 = [(t, off) for t, off in zip(towers, self.model._tower_offsets) if t.hp_forward]
-        fused16 = len(h16) == 1 and os.environ.get("CLDRD_ADAM_H16", "1") != "0"
+        fused16 = len(h16) == 1 and _env_flag("CLDRD_ADAM_H16", "1") != "0"
         ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, shadow, lr=lr, beta1=self.betas[0],
                        beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=self.adam_step, clip=self.clip,
                        shadow16=h16[0][0].h16_buffer() if fused16 else None,
