@@ -155,15 +155,9 @@ def _numel(shape):
     return n
 
 
-_ENV_FLAGS = {}
-
-
 def _env_flag(name, default):
-    """A/B switch read from the environment ONCE per process (the step looks several of them up per layer)."""
-    v = _ENV_FLAGS.get(name)
-    if v is None:
-        v = _ENV_FLAGS[name] = os.environ.get(name, default)
-    return v
+    """A/B switch, read from the environment at every use: tests (and tools) flip them inside one process."""
+    return os.environ.get(name, default)
 
 
 class FlatLayout:

@@ -99,7 +99,7 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
     # small-M problems (CLS-only last layer, query tower) are split along K when that fills the chip: fp32 partials in a scratch tensor
     ws, ws_bytes = None, 0
     if M < 1024:
-        key = (M, N, K)                      # CLDRD_GEMM_SPLITK is read by the library when the first problem of a shape is sized
+        key = (M, N, K, os.environ.get("CLDRD_GEMM_SPLITK"))      # the library reads the switch per call: so does the cache key
         ws_bytes = _SPLITK_WS.get(key)
         if ws_bytes is None:
             ws_bytes = _SPLITK_WS[key] = int(_lib.load().cldrd_gemm_nt_splitk_workspace(M, N, K))
