@@ -321,7 +321,9 @@ __global__ __launch_bounds__(1024) void select_compact_kernel(const int* __restr
                 __syncthreads();
             }
             t_hat = from_orderable(sel_prefix);
-            cut = t_hat - 2.0f * eps[q];
+            // rounded DOWN: with |t^| >> eps the fp32 rounding of t^ - 2 eps (half an ulp of t^) can exceed the 1e-6 relative slack
+            // inside eps, and a row with scan score in [t^ - 2 eps, cut) would fall outside the proven band
+            cut = from_orderable(orderable((float)((double)t_hat - 2.0 * (double)eps[q])) - 1u);       // the next float below
             if (!(thr[q] <= cut)) st |= 8;
         }
     }
@@ -742,6 +744,8 @@ int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows,
                            float* cand_scores, int cap, int f16, hipStream_t st);
 extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
                                       int* cand_rows, float* cand_scores, int cap, int f16, void* stream);
+extern "C" int cldrd_topk_scan_filter_tiled(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts,
+                                            int* cand_rows, float* cand_scores, int cap, int f16, void* stream);
 
 // The whole search of one shard for nq queries (device resident, fp32 + fp16 copies), in batches of 128 as the reference searches
 // (retriever/retrieve_top_passages.py:88, retrieval_utils.py:131-153), enqueued back to back on `stream` with no host round trip:
@@ -750,14 +754,18 @@ extern "C" int cldrd_topk_scan_filter(const void* Q, const void* P, int nq, long
 // queries; d = 768 keeps 256 queries in the registers of a CU).  counts: int[nb * (qtile + 1)] zeroed by the caller
 // (nb = ceil(nq / qtile); per pass qtile list lengths + 1 dropped-hit counter); cand_rows / cand_scores: [qtile, cap] scratch;
 // rows2 / scores2: [qtile, cap2] scratch; n2, status, khat: [nq]; D, I: [nq, k].
-// exhaustive != 0 (rows <= cap): no scan, every row is re-scored.  The caller reads `status` once at the end and redoes the
-// (rare) unproven queries with thresholds of its choice through this same entry point.
+// exhaustive: bit 0 (rows <= cap): no scan, every row is re-scored; bit 1: scan with the TILED kernels, whose hits go straight to
+// the global candidate lists - slower, but it has no on-chip hit list and so can never drop a hit (status bit 4): the retry form
+// for passes whose hit density overflowed the streaming scan's per-wave lists.  The caller reads `status` once at the end and
+// redoes the (rare) unproven queries with thresholds of its choice through this same entry point.
 extern "C" int cldrd_flatip_search(const float* q32, const void* qh, const float* thr, const float* eps, const void* Ph, const float* P32,
                                    long long rows, int d, int nq, int k, int qtile, int* counts, int* cand_rows, float* cand_scores, int cap,
                                    int* rows2, float* scores2, int cap2, int* n2, int* status, float* khat, float* D, int* I,
                                    int exhaustive, void* stream) {
     CLDRD_CHECK(nq > 0 && rows > 0 && k > 0 && cap > 0 && cap <= 8192 && cap2 > 0 && cap2 <= 8192 && d % 4 == 0, "flatip_search: bad arguments");
     CLDRD_CHECK(qtile == 128 || qtile == 256, "flatip_search: the query tile is 128 (the reference's batch) or 256 (two batches per pass over the index)");
+    const int tiled = (exhaustive >> 1) & 1;
+    exhaustive &= 1;
     CLDRD_CHECK(!exhaustive || rows <= cap, "flatip_search: exhaustive mode needs rows <= cap");
     hipStream_t st = (hipStream_t)stream;
     const int kk = (int)(k < rows ? k : rows);
@@ -768,6 +776,14 @@ extern "C" int cldrd_flatip_search(const float* q32, const void* qh, const float
         if (exhaustive) {
             hipLaunchKernelGGL(all_candidates_kernel, dim3((unsigned)((rows + 255) / 256), m), dim3(256), 0, st, cb, cand_rows, cand_scores, (int)rows, cap);
             CLDRD_LAUNCH_CHECK();
+        } else if (tiled) {
+            // the tiled kernels take at most 128 queries per call; list lengths of query j of this pass stay at cb[j]
+            for (int h = 0; h < m; h += 128) {
+                const int mh = m - h < 128 ? m - h : 128;
+                rc = cldrd_topk_scan_filter_tiled((const char*)qh + (size_t)(lo + h) * d * 2, Ph, mh, rows, d, thr + lo + h, cb + h,
+                                                  cand_rows + (size_t)h * cap, cand_scores + (size_t)h * cap, cap, 1, st);
+                if (rc) return rc;
+            }
         } else {
             rc = cldrd_topk_scan_filter(qh ? (const char*)qh + (size_t)lo * d * 2 : nullptr, Ph, m, rows, d, thr + lo, cb, cand_rows, cand_scores, cap, 1, st);
             if (rc) return rc;

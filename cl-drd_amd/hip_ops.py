@@ -480,8 +480,9 @@ def topk_select(counts, cand_rows, cand_scores, kk, thr, eps, rows2, n2, status,
 
 
 def flatip_search(q32, qh, thr, eps, P16, P32, k, counts, cand_rows, cand_scores, rows2, scores2, n2, status, khat, D, I, exhaustive=False,
-                  qtile=128):
-    """The whole search of one shard (include/cldrd_hip.h: cldrd_flatip_search); everything device resident, no host sync."""
+                  qtile=128, tiled=False):
+    """The whole search of one shard (include/cldrd_hip.h: cldrd_flatip_search); everything device resident, no host sync.
+    ``tiled``: scan through the tiled kernels (cannot drop hits; the retry form for passes with status bit 4)."""
     _chk(q32, F32, "q32", 2), _chk(P32, F32, "P32", 2), _chk(thr, F32, "thr", 1), _chk(eps, F32, "eps", 1)
     _chk(D, F32, "D", 2), _chk(I, torch.int32, "I", 2)
     nq, d = q32.shape
@@ -496,7 +497,7 @@ def flatip_search(q32, qh, thr, eps, P16, P32, k, counts, cand_rows, cand_scores
         raise ValueError("flatip_search: operands must be contiguous")
     call("cldrd_flatip_search", _p(q32), _p(qh), _p(thr), _p(eps), _p(P16), _p(P32), rows, d, nq, int(k), int(qtile), _p(counts), _p(cand_rows),
          _p(cand_scores), cand_rows.shape[1], _p(rows2), _p(scores2), rows2.shape[1], _p(n2), _p(status), _p(khat), _p(D), _p(I),
-         1 if exhaustive else 0, _stream())
+         (1 if exhaustive else 0) | (2 if tiled else 0), _stream())
 
 
 def topk_kth_largest(scores, S, kth, thr):

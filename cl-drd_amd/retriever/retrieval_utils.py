@@ -121,6 +121,7 @@ class FlatIPIndex:
             self.ids = None if self.ids is None or ids is None else np.concatenate([self.ids, ids])
         self.ntotal = self.embeddings.shape[0]
         self._p32 = self._p16 = self._sample = self._ids_dev = None
+        self._ws = None
 
     def add(self, embeddings):
         self.add_with_ids(embeddings, None)
@@ -145,6 +146,7 @@ class FlatIPIndex:
     def _attach(self, p32: torch.Tensor):
         device = p32.device
         self.device = device
+        self._ws = None
         with torch.cuda.device(device):
             self._p32 = p32
             n, d = self._p32.shape
@@ -238,17 +240,37 @@ class FlatIPIndex:
             ops.topk_thresholds(est, qnorm, self._max_norm, d, thr, eps)
         cap2 = CAND_CAP if exhaustive else self._cap2(kk)
         D, I = torch.empty(nq, k, **f32), torch.empty(nq, k, **i32)
-        ws = self._workspace(cap2)
+        QT = self.query_tile
         if self.profile:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        st, counts, n2, khat = self._run(q32, qh, thr, eps, k, ws, D, I, exhaustive)
+        # How many rows survive the select (k + the 2 eps band) depends on the corpus: ~1.3 k on isotropic embeddings, where the k-th
+        # score sits far out in a thin tail, 2-3 k on CLS-like ones, where every row scores close to every other (top-k
+        # notes).  A search of more than two passes therefore runs its first pass as a PROBE with the default buffer, reads that pass's
+        # kept-set sizes (one extra host sync per search) and sizes the buffer of the remaining passes from them - instead of
+        # overflowing it query after query and scanning those a second time.
+        probe = 0 if (exhaustive or nq <= 2 * QT or os.environ.get("CLDRD_TOPK_PROBE", "1") == "0") else QT
+        if probe:
+            st_p, cnt_p, n2_p, kh_p = self._run(q32[:probe], qh[:probe], thr[:probe], eps[:probe], k, self._workspace(cap2), D[:probe], I[:probe], False)
+            pr = torch.stack([st_p, n2_p]).cpu().numpy()
+            ok = (pr[0] & 16) == 0
+            need = int(pr[1].max()) if ok.all() else CAND_CAP
+            cap2_rest = cap2
+            while cap2_rest < min(CAND_CAP, int(1.25 * need) + 64):
+                cap2_rest *= 2
+            cap2_rest = min(cap2_rest, CAND_CAP)
+            stats["cap2"] = [cap2, cap2_rest]
+            st_r, cnt_r, n2_r, kh_r = self._run(q32[probe:], qh[probe:], thr[probe:], eps[probe:], k, self._workspace(cap2_rest), D[probe:], I[probe:], False)
+            st, n2, khat = torch.cat([st_p, st_r]), torch.cat([n2_p, n2_r]), torch.cat([kh_p, kh_r])
+            counts = torch.cat([cnt_p, cnt_r])
+            cap2 = cap2_rest
+        else:
+            st, counts, n2, khat = self._run(q32, qh, thr, eps, k, self._workspace(cap2), D, I, exhaustive)
         if self.profile:
             e1.record()
-        status = st.cpu().numpy()                       # the one synchronisation of a search
+        status = st.cpu().numpy()                       # the synchronisation of a search (plus the probe's)
         if int(flag.item()):
             raise ValueError("queries must be finite and inside the fp16 range (|x| <= 65504)")
-        QT = self.query_tile
         nb = (nq + QT - 1) // QT
         stats["scans"] = 0 if exhaustive else nb
         stats["query_tile"] = QT
@@ -257,16 +279,26 @@ class FlatIPIndex:
             c_all = counts.view(nb, QT + 1)[:, :QT].reshape(-1)[:nq]
             stats["search_ms"] = e0.elapsed_time(e1)
             stats["rescored"] = int(n2.sum().item())
+            stats["rescored_max"] = int(n2.max().item())
             stats["candidates"] = int(c_all.clamp(max=CAND_CAP).sum().item())
         bad = np.nonzero(status)[0]
         stats["unproven_first_pass"] = int(bad.size)
+        stats["fallback_queries"] = 0
         attempt = 0
         thr_h = eps_h = None
         while bad.size:
             attempt += 1
-            if attempt > MAX_ATTEMPTS or exhaustive:
-                raise RuntimeError("top-k search did not converge (more ties / near-ties at the k-th score than the candidate "
-                                   f"buffers hold: status bits {sorted(set(status[bad].tolist()))})")
+            if exhaustive:
+                raise RuntimeError(f"exhaustive top-k left queries unproven (status bits {sorted(set(status[bad].tolist()))}): a bug")
+            if attempt > MAX_ATTEMPTS:
+                # More ties / near-ties around the k-th score than the candidate buffers hold (or a threshold that would not settle):
+                # the remaining queries are searched EXACTLY, chunk by chunk, with every row re-scored in fp32 - slow, cannot fail.
+                idx = torch.from_numpy(bad).to(dev)
+                Db, Ib = self._search_exhaustive_chunks(q32.index_select(0, idx), k)
+                D.index_copy_(0, idx, Db)
+                I.index_copy_(0, idx, Ib)
+                stats["fallback_queries"] = int(bad.size)
+                break
             if thr_h is None:
                 thr_h, eps_h = thr.cpu().numpy().astype(np.float64), eps.cpu().numpy().astype(np.float64)
             khat_h = khat.cpu().numpy().astype(np.float64)
@@ -277,18 +309,25 @@ class FlatIPIndex:
             high = ((st_b & 8) != 0) & ~over & ~few
             # proven bound: the list was complete and long enough, only the threshold sat above t^ - 2 eps
             t_b[high] = kh_b[high] - 2.0 * e_b[high] * (1.0 + 1e-3) - 1e-6 * np.abs(kh_b[high]) - 1e-30
-            # too few candidates: the estimate was too high; lower it, faster every attempt
-            t_b[few] = t_b[few] - np.maximum(4.0 * e_b[few], 0.05 * np.abs(t_b[few]) + 1e-3) * (2.0 ** (attempt - 1))
+            # too few candidates: the estimate was too high; lower it, faster every attempt (but never by more than 8 eps + 20 % at once:
+            # a threshold far below t^ only fills the lists)
+            t_b[few] = t_b[few] - np.minimum(np.maximum(4.0 * e_b[few], 0.05 * np.abs(t_b[few]) + 1e-3) * (2.0 ** (attempt - 1)),
+                                             8.0 * e_b[few] * attempt + 0.2 * np.abs(t_b[few]) + 1e-3)
             # overflow: the list holds an arbitrary `cap` of the c rows above thr; its k-th largest score is a (low) estimate of t^
             up = np.where(has_k, kh_b - 2.0 * e_b, -np.inf)
             t_b[over] = np.maximum(t_b[over] + np.maximum(e_b[over], 1e-3 * np.abs(t_b[over])) * (2.0 ** (attempt - 1)), up[over])
+            # status bit 4: the streaming scan dropped hits (its per-wave on-chip lists overflowed inside one tile: hit density above
+            # ~5 % of a tile, e.g. k = 1000 on an index of a few 10k rows).  Every query of such a pass carries the bit and the same
+            # kernel would drop the same hits again: the retry scans with the tiled kernels, which have no on-chip list.  Queries with
+            # ONLY that bit keep their threshold.
+            tiled = bool(((st_b & 4) != 0).any())
             cap2_b = CAND_CAP if ((st_b & 16) != 0).any() else cap2
             idx = torch.from_numpy(bad).to(dev)
             qb32, qbh = q32.index_select(0, idx), qh.index_select(0, idx)
             thr_b = torch.from_numpy(t_b.astype(np.float32)).to(dev)
             eps_b = eps.index_select(0, idx)
             Db, Ib = torch.empty(bad.size, k, **f32), torch.empty(bad.size, k, **i32)
-            st2, _, _, khat2 = self._run(qb32, qbh, thr_b, eps_b, k, self._workspace(cap2_b), Db, Ib, False)
+            st2, _, _, khat2 = self._run(qb32, qbh, thr_b, eps_b, k, self._workspace(cap2_b), Db, Ib, False, tiled=tiled)
             status_b = st2.cpu().numpy()
             good = status_b == 0
             if good.any():
@@ -302,12 +341,48 @@ class FlatIPIndex:
             nbad = (bad.size + QT - 1) // QT
             stats["scans"] += nbad
             stats["rescans"] += nbad
+            # a kept set that does not fit the largest buffer (bit 16 at cap2 = CAND_CAP) cannot be helped by another threshold:
+            # those queries go straight to the exact fallback on the next turn
+            if cap2_b == CAND_CAP and ((status_b & 16) != 0).any():
+                attempt = MAX_ATTEMPTS
             bad = bad[~good]
         return D, I, stats
 
+    def _search_exhaustive_chunks(self, q32: torch.Tensor, k: int):
+        """Exact top-k of a few queries with EVERY row re-scored in fp32, CAND_CAP rows at a time (the exhaustive form of
+        cldrd_flatip_search on row slices), the running top-k merged with each chunk's by the same sort kernel (score desc, row position
+        asc).  The last resort of :meth:`search_device`: reads the fp32 rows once per 128/256 queries, needs no threshold, cannot fail."""
+        dev = self.device
+        n, d = self._p32.shape
+        nq = q32.shape[0]
+        if 2 * k > CAND_CAP:
+            raise ValueError(f"exact fallback: top_k = {k} > {CAND_CAP // 2}")
+        i32, f32 = dict(dtype=torch.int32, device=dev), dict(dtype=torch.float32, device=dev)
+        D = torch.full((nq, k), -float("inf"), **f32)
+        I = torch.full((nq, k), -1, **i32)
+        eps = torch.zeros(nq, **f32)
+        thr = torch.full((nq,), -float("inf"), **f32)
+        ws = self._workspace(CAND_CAP)
+        two = torch.full((nq,), 2 * k, **i32)
+        for lo in range(0, n, CAND_CAP):
+            hi = min(n, lo + CAND_CAP)
+            Dc, Ic = torch.empty(nq, k, **f32), torch.empty(nq, k, **i32)
+            QT = self.query_tile
+            nb = (nq + QT - 1) // QT
+            counts = torch.zeros(nb * (QT + 1), **i32)
+            n2, st, khat = torch.empty(nq, **i32), torch.empty(nq, **i32), torch.empty(nq, **f32)
+            ops.flatip_search(q32, None, thr, eps, None, self._p32[lo:hi], k, counts, ws["cand_rows"], ws["cand_scores"], ws["rows2"], ws["scores2"],
+                              n2, st, khat, Dc, Ic, exhaustive=True, qtile=QT)
+            Ic = torch.where(Ic >= 0, Ic + lo, Ic)
+            rows = torch.cat([I, Ic], dim=1).contiguous()
+            scores = torch.cat([D, Dc], dim=1).contiguous()
+            D, I = torch.empty(nq, k, **f32), torch.empty(nq, k, **i32)
+            ops.topk_sort(two, rows, scores, k, D, I)          # missing entries (row -1, score -inf) sort last and come out as missing
+        return D, I
+
     def _workspace(self, cap2: int):
         """Per-batch scratch of the search (reused by every 128-query batch of every search: same stream, so no hazard)."""
-        key = int(cap2)
+        key = (int(cap2), str(self.device), int(self.query_tile))      # moving / refilling the index must not hand out stale buffers
         ws = getattr(self, "_ws", None)
         if ws is None:
             ws = self._ws = {}
@@ -319,7 +394,7 @@ class FlatIPIndex:
                            scores2=torch.empty(QT, cap2, dtype=torch.float32, device=dev))
         return ws[key]
 
-    def _run(self, q32, qh, thr, eps, k, ws, D, I, exhaustive):
+    def _run(self, q32, qh, thr, eps, k, ws, D, I, exhaustive, tiled=False):
         dev = self.device
         nq, QT = q32.shape[0], self.query_tile
         nb = (nq + QT - 1) // QT
@@ -328,7 +403,7 @@ class FlatIPIndex:
         status = torch.empty(nq, dtype=torch.int32, device=dev)
         khat = torch.empty(nq, dtype=torch.float32, device=dev)
         ops.flatip_search(q32, qh, thr, eps, self._p16, self._p32, k, counts, ws["cand_rows"], ws["cand_scores"], ws["rows2"], ws["scores2"],
-                          n2, status, khat, D, I, exhaustive=exhaustive, qtile=QT)
+                          n2, status, khat, D, I, exhaustive=exhaustive, qtile=QT, tiled=tiled)
         return status, counts, n2, khat
 
     # -- persistence (own format; faiss' binary layout is not reproduced) ----------------

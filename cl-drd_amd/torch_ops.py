@@ -107,14 +107,17 @@ def _(q, p, B, N, mode):
 
 @torch.library.custom_op("cldrd::nway_score_bwd", mutates_args=(), device_types="cuda")
 def nway_score_bwd(dlogits: Tensor, q: Tensor, p: Tensor, B: int, N: int, mode: int) -> Tuple[Tensor, Tensor]:
-    dq, dp = torch.empty_like(q), torch.empty_like(p)
+    # row-major outputs whatever the strides of q / p (empty_like would keep the strides of a dense non-contiguous input, e.g. a
+    # transposed view, while the kernel writes row-major: silently permuted gradients)
+    dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+    dp = torch.empty(p.shape, dtype=p.dtype, device=p.device)
     ops.score_bwd(dlogits.contiguous().float(), q.contiguous(), p.contiguous(), dq, dp, B, N, mode)
     return dq, dp
 
 
 @nway_score_bwd.register_fake
 def _(dlogits, q, p, B, N, mode):
-    return torch.empty_like(q), torch.empty_like(p)
+    return q.new_empty(q.shape), p.new_empty(p.shape)
 
 
 def _score_setup(ctx, inputs, output):

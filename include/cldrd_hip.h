@@ -205,7 +205,8 @@ int cldrd_transpose_bf16_batched(const void* src, void* dst, const long long* de
  *   rescore: exact fp32 <q, P32[row]> of the kept rows (fixed summation order);
  *   sort:    (score desc, row asc), first k -> D[nq,k], I[nq,k] (row index, -1 / -inf = missing).
  * The caller reads `status` once per search and redoes unproven queries with thresholds of its choice (same entry point).
- * exhaustive != 0 (rows <= cap): no scan, every row is re-scored.
+ * `exhaustive` is a bit mask: bit 0 (rows <= cap): no scan, every row is re-scored; bit 1: the scan runs through the tiled kernels
+ * (cldrd_topk_scan_filter_tiled: no on-chip hit list, so status bit 4 cannot occur) - the retry form for passes that dropped hits.
  * Pieces, also callable one by one: prep (fp16 + bf16 copies and norms of the queries; *flag |= 1 if a value exceeds the fp16
  * range), kth (thr estimate: kth largest of sample scores), thresholds (eps[q] = bound on |scan - exact|, thr = est - 2 eps). */
 int cldrd_cast_f16(const float* src, void* dst, size_t n, unsigned int* flag, void* stream);

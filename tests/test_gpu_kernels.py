@@ -930,6 +930,14 @@ def test_torch_library_ops_on_the_gpu():
             close(logits, ref, 1e-5, 1e-4, "nway_score")
         logits.sum().backward()
     torch.library.opcheck(torch.ops.cldrd.nway_score, (q.detach(), p.detach(), 4, 8, 0), test_utils=("test_schema", "test_faketensor"))
+    # dense but non-contiguous inputs (transposed views): the gradients must come back in the inputs' logical layout
+    qt = torch.randn(768, 4, device=DEV).t().requires_grad_(True)
+    pt = torch.randn(768, 32, device=DEV).t().requires_grad_(True)
+    wgt = torch.randn(4, 8, device=DEV)
+    (torch.ops.cldrd.nway_score(qt, pt, 4, 8, 0) * wgt).sum().backward()
+    qc, pc = qt.detach().contiguous().requires_grad_(True), pt.detach().contiguous().requires_grad_(True)
+    (torch.ops.cldrd.nway_score(qc, pc, 4, 8, 0) * wgt).sum().backward()
+    assert torch.equal(qt.grad, qc.grad) and torch.equal(pt.grad, pc.grad)
     yp = torch.randn(4, 8, device=DEV, requires_grad=True)
     yt = torch.randn(4, 8, device=DEV)
     out, grad = torch.ops.cldrd.listwise_loss(yp, yt, 1, None, 1.0, -1.0, True)
