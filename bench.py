@@ -83,8 +83,8 @@ def pmc_traffic(kernel_substr, timeout_s=150):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # >= 50 steady-state steps after >= 10 warm-up steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (queries)")
     ap.add_argument("--nway", type=int, default=32)
     ap.add_argument("--seq-len", type=int, default=128)
@@ -100,12 +100,17 @@ def main():
     ap.add_argument("--retrieve-queries", type=int, default=6980, help="queries searched against the shard (MS MARCO dev: 6980)")
     args = ap.parse_args()
 
+    import torch                      # counting devices does not initialise the GPU (nothing here may before the ranks are spawned)
+    if args.gpus > torch.cuda.device_count():
+        # fail fast, on every rank and before any rendezvous: a rank that cannot get its GPU must not leave the others waiting in
+        # init_process_group
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs on this node, found {torch.cuda.device_count()} "
+                         f"(one process per GPU over RCCL; no scaling number can be measured here)")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N rank processes ourselves (one per GPU, RCCL), as a CHILD
         # of this process and before anything here has touched the GPU (a process that has initialised HIP must never exec).
         sys.exit(spawn_ranks(args.gpus))
 
-    import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))

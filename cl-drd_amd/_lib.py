@@ -19,7 +19,7 @@ SIGNATURES = {
     "cldrd_gemm_nt_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp]),
     "cldrd_gemm_nt_bf16_ln": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp, vp, vp, vp, vp]),
     "cldrd_gemm_nt_splitk_workspace": (csz, [ci, ci, ci]),
-    "cldrd_gemm_nt_bf16_ws": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp, vp, vp, vp, vp, csz, vp]),
+    "cldrd_gemm_nt_bf16_ws": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp, vp, vp, vp, vp, vp, csz, vp]),
     "cldrd_wgrad_splits": (ci, [ci, ci, ci]),
     "cldrd_wgrad_bf16": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, csz, ci, vp]),
     "cldrd_wgrad_group_workspace": (csz, [vp, vp, vp, ci]),
@@ -35,7 +35,7 @@ SIGNATURES = {
     "cldrd_ln_partial_blocks": (ci, [ci]),
     "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, ci, vp]),
     "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp]),
-    "cldrd_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, ci, ci, vp, ci, vp]),
+    "cldrd_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, ci, ci, vp, ci, vp, vp]),
     "cldrd_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cull, ci, ci, vp]),
     "cldrd_ln_reduce_group": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "cldrd_colsum_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
@@ -64,6 +64,8 @@ SIGNATURES = {
     "cldrd_topk_sort": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "cldrd_row_sqnorm_max": (ci, [vp, csz, ci, vp, vp]),
     "cldrd_gather_cast_rows": (ci, [vp, vp, csz, csz, ci, vp]),
+    "cldrd_write_run_file": (C.c_longlong, [C.c_char_p, vp, vp, vp, C.c_longlong, ci, ci]),
+    "cldrd_py_float_repr": (ci, [C.c_double, C.c_char_p]),
 }
 
 

@@ -24,7 +24,9 @@ struct GemmNtArgs {
     int out_f32;
     // EPI_FILTER (top-k scan): keep C[m][n] >= thr[m] as candidate (n, score) of query m
     const float* thr; int* counts; int* cand_rows; float* cand_scores; int cap;
-    int in_f16 = 0;               // top-k scan only: the operands are fp16 (EPI_F16IN instances), not bf16
+    int in_f16 = 0;               // the operands (and a 16-bit C) are fp16, not bf16: top-k scan, high-precision forward flavours
+    bf16_t* c_copy = nullptr;     // with in_f16 and a 16-bit C: a bf16 copy of C [M, ldc] (the backward's MFMAs read bf16: the tape of an
+                                  // fp16-operand forward GEMM), or null
     int ksplit = 1;               // small-M kernel: K range split over ksplit workgroups per tile, fp32 partials in `slabs` ([ksplit][M][N]),
     float* slabs = nullptr;       //   summed in a fixed order and finished (epilogue) by splitk_finish_kernel
     int gn = 0;                   // ring kernel: N tiles are walked in groups of gn inside an XCD's range (0: row-major)
@@ -169,8 +171,13 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         *(float4*)C = make_float4(v[0], v[1], v[2], v[3]);
         *(float4*)(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        if constexpr (EPI != EPI_GENERIC && (EPI & EPI_F16IN) != 0) *(uint4*)((bf16_t*)p.C + crow) = pack8h(v);
-        else *(uint4*)((bf16_t*)p.C + crow) = pack8(v);
+        const bool h16 = EPI == EPI_GENERIC ? p.in_f16 != 0 : (EPI & EPI_F16IN) != 0;
+        if (h16) {
+            *(uint4*)((bf16_t*)p.C + crow) = pack8h(v);
+            if (p.c_copy) st16_stream(p.c_copy + crow, pack8(v));       // the tape copy: read ~10 ms later by the weight-gradient launch
+        } else {
+            *(uint4*)((bf16_t*)p.C + crow) = pack8(v);
+        }
     }
 }
 

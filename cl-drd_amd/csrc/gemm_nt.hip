@@ -166,18 +166,6 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmNtArgs p) {
         }
     }
     if (fl.gelugrad) gp = *(const uint4*)(p.gelu_pre + (size_t)m * p.ldc + n);
-    if constexpr (F16OUT) {
-        if (!fl.f32) {            // fp16 C: apply8's generic store is bf16, so finish in fp32 registers and pack here
-            GemmNtArgs q = p;
-            float tmp[8];
-            q.C = tmp - n; q.ldc = 0; q.out_f32 = 1;      // the store of apply8 lands in tmp; (m, n) stay real: the dropout mask is keyed on them
-            const EpiFlags<EPI_GENERIC> fq(q);
-            // preact / gelu_pre are indexed with ldc: the fp16 format has neither (checked by the launcher)
-            gemm_nt_apply8<EPI_GENERIC>(q, fq, v, m, n, bias8, res, resh, gp);
-            *(uint4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = pack8h(tmp);
-            return;
-        }
-    }
     gemm_nt_apply8<EPI_GENERIC>(p, fl, v, m, n, bias8, res, resh, gp);
 }
 
@@ -219,7 +207,7 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
                                      const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
-                                     const float* ln_beta, float* workspace, size_t workspace_bytes, void* stream);
+                                     const float* ln_beta, void* c_copy_bf16, float* workspace, size_t workspace_bytes, void* stream);
 extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                      const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
@@ -248,7 +236,7 @@ extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int 
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
                                      const float* ln_beta, void* stream) {
     return cldrd_gemm_nt_bf16_ws(A, B, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, preact, gelu_pre, act, alpha, dropout_p, seed, out_f32,
-                                 res_f32, io_f16, ln_mean, ln_rstd, ln_gamma, ln_beta, nullptr, 0, stream);
+                                 res_f32, io_f16, ln_mean, ln_rstd, ln_gamma, ln_beta, nullptr, nullptr, 0, stream);
 }
 
 // The same with a workspace: small-M problems whose one-pass grid would leave most CUs idle (the CLS-only last layer, the query
@@ -258,7 +246,9 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
                                      const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
-                                     const float* ln_beta, float* workspace, size_t workspace_bytes, void* stream) {
+                                     const float* ln_beta, void* c_copy_bf16, float* workspace, size_t workspace_bytes, void* stream) {
+    CLDRD_CHECK(c_copy_bf16 == nullptr || (io_f16 && !out_f32 && (uintptr_t)c_copy_bf16 % 16 == 0),
+                "gemm_nt: the bf16 copy of C goes with fp16 operands and a 16-bit C");
     {
         const int nln = (ln_mean != nullptr) + (ln_rstd != nullptr) + (ln_gamma != nullptr) + (ln_beta != nullptr);
         CLDRD_CHECK(nln == 0 || nln == 4, "gemm_nt: ln_mean / ln_rstd / ln_gamma / ln_beta go together");
@@ -285,7 +275,8 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
     a.seed = seed; a.out_f32 = out_f32;
     a.thr = nullptr; a.counts = nullptr; a.cand_rows = nullptr; a.cand_scores = nullptr; a.cap = 0;
     a.in_f16 = io_f16 ? 1 : 0;
-    if (workspace != nullptr && K % BK == 0 && N % 8 == 0 && !(io_f16 && (preact || gelu_pre))) {
+    a.c_copy = (bf16_t*)c_copy_bf16;
+    if (workspace != nullptr && K % BK == 0 && N % 8 == 0 && !(io_f16 && gelu_pre)) {
         const int ks = splitk_choice(M, N, K);
         if (ks > 1 && workspace_bytes >= (size_t)ks * M * N * sizeof(float) && (uintptr_t)workspace % 16 == 0) {
             a.ksplit = ks;
@@ -312,8 +303,14 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
     if (io_f16) {
         // fp16 operands / 16-bit output (the high-precision forward of the query tower): small-M kernel, forward flavours only
         CLDRD_CHECK(K % BK == 0, "gemm_nt: K must be a multiple of 64");
-        CLDRD_CHECK(preact == nullptr && gelu_pre == nullptr, "gemm_nt: the fp16 format has no preact / gelu_pre epilogue (forward without a tape)");
+        CLDRD_CHECK(gelu_pre == nullptr, "gemm_nt: the fp16 format has no gelu_pre epilogue (forward flavours only)");
+        {
+            const int rc = cldrd_gemm_nt_ring_dispatch(a, 0, (hipStream_t)stream);      // large-M FFN forward flavours (gemm_nt_ring16.hip)
+            if (rc >= 0) return rc;
+        }
         switch (epi_flavour(a)) {
+            case EPI_F16IN | EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU:
+                return launch_nt<EPI_F16IN | EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU>(a, (hipStream_t)stream);
             case EPI_F16IN | EPI_BIAS: return launch_nt<EPI_F16IN | EPI_BIAS>(a, (hipStream_t)stream);
             case EPI_F16IN | EPI_BIAS | EPI_GELU: return launch_nt<EPI_F16IN | EPI_BIAS | EPI_GELU>(a, (hipStream_t)stream);
             case EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32:

@@ -1,0 +1,248 @@
+// NT GEMM, large-M variant: C[M,N] = epilogue(alpha * A[M,K] . B[N,K]^T), bf16 in, fp32 accumulate.
+//
+// Why a second kernel: counters on the 128x128 kernel (profiles/r01_gemm_pmc.md) show ~43 % MFMA busy with the
+// L2 -> LDS path at ~27 B/clk/CU, i.e. bound by operand traffic: a 128x128 tile moves 32 KiB per 2.1 MFLOP.  Here:
+//   * 256 x BN output tile (BN = 256 or 192), 512 threads = 2 x 4 waves of 128 x BN/4: 1.75-2x the flops per byte;
+//   * 64-deep K tiles in two LDS slots, every DMA row a full 128-B line (32-deep slices fetched half lines and were no
+//     faster than the small tile); operands arrive by LDS-DMA (global_load_lds, 16 B/lane), XOR-swizzled on the source
+//     address (chunk ^= row & 7) and on the ds_read_b128 address: conflict-free fragment reads;
+//   * software pipeline at 32-deep k-step granularity: while the MFMAs of one k-step run, the ds_reads of the next
+//     k-step's fragments are threaded between them (pinned with sched_group_barrier) into a second register set,
+//     so a slot is free for the DMA of K tile t+2 half-way through K tile t;  ONE raw s_barrier per 64-deep K tile,
+//     placed after the first MFMAs of k-step 1 so the DMA has a whole K-tile period to land;
+//   * BN = 192 exists because N = 768 / 2304 / 3072 with M = 32768 then give 512 / 1536 / 2048 tiles:
+//     whole multiples of the 256 CUs at one workgroup per CU.
+#pragma once
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int BM = 256, BK = 64;
+constexpr int A_BYTES = BM * BK * 2;     // 32 KiB
+
+// ABL != 0: timing experiments only (tools/gemm_ablate.py; results are wrong): 1 no s_barrier, 2 no LDS-DMA inside the K loop,
+// 3 neither (and no vmcnt waits), 4 no fragment reads inside the K loop, 6 DMA issued but never waited for.
+// Measured at M = 32768, N = 768, K = 3072 (us): full 144 | 1: 139-144 | 2: 118 | 3: 112 | 4: 145 | 6: 140 -> the fragment reads are
+// free, barrier + waits cost ~4 %, the ISSUE of the LDS-DMA pieces ~16 % (spreading them one per MFMA row was worse: 157).
+template <int BN, int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int B_BYTES = BN * BK * 2;
+    constexpr int SLOT = A_BYTES + B_BYTES;
+    constexpr int NT = BN / 64;              // 16-col MFMA tiles per wave
+    constexpr int WN = BN / 4;               // wave tile width
+    constexpr int BPW = BN / 64;             // 1-KiB B pieces per wave (8 rows x 128 B each): BN/8 pieces over 8 waves
+    constexpr int NSLOT = (3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2;     // BN = 128: two K tiles in flight
+    constexpr int G = 4 + BPW;               // LDS-DMA instructions per wave per K tile
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // Tile order inside an XCD's contiguous range.  Row-major (all N tiles of an M panel, then the next panel) streams the
+    // whole B operand through the 4-MiB L2 once per round of tiles: for N = 3072, K = 768 that is 4.7 MB of weights + the
+    // A panels + the output stream, and B was re-fetched ~6x per XCD (PMC: 293 MB read for 55 MB of operands).  So the N
+    // tiles are walked in groups of `gn` (<= ~2 MB of B): chunk of `mc` M panels (= one XCD's share) x group x panel x tile.
+    int mt_, nt_;
+    if (p.gn > 0 && p.gn < ntn) {
+        const int ntm = (p.M + BM - 1) / BM;
+        const int mc = (ntm + 7) / 8;
+        const int c = tile / (mc * ntn), r = tile % (mc * ntn);
+        const int mrows = min(mc, ntm - c * mc);
+        const int g = r / (mrows * p.gn);
+        const int r2 = r - g * mrows * p.gn;
+        const int gw = min(p.gn, ntn - g * p.gn);
+        mt_ = c * mc + r2 / gw;
+        nt_ = g * p.gn + r2 % gw;
+    } else {
+        mt_ = tile / ntn;
+        nt_ = tile % ntn;
+    }
+    const int m0 = mt_ * BM, n0 = nt_ * BN;
+    const int wm = wid >> 2, wn = wid & 3;
+    const int nk_ = p.K / BK;
+
+    // ---- LDS-DMA: piece = 8 rows x 128 B; lane -> row (lane >> 3), LDS chunk (lane & 7), source chunk swizzled ----
+    // 32-bit byte offsets from the operand base (the launcher checks the operands are < 4 GiB)
+    const int prow = lane >> 3;
+    const int schunk = (lane & 7) ^ prow;
+    uint32_t oa[4], ob[BPW];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        oa[i] = (uint32_t)min(m0 + (4 * wid + i) * 8 + prow, p.M - 1) * (uint32_t)(p.lda * 2) + schunk * 16;
+#pragma unroll
+    for (int i = 0; i < BPW; ++i)
+        ob[i] = (uint32_t)min(n0 + (BPW * wid + i) * 8 + prow, p.N - 1) * (uint32_t)(p.ldb * 2) + schunk * 16;
+    auto stage = [&](int slot, int kt) {
+        char* base = smem + slot * SLOT;
+        const char* pa = (const char*)p.A + kt * (BK * 2);
+        const char* pb = (const char*)p.B + kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + oa[i]), LDS_PTR(base + (4 * wid + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BPW; ++i)
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb + ob[i]), LDS_PTR(base + A_BYTES + (BPW * wid + i) * 1024), 16, 0, 0);
+    };
+
+    // ---- fragment addressing: row (lane & 15) of a 16-row tile; 16-B chunk 4*ks + (lane >> 4), XOR (row & 7) ----
+    const int frow = lane & 15;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int ch = ((4 * ks + (lane >> 4)) ^ (frow & 7)) * 16;
+        a_off[ks] = (wm * 128 + frow) * 128 + ch;
+        b_off[ks] = A_BYTES + (wn * WN + frow) * 128 + ch;
+    }
+
+    f32x4 acc[8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 af[8], b0[NT], b1[NT];
+    auto mfma_row = [&](int mt, bf16x8 (&bc)[NT]) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = gemm_mfma<EPI>(bc[nt], af[mt], acc[mt][nt]);
+    };
+    // One 32-deep k-step.  A fragments are refilled IN PLACE for the next k-step as soon as their last MFMA has issued
+    // (the refill of af[mt] has 6*NT MFMAs to land); only the B fragments are double-buffered (bc -> bn).
+    //   MFMA rows 0,1 | [sync] | reads af[0], af[1], bn[*] | (MFMA row mt, read af[mt]) for mt = 2..7
+    // `sync` (k-step 1 only): K tile kt+1 has landed and everybody has finished with this slot -> recycle it.
+    // The DMA issue of a K tile costs a wave about as many issue cycles as its 32 MFMAs (8 pieces x 100-185 cycles,
+    // MI355X_MICROARCH.md), and the two waves of a SIMD (w and w + 4) leave the barrier together: issued at the same point
+    // they leave the MFMA pipe idle for that long.  Waves 4..7 therefore postpone their pieces to the following k-step
+    // (`late`), so one wave of each SIMD feeds the MFMA pipe while the other one issues: +2..9 % on the encoder shapes
+    // (a whole k-step later is too late for two LDS slots: -10 %).
+    const bool late_wave = wid >= 4 && p.stagger != 0;
+    auto kstep = [&](bf16x8 (&bc)[NT], bf16x8 (&bn)[NT], const char* na, const char* nb, bool sync, int slot, int kt) {
+        mfma_row(0, bc);
+        mfma_row(1, bc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sync) {
+            // K tile kt+1 must have landed; with a third slot K tile kt+2 (issued one tile ago) stays in flight
+            if (ABL == 3 || ABL == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (NSLOT == 3 && kt + 2 < nk_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (ABL != 1 && ABL != 3) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ABL != 2 && ABL != 3 && !late_wave && kt + NSLOT < nk_) stage(slot, kt + NSLOT);  // slot of K tile kt: its fragments are in registers everywhere
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (ABL != 2 && ABL != 3 && late_wave && slot >= 0 && kt + NSLOT < nk_) {
+            stage(slot, kt + NSLOT);                        // (slot, kt) of the previous K tile, freed at its barrier
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ABL == 4) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bn[t] = bc[t];
+#pragma unroll
+            for (int mt = 2; mt < 8; ++mt) mfma_row(mt, bc);
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
+        af[0] = *(const bf16x8*)(na);
+        af[1] = *(const bf16x8*)(na + 16 * 128);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bn[t] = *(const bf16x8*)(nb + t * 16 * 128);
+#pragma unroll
+        for (int mt = 2; mt < 8; ++mt) {
+            mfma_row(mt, bc);
+            af[mt] = *(const bf16x8*)(na + mt * 16 * 128);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + NT, 0);
+#pragma unroll
+        for (int mt = 2; mt < 8; ++mt) {
+            __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto klast = [&](bf16x8 (&bc)[NT]) {
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) mfma_row(mt, bc);
+    };
+
+    stage(0, 0);
+    if (NSLOT == 3 && nk_ > 1) {
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (NSLOT == 3) { if (nk_ > 2) stage(2, 2); } else { if (nk_ > 1) stage(1, 1); }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b0[t] = *(const bf16x8*)(smem + b_off[0] + t * 16 * 128);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) af[t] = *(const bf16x8*)(smem + a_off[0] + t * 16 * 128);
+
+    int cs = 0, ps = -1;                                                        // slots of K tiles kt and kt-1
+    for (int kt = 0; kt + 1 < nk_; ++kt) {
+        const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
+        const char* cur = smem + cs * SLOT;
+        const char* nxt = smem + ns * SLOT;
+        kstep(b0, b1, cur + a_off[1], cur + b_off[1], false, ps, kt - 1);       // k-step 0; prefetch k-step 1 of this slot
+        kstep(b1, b0, nxt + a_off[0], nxt + b_off[0], true, cs, kt);            // k-step 1; prefetch k-step 0 of K tile kt+1
+        ps = cs;
+        cs = ns;
+    }
+    {   // last K tile: nothing left to recycle (a postponed issue of K tile nk-2 would be for K tile nk-2+NSLOT >= nk)
+        const char* cur = smem + cs * SLOT;
+        kstep(b0, b1, cur + a_off[1], cur + b_off[1], false, -1, nk_);
+        klast(b1);
+    }
+
+    if constexpr ((EPI & EPI_FILTER) != 0 && EPI != EPI_GENERIC) {
+        gemm_nt_filter_epilogue_cols<8, NT>(p, acc, m0 + wm * 128, n0 + wn * WN, lane);
+    } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();     // last K tile fully consumed by every wave: the slots become epilogue scratch
+        asm volatile("" ::: "memory");
+        gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
+    }
+}
+
+template <int BN, int ABL>
+int launch_ring_abl(const GemmNtArgs& a, hipStream_t st) {
+    constexpr int lds = ((3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2) * (A_BYTES + BN * BK * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, 0, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nblk = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, 0, ABL>), dim3(nblk), dim3(512), lds, st, a);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int BN, int EPI>
+int launch_ring_epi(const GemmNtArgs& a, hipStream_t st) {
+    if (EPI == 0 && BN == 192) {                       // ablations exist for the plain BN = 192 instance only
+        static int abl = -1;
+        if (abl < 0) { const char* e = getenv("CLDRD_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
+        switch (abl) {
+            case 1: return launch_ring_abl<192, 1>(a, st);
+            case 2: return launch_ring_abl<192, 2>(a, st);
+            case 3: return launch_ring_abl<192, 3>(a, st);
+            case 4: return launch_ring_abl<192, 4>(a, st);
+            case 6: return launch_ring_abl<192, 6>(a, st);
+            default: break;
+        }
+    }
+    constexpr int lds = ((3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2) * (A_BYTES + BN * BK * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    const int nblk = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, EPI>), dim3(nblk), dim3(512), lds, st, a);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace

@@ -128,7 +128,8 @@ template <int DC, bool X32>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, bf16_t* __restrict__ out, float* __restrict__ out32,
                                                       float* __restrict__ mean_o, float* __restrict__ rstd_o, int T, int d_rt,
-                                                      float eps, float* __restrict__ cls_out, int cls_stride, int out_f16) {
+                                                      float eps, float* __restrict__ cls_out, int cls_stride, int out_f16,
+                                                      bf16_t* __restrict__ out_copy) {
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     }
     if (out_f16) store_row_f16(out + (size_t)row * d, d, lane, r);
     else store_row_bf16(out + (size_t)row * d, d, lane, r);
+    if (out_copy) store_row_bf16(out_copy + (size_t)row * d, d, lane, r);       // fp16 `out` for the forward GEMM + the bf16 tape copy
     if (X32 && out32) store_row_f32(out32 + (size_t)row * d, d, lane, r);
     if (lane == 0) { if (mean_o) mean_o[row] = mean; if (rstd_o) rstd_o[row] = rstd; }
 }
@@ -488,12 +490,14 @@ static inline int ln_bwd_blocks(int T) {
 extern "C" int cldrd_ln_partial_blocks(int T) { return ln_bwd_blocks(T); }
 
 extern "C" int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
-                                   int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, int out_f16, void* stream) {
+                                   int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, int out_f16,
+                                   void* out_bf16_copy, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_fwd: need 0 < d <= 1024, d % 4 == 0");
+    CLDRD_CHECK(out_bf16_copy == nullptr || out_f16, "layernorm_fwd: the bf16 copy goes with an fp16 output");
     CLDRD_CHECK(x_f32 || out32 == nullptr, "layernorm_fwd: an fp32 output copy goes with an fp32 input (the fp32 residual stream)");
     ln_dispatch(d, x_f32 != 0, [&](auto dc, auto x32) {
         hipLaunchKernelGGL((ln_fwd_kernel<decltype(dc)::value, decltype(x32)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
-                           (bf16_t*)out, out32, mean, rstd, T, d, eps, cls_out, cls_stride > 0 ? cls_stride : 1, out_f16);
+                           (bf16_t*)out, out32, mean, rstd, T, d, eps, cls_out, cls_stride > 0 ? cls_stride : 1, out_f16, (bf16_t*)out_bf16_copy);
     });
     CLDRD_LAUNCH_CHECK();
     return 0;

@@ -6,6 +6,11 @@ tokenizer (needs a local vocab: there is no network here).  ``SyntheticSequenceD
 from the portable generator, which is what the benchmarks and tests use."""
 from __future__ import annotations
 
+import json
+import os
+import time
+
+import numpy as np
 import torch
 
 from .. import synthetic as syn
@@ -17,15 +22,14 @@ class SequenceDataset(torch.utils.data.Dataset):
 
     @classmethod
     def create_from_seqs_file(cls, path, tokenizer, max_length, is_query=False):
-        ids, seqs = [], []
+        id_to_seq = {}              # the reference's dict (:31-42): a repeated id keeps its first position and its last text
         with open(path) as fh:
             for line in fh:
-                a = line.rstrip("\n").split("\t")
+                a = line.strip().split("\t")
                 if len(a) < 2:
                     continue
-                ids.append(int(a[0]))
-                seqs.append(a[1])
-        return cls(ids, seqs, tokenizer, max_length, is_query)
+                id_to_seq[int(a[0])] = a[1]
+        return cls(list(id_to_seq.keys()), list(id_to_seq.values()), tokenizer, max_length, is_query)
 
     def __len__(self):
         return len(self.ids)
@@ -35,12 +39,164 @@ class SequenceDataset(torch.utils.data.Dataset):
 
     def collate_fn(self, batch):
         ids, seqs = zip(*batch)
-        enc = self.tokenizer(list(seqs), padding=True, truncation=True, max_length=self.max_length, return_tensors="pt")
+        enc = self.tokenizer(list(seqs), padding=True, truncation="longest_first", max_length=self.max_length, return_tensors="pt")
         return {"seq": {"input_ids": enc["input_ids"], "attention_mask": enc["attention_mask"]}, "id": list(ids)}
 
 
+class SequenceTokenCache:
+    """The ``id\\ttext`` collection tokenised ONCE (for the index path): ``ids [n, max_length]`` uint16 (int32 when
+    the vocabulary needs it; zero padded), ``lens [n]`` int32, ``keys [n]`` int64, three ``.npy`` files that are memory-mapped on load.
+
+    The reference tokenises every batch of 512 passages inside ``collate_fn`` (dataset/sequence_dataset.py:44-55) with four DataLoader
+    workers, and every rank first reads the whole 8.8 M-line TSV into a dict (:31-42): a few thousand passages per second per worker
+    against an encoder that takes ~75 000 per second.  Built by one streaming pass over the TSV (rows in file order, exactly the rows
+    ``create_from_seqs_file`` keeps, a repeated id keeping its first position and last text as the reference's dict does); afterwards a
+    rank maps the files and touches only the pages of its own row range."""
+
+    def __init__(self, keys, ids, lens, meta):
+        self.keys, self.ids, self.lens, self.meta = keys, ids, lens, meta
+
+    def __len__(self):
+        return int(self.keys.shape[0])
+
+    @staticmethod
+    def stem_for(cache_dir: str, path: str, max_length: int) -> str:
+        return os.path.join(cache_dir, f"{os.path.basename(path)}.L{int(max_length)}.seqcache")
+
+    @staticmethod
+    def source_meta(path: str, tokenizer, max_length: int) -> dict:
+        st = os.stat(path)
+        return {"source": os.path.abspath(path), "source_bytes": int(st.st_size), "source_mtime_ns": int(st.st_mtime_ns),
+                "max_length": int(max_length), "tokenizer": str(getattr(tokenizer, "name_or_path", "") or type(tokenizer).__name__),
+                "vocab_size": int(len(tokenizer))}
+
+    @classmethod
+    def build(cls, path: str, tokenizer, max_length: int, stem: str, chunk: int = 8192) -> "SequenceTokenCache":
+        meta = cls.source_meta(path, tokenizer, max_length)
+        # pass 1: the rows create_from_seqs_file keeps, in the order its dict would hold them
+        order, last = {}, []
+        with open(path) as fh:
+            for ln, line in enumerate(fh):
+                a = line.strip().split("\t")
+                if len(a) != 2:
+                    if not line.strip():
+                        continue
+                    raise ValueError(f"{path}:{ln + 1}: expected 'id<TAB>text' (the reference unpacks exactly two fields)")
+                k = int(a[0])
+                if k in order:
+                    last[order[k]] = ln
+                else:
+                    order[k] = len(last)
+                    last.append(ln)
+        n = len(last)
+        keep = {ln: row for row, ln in enumerate(last)}
+        dtype = np.uint16 if meta["vocab_size"] <= 65536 else np.int32
+        os.makedirs(os.path.dirname(stem) or ".", exist_ok=True)
+        tmp = f".tmp{os.getpid()}"
+        ids = np.lib.format.open_memmap(stem + ".ids.npy" + tmp, mode="w+", dtype=dtype, shape=(n, int(max_length)))
+        lens = np.zeros(n, dtype=np.int32)
+        keys = np.zeros(n, dtype=np.int64)
+
+        def flush(rows, texts):
+            enc = tokenizer(texts, padding=False, truncation="longest_first", max_length=int(max_length))["input_ids"]
+            for r, t in zip(rows, enc):
+                ids[r, :len(t)] = t
+                lens[r] = len(t)
+
+        rows, texts = [], []
+        with open(path) as fh:      # pass 2: tokenise chunk by chunk (never the whole collection in memory)
+            for ln, line in enumerate(fh):
+                row = keep.get(ln)
+                if row is None:
+                    continue
+                a = line.strip().split("\t")
+                keys[row] = int(a[0])
+                rows.append(row)
+                texts.append(a[1])
+                if len(rows) >= chunk:
+                    flush(rows, texts)
+                    rows, texts = [], []
+        if rows:
+            flush(rows, texts)
+        ids.flush()
+        del ids
+        os.replace(stem + ".ids.npy" + tmp, stem + ".ids.npy")
+        for suffix, arr in ((".lens.npy", lens), (".keys.npy", keys)):
+            np.save(stem + suffix + tmp + ".npy", arr)
+            os.replace(stem + suffix + tmp + ".npy", stem + suffix)
+        meta["rows"] = n
+        with open(stem + ".meta.json" + tmp, "w") as fh:
+            json.dump(meta, fh)
+        os.replace(stem + ".meta.json" + tmp, stem + ".meta.json")        # last: what load() looks for
+        return cls.load(stem, meta)
+
+    @classmethod
+    def load(cls, stem: str, expect: dict | None = None) -> "SequenceTokenCache":
+        with open(stem + ".meta.json") as fh:
+            meta = json.load(fh)
+        for k, v in (expect or {}).items():
+            if k != "rows" and meta.get(k) != v:
+                raise ValueError(f"sequence token cache {stem}: built with {k}={meta.get(k)!r}, this run has {v!r}: delete it or use another --token_cache_dir")
+        ids = np.load(stem + ".ids.npy", mmap_mode="r")
+        lens, keys = np.load(stem + ".lens.npy", mmap_mode="r"), np.load(stem + ".keys.npy", mmap_mode="r")
+        if ids.shape != (meta["rows"], meta["max_length"]) or lens.shape[0] != meta["rows"] or keys.shape[0] != meta["rows"]:
+            raise ValueError(f"sequence token cache {stem}: arrays do not match their metadata (truncated write?)")
+        return cls(keys, ids, lens, meta)
+
+    @classmethod
+    def open_or_build(cls, cache_dir: str, path: str, tokenizer, max_length: int, rank: int = 0, world: int = 1, wait_s: float = 7200.0):
+        """Rank 0 builds a missing / stale cache (atomic renames); the other ranks of an index_text run - independent processes, no
+        process group on that path - wait for its metadata file to appear."""
+        stem = cls.stem_for(cache_dir, path, max_length)
+        want = cls.source_meta(path, tokenizer, max_length)
+        if os.path.exists(stem + ".meta.json"):
+            try:
+                return cls.load(stem, want)
+            except ValueError:
+                if rank != 0:
+                    raise
+        if rank == 0:
+            return cls.build(path, tokenizer, max_length, stem)
+        t0 = time.time()
+        while time.time() - t0 < wait_s:
+            if os.path.exists(stem + ".meta.json"):
+                try:
+                    return cls.load(stem, want)
+                except ValueError:
+                    pass
+            time.sleep(1.0)
+        raise TimeoutError(f"sequence token cache {stem}: rank 0 did not finish it within {wait_s:.0f} s")
+
+
+class CachedSequenceDataset(torch.utils.data.Dataset):
+    """Whole encode batches of rows [lo, hi) of a :class:`SequenceTokenCache` with the ``collate_fn`` layout of the reference
+    (dataset/sequence_dataset.py:44-55): ``input_ids`` / ``attention_mask`` int64 padded to the longest row OF THE BATCH, ``id`` list[int]."""
+
+    def __init__(self, cache: SequenceTokenCache, lo: int = 0, hi: int | None = None, batch_size: int = 512, pad_id: int = 0):
+        self.cache, self.lo, self.hi = cache, int(lo), int(len(cache) if hi is None else hi)
+        self.batch_size, self.pad_id = int(batch_size), int(pad_id)
+
+    def __len__(self):
+        return (self.hi - self.lo + self.batch_size - 1) // self.batch_size
+
+    def __getitem__(self, b):
+        a = self.lo + b * self.batch_size
+        z = min(self.hi, a + self.batch_size)
+        lens = np.asarray(self.cache.lens[a:z])
+        width = int(lens.max()) if z > a else 0
+        ids = np.asarray(self.cache.ids[a:z, :width]).astype(np.int64)
+        mask = (np.arange(width)[None, :] < lens[:, None]).astype(np.int64)
+        if self.pad_id != 0:
+            ids = np.where(mask == 1, ids, self.pad_id)
+        return {"seq": {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}, "id": [int(k) for k in self.cache.keys[a:z]]}
+
+    def loader(self, num_workers: int = 2):
+        return torch.utils.data.DataLoader(self, batch_size=None, shuffle=False, num_workers=num_workers)
+
+
 class SyntheticSequenceDataset(torch.utils.data.Dataset):
-    """n MSMARCO-shaped sequences of up to ``max_length`` tokens; deterministic in (seed, index range)."""
+    """n MSMARCO-shaped sequences of up to ``max_length`` tokens: rows [first_id, first_id + n) of one endless collection whose row r
+    depends on (seed, r) only - shards of it (``first_id`` = the shard's first row) hold exactly the rows a single process would."""
 
     def __init__(self, n, max_length, seed=99, vocab=syn.VOCAB, ragged=True, first_id=0, batch_size=512):
         self.n, self.max_length, self.seed, self.vocab, self.ragged = int(n), int(max_length), seed, vocab, ragged
@@ -52,8 +208,7 @@ class SyntheticSequenceDataset(torch.utils.data.Dataset):
     def __getitem__(self, b):
         lo = b * self.batch_size
         rows = min(self.batch_size, self.n - lo)
-        batch = syn.seq_batch(self.seed + 7919 * b, rows, self.max_length, vocab=self.vocab, ragged=self.ragged,
-                              first_id=self.first_id + lo)
+        batch = syn.seq_rows(self.seed, self.first_id + lo, rows, self.max_length, vocab=self.vocab, ragged=self.ragged)
         if self.ragged:      # pad to the longest sequence of the batch, as the HF tokenizer does (padding=True)
             longest = int(batch["seq"]["attention_mask"].sum(1).max())
             batch["seq"] = {k: v[:, :longest].contiguous() for k, v in batch["seq"].items()}

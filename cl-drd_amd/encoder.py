@@ -245,6 +245,12 @@ class HipEncoder(nn.Module):
         # copies.  CLDRD_RESIDUAL=bf16 stores them in bf16 (round-1 behaviour: ~7 % faster, 2.4x the reference's own
         # mixed-precision logit drift instead of 0.7x - tools/drift_emulation.py).
         self.stream32 = os.environ.get("CLDRD_RESIDUAL", "fp32") != "bf16"
+        # FFN forward GEMMs on fp16 operands (default with the fp32 residual stream; CLDRD_FFN_FP16=0: bf16 like every other GEMM).
+        # Of all 16-bit rounding points of a layer, the operands of ffn.lin1 / ffn.lin2 carry the logit drift: emulated on the cfg1
+        # golden, max|dlogit| is 0.234 with every operand in bf16, 0.051 with the FFN operands in fp16 and 0.024
+        # with everything in fp16 - the reference's own fp16 autocast drifts by 0.036.  Same MFMA rate; the training forward keeps a
+        # bf16 copy of the LayerNorm output and of h for the backward's MFMAs (fp16 activations x bf16 gradients do not mix).
+        self.ffn_fp16 = self.stream32 and os.environ.get("CLDRD_FFN_FP16", "1") != "0"
 
     # ------------------------------------------------------------------ parameters
     def named_flat(self):
@@ -391,9 +397,14 @@ class HipEncoder(nn.Module):
                 p64.append(t64)
             self._t_desc64 = (torch.tensor(p64, dtype=torch.int32, device=dev), t64)
 
+    @property
+    def needs_h16(self):
+        return self.hp_forward or self.ffn_fp16
+
     def h16_buffer(self):
-        """The fp16 weight shadow of a tower that runs the high-precision forward (allocated on first use), else None."""
-        if not self.hp_forward:
+        """The fp16 weight shadow of a tower whose forward reads fp16 weights (the high-precision pass of the query tower; the FFN GEMMs
+        of every tower by default), allocated on first use; else None."""
+        if not self.needs_h16:
             return None
         if self.flat_h16 is None or self.flat_h16.device != self.flat_p.device:
             self.flat_h16 = torch.empty(self.layout.total, dtype=torch.float16, device=self.flat_p.device)
@@ -408,7 +419,7 @@ class HipEncoder(nn.Module):
             self.flat_h = torch.empty(self.layout.total, dtype=torch.bfloat16, device=self.flat_p.device)
         if cast:
             ops.cast_bf16(self.flat_p, self.flat_h)
-        if self.hp_forward and (cast16 is None or cast16):
+        if self.needs_h16 and (cast16 is None or cast16):
             ops.cast_f16(self.flat_p, self.h16_buffer())
         if need_transposed and self.cfg.n_layers:
             if self.flat_t is None:
@@ -426,7 +437,7 @@ class HipEncoder(nn.Module):
         self._shadow_version = self.flat_p._version
 
     def _shadows_ok(self, need_t):
-        return (self.flat_h is not None and self._shadow_version == self.flat_p._version and (not self.hp_forward or self.flat_h16 is not None) and
+        return (self.flat_h is not None and self._shadow_version == self.flat_p._version and (not self.needs_h16 or self.flat_h16 is not None) and
                 (not need_t or (self.flat_t is not None and getattr(self, "_t_fresh", False))))
 
     def ht(self, layer, key):
@@ -554,11 +565,13 @@ class HipEncoder(nn.Module):
         # gamma / beta on the fly (`residual_ln`) - 100 MB less written per LayerNorm at cfg2, the same bytes read.
         res_ln = None                                        # LayerNorm still to be applied to x32 (None: x32 is the value itself)
         LNF = S32 and _env_flag("CLDRD_LN_ON_THE_FLY", "1") != "0"          # "0": store every fp32 LayerNorm output (A/B runs)
+        FFN16 = self.ffn_fp16 and S32 and not fp16                           # a bf16 pass whose FFN GEMMs read fp16 operands
         for i in range(cfg.n_layers):
             W = self._layer_weights(i, fp16)
+            W16 = self._layer_weights(i, True) if FFN16 else None
             s_l = seed + 7919 * (i + 1)
             if i == cfg.n_layers - 1 and self.cls_only_last:
-                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16)
+                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16, W16)
                 break
             qkv = self._buf(T, 3 * d, dev, dt16)
             ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
@@ -568,16 +581,30 @@ class HipEncoder(nn.Module):
             ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits)
             s1 = self._buf(T, d, dev, sdt)
             ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out, seed=s_l + 2, residual_ln=res_ln)
-            x1 = self._buf(T, d, dev, dt16)
             mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
             x1_32 = self._buf(T, d, dev, torch.float32) if (S32 and not LNF) else None
-            ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps, out32=x1_32)
-            hbuf = self._buf(T, f, dev, dt16)
-            pre = self._buf(T, f, dev, dt16) if save else None
-            ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=3 if save else 1)     # the tape keeps gelu'(pre-activation)
-            s2 = self._buf(T, d, dev, sdt)
-            ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=(s1 if LNF else x1_32) if S32 else x1, dropout_p=p_h, seed=s_l + 3,
-                        residual_ln=(mean1, rstd1, W["g1"], W["b1"]) if LNF else None)
+            F16 = FFN16 and LNF                                  # the FFN pair on fp16 operands (the fp16 FFN2 flavours add LayerNorm on the fly)
+            if F16:
+                # LayerNorm -> fp16 (FFN1's operand) [+ bf16 copy for the weight gradient]; FFN1 -> h in fp16 (FFN2's operand) [+ bf16 copy]
+                x1h = self._buf(T, d, dev, torch.float16)
+                x1 = self._buf(T, d, dev) if save else None
+                ops.layernorm_fwd(s1, W["g1"], W["b1"], x1h, mean1, rstd1, T, cfg.eps, out_copy=x1)
+                hh = self._buf(T, f, dev, torch.float16)
+                hbuf = self._buf(T, f, dev) if save else None
+                pre = self._buf(T, f, dev) if save else None
+                ops.gemm_nt(x1h, W16["W1"], hh, T, bias=W["bf1"], preact=pre, act=3 if save else 1, out_copy=hbuf)
+                s2 = self._buf(T, d, dev, sdt)
+                ops.gemm_nt(hh, W16["W2"], s2, T, bias=W["bf2"], residual=s1, dropout_p=p_h, seed=s_l + 3, residual_ln=(mean1, rstd1, W["g1"], W["b1"]))
+                del x1h, hh
+            else:
+                x1 = self._buf(T, d, dev, dt16)
+                ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps, out32=x1_32)
+                hbuf = self._buf(T, f, dev, dt16)
+                pre = self._buf(T, f, dev, dt16) if save else None
+                ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=3 if save else 1)     # the tape keeps gelu'(pre-activation)
+                s2 = self._buf(T, d, dev, sdt)
+                ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=(s1 if LNF else x1_32) if S32 else x1, dropout_p=p_h, seed=s_l + 3,
+                            residual_ln=(mean1, rstd1, W["g1"], W["b1"]) if LNF else None)
             xo = self._buf(T, d, dev, dt16)
             last = i == cfg.n_layers - 1
             # the CLS-only last layer gathers its fp32 residual rows from a stored copy: the layer before it still writes one
@@ -596,7 +623,7 @@ class HipEncoder(nn.Module):
         return (cls, tape) if save else cls
 
     # ------------------------------------------------------------------ last layer, CLS row only
-    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16=torch.bfloat16):
+    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16=torch.bfloat16, W16=None):
         """Only ``last_hidden_state[:, 0, :]`` is consumed (reference models/nway_dual_encoder.py:52,56,64), so the last
         layer projects K and V for every token but Q, attention, out-proj, FFN and both LayerNorms for token 0 only:
         identical CLS output, ~1/6 of the layer's FLOPs."""
@@ -621,15 +648,26 @@ class HipEncoder(nn.Module):
         ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1)
         s1 = self._buf(M, d, dev, sdt)
         ops.gemm_nt(ctxc, W["Wo"], s1, M, bias=W["bo"], residual=xc32 if S32 else xc, dropout_p=p_out, seed=s_l + 2)
-        x1 = self._buf(M, d, dev, dt16)
         x1_32 = self._buf(M, d, dev, torch.float32) if S32 else None
         mean1, rstd1 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
-        ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, M, cfg.eps, out32=x1_32)
-        hbuf = self._buf(M, f, dev, dt16)
-        pre = self._buf(M, f, dev, dt16) if save else None
-        ops.gemm_nt(x1, W["W1"], hbuf, M, bias=W["bf1"], preact=pre, act=3 if save else 1)
-        s2 = self._buf(M, d, dev, sdt)
-        ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
+        if W16 is not None and S32:         # the FFN pair on fp16 operands, as in the full layers (bf16 copies for the backward)
+            x1h = self._buf(M, d, dev, torch.float16)
+            x1 = self._buf(M, d, dev) if save else None
+            ops.layernorm_fwd(s1, W["g1"], W["b1"], x1h, mean1, rstd1, M, cfg.eps, out32=x1_32, out_copy=x1)
+            hh = self._buf(M, f, dev, torch.float16)
+            hbuf = self._buf(M, f, dev) if save else None
+            pre = self._buf(M, f, dev) if save else None
+            ops.gemm_nt(x1h, W16["W1"], hh, M, bias=W["bf1"], preact=pre, act=3 if save else 1, out_copy=hbuf)
+            s2 = self._buf(M, d, dev, sdt)
+            ops.gemm_nt(hh, W16["W2"], s2, M, bias=W["bf2"], residual=x1_32, dropout_p=p_h, seed=s_l + 3)
+        else:
+            x1 = self._buf(M, d, dev, dt16)
+            ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, M, cfg.eps, out32=x1_32)
+            hbuf = self._buf(M, f, dev, dt16)
+            pre = self._buf(M, f, dev, dt16) if save else None
+            ops.gemm_nt(x1, W["W1"], hbuf, M, bias=W["bf1"], preact=pre, act=3 if save else 1)
+            s2 = self._buf(M, d, dev, sdt)
+            ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
         xo = self._buf(M, d, dev, dt16)
         mean2, rstd2 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
         ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, M, cfg.eps, cls, 1)
@@ -684,14 +722,19 @@ class HipEncoder(nn.Module):
         return g
 
     # ------------------------------------------------------------------ backward
-    def backward_from_cls(self, tape: _Tape, dcls: torch.Tensor, after_layer=None, accumulate: bool = True, check_grads: bool = False):
+    def backward_from_cls(self, tape: _Tape, dcls: torch.Tensor, after_layer=None, accumulate: bool = True, check_grads: bool = False,
+                          before_last_wgrad=None):
         """Accumulate parameter gradients of this tower into ``flat_g`` given dL/dCLS (fp32 [M, d]).
 
         ``after_layer(i)`` (optional) is called when the gradients of transformer layer i are complete (and with
         -1 after the embedding gradients): the hook the trainer uses to launch that bucket's all-reduce.
 
         ``accumulate=False`` (trainer, unshared towers): every weight / bias / LayerNorm gradient is WRITTEN instead of added
-        to, so ``flat_g`` needs no zeroing except the embedding tables (scatter-add by atomics)."""
+        to, so ``flat_g`` needs no zeroing except the embedding tables (scatter-add by atomics).
+
+        ``before_last_wgrad()`` (optional) is called once, right before the LAST group of deferred weight gradients is launched:
+        from there on this stream runs one long launch that is on nobody's critical path - the place where the trainer puts
+        the other tower's latency-bound backward."""
         self._acc = bool(accumulate)
         cfg = self.cfg
         self.ensure_grads(check_all=check_grads)
@@ -716,6 +759,8 @@ class HipEncoder(nn.Module):
             else:
                 waiting.append(i)
             if force or (flush_every > 0 and len(waiting) >= flush_every):
+                if force and before_last_wgrad is not None:
+                    before_last_wgrad()
                 if self._lnq is not None:
                     self._lnq.flush(accumulate=self._acc)
                 self._wq.flush(accumulate=self._acc)

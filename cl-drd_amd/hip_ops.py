@@ -62,11 +62,13 @@ def pad_rows(rows: int) -> int:
 
 
 def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pre=None, act=0, alpha=1.0,
-            dropout_p=0.0, seed=0, residual_ln=None):
+            dropout_p=0.0, seed=0, residual_ln=None, out_copy=None):
     """out[M,N] = epilogue(alpha * A[M,K] @ B[N,K]^T); A, B bf16 (or both fp16: forward flavours, M < 1024); out 16-bit like A, or fp32.
 
     ``act``: bit 0 = erf-GELU; bit 1 = derivative form: ``preact`` receives gelu'(pre-activation) (act=3), ``gelu_pre`` holds it (act=2).
-    ``residual_ln`` = (mean[M], rstd[M], gamma[N], beta[N]): the fp32 ``residual`` is a pre-LN sum and LayerNorm(residual) is what is added."""
+    ``residual_ln`` = (mean[M], rstd[M], gamma[N], beta[N]): the fp32 ``residual`` is a pre-LN sum and LayerNorm(residual) is what is added.
+    fp16 operands with M >= 1024: the forward FFN flavours only (bias + GELU [+ tape]; bias [+ dropout] + residual_ln -> fp32 out).
+    ``out_copy`` (bf16, shaped like a 16-bit fp16 ``out``): receives the same values in bf16 - the tape entry for the backward."""
     io_f16 = _fmt16(A, "A")
     dt16 = F16 if io_f16 else BF16
     _chk(A, dt16, "A", 2), _chk(B, dt16, "B", 2)
@@ -96,6 +98,12 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
         _chk(mean, F32, "ln mean", 1), _chk(rstd, F32, "ln rstd", 1), _chk(gamma, F32, "ln gamma", 1), _chk(beta, F32, "ln beta", 1)
         if mean.numel() < M or rstd.numel() < M or gamma.numel() != N or beta.numel() != N:
             raise ValueError("gemm_nt: residual_ln = (mean[>= M], rstd[>= M], gamma[N], beta[N])")
+    if out_copy is not None:
+        if not io_f16 or out_f32:
+            raise ValueError("gemm_nt: out_copy goes with fp16 operands and a 16-bit out")
+        _chk(out_copy, BF16, "out_copy", 2)
+        if out_copy.shape[1] != N or out_copy.shape[0] < M or out_copy.stride(0) != out.stride(0):
+            raise ValueError("gemm_nt: out_copy must have the layout of out")
     # small-M problems (CLS-only last layer, query tower) are split along K when that fills the chip: fp32 partials in a scratch tensor
     ws, ws_bytes = None, 0
     if M < 1024:
@@ -107,7 +115,7 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
             ws = torch.empty(ws_bytes // 4, dtype=F32, device=A.device)
     call("cldrd_gemm_nt_bf16_ws", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
          _p(residual), residual.stride(0) if residual is not None else 0, _p(preact), _p(gelu_pre), act, alpha, dropout_p, seed,
-         out_f32, res_f32, io_f16, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(ws), ws_bytes, _stream())
+         out_f32, res_f32, io_f16, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(out_copy), _p(ws), ws_bytes, _stream())
     return out
 
 
@@ -254,16 +262,21 @@ def embed_ln_bwd(dy, ids, word, pos, type0, gamma, mean, rstd, dword, dpos, dtyp
          1 if accumulate else 0, _stream())
 
 
-def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_stride=0, out32=None):
-    """x bf16, or fp32 (pre-LN sum of the fp32 residual stream; then out32, optional, receives the fp32 output as well)."""
+def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_stride=0, out32=None, out_copy=None):
+    """x bf16, or fp32 (pre-LN sum of the fp32 residual stream; then out32, optional, receives the fp32 output as well).
+    ``out_copy`` (bf16, with an fp16 ``out``): the same values in bf16 (the backward's MFMA operand)."""
     x_f32 = 1 if x.dtype == F32 else 0
     out_f16 = _fmt16(out, "out")
     _chk(x, F32 if x_f32 else BF16, "x", 2), _chk(out, F16 if out_f16 else BF16, "out", 2), _chk(gamma, F32, "gamma", 1), _chk(beta, F32, "beta", 1)
     if out32 is not None:
         _chk(out32, F32, "out32", 2)
     d = x.shape[1]
+    if out_copy is not None:
+        if not out_f16:
+            raise ValueError("layernorm_fwd: out_copy goes with an fp16 out")
+        _chk(out_copy, BF16, "out_copy", 2)
     call("cldrd_layernorm_fwd", _p(x), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd), T, d, eps, _p(cls_out),
-         cls_stride, x_f32, _p(out32), out_f16, _stream())
+         cls_stride, x_f32, _p(out32), out_f16, _p(out_copy), _stream())
     return out
 
 

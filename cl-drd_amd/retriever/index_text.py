@@ -15,7 +15,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-from ..dataset import SequenceDataset, SyntheticSequenceDataset
+from ..dataset import CachedSequenceDataset, SequenceDataset, SequenceTokenCache, SyntheticSequenceDataset
 from ..models.nway_dual_encoder import NwayDualEncoder
 from .retrieval_utils import ShardedFlatIPIndex, construct_flatindex_from_embeddings, get_embeddings_from_scratch, write_index
 
@@ -32,6 +32,7 @@ _FLAGS = {
     "is_parallel": dict(default=True),
     "share_weights": dict(action="store_true", default=False),
     "synthetic_rows": dict(type=int, default=0),          # ours: encode N generated MSMARCO-shaped passages
+    "token_cache_dir": dict(default=""),                  # ours: tokenise the collection once (dataset.SequenceTokenCache), memory-map it afterwards
 }
 
 
@@ -48,10 +49,26 @@ def get_args(argv=None):
 def load_checkpoint_into(model, path, is_parallel=True):
     """``checkpoint["state_dict"]`` of a trainer checkpoint into ``model``; DDP's ``module.`` prefix goes when ``is_parallel``
     (reference index_text.py:63-73)."""
-    sd = torch.load(path, map_location="cpu")["state_dict"]
+    # weights_only=False: a reference checkpoint carries its optimizer and a pickled LambdaLR scheduler next to the weights
+    # (nway_listwise_1.py:418-426), which torch >= 2.6 refuses under the default weights_only=True
+    sd = torch.load(path, map_location="cpu", weights_only=False)["state_dict"]
     if is_parallel:
         sd = OrderedDict((k[len("module."):] if k.startswith("module.") else k, v) for k, v in sd.items())
     model.load_state_dict(sd)
+
+
+def collection_loader(path, tokenizer, max_length, is_query, token_cache_dir, rank, world):
+    """Batches of 512 rows of this rank's contiguous row range (reference index_text.py:84: bs 512, 4 workers).  With a token cache
+    the rank memory-maps the tokenised collection and reads only its own rows; without, it parses the TSV and tokenises per batch as the
+    reference does."""
+    if token_cache_dir:
+        cache = SequenceTokenCache.open_or_build(token_cache_dir, path, tokenizer, max_length, rank, world)
+        lo, hi = ShardedFlatIPIndex.shard_bounds(len(cache), world, rank)
+        return CachedSequenceDataset(cache, lo, hi, batch_size=512, pad_id=int(getattr(tokenizer, "pad_token_id", 0) or 0)).loader()
+    dataset = SequenceDataset.create_from_seqs_file(path, tokenizer, max_length, is_query=is_query)
+    lo, hi = ShardedFlatIPIndex.shard_bounds(len(dataset), world, rank)
+    dataset.ids, dataset.seqs = dataset.ids[lo:hi], dataset.seqs[lo:hi]
+    return torch.utils.data.DataLoader(dataset, batch_size=512, shuffle=False, num_workers=4, collate_fn=dataset.collate_fn)
 
 
 def main(args):
@@ -73,10 +90,7 @@ def main(args):
     else:
         from transformers import AutoTokenizer
         tokenizer = AutoTokenizer.from_pretrained(args.tokenizer_name_or_path)
-        dataset = SequenceDataset.create_from_seqs_file(args.passages_path, tokenizer, args.max_length, is_query=args.is_query)
-        lo, hi = ShardedFlatIPIndex.shard_bounds(len(dataset), world, rank)
-        dataset.ids, dataset.seqs = dataset.ids[lo:hi], dataset.seqs[lo:hi]
-        text_loader = torch.utils.data.DataLoader(dataset, batch_size=512, shuffle=False, num_workers=4, collate_fn=dataset.collate_fn)
+        text_loader = collection_loader(args.passages_path, tokenizer, args.max_length, args.is_query, args.token_cache_dir, rank, world)
 
     text_embs, text_ids = get_embeddings_from_scratch(model, text_loader, use_fp16=True, is_query=args.is_query, show_progress_bar=True)
     text_id_to_idx = {tid: idx for idx, tid in enumerate(text_ids)}

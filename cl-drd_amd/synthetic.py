@@ -139,6 +139,26 @@ def seq_batch(seed: int, rows: int, length: int, *, vocab: int = VOCAB, ragged: 
             "id": list(range(first_id, first_id + rows))}
 
 
+def seq_rows(seed: int, first_row: int, rows: int, length: int, *, vocab: int = VOCAB, ragged: bool = False) -> dict:
+    """Rows [first_row, first_row + rows) of ONE endless synthetic collection: row r is a function of (seed, r) only, so any
+    sharding / batching of the collection encodes the same passages (index_text.py under RANK / WORLD_SIZE must give the rows the
+    single-process run gives).  Same layout as :func:`seq_batch`, ids = global row numbers."""
+    lo = BODY_LO if BODY_LO < vocab - 1 else 3
+    ids = randint(seed, lo, vocab, rows * length, offset=first_row * length).reshape(rows, length)
+    ids[:, 0] = CLS_ID if vocab > CLS_ID else 1
+    ids[:, -1] = SEP_ID if vocab > SEP_ID else 2
+    mask = np.ones_like(ids)
+    if ragged:
+        z = normal(seed + 1, 2 * rows, offset=first_row)[0::2]          # Box-Muller pair (first_row + j) -> row first_row + j
+        lens = np.clip(np.rint(np.exp(4.3 + 0.35 * z)), min(16, length), length).astype(np.int64)
+        ar = np.arange(length)[None, :]
+        mask = (ar < lens[:, None]).astype(np.int64)
+        ids = np.where(ar < lens[:, None], ids, 0)
+        ids[np.arange(rows), lens - 1] = SEP_ID if vocab > SEP_ID else 2
+    return {"seq": {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)},
+            "id": list(range(first_row, first_row + rows))}
+
+
 def corpus_embeddings(seed: int, rows: int, dim: int = 768, offset_rows: int = 0) -> np.ndarray:
     """CLS-like rows: unit-variance Gaussian direction scaled to a per-row norm ~ U(9, 12)."""
     g = normal(seed, rows * dim, offset_rows * dim).reshape(rows, dim)

@@ -117,6 +117,8 @@ class NwayTrainer:
         self.clip = torch.zeros(3, dtype=torch.float32, device=dev)
         self.norm_partial = torch.empty(ops.sqnorm_blocks(), dtype=torch.float32, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.distributed else None
+        if self.comm_stream is not None:
+            self.flat_g.record_stream(self.comm_stream)        # the bucket slices are used on it (the buffer lives as long as the trainer)
         self.q_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = []
         if self.distributed:
@@ -142,13 +144,28 @@ class NwayTrainer:
         index = {(b[0], b[1]): (b[2], b[3]) for b in self.buckets}
 
         def hook(layer):
+            # The bucket's gradients are complete on the stream the hook is called on: the communication stream waits for exactly
+            # that point, then the all-reduce is issued ASYNCHRONOUSLY from it and its Work handle kept.  Nothing here relies on what a
+            # blocking collective does to the caller's stream (ProcessGroupNCCL makes the current stream wait for its internal one,
+            # gloo blocks the host): `_wait_pending` below is the one place where the result is ordered before its consumer.
             a, b = index[(ti, layer)]
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM)
+                work = dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, async_op=True)
+            self._pending.append(work)
         return hook
+
+    def _wait_pending(self):
+        """Order every outstanding bucket all-reduce before whatever the CURRENT stream runs next (the gradient norm / optimizer):
+        ``Work.wait()`` makes the current stream wait for the collective under ProcessGroupNCCL (no host block) and blocks the host
+        until completion under gloo; the stream-level join with the communication stream covers the copies gloo does on it."""
+        pending, self._pending = self._pending, []
+        for w in pending:
+            w.wait()
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     def forward_backward(self, batch):
         """Runs forward + backward (+ overlapped gradient all-reduce).  Returns (loss_out[2] device tensor, logits)."""
@@ -200,14 +217,24 @@ class NwayTrainer:
             if self.distributed:
                 dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
         else:
-            side.wait_stream(main)
-            dq.record_stream(side)
-            with torch.cuda.stream(side):
-                qe.backward_from_cls(q_tape, dq, after_layer=self._bucket_hook(0), accumulate=not write_once)
-            pe.backward_from_cls(p_tape, dp, after_layer=self._bucket_hook(1), accumulate=not write_once)
+            def query_backward():
+                side.wait_stream(main)
+                dq.record_stream(side)
+                with torch.cuda.stream(side):
+                    qe.backward_from_cls(q_tape, dq, after_layer=self._bucket_hook(0), accumulate=not write_once)
+            # Where the query tower's ~150 small backward launches run: next to the passage tower's data-gradient chain (default), or
+            # (CLDRD_Q_BWD=late) next to its LAST weight-gradient group - one ~3-ms launch off the critical path, where a stolen CU
+            # should cost least.  Measured the other way round (profiles/r03_microbench.txt: late = +1.2 % step time, twice on one
+            # box): the weight-gradient group loses more to the intruders (its workgroups share operand panels through L2 only while
+            # they stay in step) than the GEMM chain does.
+            late = side is not main and _env_flag("CLDRD_Q_BWD", "early") == "late"
+            if not late:
+                query_backward()
+            pe.backward_from_cls(p_tape, dp, after_layer=self._bucket_hook(1), accumulate=not write_once,
+                                 before_last_wgrad=query_backward if late else None)
             main.wait_stream(side)
             if self.distributed:
-                main.wait_stream(self.comm_stream)
+                self._wait_pending()
         return loss_out, logits
 
     def optimizer_step(self):
@@ -219,13 +246,13 @@ class NwayTrainer:
         towers = self.model.towers()
         # one AdamW launch over the joint buffer; it also writes the bf16 shadow of every tower
         shadow = self._joint_shadow()
-        # ... and the fp16 shadow of the (one) tower that runs the high-precision forward: the query tower
-        h16 = [(t, off) for t, off in zip(towers, self.model._tower_offsets) if t.hp_forward]
-        fused16 = len(h16) == 1 and _env_flag("CLDRD_ADAM_H16", "1") != "0"
+        # ... and the fp16 shadow of the towers whose forward reads fp16 weights (the FFN GEMMs of every tower by default, the whole
+        # high-precision pass of the query tower): one contiguous range of the joint buffer
+        s16, r16 = self._joint_shadow16()
+        fused16 = s16 is not None and _env_flag("CLDRD_ADAM_H16", "1") != "0"
         ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, shadow, lr=lr, beta1=self.betas[0],
                        beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=self.adam_step, clip=self.clip,
-                       shadow16=h16[0][0].h16_buffer() if fused16 else None,
-                       h16_range=(h16[0][1], h16[0][1] + h16[0][0].layout.total) if fused16 else None)
+                       shadow16=s16[r16[0]:r16[1]] if fused16 else None, h16_range=r16 if fused16 else None)
         for t in towers:
             t.refresh_shadows(need_transposed=True, cast=False, cast16=not fused16)
         return lr
@@ -234,10 +261,30 @@ class NwayTrainer:
         if getattr(self, "_shadow", None) is None:
             towers = self.model.towers()
             self._shadow = torch.empty(self.flat_p.numel(), dtype=torch.bfloat16, device=self.flat_p.device)
+            self._joint_shadow16()
             for t, off in zip(towers, self.model._tower_offsets):
                 t.flat_h = self._shadow[off:off + t.layout.total]
                 t.refresh_shadows(need_transposed=True)
         return self._shadow
+
+    def _joint_shadow16(self):
+        """(joint fp16 shadow or None, (begin, end) of the parameters it mirrors): the towers that need fp16 weights are adjacent in the
+        joint buffer, so one range covers them; each such tower's ``flat_h16`` is a slice of the joint tensor."""
+        if getattr(self, "_shadow16", None) is None:
+            towers, offs = self.model.towers(), self.model._tower_offsets
+            need = [(t, off) for t, off in zip(towers, offs) if t.needs_h16]
+            if not need:
+                self._shadow16 = (None, None)
+            else:
+                lo, hi = need[0][1], need[-1][1] + need[-1][0].layout.total
+                if sum(t.layout.total for t, _ in need) != hi - lo:
+                    raise RuntimeError("towers with fp16 weights are not adjacent in the joint buffer")
+                buf = torch.empty(self.flat_p.numel(), dtype=torch.float16, device=self.flat_p.device)
+                for t, off in need:
+                    t.flat_h16 = buf[off:off + t.layout.total]
+                    t._shadow_version = -1
+                self._shadow16 = (buf, (lo, hi))
+        return self._shadow16
 
     def train_step(self, batch):
         """One full step; returns the device tensor {loss, pair count} (no host sync)."""

@@ -59,13 +59,16 @@ int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, i
 
 /* The same with a workspace: problems of fewer than 1024 rows whose one-pass grid would leave most CUs idle (CLS-only last layer, query
  * tower) are split along K: fp32 partials in `workspace` (cldrd_gemm_nt_splitk_workspace() bytes; 0 = this shape is not split), summed in
- * a fixed order and finished with the same epilogue by a second launch.  workspace = NULL: cldrd_gemm_nt_bf16_ln. */
+ * a fixed order and finished with the same epilogue by a second launch.  workspace = NULL: cldrd_gemm_nt_bf16_ln.
+ * io_f16 here also serves M >= 1024 for the forward FFN flavours (bias + GELU [+ tape], bias [+ dropout] + fp32 LayerNorm-on-the-fly
+ * residual -> fp32): csrc/gemm_nt_ring16.hip.  c_copy_bf16 (optional, with io_f16 and a 16-bit C): a bf16 copy of C - the tape entry the
+ * backward's bf16 MFMAs read when the forward GEMM ran on fp16 operands (FFN1 writes h in fp16 for FFN2 and in bf16 for the weight gradient). */
 size_t cldrd_gemm_nt_splitk_workspace(int M, int N, int K);
 int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                           const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                           int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int io_f16,
                           const float* ln_mean, const float* ln_rstd, const float* ln_gamma, const float* ln_beta,
-                          float* workspace, size_t workspace_bytes, void* stream);
+                          void* c_copy_bf16, float* workspace, size_t workspace_bytes, void* stream);
 
 /* Weight gradient dW[N1,N2] (+)= A[M,N1]^T . B[M,N2]   (A = dY, B = layer input; autograd's Linear backward), and,
  * when dbias != NULL, the bias gradient dbias[N1] (+)= column sums of A in the same pass.
@@ -125,9 +128,12 @@ int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, 
 /* out = LN(x)*gamma+beta (bf16); cls_out (fp32 [T/cls_stride, d], optional) receives rows r % cls_stride == 0:
  * the `[0][:, 0, :]` CLS pooling of models/nway_dual_encoder.py:52,56,64.
  * x_f32 != 0: x is fp32 (the pre-LN sum of the fp32 residual stream) and out32 (optional) receives the fp32 output next to
- * the bf16 copy the GEMMs read; cldrd_embed_ln_fwd has the same optional out32. */
+ * the bf16 copy the GEMMs read; cldrd_embed_ln_fwd has the same optional out32.
+ * out_f16 != 0: `out` is fp16 (operand of an fp16 forward GEMM) and out_bf16_copy (optional) receives the same values in bf16: the
+ * backward's MFMAs multiply the saved activations with bf16 gradients, so a training forward whose FFN GEMMs read fp16 keeps both. */
 int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* out, float* mean, float* rstd,
-                        int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, int out_f16, void* stream);
+                        int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, int out_f16,
+                        void* out_bf16_copy, void* stream);
 /* dx = LN backward of dy; dx_dropped (optional) = dropout-masked dx for the branch that passed through dropout;
  * dgamma/dbeta/dbias (each optional) receive sum(dy*xhat), sum(dy), sum(dx_dropped or dx). */
 int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
@@ -231,6 +237,14 @@ int cldrd_topk_sort(const int* counts, const int* cand_rows, const float* cand_s
                     int* I, void* stream);
 int cldrd_row_sqnorm_max(const float* P, size_t rows, int d, unsigned int* out, void* stream);
 int cldrd_gather_cast_rows(const float* src, void* dst, size_t n_out, size_t stride, int d, void* stream);
+
+/* ---- run file (retriever/retrieve_top_passages.py:98-105), HOST side: no GPU work -----------------------------------------
+ * Writes `qid\tdocid\trank\tscore\n` for nq queries x k hits (rank 1..k) to `path`; the score text is Python's repr of the fp32
+ * value widened to a double, which is what the reference's f-string prints.  All pointers are HOST pointers.  Formatted by nthreads
+ * host threads (<= 0: one per hardware thread, at most 64).  Returns the number of lines or -1. */
+long long cldrd_write_run_file(const char* path, const long long* qids, const long long* docids, const float* scores,
+                               long long nq, int k, int nthreads);
+int cldrd_py_float_repr(double x, char* out32);
 
 #ifdef __cplusplus
 }

@@ -93,6 +93,18 @@ def main():
     dump("mode1", ds, [1, 2, 3, 4])
     np.savez_compressed(os.path.join(HERE, "nway_dataset.npz"), **blob)
     print("wrote", len(blob), "arrays")
+    # index path: the reference's SequenceDataset (dataset/sequence_dataset.py:31-55) over the same collection, batches of 7 rows through its
+    # collate_fn (tokenise + pad to the longest row of the batch), max_length 12 (some rows are truncated)
+    from dataset.sequence_dataset import SequenceDataset as RefSeq
+    rs = RefSeq.create_from_seqs_file(c, tok, 12, False)
+    sblob = {"n": len(rs)}
+    for b, lo in enumerate(range(0, len(rs), 7)):
+        batch = rs.collate_fn([rs[i] for i in range(lo, min(len(rs), lo + 7))])
+        sblob[f"b{b}.input_ids"] = batch["seq"]["input_ids"].numpy()
+        sblob[f"b{b}.attention_mask"] = batch["seq"]["attention_mask"].numpy()
+        sblob[f"b{b}.id"] = np.asarray(batch["id"])
+    np.savez_compressed(os.path.join(HERE, "sequence_dataset.npz"), **sblob)
+    print("wrote sequence_dataset.npz:", len(rs), "rows")
 
 
 if __name__ == "__main__":

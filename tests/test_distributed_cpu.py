@@ -121,3 +121,21 @@ def test_equal_steps_per_epoch_gloo_world2(tmp_path):
     out = str(tmp_path / "ok")
     mp.spawn(_steps_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     assert open(out).read() == "ok"
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`python bench.py --gpus N` on a node with fewer than N GPUs (this container: none; the GPU box: one) must end at once with a
+    clear message - before any rank is spawned and before any rendezvous a missing rank would leave hanging."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    for env_extra in ({}, {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29555"}):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        env.update(env_extra)
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                           env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and "visible GPUs" in (r.stderr + r.stdout), (r.returncode, r.stderr[-500:])
+        assert time.time() - t0 < 60

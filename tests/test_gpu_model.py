@@ -13,6 +13,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import cldrd_amd.synthetic as syn
+from cldrd_amd import hip_ops as ops
 import selftest
 from cldrd_amd.encoder import EncoderConfig
 from cldrd_amd.models import NwayDualEncoder
@@ -270,9 +271,18 @@ def test_full_size_configs_match_reference_goldens(name):
         err = np.abs(got - ref).max()
         ratio = err / amp_err
         rms, amp_rms = np.sqrt(np.mean((got - ref) ** 2)), np.sqrt(np.mean((g["logits_autocast_bf16"] - ref) ** 2))
-        print(f"{name}/{loss_kind}: max|dlogit| {err:.4f} = {ratio:.2f} x the reference's autocast drift {amp_err:.4f} (max|logit| {np.abs(ref).max():.2f}); "
+        print(f"{name}/{loss_kind}: max|dlogit| {err:.4f} = {ratio:.2f} x the reference's bf16-autocast drift {amp_err:.4f} (max|logit| {np.abs(ref).max():.2f}); "
               f"rms {rms:.4f} = {rms / amp_rms:.2f} x its rms {amp_rms:.4f}")
-        assert ratio <= 1.0, f"{name}: bf16 drift {err:.4f} exceeds the reference's own autocast drift {amp_err:.4f}"
+        assert ratio <= 1.0, f"{name}: drift {err:.4f} exceeds the reference's own bf16-autocast drift {amp_err:.4f}"
+        assert rms <= amp_rms, f"{name}: rms drift {rms:.4f} exceeds the reference's own bf16-autocast rms drift {amp_rms:.4f}"
+        if "logits_autocast_fp16" in g.files:
+            # the mode the reference actually trains in is fp16 autocast (nway_listwise_1.py:334): 8x finer operand rounding than ours
+            a16 = np.abs(g["logits_autocast_fp16"] - ref)
+            print(f"{name}/{loss_kind}: the reference's fp16-autocast drift is max {a16.max():.4f} rms {np.sqrt(np.mean(a16 ** 2)):.4f}: ours = "
+                  f"{err / a16.max():.2f} x / {rms / np.sqrt(np.mean(a16 ** 2)):.2f} x; relative to max|logit|: {err / np.abs(ref).max():.2e}")
+        if model.passage_encoder.ffn_fp16:
+            # GPU vs fp32 oracle, logits <= 5e-3 relative (met since the FFN GEMMs read fp16 operands)
+            assert err <= 5e-3 * np.abs(ref).max(), f"{name}: max|dlogit| {err:.4f} above 5e-3 x max|logit| = {5e-3 * np.abs(ref).max():.4f}"
         if "loss" in g.files:                                # cfg1 golden (round 1 layout)
             ref_loss, names, vals = float(g["loss"]), [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]
             amp_loss, _ = ORACLE_LOSS[gk](g["logits_autocast_bf16"], batch["labels"].numpy())
@@ -305,6 +315,42 @@ def test_full_size_configs_match_reference_goldens(name):
                 checked += 1
         assert checked > 100
         print(f"{name}/{loss_kind}: loss {loss_out[0].item():.6f} vs {ref_loss:.6f}; worst per-tensor grad-norm error {worst:.4f} over {checked} tensors")
+        # d loss / d logits: the loss kernel's gradient on OUR logits against the reference's on ITS fp32 logits - no further from it than
+        # the reference's own bf16-autocast path is (same bar as the logits), and pointing the same way
+        dkey = f"dlogits_{gk}"
+        if dkey in g.files:
+            _, dl = ops.loss_fwd_bwd(loss_kind, logits, batch["labels"].to(logits.device).float().contiguous())
+            dl, dref = dl.cpu().numpy().astype(np.float64), g[dkey].astype(np.float64)
+            damp = (g[dkey + "_autocast"] if dkey + "_autocast" in g.files else ORACLE_LOSS[gk](g["logits_autocast_bf16"], labels_np)[1]).astype(np.float64)
+            e_our, e_amp = np.abs(dl - dref).max(), np.abs(damp - dref).max()
+            cos_dl = float((dl * dref).sum() / (np.linalg.norm(dl) * np.linalg.norm(dref)))
+            print(f"{name}/{loss_kind}: max|d(dlogits)| {e_our:.3e} (reference autocast {e_amp:.3e}, max|dlogits| {np.abs(dref).max():.3e}); cosine {cos_dl:.6f}")
+            assert e_our <= max(e_amp, 1e-6 * np.abs(dref).max()) and cos_dl >= (0.99 if loss_kind == "lambda_mrr" else 0.999)
+        # gradient DIRECTIONS: stored fp32 reference gradients (every 1-D parameter of layers 0, 2, 5 and the embedding LayerNorm in full,
+        # the first 16 rows of the weight matrices of layers 0 and 5 and of the position embeddings).  Bar per tensor: cosine >= 0.999,
+        # or - where the reference's OWN bf16-autocast backward turns that gradient further than that (sums of many nearly cancelling
+        # terms, e.g. the position-embedding rows) - no more than 1.5x as far from the fp32 direction as the reference's autocast run is.
+        nkey = f"gslice_names_{gk}"
+        if nkey in g.files:
+            def cosine(a, b):
+                return float((a * b).sum() / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
+            rows = []
+            for n in [str(x) for x in g[nkey]]:
+                want = g[f"gslice/{gk}/{n}"].astype(np.float64)
+                have = params[n].grad.detach()
+                have = (have if have.dim() == 1 else have[:want.shape[0]]).double().cpu().numpy()
+                if np.linalg.norm(want) < 1e-3 * big:
+                    continue
+                akey = f"gslice_autocast/{gk}/{n}"
+                c_amp = cosine(want, g[akey].astype(np.float64)) if akey in g.files else 1.0
+                rows.append((cosine(want, have), c_amp, n))
+            rows.sort()
+            for c, c_amp, n in rows[:6]:
+                print(f"{name}/{loss_kind}: gradient cosine {c:.5f} (reference bf16-autocast backward {c_amp:.5f}) {n}")
+            print(f"{name}/{loss_kind}: gradient cosine >= {rows[0][0]:.5f} over {len(rows)} stored tensors; {sum(c >= 0.999 for c, _, _ in rows)} of them >= 0.999")
+            assert len(rows) >= 40
+            for c, c_amp, n in rows:
+                assert (1.0 - c) <= max(1e-3, 1.5 * (1.0 - c_amp)), f"{name}/{loss_kind}: gradient of {n}: cosine {c:.5f} (reference autocast {c_amp:.5f})"
         del tr
 
 

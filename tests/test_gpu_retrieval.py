@@ -464,3 +464,57 @@ def test_cls_like_anisotropic_corpus_at_shard_size():
     swaps = same_ranking(D[sel], I[sel], Dg, Ig)
     print(f"cls-like shard: {swaps} positions differ inside near-tie runs (1e-5 relative) over {len(sel)} checked queries")
     assert st["fallback_queries"] == 0 and st["rescans"] <= 4
+
+
+def _run_cli(mod, argv, env_extra, cwd):
+    import subprocess
+    import sys as _sys
+    env = dict(os.environ)
+    env.update(env_extra)
+    env["PYTHONPATH"] = cwd + os.pathsep + env.get("PYTHONPATH", "")
+    return subprocess.Popen([_sys.executable, "-m", mod] + argv, env=env, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+def test_sharded_index_and_retrieve_clis_equal_the_single_process_run(tmp_path):
+    """SURVEY.md section 8e (e-index / e-retrieve), the reference flow retriever/index_text.py:84-109 -> retrieve_top_passages.py:85-107:
+    index_text under RANK=0/1, WORLD_SIZE=2 writes two row-range shards; retrieve_top_passages as two ranks (gloo, both on this one GPU)
+    searches its shard each and rank 0 merges: the run file must be the single-process run file BYTE FOR BYTE."""
+    import socket
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = selftest.tiny_config()
+    model = selftest.build_tiny_model(cfg).cuda().eval()
+    mdir = tmp_path / "model"
+    model.query_encoder.save_pretrained(str(mdir))
+    ckpt = tmp_path / "checkpoint_10.pth.tar"
+    torch.save({"state_dict": {"module." + k: v.cpu() for k, v in model.state_dict().items()}, "scheduler": {"last_epoch": 3}}, ckpt)
+    rows, nq, k = 1301, 45, 20
+    common = ["--resume", str(ckpt), "--model_name_or_path", str(mdir)]
+    # single process
+    p = _run_cli("cldrd_amd.retriever.index_text", common + ["--index_dir", str(tmp_path / "one"), "--max_length", "32", "--synthetic_rows", str(rows)], {}, root)
+    out, _ = p.communicate(timeout=600)
+    assert p.returncode == 0, out[-2000:]
+    one_index = str(tmp_path / "one" / "checkpoint_10.index")
+    p = _run_cli("cldrd_amd.retriever.retrieve_top_passages", common + ["--index_path", one_index, "--max_length", "16", "--top_k", str(k), "--synthetic_queries", str(nq),
+                                                                  "--output_path", str(tmp_path / "one" / "dev.run")], {}, root)
+    out, _ = p.communicate(timeout=600)
+    assert p.returncode == 0, out[-2000:]
+    # two shards, written by two index_text processes (no collective on that path)
+    for r in range(2):
+        p = _run_cli("cldrd_amd.retriever.index_text", common + ["--index_dir", str(tmp_path / "two"), "--max_length", "32", "--synthetic_rows", str(rows)],
+                     {"RANK": str(r), "WORLD_SIZE": "2", "LOCAL_RANK": "0"}, root)
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0, out[-2000:]
+    shard_files = sorted(f for f in os.listdir(tmp_path / "two") if f.endswith(".meta.pkl") or f.endswith(".npy"))
+    assert any("shard0of2" in f for f in shard_files) and any("shard1of2" in f for f in shard_files), shard_files
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [_run_cli("cldrd_amd.retriever.retrieve_top_passages",
+                      common + ["--index_path", str(tmp_path / "two" / "checkpoint_10.index"), "--max_length", "16", "--top_k", str(k), "--synthetic_queries", str(nq),
+                                "--output_path", str(tmp_path / "two" / "dev.run")],
+                      {"RANK": str(r), "WORLD_SIZE": "2", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)}, root) for r in range(2)]
+    outs = [pr.communicate(timeout=600)[0] for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), outs[0][-1500:] + outs[1][-1500:]
+    a, b = (tmp_path / "one" / "dev.run").read_bytes(), (tmp_path / "two" / "dev.run").read_bytes()
+    assert len(a.splitlines()) == nq * k
+    assert a == b, "the merged run file of the two-shard run differs from the single-process run file"
