@@ -31,6 +31,14 @@ def flops_seq_fwd(L):
     return NL * (8 * L * D * D + 4 * L * D * DFF + 4 * L * L * D)
 
 
+def flops_seq_fwd_executed(L):
+    """What the build actually runs per sequence: the LAST layer only needs token 0 (CLS pooling, reference models/nway_dual_encoder.py:52,
+    56,64), so it projects K and V for every token but Q, attention, out-projection, FFN for one row."""
+    full = (NL - 1) * (8 * L * D * D + 4 * L * D * DFF + 4 * L * L * D)
+    last = 4 * L * D * D + 2 * D * D + 4 * L * D + 2 * D * D + 4 * D * DFF
+    return full + last
+
+
 EVENT_STRIDE = 5
 
 
@@ -142,7 +150,33 @@ def main():
     batch = syn.nway_batch(4680 + 1000 * rank, B, N, Lq, L, ragged=False, label_kind="teacher")
     batch = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in batch.items()}
 
-    # ---- live per-launch timing of the dominant kernel (HIP events on the launch stream) ----
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- the timed region: W warm-up steps, then exactly K steps between barriers.  At N = 1 the trainer replays the step as a HIP graph
+    # after its first three eager steps (trainer/nway_listwise.py: train_step); under torch.distributed the step is eager.
+    for _ in range(args.warmup):
+        trainer.train_step(batch)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss_out = trainer.train_step(batch)
+    sync_all()
+    dt = time.perf_counter() - t0
+    graph_replay = bool(getattr(trainer, "_graphs", None)) and any(e["graph"] is not None for e in trainer._graphs.values())
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    samples_per_s = world * B * args.steps / dt
+    final_loss = float(loss_out[0].item())
+
+    # ---- live per-launch timing of the dominant kernel (HIP events on the launch stream).  A kernel inside a replayed graph cannot be
+    # bracketed by events, so the brackets go around the SAME K steps run eagerly right after the timed region (same process, same
+    # buffers, same clocks; CLDRD_GRAPH=0 for this pass only) - the committed rocprofv3 summary is of the graph-replay region itself.
     gemm_events = []
     if not args.no_kernel_events:
         raw_gemm = ops.gemm_nt
@@ -151,7 +185,7 @@ def main():
             m = A.shape[0] if M is None else M
             # the dominant kernel is gemm_nt_ring_kernel: large-M launches (dispatch rule of cldrd_gemm_nt_ring_dispatch);
             # the query tower's M = 240 launches run the small-tile kernel on the side stream and are not part of it.
-            # Every EVENT_STRIDE-th such launch of the timed region is bracketed by HIP events (the stride is coprime to
+            # Every EVENT_STRIDE-th such launch of the pass is bracketed by HIP events (the stride is coprime to
             # the 42 launches of a step, so every call site is sampled): an event pair per launch costs ~0.5 ms per step
             ring = m >= 1024 and (Bm.shape[0] % 192 == 0 or Bm.shape[0] % 256 == 0) and Bm.shape[1] % 64 == 0
             if not (timed_gemm.on and ring):
@@ -168,31 +202,53 @@ def main():
         timed_gemm.on = False
         timed_gemm.count = 0
         ops.gemm_nt = timed_gemm
+        old_graph = os.environ.get("CLDRD_GRAPH")
+        os.environ["CLDRD_GRAPH"] = "0"
+        try:
+            for _ in range(3):
+                trainer.train_step(batch)
+            sync_all()
+            timed_gemm.on = True
+            t0e = time.perf_counter()
+            for _ in range(args.steps):
+                trainer.train_step(batch)
+            sync_all()
+            dt_events_pass = time.perf_counter() - t0e
+            timed_gemm.on = False
+        finally:
+            ops.gemm_nt = raw_gemm
+            if old_graph is None:
+                os.environ.pop("CLDRD_GRAPH", None)
+            else:
+                os.environ["CLDRD_GRAPH"] = old_graph
 
-    def sync_all():
-        torch.cuda.synchronize()
+    # ---- the same step on an MSMARCO-SHAPED batch (true lengths ~ clip(LogNormal(4.3, 0.35), 16, L): median 74 of 128 tokens; SURVEY.md
+    # section 8d), padded as the reference computes it and PACKED (csrc/pack.hip: Linear / LayerNorm / weight gradients on the real tokens
+    # only).  Extra keys: the headline above stays the all-ones batch the survey defines.
+    ragged = None
+    try:
+        rb = syn.nway_batch(4680 + 1000 * rank, B, N, Lq, L, ragged=True, label_kind="teacher")
+        lens = rb["nway_passages"]["attention_mask"].sum(-1).reshape(-1)
+        rb = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in rb.items()}
+        rs = {}
+        for tag in ("padded", "packed"):
+            if tag == "packed":
+                rb["nway_passages"]["lengths"] = lens
+            for _ in range(5):
+                trainer.train_step(rb)
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                trainer.train_step(rb)
+            sync_all()
+            rs[tag] = time.perf_counter() - t1
+        tr_ = torch.tensor([rs["padded"], rs["packed"]], dtype=torch.float64, device=dev)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        trainer.train_step(batch)
-    sync_all()
-    if not args.no_kernel_events:
-        timed_gemm.on = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss_out = trainer.train_step(batch)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if not args.no_kernel_events:
-        timed_gemm.on = False
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    samples_per_s = world * B * args.steps / dt
-    final_loss = float(loss_out[0].item())
+            dist.all_reduce(tr_, op=dist.ReduceOp.MAX)
+        ragged = {"token_fill": round(float(lens.sum()) / (B * N * L), 3), "padded_samples_per_s": round(world * B * 10 / float(tr_[0]), 1),
+                  "packed_samples_per_s": round(world * B * 10 / float(tr_[1]), 1), "steps": 10}
+    except Exception as exc:
+        ragged = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     roofline = None
     if gemm_events and rank == 0:
@@ -216,7 +272,10 @@ def main():
                     "launches_timed": len(gemm_events), "launches": timed_gemm.count, "avg_launch_us": round(1e3 * tot_ms / len(gemm_events), 2),
                     "avg_bracket_us": round(1e3 * raw_ms / len(gemm_events), 2), "empty_bracket_us": round(1e3 * bracket_ms, 2),
                     "gflop_per_launch": round(tot_fl / len(gemm_events) / 1e9, 2),
-                    "time_share_of_step": round(tot_ms * 1e-3 * timed_gemm.count / len(gemm_events) / dt, 3)}
+                    "time_share_of_step": round(tot_ms * 1e-3 * timed_gemm.count / len(gemm_events) / dt_events_pass, 3),
+                    "events_pass": (f"the same {args.steps} steps run eagerly right after the timed region, every {EVENT_STRIDE}th launch bracketed by HIP events "
+                                    f"({1e3 * dt_events_pass / args.steps:.3f} ms/step with the brackets); the timed region "
+                                    + ("replays a HIP graph, whose kernels cannot be bracketed" if graph_replay else "was eager as well"))}
 
     # ---- index path: encode passages/s (retriever/index_text.py: bs = 512) ----
     index = None
@@ -236,6 +295,23 @@ def main():
                 torch.cuda.synchronize()
                 di = time.perf_counter() - t1
             index = {"seconds": di, "it": it}
+            # MSMARCO-shaped lengths, padded to the longest row of the batch as the tokenizer does, packed vs computed on the padding
+            rbq = syn.seq_batch(199 + rank, 512, L, ragged=True)["seq"]
+            ilen = rbq["attention_mask"].sum(-1)
+            longest = int(ilen.max())
+            rid, rmask = rbq["input_ids"][:, :longest].contiguous().to(dev), rbq["attention_mask"][:, :longest].contiguous().to(dev)
+            with torch.no_grad():
+                for tag, extra in (("padded", {}), ("packed", {"lengths": ilen})):
+                    enc = {"input_ids": rid, "attention_mask": rmask, **extra}
+                    for _ in range(2):
+                        model.passage_embs(enc)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(it):
+                        model.passage_embs(enc)
+                    torch.cuda.synchronize()
+                    index[f"ragged_{tag}_s"] = time.perf_counter() - t1
+            index["ragged_fill"] = float(ilen.sum()) / (512 * longest)
     except Exception as exc:      # a secondary leg must not take the headline line down with it
         index = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     if not args.no_index:         # the collective sits outside the try: every rank reaches it whatever happened above
@@ -244,8 +320,13 @@ def main():
             dist.all_reduce(ti, op=dist.ReduceOp.MAX)
         if math.isfinite(float(ti.item())) and "error" not in index:
             pps = world * 512 * index["it"] / float(ti.item())
+            extra = {}
+            if "ragged_packed_s" in index:
+                extra = {"msmarco_shaped": {"token_fill_of_padded_batch": round(index["ragged_fill"], 3),
+                                            "padded_passages_per_s": round(world * 512 * index["it"] / index["ragged_padded_s"], 1),
+                                            "packed_passages_per_s": round(world * 512 * index["it"] / index["ragged_packed_s"], 1)}}
             index = {"value": round(pps, 1), "unit": "passages/s", "batch": 512, "seq_len": L,
-                     "mfma_frac": round(pps * flops_seq_fwd(L) / (world * PEAK_BF16_TFLOPS * 1e12), 4)}
+                     "mfma_frac": round(pps * flops_seq_fwd(L) / (world * PEAK_BF16_TFLOPS * 1e12), 4), **extra}
         elif "error" not in index:
             index = {"error": "another rank failed in the index leg"}
 
@@ -276,12 +357,22 @@ def main():
             flat_index.profile = True
             _, _, st = flat_index.search_device(qn, kq)
             flat_index.profile = False
-            # (3) the reference-shaped host API (numpy in, numpy out: PCIe both ways + id mapping), for the record
+            # (3) the reference-shaped host API (numpy in, numpy out: PCIe both ways + id mapping), then the run file of those results
+            # (retrieve_top_passages.py:90-107: 6980 x 1000 lines) through the native writer - the host tail of the CLI, for the record
             qh = qn.cpu().numpy()
             sync_all()
             t3 = time.perf_counter()
-            flat_index.search(qh, kq)
+            Dh, Ih = flat_index.search(qh, kq)
             dh = time.perf_counter() - t3
+            run_file_s = None
+            if rank == 0:
+                import tempfile
+                from cldrd_amd.retriever.retrieve_top_passages import write_run_file
+                with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                    t4 = time.perf_counter()
+                    write_run_file(os.path.join(td, "dev.run"), list(range(nq_r)), Ih, Dh)
+                    run_file_s = time.perf_counter() - t4
+            del Dh, Ih
             # (4) the dominant kernel alone: the fp16 streaming scan of one 128-query batch, HIP events on its stream
             from cldrd_amd import hip_ops as ops2
             qh16 = qn[:128].half().contiguous()
@@ -311,14 +402,21 @@ def main():
                         "scans": st["scans"], "rescans": st["rescans"], "unproven_first_pass": st["unproven_first_pass"],
                         "candidates_per_query": round(st["candidates"] / nq_r, 1), "rescored_per_query": round(st["rescored"] / nq_r, 1),
                         "queries_per_pass": QT, "scan_pass_ms": round(scan_pass_ms, 3),
+                        # what the scan kernel physically does per pass of QT queries: bytes streamed once, and its MFMA work - it sits on
+                        # NEITHER roof (issue-bound: LDS-DMA issue + MFMA of two waves per SIMD); `scan_hbm_frac` below is the ALGORITHMIC
+                        # figure of SURVEY.md section 8d (bytes of one 128-query reference batch per shard scan / time per such batch)
                         "scan_physical_hbm_gb_s": round((rows * D * 2 + QT * D * 2) / scan_pass_ms / 1e6, 1),
+                        "scan_physical_hbm_frac": round((rows * D * 2 + QT * D * 2) / scan_pass_ms / 1e6 / 8000.0, 4),
+                        "scan_mfma_frac": round(2.0 * QT * rows * D / scan_pass_ms / 1e9 / PEAK_BF16_TFLOPS, 4),
+                        "scan_bound": "issue (neither roof): physical HBM and fp16 MFMA fractions above; the algorithmic HBM fraction counts the index bytes once per 128-query batch",
                         "scan_kernel_ms": round(scan_ms, 3), "scan_hbm_gb_s": round(scan_bytes / scan_ms / 1e6, 1),
                         "scan_hbm_frac": round(scan_bytes / scan_ms / 1e6 / 8000.0, 4),
                         "scan_tflops": round(2.0 * 128 * rows * D / scan_ms / 1e9, 1),
                         "path_ms_per_batch": round(batch_ms, 3), "path_hbm_gb_s": round(scan_bytes / batch_ms / 1e6, 1),
                         "path_hbm_frac": round(scan_bytes / batch_ms / 1e6 / 8000.0, 4),
                         "wall_ms_per_batch": round(1e3 * dr / nb, 3), "wall_hbm_frac": round(scan_bytes / (1e3 * dr / nb) / 1e6 / 8000.0, 4),
-                        "host_api_queries_per_s": round(nq_r / dh, 1)}
+                        "host_api_queries_per_s": round(nq_r / dh, 1), "host_api_s": round(dh, 4),
+                        "run_file_s": None if run_file_s is None else round(run_file_s, 4), "run_file_lines": nq_r * kq}
             del flat_index, P
     except Exception as exc:      # a secondary leg must not take the headline line down with it
         retrieve = {"error": f"{type(exc).__name__}: {exc}"[:300]}
@@ -349,17 +447,24 @@ def main():
 
     if rank == 0:
         flops_per_sample = 3.0 * (N * flops_seq_fwd(L) + flops_seq_fwd(Lq))
+        exec_per_sample = 3.0 * (N * flops_seq_fwd_executed(L) + flops_seq_fwd_executed(Lq))
         out = {
             "metric": "train (q,N-psg) samples/sec + index passages/sec, DistilBERT N=32 at 1/8 GPUs",
             "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "step_launch": "hip graph replay" if graph_replay else "eager",
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"cfg2: DistilBERT-6L dual encoder (2 unshared towers), N={N}, {args.loss}, seq_len={L}, q_len={Lq}, "
-                                   f"per-GPU batch {B}, dropout {args.dropout:g}, fwd+loss+bwd+allreduce+clip+AdamW",
+                                   f"per-GPU batch {B}, dropout {args.dropout:g}, fwd+loss+bwd+allreduce+clip+AdamW; bf16 MFMA operands "
+                                   f"(forward FFN GEMMs: fp16 operands, same rate), fp32 accumulate / residual stream / master weights",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "model_tflop_per_sample": round(flops_per_sample / 1e12, 4),
             "step_mfma_frac": round(samples_per_s * flops_per_sample / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            # model FLOPs count the full last layer (SURVEY.md section 8d convention); the build computes only its CLS row:
+            "executed_tflop_per_step": round(B * exec_per_sample / 1e12, 3),
+            "step_mfma_frac_executed": round(samples_per_s * exec_per_sample / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "final_loss": final_loss,
+            "msmarco_shaped_train": ragged,
             "index": index, "retrieve": retrieve, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -33,8 +33,8 @@ SIGNATURES = {
     "cldrd_attention_cls_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
     "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, vp]),
     "cldrd_ln_partial_blocks": (ci, [ci]),
-    "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, ci, vp]),
-    "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp]),
+    "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, ci, vp, vp]),
+    "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp, vp]),
     "cldrd_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, ci, ci, vp, ci, vp, vp]),
     "cldrd_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cull, ci, ci, vp]),
     "cldrd_ln_reduce_group": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, vp]),
@@ -64,6 +64,13 @@ SIGNATURES = {
     "cldrd_topk_sort": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "cldrd_row_sqnorm_max": (ci, [vp, csz, ci, vp, vp]),
     "cldrd_gather_cast_rows": (ci, [vp, vp, csz, csz, ci, vp]),
+    "cldrd_unpack_rows16": (ci, [vp, vp, vp, ci, ci, ci, vp]),
+    "cldrd_gather_rows": (ci, [vp, vp, vp, ci, ci, vp]),
+    "cldrd_scatter_cls_grad_idx": (ci, [vp, vp, ci, ci, vp, ci, vp]),
+    "cldrd_add_rows_idx": (ci, [vp, vp, ci, ci, vp, vp]),
+    "cldrd_set_seed_base": (None, [vp]),
+    "cldrd_set_optim_hyper": (None, [vp]),
+    "cldrd_write_step_state": (ci, [vp, cull, cull, vp, cf, cf, cf, ci, vp]),
     "cldrd_write_run_file": (C.c_longlong, [C.c_char_p, vp, vp, vp, C.c_longlong, ci, ci]),
     "cldrd_py_float_repr": (ci, [C.c_double, C.c_char_p]),
 }

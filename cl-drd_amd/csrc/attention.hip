@@ -83,7 +83,8 @@ __device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld,
 template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
-                                                        float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+                                                        float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+    const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
     char* sQ = smem;
@@ -191,8 +192,9 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
 template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                          bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
-                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed, int nitems,
+                                                         float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
                                                          uint32_t* __restrict__ bits_out) {
+    const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
     constexpr int TILE = Lp * RSB;
@@ -368,7 +370,8 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
 template <int NKB, bool DROP>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
-                                                        float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+                                                        float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+    const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
     constexpr int NWAVES = NKB > 4 ? 8 : 4;          // one query / key block per wave up to L = 256 (2 waves per SIMD at one workgroup per CU)
@@ -468,7 +471,8 @@ template <int NKB, bool DROP>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
-                                                        float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+                                                        float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+    const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
     constexpr int NWAVES = NKB > 4 ? 8 : 4;          // one query / key block per wave up to L = 256 (2 waves per SIMD at one workgroup per CU)
@@ -668,8 +672,9 @@ template <int NKB, bool DROP, bool BITS>
 __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                          const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
-                                                         float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed, int nitems,
+                                                         float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
                                                          const uint32_t* __restrict__ drop_bits) {
+    const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
     constexpr int TILE = Lp * RSB;
@@ -926,7 +931,7 @@ int launch_fwd_f16(const void* qkv, const long long* mask, void* ctx, float* lse
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
     (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP, true>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed));
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -948,18 +953,18 @@ int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, 
             const size_t lds2 = 2 * (lds + (DROP ? 32 * NKB * NKB * sizeof(uint32_t) : 0));
             (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipLaunchKernelGGL((attn_fwd2_kernel<NKB, DROP>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                               (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed, nitems,
+                               (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems,
                                bits_out);
             CLDRD_LAUNCH_CHECK();
             return 0;
         }
         (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed));
     } else {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(512), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed));
     }
     CLDRD_LAUNCH_CHECK();
     return 0;
@@ -999,12 +1004,12 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
                 (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
                 hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, DROP>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                    (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed, nitems, drop_bits);
+                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, drop_bits);
             } else {
                 (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
                 hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, false>), dim3(cus), dim3(512), 2 * lds1, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                    (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed, nitems, (const uint32_t*)nullptr);
+                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, (const uint32_t*)nullptr);
             }
             CLDRD_LAUNCH_CHECK();
             return 0;
@@ -1014,7 +1019,7 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                        (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                       DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), (uint64_t)seed);
+                       DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed));
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -1111,7 +1116,8 @@ template <bool F16>
 __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
                                                            const int64_t* __restrict__ mask, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ probs, int L, int H, float scale,
-                                                           uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+                                                           uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+    const uint64_t seed = seed_a.get();
     __shared__ float sp[256];
     __shared__ float sq[64];
     const int seq = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x;
@@ -1168,7 +1174,8 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
 __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
                                                            const float* __restrict__ probs, const bf16_t* __restrict__ dctx,
                                                            bf16_t* __restrict__ dqc, bf16_t* __restrict__ dkv, int L, int H,
-                                                           float scale, uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+                                                           float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+    const uint64_t seed = seed_a.get();
     __shared__ float sds[256], spd[256], sdo[64];
     const int seq = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x;
     const int dm = H * 64;
@@ -1243,10 +1250,10 @@ extern "C" int cldrd_attention_cls_fwd(const void* qc, const void* kv, const lon
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     if (io_f16)
         hipLaunchKernelGGL(attn_cls_fwd_kernel<true>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
-                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
     else
         hipLaunchKernelGGL(attn_cls_fwd_kernel<false>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
-                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -1257,7 +1264,7 @@ extern "C" int cldrd_attention_cls_bwd(const void* qc, const void* kv, const flo
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_cls_bwd: need 0 < L <= 256");
     hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv, probs,
                        (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f,
-                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), seed_arg(seed));
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

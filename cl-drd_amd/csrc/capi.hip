@@ -1,5 +1,6 @@
 // Error reporting + version for the C-ABI library (include/cldrd_hip.h).
 #include "common.h"
+#include <math.h>
 #include <string.h>
 
 static thread_local char g_err[512] = "";
@@ -18,4 +19,35 @@ extern "C" int cldrd_device_ok(void) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+
+// ---- per-step state in device memory (HIP-graph replay of the training step) --------------------------------------------------
+thread_local const unsigned long long* g_cldrd_seed_base = nullptr;
+thread_local const float* g_cldrd_optim_hyper = nullptr;
+
+// Every launch made by this thread from now on adds *base (read on the device, at run time) to its dropout seed; null: off.
+extern "C" void cldrd_set_seed_base(const unsigned long long* base) { g_cldrd_seed_base = base; }
+// cldrd_adamw_step* launched by this thread from now on take {lr, step size = lr sqrt(1 - beta2^t) / (1 - beta1^t)} from this device
+// float[2] instead of their by-value arguments; null: off.
+extern "C" void cldrd_set_optim_hyper(const float* hyper) { g_cldrd_optim_hyper = hyper; }
+
+namespace {
+__global__ void step_state_kernel(unsigned long long* seeds, unsigned long long s0, unsigned long long s1, float* hyper, float lr, float step_size) {
+    if (threadIdx.x == 0) {
+        if (seeds) { seeds[0] = s0; seeds[1] = s1; }
+        if (hyper) { hyper[0] = lr; hyper[1] = step_size; }
+    }
+}
+}  // namespace
+
+// One tiny launch that writes this step's values (two seed words, lr, Adam step size for bias-correction step `adam_step`) to device
+// memory, in stream order in front of the replay that reads them.
+extern "C" int cldrd_write_step_state(unsigned long long* seeds, unsigned long long seed0, unsigned long long seed1, float* hyper, float lr,
+                                      float beta1, float beta2, int adam_step, void* stream) {
+    CLDRD_CHECK(adam_step >= 1, "write_step_state: the Adam step is 1-based");
+    const double bc1 = 1.0 - pow((double)beta1, (double)adam_step), bc2 = 1.0 - pow((double)beta2, (double)adam_step);
+    hipLaunchKernelGGL(step_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seeds, seed0, seed1, hyper, lr, (float)((double)lr * sqrt(bc2) / bc1));
+    CLDRD_LAUNCH_CHECK();
+    return 0;
 }

@@ -104,6 +104,19 @@ __device__ __forceinline__ bool dropout_keep(uint32_t rowkey, uint32_t col, uint
 }
 static inline uint32_t dropout_thresh16(float p) { return (uint32_t)(p * 65536.0f + 0.5f); }
 
+// A dropout seed as a kernel argument: the value the caller passed plus, when a seed base is installed (cldrd_set_seed_base), a 64-bit word
+// read from DEVICE memory at run time.  A training step captured into a HIP graph replays its kernel arguments unchanged; the part of
+// the seed that must change from step to step therefore lives in device memory (the trainer updates it with one tiny launch in front of
+// each replay) and the captured arguments are only offsets (layer, call site).  No base installed: the value itself, as before.
+struct SeedArg {
+    unsigned long long val;
+    const unsigned long long* base;
+    __device__ __forceinline__ uint64_t get() const { return base ? val + *base : val; }
+};
+extern thread_local const unsigned long long* g_cldrd_seed_base;      // capi.hip; host side
+extern thread_local const float* g_cldrd_optim_hyper;                 // capi.hip: device float[2] = {lr, step size} or null
+static inline SeedArg seed_arg(unsigned long long s) { return SeedArg{s, g_cldrd_seed_base}; }
+
 // XCD-aware bijective block remap (cdna_hip_programming.md section 5, T1): blocks b and b+8 share an XCD, so
 // give each XCD a contiguous range of logical tiles (neighbouring tiles share operand panels in that XCD's L2).
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

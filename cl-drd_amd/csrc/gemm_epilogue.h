@@ -21,6 +21,7 @@ struct GemmNtArgs {
     uint32_t drop_thresh;         // 0 = no dropout
     float drop_scale;
     uint64_t seed;
+    const unsigned long long* seed_base = nullptr;      // SeedArg of common.h: added to `seed` on the device when set
     int out_f32;
     // EPI_FILTER (top-k scan): keep C[m][n] >= thr[m] as candidate (n, score) of query m
     const float* thr; int* counts; int* cand_rows; float* cand_scores; int cap;
@@ -147,7 +148,7 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         for (int j = 0; j < 8; ++j) v[j] *= fl.dgelu ? g[j] : gelu_grad_f(g[j]);
     }
     if (fl.dropout) {
-        const uint32_t rk = drop_rowkey(p.seed, (uint32_t)m);      // n is a multiple of 8: four column pairs
+        const uint32_t rk = drop_rowkey(p.seed_base ? p.seed + *p.seed_base : p.seed, (uint32_t)m);      // n is a multiple of 8: four column pairs
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
             const uint32_t h = drop_pair(rk, (uint32_t)(n + j));

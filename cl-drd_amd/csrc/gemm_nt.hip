@@ -272,7 +272,7 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
     a.act = act; a.alpha = alpha;
     a.drop_thresh = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     a.drop_scale = 1.0f / (1.0f - dropout_p);
-    a.seed = seed; a.out_f32 = out_f32;
+    a.seed = seed; a.seed_base = g_cldrd_seed_base; a.out_f32 = out_f32;
     a.thr = nullptr; a.counts = nullptr; a.cand_rows = nullptr; a.cand_scores = nullptr; a.cap = 0;
     a.in_f16 = io_f16 ? 1 : 0;
     a.c_copy = (bf16_t*)c_copy_bf16;

@@ -209,7 +209,7 @@ __device__ __forceinline__ void pers_epilogue(const GemmNtArgs& p, f32x4 (&acc)[
         if constexpr (DROP) {
 #pragma unroll
             for (int t = 0; t < MTG; ++t) {
-                const uint32_t rk = drop_rowkey(p.seed, (uint32_t)(r0 + (g * MTG + t) * 16));
+                const uint32_t rk = drop_rowkey(p.seed_base ? p.seed + *p.seed_base : p.seed, (uint32_t)(r0 + (g * MTG + t) * 16));
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll

@@ -165,7 +165,9 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             bf16_t* __restrict__ out, float* __restrict__ out32, float* __restrict__ mean_o,
                                                             float* __restrict__ rstd_o, int T, int L, int d_rt, int vocab, float eps,
-                                                            uint32_t drop_thresh, float drop_scale, uint64_t seed, int out_f16) {
+                                                            uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int out_f16,
+                                                            const int* __restrict__ pos_idx) {
+    const uint64_t seed = seed_a.get();
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     RowF r, p;
     load_row_f32(word + (size_t)id * d, d, lane, r);
-    load_row_f32(pos + (size_t)(row % L) * d, d, lane, p);
+    load_row_f32(pos + (size_t)(pos_idx ? pos_idx[row] : row % L) * d, d, lane, p);      // pos_idx: packed batches (csrc/pack.hip)
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
@@ -269,7 +271,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                       const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                       const float* __restrict__ gamma, bf16_t* __restrict__ dx,
                                                       bf16_t* __restrict__ dx2, float* __restrict__ partial, int T, int d_rt,
-                                                      uint32_t drop_thresh, float drop_scale, uint64_t seed) {
+                                                      uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+    const uint64_t seed = seed_a.get();
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     const int lane = threadIdx.x & 63;
@@ -336,7 +339,9 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
                                                             const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                             float* __restrict__ dword, float* __restrict__ dpos,
                                                             float* __restrict__ partial, int T, int L, int d_rt, int vocab,
-                                                            uint32_t drop_thresh, float drop_scale, uint64_t seed, int pos_uniform) {
+                                                            uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int pos_uniform,
+                                                            const int* __restrict__ pos_idx) {
+    const uint64_t seed = seed_a.get();
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     const int lane = threadIdx.x & 63;
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += gridDim.x * 4) {
         int64_t id = ids[row];
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
-        const int l = row % L;
+        const int l = pos_idx ? pos_idx[row] : row % L;
         RowF g, xr, p;
         load_row_bf16_i(dy + (size_t)row * d, d, lane, g);
         {   // a row whose incoming gradient is exactly zero (padded positions: nothing attends to them) contributes exactly
@@ -505,13 +510,14 @@ extern "C" int cldrd_layernorm_fwd(const void* x, const float* gamma, const floa
 
 extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
                                   const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
-                                  int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, int out_f16, void* stream) {
+                                  int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, int out_f16,
+                                  const int* pos_idx, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_fwd: bad shape");
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
         hipLaunchKernelGGL((embed_ln_fwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                            (const int64_t*)ids, word, pos, type0, gamma, beta, (bf16_t*)out, out32, mean, rstd, T, L, d, vocab, eps, th,
-                           1.0f / (1.0f - dropout_p), (uint64_t)seed, out_f16);
+                           1.0f / (1.0f - dropout_p), seed_arg(seed), out_f16, pos_idx);
     });
     CLDRD_LAUNCH_CHECK();
     return 0;
@@ -571,10 +577,10 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
         const size_t lds = (512 / 128) * 3 * MAX_IT * 64 * sizeof(float4);
         if (x_f32)
             hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true>), dim3(nb), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dy, x, mean, rstd, gamma,
-                               (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                               (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
         else
             hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, false>), dim3(nb), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dy, x, mean, rstd, gamma,
-                               (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed);
+                               (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
     });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dbias, accumulate, (hipStream_t)stream);
@@ -603,19 +609,19 @@ extern "C" int cldrd_ln_reduce_group(const float* const* partial, const int* T, 
 extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,
                                   const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
                                   float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,
-                                  float dropout_p, unsigned long long seed, int accumulate, void* stream) {
+                                  float dropout_p, unsigned long long seed, int accumulate, const int* pos_idx, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_bwd: bad shape");
     int nb = ln_bwd_blocks(T);                      // the caller sized `partial` for this many blocks; fewer is fine
     int g4 = 4, r = L;                              // gcd(4, L)
     while (r) { const int t = g4 % r; g4 = r; r = t; }
     const int step = L / g4;                        // grids that are multiples of this make the wave row stride 4*nb a multiple of L
-    const int pos_uniform = nb >= step;
+    const int pos_uniform = nb >= step && pos_idx == nullptr;       // packed rows: a wave's rows sit at different positions
     if (pos_uniform) nb = (nb / step) * step;
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
         hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3(nb), dim3(256), (256 / 128) * 3 * MAX_IT * 64 * sizeof(float4),
                            (hipStream_t)stream, (const bf16_t*)dy, (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial,
-                           T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), (uint64_t)seed, pos_uniform);
+                           T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx);
     });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dtype0, accumulate, (hipStream_t)stream);

@@ -50,6 +50,7 @@ struct AdamArgs {
     size_t n4; float lr, beta1, beta2, eps, wd, step_size; const float* coef;
     int reverse;
     uint16_t* shadow16; size_t h_lo4, h_hi4;      // fp16 copy of parameters [4 h_lo4, 4 h_hi4) (shadow16[0] = parameter 4 h_lo4), or null
+    const float* hyper;                           // device {lr, step_size} replacing the by-value pair (a captured step reads them at replay), or null
 };
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
@@ -65,6 +66,7 @@ __device__ __forceinline__ void ntstore4(float4* p, const float4& v) {
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     const float coef = a.coef ? a.coef[1] : 1.0f;
     const bool skip = a.coef && a.coef[2] != 0.f;        // non-finite gradient norm: leave the weights untouched
+    const float lr = a.hyper ? a.hyper[0] : a.lr, step_size = a.hyper ? a.hyper[1] : a.step_size;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < a.n4; i0 += stride) {
         // the sweep runs from the END of the buffer: the norm pass in front of this kernel has just read g front to back, so its
@@ -83,8 +85,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
             for (int j = 0; j < 4; ++j) {
                 mm[j] = a.beta1 * mm[j] + (1.f - a.beta1) * gg[j];
                 vv[j] = a.beta2 * vv[j] + (1.f - a.beta2) * gg[j] * gg[j];
-                pp[j] -= a.step_size * mm[j] / (sqrtf(vv[j]) + a.eps);
-                if (dec) pp[j] -= a.lr * a.wd * pp[j];
+                pp[j] -= step_size * mm[j] / (sqrtf(vv[j]) + a.eps);
+                if (dec) pp[j] -= lr * a.wd * pp[j];
             }
             p = make_float4(pp[0], pp[1], pp[2], pp[3]);
             ntstore4((float4*)a.p + i, p);
@@ -216,6 +218,7 @@ extern "C" int cldrd_adamw_step_h16(float* p, const float* g, float* m, float* v
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay; a.coef = clip;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     a.step_size = (float)((double)lr * sqrt(bc2) / bc1);
+    a.hyper = g_cldrd_optim_hyper;
     hipLaunchKernelGGL(adamw_kernel, dim3(stream_blocks(a.n4)), dim3(256), 0, (hipStream_t)stream, a);
     CLDRD_LAUNCH_CHECK();
     return 0;

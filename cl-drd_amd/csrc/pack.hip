@@ -1,0 +1,87 @@
+// Variable-length packing of a batch (MI355X-first replacement for the padding the reference inherits from HuggingFace: its tokenizer pads
+// every sequence of a batch to the longest one, dataset/sequence_dataset.py:50-51, dataset/nway_dataset.py:103-107, and every Linear /
+// LayerNorm of the encoder then runs over the padding too - ~40 % of the rows of an MS MARCO batch).
+//
+// Packed layout: the tokens of sequence m are rows cu[m] .. cu[m] + len[m] of a [Tp, features] matrix, Tp = sum of the lengths.  GEMMs,
+// LayerNorm and the weight gradients work on any row count, so they simply see fewer rows.  Attention keeps its padded [nseq * L, .]
+// layout (one item = one sequence x head, keys >= len masked): these kernels move rows between the two layouts.  CLS rows are rows cu[m].
+#include "common.h"
+
+namespace {
+
+// dst[(m * L + j), :] = j < len[m] ? src[cu[m] + j, :] : 0     (16-bit elements, w % 8 == 0); one wave per destination row
+__global__ __launch_bounds__(256) void unpack_rows16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, const int* __restrict__ cu,
+                                                             int nseq, int L, int w) {
+    const int lane = threadIdx.x & 63;
+    const long long rows = (long long)nseq * L;
+    for (long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long long)gridDim.x * 4) {
+        const int m = (int)(r / L), j = (int)(r % L);
+        const int c0 = cu[m], len = cu[m + 1] - c0;
+        uint4* d = (uint4*)(dst + (size_t)r * w);
+        if (j < len) {
+            const uint4* s = (const uint4*)(src + (size_t)(c0 + j) * w);
+            for (int c = lane; c < w / 8; c += 64) d[c] = s[c];
+        } else {
+            for (int c = lane; c < w / 8; c += 64) d[c] = make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
+// dst[p, :] = src[idx[p], :]   (rows of `bytes` bytes, bytes % 16 == 0); one wave per row
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict__ src, const int* __restrict__ idx, char* __restrict__ dst, int n, int bytes) {
+    const int lane = threadIdx.x & 63;
+    for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += gridDim.x * 4) {
+        const uint4* s = (const uint4*)(src + (size_t)idx[p] * bytes);
+        uint4* d = (uint4*)(dst + (size_t)p * bytes);
+        for (int c = lane; c < bytes / 16; c += 64) d[c] = s[c];
+    }
+}
+
+// g[idx[r], :] = bf16(dcls[r, :])   (g zeroed by the launcher)
+__global__ void scatter_cls_idx_kernel(const float* __restrict__ dcls, bf16_t* __restrict__ g, const int* __restrict__ idx, int d) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) g[(size_t)idx[r] * d + c] = f2bf(dcls[(size_t)r * d + c]);
+}
+
+// dst[idx[m], :] += src[m, :]   (bf16 rows, fp32 add, one rounding)
+__global__ void add_rows_idx_kernel(bf16_t* __restrict__ dst, const bf16_t* __restrict__ src, const int* __restrict__ idx, int d) {
+    const int m = blockIdx.x;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        const size_t o = (size_t)idx[m] * d + c;
+        dst[o] = f2bf(bf2f(dst[o]) + bf2f(src[(size_t)m * d + c]));
+    }
+}
+
+}  // namespace
+
+extern "C" int cldrd_unpack_rows16(const void* src_packed, void* dst_padded, const int* cu, int nseq, int L, int w, void* stream) {
+    CLDRD_CHECK(nseq > 0 && L > 0 && w > 0 && w % 8 == 0, "unpack_rows16: bad shape (w must be a multiple of 8)");
+    const long long rows = (long long)nseq * L;
+    const int nb = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+    hipLaunchKernelGGL(unpack_rows16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src_packed, (bf16_t*)dst_padded, cu, nseq, L, w);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_gather_rows(const void* src, const int* idx, void* dst, int n, int row_bytes, void* stream) {
+    CLDRD_CHECK(n > 0 && row_bytes > 0 && row_bytes % 16 == 0, "gather_rows: rows must be a multiple of 16 bytes");
+    const int nb = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const char*)src, idx, (char*)dst, n, row_bytes);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_scatter_cls_grad_idx(const float* dcls, void* g, int R, int d, const int* idx, int T, void* stream) {
+    CLDRD_CHECK(R > 0 && d > 0 && T >= R, "scatter_cls_grad_idx: bad shape");
+    if (hipMemsetAsync(g, 0, (size_t)T * d * sizeof(bf16_t), (hipStream_t)stream) != hipSuccess) return cldrd_set_error("scatter_cls_grad_idx: memset failed");
+    hipLaunchKernelGGL(scatter_cls_idx_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, (bf16_t*)g, idx, d);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_add_rows_idx(void* dst, const void* src, int M, int d, const int* idx, void* stream) {
+    CLDRD_CHECK(M > 0 && d > 0, "add_rows_idx: bad shape");
+    hipLaunchKernelGGL(add_rows_idx_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst, (const bf16_t*)src, idx, d);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}

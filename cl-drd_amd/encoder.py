@@ -213,7 +213,28 @@ def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
 
 class _Tape:
     """Activations saved by one training forward of one tower."""
-    __slots__ = ("M", "L", "T", "ids", "mask", "seed", "mean0", "rstd0", "layers", "p_embed")
+    __slots__ = ("M", "L", "T", "ids", "mask", "seed", "mean0", "rstd0", "layers", "p_embed", "pack")
+
+
+class _Pack:
+    """Row maps of a packed batch (csrc/pack.hip): sequence m owns rows cu[m] .. cu[m + 1] of the packed matrices."""
+    __slots__ = ("Tp", "cu", "tok_idx", "pos", "cls_idx")
+
+    @classmethod
+    def build(cls, lengths, L, dev):
+        import numpy as np
+        lens = np.asarray(lengths, dtype=np.int64).reshape(-1)
+        cu = np.zeros(lens.shape[0] + 1, dtype=np.int64)
+        np.cumsum(lens, out=cu[1:])
+        seq = np.repeat(np.arange(lens.shape[0], dtype=np.int64), lens)
+        pos = np.arange(int(cu[-1]), dtype=np.int64) - cu[seq]
+        pk = cls()
+        pk.Tp = int(cu[-1])
+        pk.cu = torch.from_numpy(cu.astype(np.int32)).to(dev, non_blocking=True)
+        pk.tok_idx = torch.from_numpy((seq * L + pos).astype(np.int32)).to(dev, non_blocking=True)
+        pk.pos = torch.from_numpy(pos.astype(np.int32)).to(dev, non_blocking=True)
+        pk.cls_idx = pk.cu[:-1]
+        return pk
 
 
 class HipEncoder(nn.Module):
@@ -502,7 +523,7 @@ class HipEncoder(nn.Module):
         return torch.empty(ops.pad_rows(rows), cols, dtype=dtype, device=dev)
 
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None, *, train: bool | None = None,
-               save: bool = False, seed: int | None = None, fp16: bool | None = None):
+               save: bool = False, seed: int | None = None, fp16: bool | None = None, lengths=None):
         """CLS embeddings fp32 [M, d] (== HF ``model(**enc)[0][:, 0, :]``).  With ``save`` also returns the tape.
 
         ``fp16`` (default: ``self.hp_forward``, which NwayDualEncoder sets on the QUERY tower): high-precision forward - the same
@@ -511,20 +532,38 @@ class HipEncoder(nn.Module):
         dq.p + q.dp, there are N passages per query, and with CLS vectors that share a large common component every logit of a row
         inherits the SAME dq.p term - B draws dominate max|dlogit| - while the query tower is ~1 % of the FLOPs and runs on a side
         stream.  The backward needs bf16 operands, so with ``save`` the bf16 forward runs as well (it fills the tape; same dropout
-        masks: same seed) and only the returned CLS comes from the fp16 pass."""
+        masks: same seed) and only the returned CLS comes from the fp16 pass.
+
+        ``lengths`` (host-side ints, one per sequence: the number of leading 1s of its mask row): with them a padded batch is PACKED -
+        the Linear / LayerNorm / weight-gradient kernels run on the real tokens only (the reference pads every sequence to the longest of
+        the batch and computes on the padding: ~40 % of the rows of an MS MARCO batch); attention keeps the padded layout; the CLS output
+        is the same up to the order of fp32 summation.  Without them nothing is packed (finding the row count would cost a host sync)."""
         fp16 = self.hp_forward if fp16 is None else fp16
+        base = getattr(self, "seed_base_ptr", None)
+        if base:
+            # graph mode (NwayTrainer): the per-step part of the seed lives in device memory at `seed_base_ptr` (the trainer advances
+            # step_seed and writes next_seed() there before each step); the launches carry offsets only
+            with ops.seed_base(base):
+                return self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=0, fp16=fp16, lengths=lengths)
         if seed is None:
-            self.step_seed += 1
-            seed = (self.step_seed * 0x9E3779B1) & 0x7FFFFFFFFFFF
+            seed = self.next_seed()
+        return self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=fp16, lengths=lengths)
+
+    def next_seed(self) -> int:
+        """Advance the step counter; the dropout seed of the step (what encode() draws when no seed is given)."""
+        self.step_seed += 1
+        return (self.step_seed * 0x9E3779B1) & 0x7FFFFFFFFFFF
+
+    def _encode_pair(self, input_ids, attention_mask, *, train, save, seed, fp16, lengths=None):
         if fp16 and self.stream32 and self.hp_forward and input_ids.dim() == 2 and input_ids.shape[1] <= 128:
             tape = None
             if save:
                 _, tape = self._encode(input_ids, attention_mask, train=train, save=True, seed=seed, fp16=False)
             cls = self._encode(input_ids, attention_mask, train=train, save=False, seed=seed, fp16=True)
             return (cls, tape) if save else cls
-        return self._encode(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=False)
+        return self._encode(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=False, lengths=lengths)
 
-    def _encode(self, input_ids, attention_mask, *, train, save, seed, fp16):
+    def _encode(self, input_ids, attention_mask, *, train, save, seed, fp16, lengths=None):
         cfg = self.cfg
         train = self.training if train is None else train
         if input_ids.dim() != 2:
@@ -538,14 +577,25 @@ class HipEncoder(nn.Module):
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         mask = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         T, d, f, H = M * L, cfg.dim, cfg.hidden_dim, cfg.n_heads
+        TP = T                                                   # rows of the padded layout (attention); T becomes the packed row count
         p_h = cfg.dropout if train else 0.0
         p_a = cfg.attention_dropout if train else 0.0
         dt16 = torch.float16 if fp16 else torch.bfloat16         # 16-bit activation format of this pass
+        pk = None
+        if (lengths is not None and mask is not None and not fp16 and self.cls_only_last and cfg.n_layers >= 1 and L > 1
+                and _env_flag("CLDRD_PACK", "1") != "0"):
+            n_tok = int(sum(int(v) for v in (lengths.reshape(-1).tolist() if hasattr(lengths, "reshape") else lengths)))
+            if len(lengths) != M:
+                raise ValueError("lengths: one entry per sequence")
+            if 0 < n_tok <= int(0.92 * T):                       # enough padding to pay for the row moves around attention
+                pk = _Pack.build(lengths, L, dev)
+                T = pk.Tp
+                ids_padded, ids = ids, torch.index_select(ids.view(-1), 0, pk.tok_idx.long())
         tape = None
         if save:
             tape = _Tape()
             tape.M, tape.L, tape.T, tape.ids, tape.mask, tape.seed, tape.layers = M, L, T, ids, mask, seed, []
-            tape.p_embed = p_h
+            tape.p_embed, tape.pack = p_h, pk
         f32 = dict(dtype=torch.float32, device=dev)
         S32 = self.stream32
         sdt = torch.float32 if S32 else torch.bfloat16         # storage type of the pre-LN sums
@@ -555,7 +605,8 @@ class HipEncoder(nn.Module):
         type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
         ops.embed_ln_fwd(ids.view(-1), self.w("embeddings.word_embeddings.weight"),
                          self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
-                         self.w("embeddings.LayerNorm.bias"), x, mean0, rstd0, T, L, cfg.eps, p_h, seed, out32=x32)
+                         self.w("embeddings.LayerNorm.bias"), x, mean0, rstd0, T, L, cfg.eps, p_h, seed, out32=x32,
+                         pos_idx=pk.pos if pk is not None else None)
         if save:
             tape.mean0, tape.rstd0 = mean0, rstd0
         cls = torch.empty(M, d, **f32)
@@ -571,14 +622,26 @@ class HipEncoder(nn.Module):
             W16 = self._layer_weights(i, True) if FFN16 else None
             s_l = seed + 7919 * (i + 1)
             if i == cfg.n_layers - 1 and self.cls_only_last:
-                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16, W16)
+                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16, W16, pk)
                 break
             qkv = self._buf(T, 3 * d, dev, dt16)
             ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
-            ctx = self._buf(T, d, dev, dt16)
             lse = torch.empty(M, H, L, **f32) if save else None
             dbits = ops.attention_drop_bits(M, L, H, p_a, dev) if (save and dt16 == torch.bfloat16) else None      # dropout keep bits for the backward
-            ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits)
+            ctx_pad = None
+            if pk is None:
+                ctx = self._buf(T, d, dev, dt16)
+                ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits)
+            else:
+                # packed batch: attention works on the padded [M * L, .] layout (one item = one sequence x head, keys >= len masked): move
+                # the rows there (zeros in the padding: a masked key contributes exp(-inf) * v = 0 only for finite v) and the context back
+                qkv_p, qkv = qkv, self._buf(TP, 3 * d, dev, dt16)
+                ops.unpack_rows16(qkv_p, qkv, pk.cu, M, L)
+                ctx_pad = self._buf(TP, d, dev, dt16)
+                ops.attention_fwd(qkv, mask, ctx_pad, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits)
+                ctx = self._buf(T, d, dev, dt16)
+                ops.gather_rows(ctx_pad, pk.tok_idx, ctx, T)
+                del qkv_p
             s1 = self._buf(T, d, dev, sdt)
             ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out, seed=s_l + 2, residual_ln=res_ln)
             mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
@@ -613,7 +676,7 @@ class HipEncoder(nn.Module):
             mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
             ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32)
             if save:
-                tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, lse=lse, dbits=dbits, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
+                tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, ctx_pad=ctx_pad, lse=lse, dbits=dbits, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
                                         h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h, p_a=p_a, p_out=p_out))
             x = xo
             if S32:
@@ -623,7 +686,7 @@ class HipEncoder(nn.Module):
         return (cls, tape) if save else cls
 
     # ------------------------------------------------------------------ last layer, CLS row only
-    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16=torch.bfloat16, W16=None):
+    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16=torch.bfloat16, W16=None, pk=None):
         """Only ``last_hidden_state[:, 0, :]`` is consumed (reference models/nway_dual_encoder.py:52,56,64), so the last
         layer projects K and V for every token but Q, attention, out-proj, FFN and both LayerNorms for token 0 only:
         identical CLS output, ~1/6 of the layer's FLOPs."""
@@ -636,11 +699,19 @@ class HipEncoder(nn.Module):
         S32 = x32 is not None
         sdt = torch.float32 if S32 else torch.bfloat16
         xc = self._buf(M, d, dev, dt16)
-        xc[:M].copy_(x[:T].view(M, L, d)[:, 0, :])                 # gather the CLS rows (a copy, no arithmetic)
-        xc32 = None
-        if S32:
-            xc32 = self._buf(M, d, dev, torch.float32)
-            xc32[:M].copy_(x32[:T].view(M, L, d)[:, 0, :])
+        xc32 = self._buf(M, d, dev, torch.float32) if S32 else None
+        if pk is None:
+            xc[:M].copy_(x[:T].view(M, L, d)[:, 0, :])             # gather the CLS rows (a copy, no arithmetic)
+            if S32:
+                xc32[:M].copy_(x32[:T].view(M, L, d)[:, 0, :])
+        else:
+            # packed batch: the CLS token of sequence m is row cu[m]; K / V go to the padded layout the CLS attention kernel reads
+            ops.gather_rows(x, pk.cls_idx, xc, M)
+            if S32:
+                ops.gather_rows(x32, pk.cls_idx, xc32, M)
+            kv_p, kv = kv, self._buf(M * L, 2 * d, dev, dt16)
+            ops.unpack_rows16(kv_p, kv, pk.cu, M, L)
+            del kv_p
         qc = self._buf(M, d, dev, dt16)
         ops.gemm_nt(xc, W["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
         ctxc = self._buf(M, d, dev, dt16)
@@ -709,8 +780,13 @@ class HipEncoder(nn.Module):
         dctx = self._buf(M, d, dev)
         ops.gemm_nt(dA, self.ht(i, "o"), dctx, M)
         dqc = self._buf(M, d, dev)
-        dkv = self._buf(T, 2 * d, dev)
+        pk = tape.pack
+        dkv = self._buf(M * L, 2 * d, dev)
         ops.attention_cls_bwd(a["qc"], a["kv"], a["probs"], dctx, dqc, dkv, M, L, H, p_a, s_l + 1)
+        if pk is not None:                                          # padded -> packed rows (T = the packed row count)
+            dkv_pad, dkv = dkv, self._buf(T, 2 * d, dev)
+            ops.gather_rows(dkv_pad, pk.tok_idx, dkv, T)
+            del dkv_pad
         self._wq.add(dqc, a["xc"], G["Wqkv"][:d], M, dbias=G["bqkv"][:d])
         self._wq.add(dkv, a["x_in"], G["Wqkv"][d:], T, dbias=G["bqkv"][d:])
         wt = self.ht(i, "qkv")                                      # [d, 3d] = Wqkv^T
@@ -718,7 +794,10 @@ class HipEncoder(nn.Module):
         ops.gemm_nt(dkv, wt[:, d:], g, T)                           # through K and V: every token
         gq = self._buf(M, d, dev)
         ops.gemm_nt(dqc, wt[:, :d], gq, M, residual=ds1)            # through Q and the residual: CLS rows only
-        ops.add_rows_strided(g, gq, M, L)
+        if pk is None:
+            ops.add_rows_strided(g, gq, M, L)
+        else:
+            ops.add_rows_idx(g, gq, pk.cls_idx, M)
         return g
 
     # ------------------------------------------------------------------ backward
@@ -735,6 +814,15 @@ class HipEncoder(nn.Module):
         ``before_last_wgrad()`` (optional) is called once, right before the LAST group of deferred weight gradients is launched:
         from there on this stream runs one long launch that is on nobody's critical path - the place where the trainer puts
         the other tower's latency-bound backward."""
+        base = getattr(self, "seed_base_ptr", None)
+        if base and not getattr(self, "_in_seed_ctx", False):
+            self._in_seed_ctx = True
+            try:
+                with ops.seed_base(base):
+                    return self.backward_from_cls(tape, dcls, after_layer=after_layer, accumulate=accumulate, check_grads=check_grads,
+                                                  before_last_wgrad=before_last_wgrad)
+            finally:
+                self._in_seed_ctx = False
         self._acc = bool(accumulate)
         cfg = self.cfg
         self.ensure_grads(check_all=check_grads)
@@ -808,8 +896,20 @@ class HipEncoder(nn.Module):
             self._wq.add(dA, a["ctx"], G["Wo"], T)
             dctx = self._buf(T, d, dev)
             ops.gemm_nt(dA, self.ht(i, "o"), dctx, T)
-            dqkv = self._buf(T, 3 * d, dev)
-            ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1, drop_bits=a.get("dbits"))
+            pk = tape.pack
+            if pk is None:
+                dqkv = self._buf(T, 3 * d, dev)
+                ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1, drop_bits=a.get("dbits"))
+            else:
+                # packed batch: the context gradient goes to the padded layout attention works on (zero rows in the padding), the
+                # q / k / v gradients come back packed
+                dctx_pad = self._buf(M * L, d, dev)
+                ops.unpack_rows16(dctx, dctx_pad, pk.cu, M, L)
+                dqkv_pad = self._buf(M * L, 3 * d, dev)
+                ops.attention_bwd(a["qkv"], tape.mask, a["ctx_pad"], dctx_pad, a["lse"], dqkv_pad, M, L, H, p_a, s_l + 1, drop_bits=a.get("dbits"))
+                dqkv = self._buf(T, 3 * d, dev)
+                ops.gather_rows(dqkv_pad, pk.tok_idx, dqkv, T)
+                del dctx_pad, dqkv_pad
             self._wq.add(dqkv, a["x_in"], G["Wqkv"], T, dbias=G["bqkv"])
             g = self._buf(T, d, dev)
             ops.gemm_nt(dqkv, self.ht(i, "qkv"), g, T, residual=ds1)
@@ -821,7 +921,8 @@ class HipEncoder(nn.Module):
                          self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
                          tape.mean0, tape.rstd0, self.g("embeddings.word_embeddings.weight"),
                          self.g("embeddings.position_embeddings.weight"), dtype0, self.g("embeddings.LayerNorm.weight"),
-                         self.g("embeddings.LayerNorm.bias"), partial, T, L, tape.p_embed, tape.seed, accumulate=self._acc)
+                         self.g("embeddings.LayerNorm.bias"), partial, T, L, tape.p_embed, tape.seed, accumulate=self._acc,
+                         pos_idx=tape.pack.pos if tape.pack is not None else None)
         layer_done(-1, force=True)
 
     # ------------------------------------------------------------------ HF-style call surface
@@ -908,8 +1009,8 @@ class _EncodeFn(torch.autograd.Function):
     when the CLS gradient arrives; parameter gradients are accumulated straight into ``flat_g`` / ``param.grad``."""
 
     @staticmethod
-    def forward(ctx, anchor, enc, ids, mask, fp16):
-        cls, tape = enc.encode(ids, mask, save=True, fp16=fp16)
+    def forward(ctx, anchor, enc, ids, mask, fp16, lengths=None):
+        cls, tape = enc.encode(ids, mask, save=True, fp16=fp16, lengths=lengths)
         ctx.enc, ctx.tape = enc, tape
         return cls
 
@@ -917,12 +1018,12 @@ class _EncodeFn(torch.autograd.Function):
     def backward(ctx, dcls):
         ctx.enc.backward_from_cls(ctx.tape, dcls.contiguous().float(), check_grads=True)
         ctx.tape = None
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
-def encode_autograd(enc: HipEncoder, ids, mask, fp16=None):
+def encode_autograd(enc: HipEncoder, ids, mask, fp16=None, lengths=None):
     if torch.is_grad_enabled() and any(p.requires_grad for p in enc.parameters()):
         if getattr(enc, "_anchor", None) is None or enc._anchor.device != enc.flat_p.device:
             enc._anchor = torch.zeros(1, device=enc.flat_p.device, requires_grad=True)
-        return _EncodeFn.apply(enc._anchor, enc, ids, mask, fp16)
-    return enc.encode(ids, mask, save=False, fp16=fp16)
+        return _EncodeFn.apply(enc._anchor, enc, ids, mask, fp16, lengths)
+    return enc.encode(ids, mask, save=False, fp16=fp16, lengths=lengths)

@@ -55,6 +55,43 @@ def _chk(t, dtype, name, dim=None):
     return t
 
 
+class seed_base:
+    """``with seed_base(ptr):`` every launch inside passes its ``seed`` argument as an OFFSET: the kernels add the 64-bit word at the device
+    address ``ptr`` at run time (include/cldrd_hip.h: cldrd_set_seed_base).  ``ptr`` None / 0: a no-op context."""
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr) if ptr else None
+
+    def __enter__(self):
+        if self.ptr:
+            _lib.load().cldrd_set_seed_base(self.ptr)
+
+    def __exit__(self, *exc):
+        if self.ptr:
+            _lib.load().cldrd_set_seed_base(None)
+
+
+class optim_hyper:
+    """``with optim_hyper(ptr):`` adamw_step launches inside read {lr, step size} from the device float[2] at ``ptr``."""
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr) if ptr else None
+
+    def __enter__(self):
+        if self.ptr:
+            _lib.load().cldrd_set_optim_hyper(self.ptr)
+
+    def __exit__(self, *exc):
+        if self.ptr:
+            _lib.load().cldrd_set_optim_hyper(None)
+
+
+def write_step_state(seeds, seed0, seed1, hyper, lr, beta1, beta2, adam_step):
+    """seeds: device int64[>= 2]; hyper: device float32[>= 2] (either may be None)."""
+    call("cldrd_write_step_state", _p(seeds), int(seed0) & 0xFFFFFFFFFFFFFFFF, int(seed1) & 0xFFFFFFFFFFFFFFFF, _p(hyper), float(lr), float(beta1),
+         float(beta2), int(adam_step), _stream())
+
+
 def pad_rows(rows: int) -> int:
     """Activation / gradient buffers are allocated with rows rounded up to 64 (allocation granularity only: no kernel reads the
     rows past M any more - the weight-gradient kernel fetches them from a zero page)."""
@@ -244,22 +281,61 @@ def ln_partial_elems(T, d) -> int:
     return _lib.load().cldrd_ln_partial_blocks(T) * 3 * d
 
 
-def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps, dropout_p=0.0, seed=0, out32=None):
+def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps, dropout_p=0.0, seed=0, out32=None, pos_idx=None):
+    """``pos_idx`` (int32 [T], packed batches): the position of every row inside its sequence; None: row % L."""
     _chk(ids, torch.int64, "ids")
     d = word.shape[1]
     if out32 is not None:
         _chk(out32, F32, "out32", 2)
+    if pos_idx is not None:
+        _chk(pos_idx, torch.int32, "pos_idx", 1)
     call("cldrd_embed_ln_fwd", _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd),
-         T, L, d, word.shape[0], eps, dropout_p, seed, _p(out32), _fmt16(out, "out"), _stream())
+         T, L, d, word.shape[0], eps, dropout_p, seed, _p(out32), _fmt16(out, "out"), _p(pos_idx), _stream())
     return out
 
 
 def embed_ln_bwd(dy, ids, word, pos, type0, gamma, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, partial, T, L,
-                 dropout_p=0.0, seed=0, accumulate=True):
+                 dropout_p=0.0, seed=0, accumulate=True, pos_idx=None):
     d = word.shape[1]
+    if pos_idx is not None:
+        _chk(pos_idx, torch.int32, "pos_idx", 1)
     call("cldrd_embed_ln_bwd", _p(dy), _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(mean), _p(rstd), _p(dword),
          _p(dpos), _p(dtype0), _p(dgamma), _p(dbeta), _p(partial), T, L, d, word.shape[0], dropout_p, seed,
-         1 if accumulate else 0, _stream())
+         1 if accumulate else 0, _p(pos_idx), _stream())
+
+
+# ---- variable-length packing (csrc/pack.hip) ---------------------------------------------------------------------------------------
+def unpack_rows16(src_packed, dst_padded, cu, nseq, L):
+    """dst[m * L + j] = j < len[m] ? src[cu[m] + j] : 0 for 16-bit rows (cu: int32 [nseq + 1] on the device)."""
+    _chk(cu, torch.int32, "cu", 1)
+    if src_packed.dtype not in (BF16, F16) or dst_padded.dtype != src_packed.dtype or src_packed.shape[1] != dst_padded.shape[1]:
+        raise TypeError("unpack_rows16: 16-bit matrices of the same width")
+    if not (src_packed.is_contiguous() and dst_padded.is_contiguous()) or dst_padded.shape[0] < nseq * L or cu.numel() < nseq + 1:
+        raise ValueError("unpack_rows16: contiguous operands, dst with nseq * L rows, cu with nseq + 1 entries")
+    call("cldrd_unpack_rows16", _p(src_packed), _p(dst_padded), _p(cu), nseq, L, src_packed.shape[1], _stream())
+    return dst_padded
+
+
+def gather_rows(src, idx, dst, n=None):
+    """dst[p] = src[idx[p]] for p < n (rows of any dtype whose byte length is a multiple of 16)."""
+    _chk(idx, torch.int32, "idx", 1)
+    n = idx.numel() if n is None else n
+    rb = src.shape[1] * src.element_size()
+    if src.dtype != dst.dtype or src.shape[1] != dst.shape[1] or not (src.is_contiguous() and dst.is_contiguous()) or dst.shape[0] < n or idx.numel() < n:
+        raise ValueError("gather_rows: shape mismatch")
+    if n > 0:
+        call("cldrd_gather_rows", _p(src), _p(idx), _p(dst), n, rb, _stream())
+    return dst
+
+
+def scatter_cls_grad_idx(dcls, g, idx, T):
+    _chk(dcls, F32, "dcls", 2), _chk(g, BF16, "g", 2), _chk(idx, torch.int32, "idx", 1)
+    call("cldrd_scatter_cls_grad_idx", _p(dcls), _p(g), dcls.shape[0], dcls.shape[1], _p(idx), T, _stream())
+
+
+def add_rows_idx(dst, src, idx, M):
+    _chk(dst, BF16, "dst", 2), _chk(src, BF16, "src", 2), _chk(idx, torch.int32, "idx", 1)
+    call("cldrd_add_rows_idx", _p(dst), _p(src), M, src.shape[1], _p(idx), _stream())
 
 
 def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_stride=0, out32=None, out_copy=None):

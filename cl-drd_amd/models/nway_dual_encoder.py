@@ -20,6 +20,18 @@ def score_mode(in_batch_loss: bool, all_in_batch_neg: bool) -> int:
     return 0 if not in_batch_loss else (1 if all_in_batch_neg else 2)
 
 
+def _lengths(mapping):
+    """Host-side token counts of a batch mapping ("lengths": list / CPU tensor, any shape, one entry per sequence), or None."""
+    ln = mapping.get("lengths") if hasattr(mapping, "get") else None
+    if ln is None:
+        return None
+    if isinstance(ln, torch.Tensor):
+        if ln.is_cuda:
+            return None                      # a device tensor would cost the host sync packing is meant to avoid
+        return ln.reshape(-1).tolist()
+    return [int(v) for v in ln]
+
+
 class NwayDualEncoder(nn.Module):
     def __init__(self, model_name_or_path, share_weights, in_batch_loss=False, all_in_batch_neg=True):
         super().__init__()
@@ -54,13 +66,15 @@ class NwayDualEncoder(nn.Module):
         return encode_autograd(self.query_encoder, queries["input_ids"], queries.get("attention_mask"), fp16=self.query_fp16)
 
     def passage_embs(self, passages):
-        return encode_autograd(self.passage_encoder, passages["input_ids"], passages.get("attention_mask"), fp16=False)
+        # "lengths" (ours, optional: host-side token counts, one per sequence): the batch is packed (encoder.HipEncoder.encode)
+        return encode_autograd(self.passage_encoder, passages["input_ids"], passages.get("attention_mask"), fp16=False,
+                               lengths=_lengths(passages))
 
     def nway_passage_embs(self, nway_passages):
         input_ids, attention_mask = nway_passages["input_ids"], nway_passages["attention_mask"]
         bz, nway, seq_len = input_ids.shape
         input_ids, attention_mask = input_ids.reshape(bz * nway, seq_len), attention_mask.reshape(bz * nway, seq_len)
-        passage_reps = encode_autograd(self.passage_encoder, input_ids, attention_mask, fp16=False)
+        passage_reps = encode_autograd(self.passage_encoder, input_ids, attention_mask, fp16=False, lengths=_lengths(nway_passages))
         return passage_reps.view(bz, nway, -1)
 
     # -- MI355X-specific ----------------------------------------------------------------------------------------

@@ -48,6 +48,17 @@ MAX_ATTEMPTS = 12
 
 
 def batch_to_device(batch, target_device: torch.device):
+    seq = batch.get("seq") if hasattr(batch, "get") else None
+    if seq is not None and hasattr(seq, "keys") and "lengths" not in seq and isinstance(seq.get("attention_mask"), torch.Tensor) \
+            and not seq["attention_mask"].is_cuda:
+        # token counts while the mask is still on the host: the encoder packs the batch (HipEncoder.encode) - the tokenizer pads every
+        # sequence to the longest of its batch of 512, about half of the rows of an MS MARCO batch
+        m = seq["attention_mask"]
+        lens = m.sum(-1).reshape(-1)
+        if m.dim() == 2 and torch.equal(m != 0, torch.arange(m.shape[1])[None, :] < lens[:, None]):       # right-padded, as HF tokenizers pad
+            seq = dict(seq.items())
+            batch["seq"] = seq
+            seq["lengths"] = lens.tolist()
     for key in batch:
         if isinstance(batch[key], torch.Tensor):
             batch[key] = batch[key].to(target_device)

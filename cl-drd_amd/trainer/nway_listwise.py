@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from .. import hip_ops as ops
 from ..encoder import _env_flag
-from ..models.nway_dual_encoder import NwayDualEncoder, score_mode
+from ..models.nway_dual_encoder import NwayDualEncoder, _lengths, score_mode
 
 LOSS_KINDS = ("lambda_mrr", "ranknet", "kl_div", "margin_mse")
 
@@ -167,9 +167,13 @@ class NwayTrainer:
         if self.comm_stream is not None:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
-    def forward_backward(self, batch):
+    def forward_backward(self, batch, _state_written=False):
         """Runs forward + backward (+ overlapped gradient all-reduce).  Returns (loss_out[2] device tensor, logits)."""
         model = self.model
+        if self._state is not None and not _state_written and not torch.cuda.is_current_stream_capturing():
+            # called on its own (tests, custom loops) while the towers read their dropout seeds from device memory: fresh seeds first
+            seeds = [t.next_seed() for t in model.towers()]
+            ops.write_step_state(self._state["seeds"], seeds[0], seeds[1] if len(seeds) > 1 else 0, None, 0.0, self.betas[0], self.betas[1], 1)
         qe, pe = model.query_encoder, model.passage_encoder
         q, nw = batch["query"], batch["nway_passages"]
         bz, nway, L = nw["input_ids"].shape
@@ -191,7 +195,7 @@ class NwayTrainer:
         with torch.cuda.stream(side):
             q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True, fp16=model.query_fp16)
         p_cls, p_tape = pe.encode(nw["input_ids"].reshape(bz * nway, L), nw["attention_mask"].reshape(bz * nway, L),
-                                  train=True, save=True, fp16=False)
+                                  train=True, save=True, fp16=False, lengths=_lengths(nw))      # "lengths" given: a packed batch
         if side is not main:
             main.wait_stream(side)
             q_cls.record_stream(main)
@@ -242,6 +246,12 @@ class NwayTrainer:
         self.global_step += 1
         self.adam_step += 1
         lr = self.lr(self.global_step - 1)          # the lr in effect during this step (scheduler steps afterwards)
+        self._optimizer_launches(lr, self.adam_step)
+        return lr
+
+    def _optimizer_launches(self, lr, adam_step):
+        """The device work of one optimizer step.  Under a captured step (`_state` installed) lr and the bias-corrected step size are
+        read from device memory at replay time and the by-value arguments given here are ignored by the kernel."""
         ops.grad_clip_coef(self.flat_g, self.max_grad_norm, self.norm_partial, self.clip)
         towers = self.model.towers()
         # one AdamW launch over the joint buffer; it also writes the bf16 shadow of every tower
@@ -250,12 +260,12 @@ class NwayTrainer:
         # high-precision pass of the query tower): one contiguous range of the joint buffer
         s16, r16 = self._joint_shadow16()
         fused16 = s16 is not None and _env_flag("CLDRD_ADAM_H16", "1") != "0"
-        ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, shadow, lr=lr, beta1=self.betas[0],
-                       beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=self.adam_step, clip=self.clip,
-                       shadow16=s16[r16[0]:r16[1]] if fused16 else None, h16_range=r16 if fused16 else None)
+        with ops.optim_hyper(self._state["hyper"].data_ptr() if self._state else None):
+            ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, shadow, lr=lr, beta1=self.betas[0],
+                           beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=adam_step, clip=self.clip,
+                           shadow16=s16[r16[0]:r16[1]] if fused16 else None, h16_range=r16 if fused16 else None)
         for t in towers:
             t.refresh_shadows(need_transposed=True, cast=False, cast16=not fused16)
-        return lr
 
     def _joint_shadow(self):
         if getattr(self, "_shadow", None) is None:
@@ -287,12 +297,117 @@ class NwayTrainer:
         return self._shadow16
 
     def train_step(self, batch):
-        """One full step; returns the device tensor {loss, pair count} (no host sync)."""
+        """One full step; returns the device tensor {loss, pair count} (no host sync).
+
+        After ``CLDRD_GRAPH_WARMUP`` (3) eager steps on one batch shape the step - forward, loss, backward, clip, AdamW, shadows, both
+        streams: ~370 kernel launches - is captured into a HIP graph and replayed (``CLDRD_GRAPH=0``: always eager; never under
+        torch.distributed: the bucket all-reduces are issued from hooks).  The host then spends ~0.1 ms per step instead of ~3.7 ms,
+        which is what an enqueue-bound shape (cfg1: B = 4, N = 8) and eight rank processes sharing one host need.  What changes
+        from step to step - the two towers' dropout seeds, lr, Adam's bias-corrected step size - lives in device memory and is
+        written by one small launch in front of each replay (``ops.write_step_state``); results are bit-identical to the eager path."""
         self._joint_shadow()
-        loss_out, logits = self.forward_backward(batch)
-        self.optimizer_step()
+        if self._graph_wanted() and _lengths(batch["nway_passages"]) is None:      # a packed batch changes its row count every step: eager
+            out = self._train_step_graph(batch)
+            if out is not None:
+                return out
+        if self._state is not None:
+            # a captured shape exists, so the towers read their seeds (and AdamW its lr) from device memory: an eager step (another
+            # batch shape) writes this step's values there first, exactly as a replay does
+            lr = self._advance_step_state()
+            loss_out, logits = self.forward_backward(batch, _state_written=True)
+            self._optimizer_launches(lr, self.adam_step)
+        else:
+            loss_out, logits = self.forward_backward(batch)
+            self.optimizer_step()
         self.last_logits = logits
         return loss_out
+
+    def _advance_step_state(self):
+        """Host bookkeeping of one step (what optimizer_step / encode do in the eager path) + the launch that writes the step's seeds, lr
+        and Adam step size to device memory, in stream order in front of the launches that read them.  Returns lr."""
+        self.global_step += 1
+        self.adam_step += 1
+        lr = self.lr(self.global_step - 1)
+        seeds = [t.next_seed() for t in self.model.towers()]
+        ops.write_step_state(self._state["seeds"], seeds[0], seeds[1] if len(seeds) > 1 else 0, self._state["hyper"], lr, self.betas[0],
+                             self.betas[1], self.adam_step)
+        return lr
+
+    # ---- HIP-graph replay of the step --------------------------------------------------------------------------------------
+    _state = None
+
+    def _graph_wanted(self):
+        return (not self.distributed and not self.model.share_weights and not getattr(self, "_graph_broken", False)
+                and _env_flag("CLDRD_GRAPH", "1") != "0" and self.flat_p.is_cuda)
+
+    @staticmethod
+    def _batch_key(batch):
+        q, nw = batch["query"], batch["nway_passages"]
+        return (tuple(q["input_ids"].shape), q.get("attention_mask") is not None, tuple(nw["input_ids"].shape), tuple(batch["labels"].shape))
+
+    def _train_step_graph(self, batch):
+        key = self._batch_key(batch)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        entry = graphs.get(key)
+        if entry is None:
+            entry = graphs[key] = {"seen": 0, "graph": None}
+        warm = int(_env_flag("CLDRD_GRAPH_WARMUP", "3"))
+        if entry["graph"] is None and entry["seen"] < warm:
+            entry["seen"] += 1              # eager: allocator warm-up, one-time kernel attributes
+            return None
+        dev = self.flat_p.device
+        if self._state is None:
+            self._state = {"seeds": torch.zeros(2, dtype=torch.int64, device=dev), "hyper": torch.zeros(2, dtype=torch.float32, device=dev)}
+        towers = self.model.towers()
+        if entry["graph"] is None:
+            if len(graphs) > 4:            # a few shapes at most (the last partial batch is dropped: drop_last): anything else stays eager
+                return None
+            try:
+                entry.update(self._capture(batch))
+            except Exception as exc:       # a capture problem must never take training down: fall back to the eager step for good
+                import warnings
+                warnings.warn(f"HIP-graph capture of the training step failed ({type(exc).__name__}: {exc}); staying eager")
+                self._graph_broken = True
+                for t in towers:
+                    t.seed_base_ptr = None
+                self._state = None
+                torch.cuda.synchronize()
+                return None
+        # this step's inputs and state, in stream order in front of the replay
+        for dst, src in zip(entry["inputs"], self._flat_inputs(batch)):
+            dst.copy_(src, non_blocking=True)
+        self._advance_step_state()
+        entry["graph"].replay()
+        self.last_logits = entry["logits"]
+        return entry["loss_out"]
+
+    @staticmethod
+    def _flat_inputs(batch):
+        q, nw = batch["query"], batch["nway_passages"]
+        t = [q["input_ids"], nw["input_ids"], nw["attention_mask"], batch["labels"]]
+        if q.get("attention_mask") is not None:
+            t.append(q["attention_mask"])
+        return t
+
+    def _capture(self, batch):
+        dev = self.flat_p.device
+        towers = self.model.towers()
+        q, nw = batch["query"], batch["nway_passages"]
+        static = {"query": {"input_ids": q["input_ids"].to(dev).clone()},
+                  "nway_passages": {"input_ids": nw["input_ids"].to(dev).clone(), "attention_mask": nw["attention_mask"].to(dev).clone()},
+                  "labels": batch["labels"].to(device=dev, dtype=torch.float32).clone()}
+        if q.get("attention_mask") is not None:
+            static["query"]["attention_mask"] = q["attention_mask"].to(dev).clone()
+        for i, t in enumerate(towers):
+            t.seed_base_ptr = self._state["seeds"].data_ptr() + 8 * i
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        # the captured launches take seeds / lr from device memory: nothing of THIS step's values is baked in (the counters are not
+        # advanced here; the capture itself executes nothing)
+        with torch.cuda.graph(g):
+            loss_out, logits = self.forward_backward(static)
+            self._optimizer_launches(0.0, 1)
+        return {"graph": g, "inputs": self._flat_inputs(static), "loss_out": loss_out, "logits": logits, "static": static}
 
     # ---------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -575,12 +690,23 @@ def common_steps_per_epoch(local_steps: int, distributed: bool, dev=None, group=
 
 
 def batch_to_device(batch, dev):
+    """Move a collated batch to the device.  The passages' token counts are taken from the attention mask while it is still on the host
+    ("lengths": what lets the encoder pack the batch without a device -> host sync; CLDRD_PACK=0 turns packing off)."""
+    nw = batch.get("nway_passages")
+    if hasattr(nw, "items") and "lengths" not in nw and isinstance(nw.get("attention_mask"), torch.Tensor) and not nw["attention_mask"].is_cuda:
+        m = nw["attention_mask"]
+        lens = m.sum(-1)
+        if torch.equal(m != 0, torch.arange(m.shape[-1]).expand_as(m) < lens.unsqueeze(-1)):       # right-padded, as HF tokenizers pad
+            nw = dict(nw.items())
+            nw["lengths"] = lens.reshape(-1)
+            batch = dict(batch.items())
+            batch["nway_passages"] = nw
     out = {}
     for k, v in batch.items():
         if isinstance(v, torch.Tensor):
             out[k] = v.to(dev, non_blocking=True)
         elif hasattr(v, "items"):
-            out[k] = {kk: (vv.to(dev, non_blocking=True) if isinstance(vv, torch.Tensor) else vv) for kk, vv in v.items()}
+            out[k] = {kk: (vv.to(dev, non_blocking=True) if (isinstance(vv, torch.Tensor) and kk != "lengths") else vv) for kk, vv in v.items()}
         else:
             out[k] = v
     return out

@@ -120,11 +120,12 @@ int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_
 int cldrd_ln_partial_blocks(int T);
 int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
-                       int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, int out_f16, void* stream);
+                       int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, int out_f16,
+                       const int* pos_idx, void* stream);
 int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
                        float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,
-                       float dropout_p, unsigned long long seed, int accumulate, void* stream);
+                       float dropout_p, unsigned long long seed, int accumulate, const int* pos_idx, void* stream);
 /* out = LN(x)*gamma+beta (bf16); cls_out (fp32 [T/cls_stride, d], optional) receives rows r % cls_stride == 0:
  * the `[0][:, 0, :]` CLS pooling of models/nway_dual_encoder.py:52,56,64.
  * x_f32 != 0: x is fp32 (the pre-LN sum of the fp32 residual stream) and out32 (optional) receives the fp32 output next to
@@ -237,6 +238,29 @@ int cldrd_topk_sort(const int* counts, const int* cand_rows, const float* cand_s
                     int* I, void* stream);
 int cldrd_row_sqnorm_max(const float* P, size_t rows, int d, unsigned int* out, void* stream);
 int cldrd_gather_cast_rows(const float* src, void* dst, size_t n_out, size_t stride, int d, void* stream);
+
+/* ---- variable-length packing (csrc/pack.hip) -----------------------------------------------------------------------------------
+ * The reference pads every sequence of a batch to the longest one (dataset/sequence_dataset.py:50-51, nway_dataset.py:103-107) and the
+ * encoder computes on the padding.  Packed layout: tokens of sequence m = rows cu[m] .. cu[m+1] of a [Tp, features] matrix (cu: device
+ * int32 [nseq + 1]); Linear / LayerNorm / weight gradients run on the Tp real rows, attention on the padded [nseq * L, .] layout.
+ * cldrd_embed_ln_fwd / _bwd take pos_idx (device int32 [T], the position of every row inside its sequence; NULL: row % L).
+ *   unpack_rows16: dst[m * L + j] = j < len[m] ? src[cu[m] + j] : 0  (16-bit rows of w elements);  gather_rows: dst[p] = src[idx[p]]
+ *   (rows of row_bytes bytes: packing, CLS rows);  scatter_cls_grad_idx: g = 0, g[idx[r]] = bf16(dcls[r]);  add_rows_idx: dst[idx[m]] += src[m]. */
+int cldrd_unpack_rows16(const void* src_packed, void* dst_padded, const int* cu, int nseq, int L, int w, void* stream);
+int cldrd_gather_rows(const void* src, const int* idx, void* dst, int n, int row_bytes, void* stream);
+int cldrd_scatter_cls_grad_idx(const float* dcls, void* g, int R, int d, const int* idx, int T, void* stream);
+int cldrd_add_rows_idx(void* dst, const void* src, int M, int d, const int* idx, void* stream);
+
+/* ---- per-step state in device memory: what lets a whole training step be captured into a HIP graph and replayed -------------------
+ * Kernel arguments are frozen at capture; a dropout seed and the optimizer's lr / bias-corrected step size change every step.  With a
+ * seed base installed, every launch of the calling thread passes its `seed` argument as an OFFSET and the kernels add the 64-bit word at
+ * `base` (device memory) at run time; with the optimizer hyper-parameters installed, cldrd_adamw_step* read {lr, step size} from the
+ * device float[2].  cldrd_write_step_state writes both (seeds[0..1]: one word per tower) in stream order - the one launch the trainer
+ * makes in front of each replay.  NULL uninstalls; nothing installed = the by-value arguments, as before (bit-identical results). */
+void cldrd_set_seed_base(const unsigned long long* base);
+void cldrd_set_optim_hyper(const float* hyper);
+int cldrd_write_step_state(unsigned long long* seeds, unsigned long long seed0, unsigned long long seed1, float* hyper, float lr,
+                           float beta1, float beta2, int adam_step, void* stream);
 
 /* ---- run file (retriever/retrieve_top_passages.py:98-105), HOST side: no GPU work -----------------------------------------
  * Writes `qid\tdocid\trank\tscore\n` for nq queries x k hits (rank 1..k) to `path`; the score text is Python's repr of the fp32
