@@ -33,7 +33,7 @@ SIGNATURES = {
     "cldrd_attention_cls_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
     "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, vp]),
     "cldrd_ln_partial_blocks": (ci, [ci]),
-    "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, ci, vp, vp]),
+    "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, ci, vp, vp, vp]),
     "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp, vp]),
     "cldrd_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, ci, ci, vp, ci, vp, vp]),
     "cldrd_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cull, ci, ci, vp]),

@@ -26,6 +26,8 @@ struct GemmNtArgs {
     // EPI_FILTER (top-k scan): keep C[m][n] >= thr[m] as candidate (n, score) of query m
     const float* thr; int* counts; int* cand_rows; float* cand_scores; int cap;
     int in_f16 = 0;               // the operands (and a 16-bit C) are fp16, not bf16: top-k scan, high-precision forward flavours
+    int c_bf16 = 0;               // with in_f16: a 16-bit C is bf16 all the same (fp16 operands, bf16 result: the QKV projection, whose
+                                  // consumers - attention forward and backward - are bf16 kernels)
     bf16_t* c_copy = nullptr;     // with in_f16 and a 16-bit C: a bf16 copy of C [M, ldc] (the backward's MFMAs read bf16: the tape of an
                                   // fp16-operand forward GEMM), or null
     int ksplit = 1;               // small-M kernel: K range split over ksplit workgroups per tile, fp32 partials in `slabs` ([ksplit][M][N]),
@@ -172,7 +174,7 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         *(float4*)C = make_float4(v[0], v[1], v[2], v[3]);
         *(float4*)(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else {
-        const bool h16 = EPI == EPI_GENERIC ? p.in_f16 != 0 : (EPI & EPI_F16IN) != 0;
+        const bool h16 = (EPI == EPI_GENERIC ? p.in_f16 != 0 : (EPI & EPI_F16IN) != 0) && !p.c_bf16;
         if (h16) {
             *(uint4*)((bf16_t*)p.C + crow) = pack8h(v);
             if (p.c_copy) st16_stream(p.c_copy + crow, pack8(v));       // the tape copy: read ~10 ms later by the weight-gradient launch

@@ -247,8 +247,9 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
                                      const float* ln_beta, void* c_copy_bf16, float* workspace, size_t workspace_bytes, void* stream) {
-    CLDRD_CHECK(c_copy_bf16 == nullptr || (io_f16 && !out_f32 && (uintptr_t)c_copy_bf16 % 16 == 0),
-                "gemm_nt: the bf16 copy of C goes with fp16 operands and a 16-bit C");
+    CLDRD_CHECK(io_f16 >= 0 && io_f16 <= 3 && io_f16 != 2, "gemm_nt: io_f16 is 0 (bf16), 1 (fp16 operands and 16-bit C) or 3 (fp16 operands, bf16 C)");
+    CLDRD_CHECK(c_copy_bf16 == nullptr || (io_f16 == 1 && !out_f32 && (uintptr_t)c_copy_bf16 % 16 == 0),
+                "gemm_nt: the bf16 copy of C goes with fp16 operands and an fp16 C");
     {
         const int nln = (ln_mean != nullptr) + (ln_rstd != nullptr) + (ln_gamma != nullptr) + (ln_beta != nullptr);
         CLDRD_CHECK(nln == 0 || nln == 4, "gemm_nt: ln_mean / ln_rstd / ln_gamma / ln_beta go together");
@@ -275,6 +276,7 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
     a.seed = seed; a.seed_base = g_cldrd_seed_base; a.out_f32 = out_f32;
     a.thr = nullptr; a.counts = nullptr; a.cand_rows = nullptr; a.cand_scores = nullptr; a.cap = 0;
     a.in_f16 = io_f16 ? 1 : 0;
+    a.c_bf16 = (io_f16 & 2) ? 1 : 0;
     a.c_copy = (bf16_t*)c_copy_bf16;
     if (workspace != nullptr && K % BK == 0 && N % 8 == 0 && !(io_f16 && gelu_pre)) {
         const int ks = splitk_choice(M, N, K);

@@ -1,5 +1,5 @@
 // fp16-operand instantiations of gemm_nt_ring_kernel: the forward FFN GEMMs of the encoder (HF ffn.lin1 / ffn.lin2, intermediate.dense /
-// output.dense; reference call sites models/nway_dual_encoder.py:52,56,64).
+// output.dense; reference call sites models/nway_dual_encoder.py:52,56,64) and its QKV projection (fp16 operands, bf16 result).
 //
 // Why these two GEMMs: of all 16-bit rounding points of a layer the operands of the FFN GEMMs carry the logit drift (CPU emulation on the
 // cfg1 golden, DESIGN.md section 2: every operand bf16 0.234, FFN operands fp16 and the rest bf16 0.051, everything fp16 0.024, against
@@ -14,6 +14,7 @@ namespace {
 template <int BN>
 int launch_ring16(const GemmNtArgs& a, hipStream_t st) {
     switch (epi_flavour(a)) {
+        case EPI_F16IN | EPI_BIAS: return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS>(a, st);      // QKV projection: fp16 operands, bf16 q / k / v (c_bf16)
         case EPI_F16IN | EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU:
             return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU>(a, st);
         case EPI_F16IN | EPI_BIAS | EPI_GELU: return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS | EPI_GELU>(a, st);

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
                                                             bf16_t* __restrict__ out, float* __restrict__ out32, float* __restrict__ mean_o,
                                                             float* __restrict__ rstd_o, int T, int L, int d_rt, int vocab, float eps,
                                                             uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int out_f16,
-                                                            const int* __restrict__ pos_idx) {
+                                                            const int* __restrict__ pos_idx, bf16_t* __restrict__ out_copy) {
     const uint64_t seed = seed_a.get();
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     const int lane = threadIdx.x & 63;
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void embed_ln_fwd_kernel(const int64_t* __rest
     }
     if (out_f16) store_row_f16(out + (size_t)row * d, d, lane, r);
     else store_row_bf16(out + (size_t)row * d, d, lane, r);
+    if (out_copy) store_row_bf16(out_copy + (size_t)row * d, d, lane, r);
     if (out32) store_row_f32(out32 + (size_t)row * d, d, lane, r);
     if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
 }
@@ -511,13 +512,14 @@ extern "C" int cldrd_layernorm_fwd(const void* x, const float* gamma, const floa
 extern "C" int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
                                   const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
                                   int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, int out_f16,
-                                  const int* pos_idx, void* stream) {
+                                  const int* pos_idx, void* out_bf16_copy, void* stream) {
+    CLDRD_CHECK(out_bf16_copy == nullptr || out_f16, "embed_ln_fwd: the bf16 copy goes with an fp16 output");
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_fwd: bad shape");
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
         hipLaunchKernelGGL((embed_ln_fwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3((T + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                            (const int64_t*)ids, word, pos, type0, gamma, beta, (bf16_t*)out, out32, mean, rstd, T, L, d, vocab, eps, th,
-                           1.0f / (1.0f - dropout_p), seed_arg(seed), out_f16, pos_idx);
+                           1.0f / (1.0f - dropout_p), seed_arg(seed), out_f16, pos_idx, (bf16_t*)out_bf16_copy);
     });
     CLDRD_LAUNCH_CHECK();
     return 0;

@@ -599,14 +599,19 @@ class HipEncoder(nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         S32 = self.stream32
         sdt = torch.float32 if S32 else torch.bfloat16         # storage type of the pre-LN sums
-        x = self._buf(T, d, dev, dt16)
+        # QKV16: the QKV projection reads fp16 operands too (bf16 q / k / v out: the attention kernels are bf16).  With the FFN pair in
+        # fp16, x_in / Wqkv are the next largest source of logit drift (emulated on the BERT-base cfg4 golden: 8.3e-3 -> 5.2e-3 relative);
+        # x then exists in fp16 (`xh`: the GEMM operand) and, when a tape is kept, in bf16 (`x`: the weight gradient's operand).
+        QKV16 = self.ffn_fp16 and S32 and not fp16 and _env_flag("CLDRD_QKV_FP16", "1") != "0"
+        x = self._buf(T, d, dev, dt16) if (save or not QKV16) else None
+        xh = self._buf(T, d, dev, torch.float16) if QKV16 else None
         x32 = self._buf(T, d, dev, torch.float32) if S32 else None      # fp32 copy of the layer input: the residual operand
         mean0, rstd0 = torch.empty(T, **f32), torch.empty(T, **f32)
         type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
         ops.embed_ln_fwd(ids.view(-1), self.w("embeddings.word_embeddings.weight"),
                          self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
-                         self.w("embeddings.LayerNorm.bias"), x, mean0, rstd0, T, L, cfg.eps, p_h, seed, out32=x32,
-                         pos_idx=pk.pos if pk is not None else None)
+                         self.w("embeddings.LayerNorm.bias"), xh if QKV16 else x, mean0, rstd0, T, L, cfg.eps, p_h, seed, out32=x32,
+                         pos_idx=pk.pos if pk is not None else None, out_copy=x if QKV16 else None)
         if save:
             tape.mean0, tape.rstd0 = mean0, rstd0
         cls = torch.empty(M, d, **f32)
@@ -622,10 +627,13 @@ class HipEncoder(nn.Module):
             W16 = self._layer_weights(i, True) if FFN16 else None
             s_l = seed + 7919 * (i + 1)
             if i == cfg.n_layers - 1 and self.cls_only_last:
-                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16, W16, pk)
+                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16, W16, pk, xh)
                 break
             qkv = self._buf(T, 3 * d, dev, dt16)
-            ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
+            if QKV16:
+                ops.gemm_nt(xh, W16["Wqkv"], qkv, T, bias=W["bqkv"])          # fp16 operands, bf16 q / k / v
+            else:
+                ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
             lse = torch.empty(M, H, L, **f32) if save else None
             dbits = ops.attention_drop_bits(M, L, H, p_a, dev) if (save and dt16 == torch.bfloat16) else None      # dropout keep bits for the backward
             ctx_pad = None
@@ -668,52 +676,69 @@ class HipEncoder(nn.Module):
                 s2 = self._buf(T, d, dev, sdt)
                 ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=(s1 if LNF else x1_32) if S32 else x1, dropout_p=p_h, seed=s_l + 3,
                             residual_ln=(mean1, rstd1, W["g1"], W["b1"]) if LNF else None)
-            xo = self._buf(T, d, dev, dt16)
+            xo = self._buf(T, d, dev, dt16) if (save or not QKV16) else None
+            xoh = self._buf(T, d, dev, torch.float16) if QKV16 else None
             last = i == cfg.n_layers - 1
             # the CLS-only last layer gathers its fp32 residual rows from a stored copy: the layer before it still writes one
             need32 = S32 and not last and ((i + 1 == cfg.n_layers - 1 and self.cls_only_last) or not LNF)
             xo32 = self._buf(T, d, dev, torch.float32) if need32 else None
             mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
-            ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32)
+            ops.layernorm_fwd(s2, W["g2"], W["b2"], xoh if QKV16 else xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32,
+                              out_copy=xo if QKV16 else None)
             if save:
                 tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, ctx_pad=ctx_pad, lse=lse, dbits=dbits, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
                                         h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h, p_a=p_a, p_out=p_out))
-            x = xo
+            x, xh = xo, xoh
             if S32:
                 x32, res_ln = (xo32, None) if need32 else (s2, (mean2, rstd2, W["g2"], W["b2"]))
         if cfg.n_layers == 0:
-            cls.copy_(x.view(ops.pad_rows(T), d)[:T].view(M, L, d)[:, 0].float())
+            src = x if x is not None else xh
+            cls.copy_(src.view(ops.pad_rows(T), d)[:T].view(M, L, d)[:, 0].float())
         return (cls, tape) if save else cls
 
     # ------------------------------------------------------------------ last layer, CLS row only
-    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16=torch.bfloat16, W16=None, pk=None):
+    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16=torch.bfloat16, W16=None, pk=None, xh=None):
         """Only ``last_hidden_state[:, 0, :]`` is consumed (reference models/nway_dual_encoder.py:52,56,64), so the last
         layer projects K and V for every token but Q, attention, out-proj, FFN and both LayerNorms for token 0 only:
         identical CLS output, ~1/6 of the layer's FLOPs."""
         cfg = self.cfg
         d, f, H = cfg.dim, cfg.hidden_dim, cfg.n_heads
-        dev = x.device
+        dev = (x if x is not None else xh).device
         f32 = dict(dtype=torch.float32, device=dev)
         kv = self._buf(T, 2 * d, dev, dt16)
-        ops.gemm_nt(x, W["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
+        Q16 = xh is not None and W16 is not None              # fp16 operands for the K / V / Q projections (bf16 results), see _encode
+        if Q16:
+            ops.gemm_nt(xh, W16["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
+        else:
+            ops.gemm_nt(x, W["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
         S32 = x32 is not None
         sdt = torch.float32 if S32 else torch.bfloat16
-        xc = self._buf(M, d, dev, dt16)
+        xc = self._buf(M, d, dev, dt16) if x is not None else None          # bf16 CLS rows: the weight gradient's operand (and, without Q16, the GEMM's)
+        xch = self._buf(M, d, dev, torch.float16) if Q16 else None
         xc32 = self._buf(M, d, dev, torch.float32) if S32 else None
         if pk is None:
-            xc[:M].copy_(x[:T].view(M, L, d)[:, 0, :])             # gather the CLS rows (a copy, no arithmetic)
+            if xc is not None:
+                xc[:M].copy_(x[:T].view(M, L, d)[:, 0, :])         # gather the CLS rows (a copy, no arithmetic)
+            if Q16:
+                xch[:M].copy_(xh[:T].view(M, L, d)[:, 0, :])
             if S32:
                 xc32[:M].copy_(x32[:T].view(M, L, d)[:, 0, :])
         else:
             # packed batch: the CLS token of sequence m is row cu[m]; K / V go to the padded layout the CLS attention kernel reads
-            ops.gather_rows(x, pk.cls_idx, xc, M)
+            if xc is not None:
+                ops.gather_rows(x, pk.cls_idx, xc, M)
+            if Q16:
+                ops.gather_rows(xh, pk.cls_idx, xch, M)
             if S32:
                 ops.gather_rows(x32, pk.cls_idx, xc32, M)
             kv_p, kv = kv, self._buf(M * L, 2 * d, dev, dt16)
             ops.unpack_rows16(kv_p, kv, pk.cu, M, L)
             del kv_p
         qc = self._buf(M, d, dev, dt16)
-        ops.gemm_nt(xc, W["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
+        if Q16:
+            ops.gemm_nt(xch, W16["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
+        else:
+            ops.gemm_nt(xc, W["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
         ctxc = self._buf(M, d, dev, dt16)
         probs = torch.empty(M, H, L, **f32)
         ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1)

@@ -109,6 +109,8 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
     io_f16 = _fmt16(A, "A")
     dt16 = F16 if io_f16 else BF16
     _chk(A, dt16, "A", 2), _chk(B, dt16, "B", 2)
+    if io_f16 and out.dtype == BF16:
+        io_f16, dt16 = 3, BF16              # fp16 operands, bf16 result (the QKV projection in front of the bf16 attention kernels)
     M = A.shape[0] if M is None else M
     N, K = B.shape
     if A.shape[1] != K or out.shape[1] != N or out.shape[0] < M or A.shape[0] < M:
@@ -281,7 +283,7 @@ def ln_partial_elems(T, d) -> int:
     return _lib.load().cldrd_ln_partial_blocks(T) * 3 * d
 
 
-def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps, dropout_p=0.0, seed=0, out32=None, pos_idx=None):
+def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps, dropout_p=0.0, seed=0, out32=None, pos_idx=None, out_copy=None):
     """``pos_idx`` (int32 [T], packed batches): the position of every row inside its sequence; None: row % L."""
     _chk(ids, torch.int64, "ids")
     d = word.shape[1]
@@ -290,7 +292,7 @@ def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps,
     if pos_idx is not None:
         _chk(pos_idx, torch.int32, "pos_idx", 1)
     call("cldrd_embed_ln_fwd", _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(beta), _p(out), _p(mean), _p(rstd),
-         T, L, d, word.shape[0], eps, dropout_p, seed, _p(out32), _fmt16(out, "out"), _p(pos_idx), _stream())
+         T, L, d, word.shape[0], eps, dropout_p, seed, _p(out32), _fmt16(out, "out"), _p(pos_idx), _p(out_copy), _stream())
     return out
 
 

@@ -222,8 +222,9 @@ class NwayTrainer:
                 dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM)
         else:
             def query_backward():
-                side.wait_stream(main)
-                dq.record_stream(side)
+                if side is not main:
+                    side.wait_stream(main)
+                    dq.record_stream(side)
                 with torch.cuda.stream(side):
                     qe.backward_from_cls(q_tape, dq, after_layer=self._bucket_hook(0), accumulate=not write_once)
             # Where the query tower's ~150 small backward launches run: next to the passage tower's data-gradient chain (default), or

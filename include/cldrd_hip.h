@@ -41,7 +41,8 @@ int cldrd_device_ok(void);            /* 1 if device 0 is a gfx950 */
  *   K % 64 == 0; A/B/C 16-byte aligned; out_f32 != 0 stores fp32 instead of bf16; res_f32 != 0: `residual` is fp32
  *   (the fp32 residual stream: out-projection / FFN2 add the fp32 LayerNorm output and store the fp32 pre-LN sum, as the
  *   reference's autocast does - trainer/multistep-curriculum/nway_listwise_1.py:334).
- *   io_f16 != 0: A, B and a 16-bit C are fp16 instead of bf16 (same MFMA rate, 11-bit significands): the forward kernels
+ *   io_f16 = 1: A, B and a 16-bit C are fp16 instead of bf16 (same MFMA rate, 11-bit significands); io_f16 = 3: fp16 A and B, bf16 C
+ *   (the QKV projection of a forward whose attention kernels are bf16); the forward kernels
  *   (this one for M < 1024, attention_fwd for L <= 128, attention_cls_fwd, layernorm_fwd, embed_ln_fwd) take this format for the
  *   high-precision forward of the query tower; the backward entry points are bf16 only. */
 int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
@@ -121,7 +122,7 @@ int cldrd_ln_partial_blocks(int T);
 int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* beta, void* out, float* mean, float* rstd, int T, int L,
                        int d, int vocab, float eps, float dropout_p, unsigned long long seed, float* out32, int out_f16,
-                       const int* pos_idx, void* stream);
+                       const int* pos_idx, void* out_bf16_copy, void* stream);
 int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
                        float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,

@@ -20,7 +20,7 @@ tr = NwayTrainer(model, loss=c["loss"])
 kind = "teacher" if c["loss"] in ("kl_div", "margin_mse") else "mode9"
 batch = syn.nway_batch(4680, c["B"], c["N"], 30, c["L"], label_kind=kind)
 batch = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in batch.items()}
-for _ in range(2): out = tr.train_step(batch)
+for _ in range(6): out = tr.train_step(batch)      # 3 eager steps, the graph capture, two replays
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps): out = tr.train_step(batch)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
