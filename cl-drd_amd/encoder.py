@@ -602,7 +602,10 @@ class HipEncoder(nn.Module):
         # QKV16: the QKV projection reads fp16 operands too (bf16 q / k / v out: the attention kernels are bf16).  With the FFN pair in
         # fp16, x_in / Wqkv are the next largest source of logit drift (emulated on the BERT-base cfg4 golden: 8.3e-3 -> 5.2e-3 relative);
         # x then exists in fp16 (`xh`: the GEMM operand) and, when a tape is kept, in bf16 (`x`: the weight gradient's operand).
-        QKV16 = self.ffn_fp16 and S32 and not fp16 and _env_flag("CLDRD_QKV_FP16", "1") != "0"
+        # Default: towers deeper than 6 layers (BERT-base; measured cfg4 0.190 -> 0.116).  The 6-layer DistilBERT configs are at 2-3.5e-3
+        # without it and would only pay its +0.9 % step time (profiles/r03_microbench.txt); CLDRD_QKV_FP16=1 / 0 forces it on / off.
+        qkv_env = _env_flag("CLDRD_QKV_FP16", "auto")
+        QKV16 = self.ffn_fp16 and S32 and not fp16 and (qkv_env == "1" or (qkv_env not in ("0", "1") and cfg.n_layers > 6))
         x = self._buf(T, d, dev, dt16) if (save or not QKV16) else None
         xh = self._buf(T, d, dev, torch.float16) if QKV16 else None
         x32 = self._buf(T, d, dev, torch.float32) if S32 else None      # fp32 copy of the layer input: the residual operand

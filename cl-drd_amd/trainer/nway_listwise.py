@@ -119,7 +119,8 @@ class NwayTrainer:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.distributed else None
         if self.comm_stream is not None:
             self.flat_g.record_stream(self.comm_stream)        # the bucket slices are used on it (the buffer lives as long as the trainer)
-        self.q_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # priority of the query tower's stream relative to torch's current stream (0): CLDRD_Q_PRIO=-1 high (A/B runs)
+        self.q_stream = torch.cuda.Stream(device=dev, priority=int(_env_flag("CLDRD_Q_PRIO", "0"))) if dev.type == "cuda" else None
         self._pending = []
         if self.distributed:
             # DDP constructor semantics (reference :250-255): rank 0's parameters win

@@ -52,7 +52,7 @@ def cfg_of(arch, layers):
 
 
 @pytest.mark.parametrize("arch,layers", [("distilbert", 3), ("bert", 2), ("distilbert", 1)])
-@pytest.mark.parametrize("ffn16,qkv16", [("1", "1"), ("1", "0"), ("0", "0")])
+@pytest.mark.parametrize("ffn16,qkv16", [("1", "1"), ("1", "0"), ("1", "auto"), ("0", "0")])
 @pytest.mark.parametrize("packed", [False, True])
 def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, ffn16, qkv16, packed):
     monkeypatch.setenv("CLDRD_FFN_FP16", ffn16)

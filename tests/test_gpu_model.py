@@ -282,7 +282,7 @@ def test_full_size_configs_match_reference_goldens(name):
                   f"{err / a16.max():.2f} x / {rms / np.sqrt(np.mean(a16 ** 2)):.2f} x; relative to max|logit|: {err / np.abs(ref).max():.2e}")
         if model.passage_encoder.ffn_fp16:
             # GPU vs fp32 oracle, logits <= 5e-3 relative (met since the FFN GEMMs read fp16 operands)
-            rel_bar = 5e-3 if arch == "distilbert" else 1e-2       # BERT-base at L = 256: see DESIGN.md section 2 (the attention-side operands)
+            rel_bar = 5e-3 if arch == "distilbert" else 7.5e-3     # BERT-base at L = 256: 5.5e-3 measured (the out-projection's operands)
             assert err <= rel_bar * np.abs(ref).max(), f"{name}: max|dlogit| {err:.4f} above {rel_bar:g} x max|logit| = {rel_bar * np.abs(ref).max():.4f}"
         if "loss" in g.files:                                # cfg1 golden (round 1 layout)
             ref_loss, names, vals = float(g["loss"]), [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]
