@@ -61,7 +61,7 @@ def pmc_traffic(kernel_substr, timeout_s=150):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "r", "--", sys.executable, here,
-                   "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-index", "--no-retrieve", "--no-kernel-events", "--no-pmc"]
+                   "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-index", "--no-retrieve", "--no-kernel-events", "--no-pmc", "--no-ragged"]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--no-retrieve", action="store_true")
+    ap.add_argument("--no-ragged", action="store_true", help="skip the MSMARCO-shaped (padded / packed) extra legs")
     ap.add_argument("--retrieve-rows", type=int, default=1105228, help="index rows per GPU (8 841 823 / 8)")
     ap.add_argument("--retrieve-queries", type=int, default=6980, help="queries searched against the shard (MS MARCO dev: 6980)")
     args = ap.parse_args()
@@ -227,6 +228,8 @@ def main():
     # only).  Extra keys: the headline above stays the all-ones batch the survey defines.
     ragged = None
     try:
+        if args.no_ragged:
+            raise RuntimeError("skipped (--no-ragged)")
         rb = syn.nway_batch(4680 + 1000 * rank, B, N, Lq, L, ragged=True, label_kind="teacher")
         lens = rb["nway_passages"]["attention_mask"].sum(-1).reshape(-1)
         rb = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in rb.items()}
@@ -248,7 +251,7 @@ def main():
         ragged = {"token_fill": round(float(lens.sum()) / (B * N * L), 3), "padded_samples_per_s": round(world * B * 10 / float(tr_[0]), 1),
                   "packed_samples_per_s": round(world * B * 10 / float(tr_[1]), 1), "steps": 10}
     except Exception as exc:
-        ragged = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        ragged = None if args.no_ragged else {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     roofline = None
     if gemm_events and rank == 0:
@@ -295,23 +298,24 @@ def main():
                 torch.cuda.synchronize()
                 di = time.perf_counter() - t1
             index = {"seconds": di, "it": it}
-            # MSMARCO-shaped lengths, padded to the longest row of the batch as the tokenizer does, packed vs computed on the padding
-            rbq = syn.seq_batch(199 + rank, 512, L, ragged=True)["seq"]
-            ilen = rbq["attention_mask"].sum(-1)
-            longest = int(ilen.max())
-            rid, rmask = rbq["input_ids"][:, :longest].contiguous().to(dev), rbq["attention_mask"][:, :longest].contiguous().to(dev)
-            with torch.no_grad():
-                for tag, extra in (("padded", {}), ("packed", {"lengths": ilen})):
-                    enc = {"input_ids": rid, "attention_mask": rmask, **extra}
-                    for _ in range(2):
-                        model.passage_embs(enc)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    for _ in range(it):
-                        model.passage_embs(enc)
-                    torch.cuda.synchronize()
-                    index[f"ragged_{tag}_s"] = time.perf_counter() - t1
-            index["ragged_fill"] = float(ilen.sum()) / (512 * longest)
+            if not args.no_ragged:
+                # MSMARCO-shaped lengths, padded to the longest row of the batch as the tokenizer does, packed vs computed on the padding
+                rbq = syn.seq_batch(199 + rank, 512, L, ragged=True)["seq"]
+                ilen = rbq["attention_mask"].sum(-1)
+                longest = int(ilen.max())
+                rid, rmask = rbq["input_ids"][:, :longest].contiguous().to(dev), rbq["attention_mask"][:, :longest].contiguous().to(dev)
+                with torch.no_grad():
+                    for tag, extra in (("padded", {}), ("packed", {"lengths": ilen})):
+                        enc = {"input_ids": rid, "attention_mask": rmask, **extra}
+                        for _ in range(2):
+                            model.passage_embs(enc)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(it):
+                            model.passage_embs(enc)
+                        torch.cuda.synchronize()
+                        index[f"ragged_{tag}_s"] = time.perf_counter() - t1
+                index["ragged_fill"] = float(ilen.sum()) / (512 * longest)
     except Exception as exc:      # a secondary leg must not take the headline line down with it
         index = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     if not args.no_index:         # the collective sits outside the try: every rank reaches it whatever happened above

@@ -37,6 +37,7 @@ struct TnProblem {
     const bf16_t* A; const bf16_t* B; float* dW; float* dbias;      // dbias may be null
     int M, N1, N2, lda, ldb;
     int tiles, nt2;                    // (N1 / T1) * (N2 / T2), N2 / T2
+    int nt1, n1_fast;                  // N1 / T1; tile order inside a split: n2 fastest (0) or n1 fastest (1), see cldrd_wgrad_group
     int first;                         // first work item of this problem; items of a problem: split-major, tile-minor
     long long slab_off;                // splits > 1: float offset of this problem's slabs in the workspace
 };
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
     const int nt2 = P.nt2, ntiles = P.tiles;
     const int local = id - P.first;
     const int split = local / ntiles, tile = local % ntiles;      // the tiles of one split are neighbours: they share A/B rows
-    const int c1 = (tile / nt2) * T1, c2 = (tile % nt2) * T2;
+    const int c1 = (P.n1_fast ? tile % P.nt1 : tile / nt2) * T1, c2 = (P.n1_fast ? tile / P.nt1 : tile % nt2) * T2;
     const int ktotal = (M + BK - 1) / BK;
     const int ksteps_per_split = (ktotal + ga.splits - 1) / ga.splits;
     const int kbeg = split * ksteps_per_split;
@@ -579,6 +580,8 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
         for (int i = 0; i < n; ++i) need += (size_t)splits * ((size_t)N1[i] * N2[i] + (size_t)N1[i]);
         CLDRD_CHECK(workspace != nullptr && ((uintptr_t)workspace % 16 == 0) && workspace_bytes >= need * sizeof(float), "wgrad: workspace too small");
     }
+    static int env_order = -2;
+    if (env_order == -2) { const char* e = getenv("CLDRD_WGRAD_N1FAST"); env_order = e ? atoi(e) : -1; }      // 0 / 1 force, default: per problem
     size_t slab_off = 0;
     for (int lo = 0; lo < n; lo += MAXP) {
         const int m = n - lo < MAXP ? n - lo : MAXP;
@@ -590,7 +593,12 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
             const int j = lo + i;
             P.A = (const bf16_t*)A[j]; P.B = (const bf16_t*)B[j]; P.dW = dW[j]; P.dbias = dbias[j];
             P.M = M[j]; P.N1 = N1[j]; P.N2 = N2[j]; P.lda = lda[j]; P.ldb = ldb[j];
-            P.nt2 = N2[j] / t.t2; P.tiles = (N1[j] / t.t1) * P.nt2;
+            P.nt2 = N2[j] / t.t2; P.nt1 = N1[j] / t.t1; P.tiles = P.nt1 * P.nt2;
+            // The 32 workgroups that run side by side on one XCD take consecutive tiles of a problem and share operand panels through its
+            // L2.  With n2 fastest they cover (32 / nt2) A panels x all nt2 B panels: fine while nt2 is small (QKV, FFN1: nt2 = 4).  FFN2 has
+            // 3 n1 tiles x 16 n2 tiles: n2 fastest covers 2 of the 3 rows, so every panel of h (the 200-MB operand) is fetched by 2 concurrent
+            // tiles now and again by the third row later; n1 fastest puts all 3 tiles of an h panel side by side: h streams from HBM once.
+            P.n1_fast = (env_order == 1 || (env_order < 0 && P.nt2 > P.nt1 && P.nt1 <= 32)) ? 1 : 0;
             P.first = items; P.slab_off = (long long)slab_off;
             items += P.tiles * splits;
             if (splits > 1) slab_off += (size_t)splits * ((size_t)N1[j] * N2[j] + (size_t)N1[j]);

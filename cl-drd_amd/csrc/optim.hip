@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
         if (!skip) {
             const float4 g = ntload4((const float4*)a.g + i);
             float4 m = ntload4((const float4*)a.m + i), v = ntload4((const float4*)a.v + i);
-            const bool dec = a.decay[i >> 4] != 0;         // flag per 64 elements
+            const bool dec = (a.decay[i >> 4] & 1) != 0;   // flag byte per 64 elements: bit 0 weight decay, bit 1 no 16-bit shadows
             const float gg[4] = {g.x * coef, g.y * coef, g.z * coef, g.w * coef};
             float pp[4] = {p.x, p.y, p.z, p.w}, mm[4] = {m.x, m.y, m.z, m.w}, vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -93,11 +93,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
             ntstore4((float4*)a.m + i, make_float4(mm[0], mm[1], mm[2], mm[3]));
             ntstore4((float4*)a.v + i, make_float4(vv[0], vv[1], vv[2], vv[3]));
         }
-        if (a.shadow) {
+        // embedding tables (35 % of the parameters) are read by the embedding kernel in fp32: nobody reads their 16-bit shadows
+        const bool no_shadow = (a.decay[i >> 4] & 2) != 0;
+        if (a.shadow && !no_shadow) {
             uint2 o; o.x = pack2bf(p.x, p.y); o.y = pack2bf(p.z, p.w);
             ((uint2*)a.shadow)[i] = o;
         }
-        if (a.shadow16 && i >= a.h_lo4 && i < a.h_hi4) {
+        if (a.shadow16 && !no_shadow && i >= a.h_lo4 && i < a.h_hi4) {
             const _Float16 h0 = (_Float16)p.x, h1 = (_Float16)p.y, h2 = (_Float16)p.z, h3 = (_Float16)p.w;
             uint2 o;
             o.x = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);

@@ -108,7 +108,10 @@ class NwayTrainer:
                     numel *= s
                 prefix = "query_encoder." if ti == 0 else "passage_encoder."
                 if not no_decay(prefix + name):
-                    flags[(toff + off) // 64:(toff + off + numel + 63) // 64] = 1
+                    flags[(toff + off) // 64:(toff + off + numel + 63) // 64] |= 1
+                if name.startswith("embeddings.") and name.endswith("_embeddings.weight"):
+                    # bit 1: no bf16 / fp16 shadow (cldrd_adamw_step): the embedding kernels read the fp32 tables
+                    flags[(toff + off) // 64:(toff + off + numel + 63) // 64] |= 2
             for li, (a, b) in enumerate(tower.layout.layer_range):
                 self.buckets.append((ti, li, toff + a, toff + b))
             a, b = tower.layout.embed_range

@@ -179,7 +179,9 @@ int cldrd_lambda_loss_fwd_bwd(const float* y_pred, const float* y_true, float* l
                               int log2_reduction, int gain_linear, void* stream);
 
 /* ---- optimizer step (trainer/multistep-curriculum/nway_listwise_1.py:353-367) ------------------------------
- * One flat fp32 buffer for all parameters.  clip out: float[3] = {grad L2 norm, clip coefficient, non-finite flag}. */
+ * One flat fp32 buffer for all parameters.  clip out: float[3] = {grad L2 norm, clip coefficient, non-finite flag}.
+ * decay_flags: one byte per 64 parameters: bit 0 = weight decay applies, bit 1 = leave the 16-bit shadows of this chunk unwritten
+ * (embedding tables: read in fp32 by the embedding kernels). */
 int cldrd_sqnorm_blocks(void);
 int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, float* partial, float* out, void* stream);
 int cldrd_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,

@@ -704,6 +704,30 @@ def test_adamw_step_writes_the_fp16_shadow_of_a_sub_range():
                        shadow16=h16, h16_range=(lo + 1, hi))
 
 
+def test_adamw_flag_bit_1_leaves_the_shadows_of_a_chunk_unwritten():
+    """decay_flags bit 1 (embedding tables: read in fp32, nobody reads their 16-bit shadows): p / m / v are updated exactly as without
+    the bit, the bf16 and fp16 shadows of those 64-element chunks keep their old contents."""
+    n = 64 * 40
+    p, g = rnd(60, (n,)), rnd(61, (n,), 0.01)
+    m, v = rnd(62, (n,), 0.001), rnd(63, (n,), 0.001).abs() * 1e-3
+    base = torch.zeros(n // 64, dtype=torch.uint8); base[::2] = 1
+    skip = base.clone(); skip[5:17] |= 2
+    outs = []
+    for flags in (base, skip):
+        pd, gd, md, vd = (a.to(DEV).clone() for a in (p, g, m, v))
+        shadow = torch.full((n,), 3.0, dtype=torch.bfloat16, device=DEV)
+        h16 = torch.full((n,), 5.0, dtype=torch.float16, device=DEV)
+        ops.adamw_step(pd, gd, md, vd, flags.to(DEV), shadow, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=2,
+                       shadow16=h16, h16_range=(0, n))
+        outs.append((pd, md, vd, shadow, h16))
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(a, b)
+    lo, hi = 5 * 64, 17 * 64
+    assert (outs[1][3][lo:hi] == 3.0).all() and (outs[1][4][lo:hi] == 5.0).all()
+    keep = torch.ones(n, dtype=torch.bool, device=DEV); keep[lo:hi] = False
+    assert torch.equal(outs[1][3][keep], outs[0][3][keep]) and torch.equal(outs[1][4][keep], outs[0][4][keep])
+
+
 def test_transpose_cast_batched():
     src = rnd(44, (128 * 96 + 64 * 200,))
     desc = torch.tensor([0, 0, 128, 96, 128 * 96, 128 * 96, 64, 200], dtype=torch.int64, device=DEV)
