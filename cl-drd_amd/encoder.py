@@ -860,9 +860,10 @@ class HipEncoder(nn.Module):
         self._wq = ops.WgradQueue()
         # LayerNorm gamma / beta (and the preceding Linear's bias) gradients can be deferred likewise (CLDRD_LN_DEFER=1): each
         # layernorm_bwd leaves its per-block sums in a scratch buffer of its own and one launch next to the weight-gradient group reduces
-        # them all.  Bit-identical and 22 launches fewer per step, but OFF by default: the step time does not move at cfg2 (the 7-us
-        # reductions cost nothing there) and the enqueue-bound cfg1 ran slower with it (profiles/r02_microbench.txt).
-        self._lnq = ops.LnReduceQueue() if _env_flag("CLDRD_LN_DEFER", "0") == "1" else None
+        # them all.  Bit-identical and 22 launches fewer per step.  Round 2 kept it off (±0 at cfg2, slower on the then enqueue-bound
+        # cfg1); measured again in round 3 with the step replayed as a HIP graph: -1.0 % step time at cfg2, twice on one box
+        # (profiles/r03_microbench.txt): on by default, CLDRD_LN_DEFER=0 restores the immediate reductions.
+        self._lnq = ops.LnReduceQueue() if _env_flag("CLDRD_LN_DEFER", "1") == "1" else None
         flush_every = int(getattr(self, "wgrad_flush_layers", 0) or 0)
         waiting = []
 

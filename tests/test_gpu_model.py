@@ -149,7 +149,7 @@ def test_trainer_step_matches_oracle_update():
     assert lr == pytest.approx(1e-3 * 0.5)
     total, coef = O.clip_coef([g.cpu().numpy()], 1.0)
     assert tr.clip[0].item() == pytest.approx(total, rel=1e-4)
-    dec = tr.decay_flags.repeat_interleave(64).bool().cpu().numpy()
+    dec = (tr.decay_flags & 1).repeat_interleave(64).bool().cpu().numpy()        # bit 0: weight decay (bit 1: no 16-bit shadow)
     gn = g.double().cpu().numpy() * coef
     z = np.zeros_like(gn)
     p1, _, _ = O.adamw_step(p0.cpu().numpy(), gn, z, z, lr=lr, step=2, weight_decay=0.0)
@@ -163,9 +163,15 @@ def test_trainer_step_matches_oracle_update():
     assert not dec[off]
     off, _ = model.query_encoder.layout.entries["transformer.layer.0.ffn.lin1.bias"]
     assert not dec[off]
-    # shadows follow the update
+    # shadows follow the update (the embedding tables have none that anybody reads: the embedding kernels take the fp32 tables)
     t = model.query_encoder
-    assert torch.equal(t.flat_h.float(), t.flat_p.to(torch.bfloat16).float())
+    used = torch.ones(t.layout.total, dtype=torch.bool, device="cuda")
+    for n in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):
+        off, shape = t.layout.entries[n]
+        used[off:off + shape[0] * shape[1]] = False
+    assert torch.equal(t.flat_h.float()[used], t.flat_p.to(torch.bfloat16).float()[used])
+    skip = (tr.decay_flags & 2).repeat_interleave(64).bool()[:t.layout.total]
+    assert torch.equal(skip, ~used)
     w2 = t.w("transformer.layer.0.ffn.lin2.weight")
     assert torch.equal(t.ht(0, "f2").float(), w2.T.contiguous().to(torch.bfloat16).float())
 
@@ -625,3 +631,28 @@ def test_packed_index_encode_matches_padded(monkeypatch):
     assert ids1 == ids0 == list(range(700))
     print(f"packed index encode: identical rows {np.mean(np.all(e1 == e0, axis=1)):.2f}, max rel diff {np.abs(e1 - e0).max() / np.abs(e0).max():.2e}")
     assert np.abs(e1 - e0).max() <= 2e-3 * np.abs(e0).max()
+
+
+@pytest.mark.parametrize("arch", ["distilbert", "bert"])
+def test_deferred_layernorm_parameter_gradients_equal_the_immediate_ones(arch, monkeypatch):
+    """CLDRD_LN_DEFER (default on since round 3: the LayerNorm gamma / beta and preceding-bias gradients of a tower are reduced by one grouped
+    launch next to each weight-gradient group) against the immediate per-LayerNorm reductions: the whole gradient buffer bit for bit outside
+    the embedding tables (float atomics)."""
+    cfg = small_cfg(arch=arch, layers=3)
+    model = selftest.build_tiny_model(cfg).cuda().train()
+    tr = NwayTrainer(model, loss="kl_div")
+    batch = syn.nway_batch(4690, 3, 4, 8, 32, vocab=cfg.vocab_size, ragged=True)
+    grads = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("CLDRD_LN_DEFER", mode)
+        tr.flat_g.fill_(7.0)
+        tr.forward_backward(batch)
+        torch.cuda.synchronize()
+        grads[mode] = tr.flat_g.clone()
+    emb = torch.zeros_like(tr.flat_g, dtype=torch.bool)
+    for tower, toff in zip(model.towers(), model._tower_offsets):
+        for n in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight"):
+            off, shape = tower.layout.entries[n]
+            emb[toff + off:toff + off + shape[0] * shape[1]] = True
+    assert torch.equal(grads["0"][~emb], grads["1"][~emb])
+    assert torch.allclose(grads["0"][emb], grads["1"][emb], rtol=1e-4, atol=1e-6)
