@@ -164,8 +164,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
         for (int mt = 0; mt < 8; ++mt) mfma_row(mt, bc);
     };
 
+    // Prologue: K tiles 0 and 1 are requested back to back - both slots are free at tile start - and only tile 0 is waited for.  (Until
+    // round 3 the two-slot instances requested tile 1 only after tile 0 had landed: its whole HBM / Infinity-Cache latency, 1.5-2 us against
+    // 1.15 us of MFMA work per K tile, sat in front of the first slot recycle of every tile; p.early1 = 0 restores that for A/B runs.)
     stage(0, 0);
-    if (NSLOT == 3 && nk_ > 1) {
+    const bool early1 = nk_ > 1 && (NSLOT == 3 || p.early1 != 0);
+    if (early1) {
         stage(1, 1);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
     } else {
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (NSLOT == 3) { if (nk_ > 2) stage(2, 2); } else { if (nk_ > 1) stage(1, 1); }
+    if (NSLOT == 3) { if (nk_ > 2) stage(2, 2); } else { if (nk_ > 1 && !early1) stage(1, 1); }
 #pragma unroll
     for (int t = 0; t < NT; ++t) b0[t] = *(const bf16x8*)(smem + b_off[0] + t * 16 * 128);
 #pragma unroll

@@ -656,3 +656,27 @@ def test_deferred_layernorm_parameter_gradients_equal_the_immediate_ones(arch, m
             emb[toff + off:toff + off + shape[0] * shape[1]] = True
     assert torch.equal(grads["0"][~emb], grads["1"][~emb])
     assert torch.allclose(grads["0"][emb], grads["1"][emb], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("all_neg,key", [(True, "logits_inbatch_all"), (False, "logits_inbatch_next")])
+def test_in_batch_negative_logits_at_full_size_match_the_reference(all_neg, key):
+    """models/nway_dual_encoder.py:30-44 at cfg1's full size (DistilBERT-6L, B = 4, N = 8, L = 128): the in-batch-negative score layouts
+    ([B, B*N] with every other sample's passages; [B, 2N] with the next sample's) against what the REFERENCE produced for the same seeded
+    weights and batch (tests/golden/full_distilbert_cfg1.npz), same bar as the N-way logits: 5e-3 of max|logit|; the trainer's step on them
+    (lambda_mrr with the -0.5 label fill, nway_listwise_1.py:341-344) runs and matches the oracle's loss on those logits."""
+    g = np.load(os.path.join(GOLDEN, "full_distilbert_cfg1.npz"))
+    model = _full_size_model("distilbert", 6)
+    model.in_batch_loss, model.all_in_batch_neg = True, all_neg
+    B, N, Lq, Lp = int(g["B"]), int(g["N"]), int(g["Lq"]), int(g["Lp"])
+    batch = syn.nway_batch(4680, B, N, Lq, Lp, ragged=True)
+    tr = NwayTrainer(model, loss="lambda_mrr")
+    loss_out, logits = tr.forward_backward(batch)
+    ref = g[key]
+    got = logits.cpu().numpy()
+    assert got.shape == ref.shape == ((B, B * N) if all_neg else (B, 2 * N))
+    err = np.abs(got - ref).max()
+    print(f"in-batch ({key}): max|dlogit| {err:.4f} = {err / np.abs(ref).max():.2e} of max|logit| {np.abs(ref).max():.2f}")
+    assert err <= 5e-3 * np.abs(ref).max()
+    labels = np.concatenate([batch["labels"].numpy(), np.full((B, ref.shape[1] - N), -0.5, np.float32)], 1)
+    assert loss_out[0].item() == pytest.approx(LR.lambda_mrr(got, labels)[0], rel=2e-5)
+    assert torch.isfinite(tr.flat_g).all().item()
