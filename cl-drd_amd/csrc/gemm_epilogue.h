@@ -34,6 +34,7 @@ struct GemmNtArgs {
     float* slabs = nullptr;       //   summed in a fixed order and finished (epilogue) by splitk_finish_kernel
     int gn = 0;                   // ring kernel: N tiles are walked in groups of gn inside an XCD's range (0: row-major)
     int stagger = 1;              // ring kernel: waves 4..7 issue their LDS-DMA one k-step after waves 0..3 (0: A/B runs)
+    int asym = 1;                 // ring kernel, two whole slots: a third A slot, A requested two K tiles ahead (0: the round-2 schedule)
     int early1 = 1;               // ring kernel, two LDS slots: K tile 1 is requested together with K tile 0 at tile start (0: after tile 0 landed)
 };
 

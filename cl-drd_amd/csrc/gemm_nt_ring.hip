@@ -47,6 +47,7 @@ int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_
     if (stagger < 0) { const char* e = getenv("CLDRD_GEMM_STAGGER"); stagger = e ? atoi(e) : 1; }
     a.stagger = stagger;
     { const char* e = getenv("CLDRD_GEMM_EARLY1"); a.early1 = e ? atoi(e) : 1; }
+    { const char* e = getenv("CLDRD_GEMM_ASYM"); a.asym = e ? atoi(e) : 1; }
     static int gn_env = -2;
     if (gn_env == -2) { const char* e = getenv("CLDRD_GEMM_GN"); gn_env = e ? atoi(e) : -1; }
     gn_force = gn_env;

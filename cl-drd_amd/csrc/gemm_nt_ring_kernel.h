@@ -19,22 +19,44 @@
 namespace {
 
 constexpr int BM = 256, BK = 64;
+
 constexpr int A_BYTES = BM * BK * 2;     // 32 KiB
 
+// LDS of one workgroup: [NA A slots | NB B slots] (see the kernel): three whole K tiles where they fit (BN = 128), else two plus a third A slot
+template <int BN>
+constexpr int ring_lds_bytes() {
+    constexpr int b = BN * BK * 2;
+    constexpr int nslot = (3 * (A_BYTES + b) <= 160 * 1024) ? 3 : 2;
+    constexpr int na = (nslot == 2 && 3 * A_BYTES + 2 * b <= 160 * 1024) ? 3 : nslot;
+    return na * A_BYTES + nslot * b;
+}
+
 // ABL != 0: timing experiments only (tools/gemm_ablate.py; results are wrong): 1 no s_barrier, 2 no LDS-DMA inside the K loop,
-// 3 neither (and no vmcnt waits), 4 no fragment reads inside the K loop, 6 DMA issued but never waited for.
+// 3 neither (and no vmcnt waits), 4 no fragment reads inside the K loop, 6 DMA issued but never waited for, 7 no epilogue (one
+// conditional store keeps the accumulators alive), 8 epilogue of every tile written to the output's first tile (no HBM write stream).
 // Measured at M = 32768, N = 768, K = 3072 (us): full 144 | 1: 139-144 | 2: 118 | 3: 112 | 4: 145 | 6: 140 -> the fragment reads are
 // free, barrier + waits cost ~4 %, the ISSUE of the LDS-DMA pieces ~16 % (spreading them one per MFMA row was worse: 157).
+// Tried in round 3 and dropped (profiles/r03_microbench.txt): the same wave tile in 128-row workgroups of 4 waves with 80 KiB of LDS, two of
+// them per CU, so that one runs its K loop while the other is in its epilogue (21 % of this kernel's time at K = 768).  Each then stages
+// its own B tile (40 instead of 28 KiB of LDS-DMA per 128 rows and K tile) and that costs more than the overlap returns: -14 % (QKV) to
+// -20 % (FFN1) at K = 768, -4..-8 % at K = 2304 / 3072, -2.7 % on the training step.
 template <int BN, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int B_BYTES = BN * BK * 2;
-    constexpr int SLOT = A_BYTES + B_BYTES;
     constexpr int NT = BN / 64;              // 16-col MFMA tiles per wave
     constexpr int WN = BN / 4;               // wave tile width
     constexpr int BPW = BN / 64;             // 1-KiB B pieces per wave (8 rows x 128 B each): BN/8 pieces over 8 waves
     constexpr int NSLOT = (3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2;     // BN = 128: two K tiles in flight
     constexpr int G = 4 + BPW;               // LDS-DMA instructions per wave per K tile
+    // Round 3: separate rings for the two operands.  LDS = [NA A slots | NB B slots].  Where only two whole K tiles fit (BN = 192 / 256:
+    // every encoder shape) the A operand still gets a THIRD slot (3 x 32 KiB + 2 x 24 / 32 KiB = 144 / 160 KiB): A is the activation matrix
+    // that streams in from HBM / the Infinity Cache (1.5-2 us per request under load, more than the 1.15 us of MFMA work per K tile), B the
+    // weight panel that lives in L2.  A is then requested TWO K tiles ahead (p.asym; 0 = two slots each, the round-2 schedule).
+    constexpr int NB_ = NSLOT;
+    constexpr int NA_MAX = (NSLOT == 2 && 3 * A_BYTES + 2 * B_BYTES <= 160 * 1024) ? 3 : NSLOT;
+    const int na_ = (NA_MAX > NSLOT && p.asym != 0) ? NA_MAX : NSLOT;        // A slots in use (uniform)
+    constexpr int BRING = NA_MAX * A_BYTES;  // byte offset of the B ring
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntn = (p.N + BN - 1) / BN;
@@ -73,16 +95,25 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
         ob[i] = (uint32_t)min(n0 + (BPW * wid + i) * 8 + prow, p.N - 1) * (uint32_t)(p.ldb * 2) + schunk * 16;
-    auto stage = [&](int slot, int kt) {
-        char* base = smem + slot * SLOT;
+    auto stageA = [&](int slot, int kt) {
+        char* base = smem + slot * A_BYTES;
         const char* pa = (const char*)p.A + kt * (BK * 2);
-        const char* pb = (const char*)p.B + kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + oa[i]), LDS_PTR(base + (4 * wid + i) * 1024), 16, 0, 0);
+    };
+    auto stageB = [&](int slot, int kt) {
+        char* base = smem + BRING + slot * B_BYTES;
+        const char* pb = (const char*)p.B + kt * (BK * 2);
 #pragma unroll
         for (int i = 0; i < BPW; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb + ob[i]), LDS_PTR(base + A_BYTES + (BPW * wid + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb + ob[i]), LDS_PTR(base + (BPW * wid + i) * 1024), 16, 0, 0);
+    };
+    // what a slot recycle at the barrier of K tile kt issues: B of K tile kt + NB into tile kt's B slot, then A of K tile kt + na into its
+    // A slot - B first, so that the wait for K tile kt+1 (all of B(kt+1), A(kt+1)) can leave exactly the youngest requests, A(kt+2), in flight
+    auto recycle = [&](int slotA, int slotB, int kt) {
+        if (kt + NB_ < nk_) stageB(slotB, kt + NB_);
+        if (kt + na_ < nk_) stageA(slotA, kt + na_);
     };
 
     // ---- fragment addressing: row (lane & 15) of a 16-row tile; 16-B chunk 4*ks + (lane >> 4), XOR (row & 7) ----
@@ -92,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     for (int ks = 0; ks < 2; ++ks) {
         const int ch = ((4 * ks + (lane >> 4)) ^ (frow & 7)) * 16;
         a_off[ks] = (wm * 128 + frow) * 128 + ch;
-        b_off[ks] = A_BYTES + (wn * WN + frow) * 128 + ch;
+        b_off[ks] = BRING + (wn * WN + frow) * 128 + ch;
     }
 
     f32x4 acc[8][NT];
@@ -117,21 +148,23 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     // (`late`), so one wave of each SIMD feeds the MFMA pipe while the other one issues: +2..9 % on the encoder shapes
     // (a whole k-step later is too late for two LDS slots: -10 %).
     const bool late_wave = wid >= 4 && p.stagger != 0;
-    auto kstep = [&](bf16x8 (&bc)[NT], bf16x8 (&bn)[NT], const char* na, const char* nb, bool sync, int slot, int kt) {
+    auto kstep = [&](bf16x8 (&bc)[NT], bf16x8 (&bn)[NT], const char* na, const char* nb, bool sync, int slot, int slotB, int kt) {
         mfma_row(0, bc);
         mfma_row(1, bc);
         __builtin_amdgcn_sched_barrier(0);
         if (sync) {
-            // K tile kt+1 must have landed; with a third slot K tile kt+2 (issued one tile ago) stays in flight
+            // K tile kt+1 must have landed; what may stay in flight are the requests for later K tiles, which are the YOUNGEST ones of this
+            // wave (recycle() order): with three slots each K tile kt+2 (G pieces), with the third A slot A(kt+2) (4 pieces)
             if (ABL == 3 || ABL == 6) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             else if (NSLOT == 3 && kt + 2 < nk_) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+            else if (NSLOT == 2 && na_ == 3 && kt + 2 < nk_) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             if (ABL != 1 && ABL != 3) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (ABL != 2 && ABL != 3 && !late_wave && kt + NSLOT < nk_) stage(slot, kt + NSLOT);  // slot of K tile kt: its fragments are in registers everywhere
+            if (ABL != 2 && ABL != 3 && !late_wave) recycle(slot, slotB, kt);      // slots of K tile kt: its fragments are in registers everywhere
             __builtin_amdgcn_sched_barrier(0);
-        } else if (ABL != 2 && ABL != 3 && late_wave && slot >= 0 && kt + NSLOT < nk_) {
-            stage(slot, kt + NSLOT);                        // (slot, kt) of the previous K tile, freed at its barrier
+        } else if (ABL != 2 && ABL != 3 && late_wave && slot >= 0) {
+            recycle(slot, slotB, kt);                       // slots of the previous K tile, freed at its barrier
             __builtin_amdgcn_sched_barrier(0);
         }
         if (ABL == 4) {
@@ -164,38 +197,48 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
         for (int mt = 0; mt < 8; ++mt) mfma_row(mt, bc);
     };
 
-    // Prologue: K tiles 0 and 1 are requested back to back - both slots are free at tile start - and only tile 0 is waited for.  (Until
-    // round 3 the two-slot instances requested tile 1 only after tile 0 had landed: its whole HBM / Infinity-Cache latency, 1.5-2 us against
-    // 1.15 us of MFMA work per K tile, sat in front of the first slot recycle of every tile; p.early1 = 0 restores that for A/B runs.)
-    stage(0, 0);
-    const bool early1 = nk_ > 1 && (NSLOT == 3 || p.early1 != 0);
+    // Prologue: every slot is free at tile start, so K tiles 0 and 1 (and A of K tile 2 with the third A slot) are requested back to back and
+    // only tile 0 is waited for.  (Until round 3 the two-slot instances requested tile 1 only after tile 0 had landed: its whole HBM /
+    // Infinity-Cache latency sat in front of the first slot recycle of every tile; p.early1 = 0 restores that for A/B runs.)
+    // Request order = what the waits count on: A0 B0 | B1 A1 | A2.
+    stageA(0, 0);
+    stageB(0, 0);
+    const bool early1 = nk_ > 1 && (NSLOT == 3 || p.early1 != 0 || na_ == 3);
+    const bool early2 = early1 && na_ == 3 && NSLOT == 2 && nk_ > 2;
     if (early1) {
-        stage(1, 1);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        stageB(1, 1);
+        stageA(1, 1);
+        if (early2) {
+            stageA(2, 2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G + 4) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+        }
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (NSLOT == 3) { if (nk_ > 2) stage(2, 2); } else { if (nk_ > 1 && !early1) stage(1, 1); }
+    if (NSLOT == 3) { if (nk_ > 2) { stageB(2, 2); stageA(2, 2); } } else { if (nk_ > 1 && !early1) { stageB(1, 1); stageA(1, 1); } }
 #pragma unroll
     for (int t = 0; t < NT; ++t) b0[t] = *(const bf16x8*)(smem + b_off[0] + t * 16 * 128);
 #pragma unroll
     for (int t = 0; t < 8; ++t) af[t] = *(const bf16x8*)(smem + a_off[0] + t * 16 * 128);
 
-    int cs = 0, ps = -1;                                                        // slots of K tiles kt and kt-1
+    int csA = 0, csB = 0, psA = -1, psB = -1;                                   // A / B slots of K tiles kt and kt-1
     for (int kt = 0; kt + 1 < nk_; ++kt) {
-        const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
-        const char* cur = smem + cs * SLOT;
-        const char* nxt = smem + ns * SLOT;
-        kstep(b0, b1, cur + a_off[1], cur + b_off[1], false, ps, kt - 1);       // k-step 0; prefetch k-step 1 of this slot
-        kstep(b1, b0, nxt + a_off[0], nxt + b_off[0], true, cs, kt);            // k-step 1; prefetch k-step 0 of K tile kt+1
-        ps = cs;
-        cs = ns;
+        const int nsA = csA == na_ - 1 ? 0 : csA + 1, nsB = csB == NB_ - 1 ? 0 : csB + 1;
+        const char* curA = smem + csA * A_BYTES;
+        const char* curB = smem + csB * B_BYTES;
+        const char* nxtA = smem + nsA * A_BYTES;
+        const char* nxtB = smem + nsB * B_BYTES;
+        kstep(b0, b1, curA + a_off[1], curB + b_off[1], false, psA, psB, kt - 1);   // k-step 0; prefetch k-step 1 of this tile's slots
+        kstep(b1, b0, nxtA + a_off[0], nxtB + b_off[0], true, csA, csB, kt);        // k-step 1; prefetch k-step 0 of K tile kt+1
+        psA = csA; psB = csB;
+        csA = nsA; csB = nsB;
     }
-    {   // last K tile: nothing left to recycle (a postponed issue of K tile nk-2 would be for K tile nk-2+NSLOT >= nk)
-        const char* cur = smem + cs * SLOT;
-        kstep(b0, b1, cur + a_off[1], cur + b_off[1], false, -1, nk_);
+    {   // last K tile: nothing left to recycle (a postponed issue of K tile nk-2 would be for K tiles >= nk)
+        kstep(b0, b1, smem + csA * A_BYTES + a_off[1], smem + csB * B_BYTES + b_off[1], false, -1, -1, nk_);
         klast(b1);
     }
 
@@ -205,13 +248,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();     // last K tile fully consumed by every wave: the slots become epilogue scratch
         asm volatile("" ::: "memory");
+        if constexpr (ABL == 7) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+            if (s == 123.456f) ((bf16_t*)p.C)[threadIdx.x] = 0;
+            return;
+        }
+        if constexpr (ABL == 8) {
+            gemm_nt_epilogue<8, NT, EPI>(p, acc, wm * 128, wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
+            return;
+        }
         gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
     }
 }
 
 template <int BN, int ABL>
 int launch_ring_abl(const GemmNtArgs& a, hipStream_t st) {
-    constexpr int lds = ((3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2) * (A_BYTES + BN * BK * 2);
+    constexpr int lds = ring_lds_bytes<BN>();
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, 0, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -234,10 +290,12 @@ int launch_ring_epi(const GemmNtArgs& a, hipStream_t st) {
             case 3: return launch_ring_abl<192, 3>(a, st);
             case 4: return launch_ring_abl<192, 4>(a, st);
             case 6: return launch_ring_abl<192, 6>(a, st);
+            case 7: return launch_ring_abl<192, 7>(a, st);
+            case 8: return launch_ring_abl<192, 8>(a, st);
             default: break;
         }
     }
-    constexpr int lds = ((3 * (A_BYTES + BN * BK * 2) <= 160 * 1024) ? 3 : 2) * (A_BYTES + BN * BK * 2);
+    constexpr int lds = ring_lds_bytes<BN>();
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

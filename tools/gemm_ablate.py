@@ -6,7 +6,7 @@ if len(sys.argv) > 1:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch
     from cldrd_amd import hip_ops as ops
-    M, N, K = 32768, 768, 3072
+    M, N, K = (int(os.environ.get(k, d)) for k, d in (("M", 32768), ("N", 768), ("K", 3072)))
     A = torch.randn(M, K, device="cuda").bfloat16(); B = (torch.randn(N, K, device="cuda") * 0.02).bfloat16()
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     os.environ["CLDRD_GEMM_TILE"] = "192"
@@ -21,8 +21,9 @@ if len(sys.argv) > 1:
         best = min(best, e0.elapsed_time(e1) / 20)
     print(f"mode {sys.argv[1]}: {best*1e3:7.1f} us  {2.0*M*N*K/best/1e9:7.1f} TF/s-equivalent")
 else:
-    names = {0: "full kernel", 1: "no s_barrier", 2: "no LDS-DMA in the K loop", 3: "no DMA, no barrier, no vmcnt waits", 4: "no fragment reads in the K loop", 6: "DMA issued, no vmcnt wait"}
-    for mode in (0, 1, 2, 3, 4, 6):
+    names = {0: "full kernel", 1: "no s_barrier", 2: "no LDS-DMA in the K loop", 3: "no DMA, no barrier, no vmcnt waits", 4: "no fragment reads in the K loop", 6: "DMA issued, no vmcnt wait",
+             7: "no epilogue", 8: "epilogue, every tile stored to the first tile's place"}
+    for mode in (0, 1, 2, 3, 4, 6, 7, 8):
         env = dict(os.environ, CLDRD_GEMM_ABLATE=str(mode))
         r = subprocess.run([sys.executable, __file__, str(mode)], env=env, capture_output=True, text=True)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], "  <-", names[mode])

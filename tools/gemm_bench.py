@@ -32,7 +32,8 @@ def main():
         for rnd in range(3):
             for v in variants:
                 os.environ["CLDRD_GEMM_PERSIST"] = "1" if v == "pers" else ("2" if v == "pers1" else "0")
-                if v.startswith("ring") and len(v) > 4: os.environ["CLDRD_GEMM_TILE"] = v[4:]
+                os.environ["CLDRD_GEMM_ASYM"] = "0" if v == "ring2s" else "1"          # ring2s: two A slots (the round-2 K-loop schedule)
+                if v.startswith("ring") and len(v) > 4 and v != "ring2s": os.environ["CLDRD_GEMM_TILE"] = v[4:]
                 else: os.environ.pop("CLDRD_GEMM_TILE", None)
                 for _ in range(2): ops.gemm_nt(A, B, out, **kw)
                 torch.cuda.synchronize()
