@@ -47,6 +47,9 @@ SIGNATURES = {
     "cldrd_lambda_loss_fwd_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cf, cf, ci, ci, ci, vp]),
     "cldrd_sqnorm_blocks": (ci, []),
     "cldrd_grad_clip_coef": (ci, [vp, csz, cf, vp, vp, vp]),
+    "cldrd_sqnorm_partial": (ci, [vp, csz, vp, ci, vp]),
+    "cldrd_clip_coef": (ci, [vp, ci, cf, vp, vp]),
+    "cldrd_copy_segments": (ci, [vp, vp, vp, ci, vp]),
     "cldrd_adamw_step": (ci, [vp, vp, vp, vp, vp, vp, csz, cf, cf, cf, cf, cf, ci, vp, vp]),
     "cldrd_adamw_step_h16": (ci, [vp, vp, vp, vp, vp, vp, csz, cf, cf, cf, cf, cf, ci, vp, vp, csz, csz, vp]),
     "cldrd_cast_bf16": (ci, [vp, vp, csz, vp]),

@@ -41,6 +41,44 @@ __global__ void step_state_kernel(unsigned long long* seeds, unsigned long long 
 }
 }  // namespace
 
+namespace {
+struct CopySegs { const void* src[8]; void* dst[8]; unsigned long long bytes[8]; int n; };
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopySegs c) {
+    const int seg = blockIdx.y;
+    if (seg >= c.n) return;
+    const unsigned long long nb = c.bytes[seg];
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((((uintptr_t)c.src[seg] | (uintptr_t)c.dst[seg] | nb) & 15) == 0) {
+        const uint4* s = (const uint4*)c.src[seg];
+        uint4* d = (uint4*)c.dst[seg];
+        for (size_t i = i0; i < nb / 16; i += stride) d[i] = s[i];
+    } else {
+        const unsigned char* s = (const unsigned char*)c.src[seg];
+        unsigned char* d = (unsigned char*)c.dst[seg];
+        for (size_t i = i0; i < nb; i += stride) d[i] = s[i];
+    }
+}
+}  // namespace
+
+// Up to 8 small device-to-device copies in ONE launch (the inputs of a captured training step go to the graph's static buffers: five
+// 5-us copy launches in front of every replay otherwise).  Host arrays of n pointers / byte counts; segments must not overlap.
+extern "C" int cldrd_copy_segments(const void* const* src, void* const* dst, const size_t* bytes, int n, void* stream) {
+    CLDRD_CHECK(n >= 1 && n <= 8, "copy_segments: 1..8 segments");
+    CopySegs c;
+    size_t biggest = 0;
+    for (int i = 0; i < 8; ++i) {
+        c.src[i] = i < n ? src[i] : nullptr; c.dst[i] = i < n ? dst[i] : nullptr; c.bytes[i] = i < n ? bytes[i] : 0;
+        if (i < n) { CLDRD_CHECK(src[i] != nullptr && dst[i] != nullptr, "copy_segments: null segment"); biggest = biggest > bytes[i] ? biggest : bytes[i]; }
+    }
+    c.n = n;
+    size_t blocks = (biggest / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, c);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
 // One tiny launch that writes this step's values (two seed words, lr, Adam step size for bias-correction step `adam_step`) to device
 // memory, in stream order in front of the replay that reads them.
 extern "C" int cldrd_write_step_state(unsigned long long* seeds, unsigned long long seed0, unsigned long long seed1, float* hyper, float lr,

@@ -247,13 +247,33 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
         }
     };
     if (fl.residual || fl.gelugrad) prefetch(0);
-#pragma unroll
-    for (int mh = 0; mh < MT / 2; ++mh) {
+    // The LDS executes one wave's instructions in order, so inside this wave-private patch a read issued after a write sees it and a write
+    // issued after a read cannot overtake it: no s_waitcnt between them (until round 3 there were two lgkmcnt(0) per chunk, i.e. two LDS
+    // round trips in front of every chunk's stores).  Chunk mh+1 is written right behind the reads of chunk mh, so its trip overlaps the
+    // arithmetic and the stores of chunk mh; the compiler waits for the read RESULTS where they are used.
+    auto write_patch = [&](int mh) {
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 *(f32x4*)(patch + (t * 16 + frow) * RS + nt * 16 + fq * 4) = acc[2 * mh + t][nt];
+    };
+    write_patch(0);
+#pragma unroll
+    for (int mh = 0; mh < MT / 2; ++mh) {
+        asm volatile("" ::: "memory");
+        float v[NPASS][8];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int r = pass * RPP + rr;
+            const float* src = patch + (r < 32 ? r : 0) * RS + rc;
+            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
+            v[pass][0] = lo[0]; v[pass][1] = lo[1]; v[pass][2] = lo[2]; v[pass][3] = lo[3];
+            v[pass][4] = hi[0]; v[pass][5] = hi[1]; v[pass][6] = hi[2]; v[pass][7] = hi[3];
+        }
+        asm volatile("" ::: "memory");
+        if (mh + 1 < MT / 2) write_patch(mh + 1);
+        asm volatile("" ::: "memory");
         uint4 cres[NPASS], cresh[NPASS], cgp[NPASS];
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) { cres[pass] = res[pass]; cresh[pass] = resh[pass]; cgp[pass] = gp[pass]; }
@@ -271,17 +291,6 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
             }
         }
         if ((fl.residual || fl.gelugrad) && mh + 1 < MT / 2) prefetch(mh + 1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float v[NPASS][8];
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int r = pass * RPP + rr;
-            const float* src = patch + (r < 32 ? r : 0) * RS + rc;
-            const f32x4 lo = *(const f32x4*)src, hi = *(const f32x4*)(src + 4);
-            v[pass][0] = lo[0]; v[pass][1] = lo[1]; v[pass][2] = lo[2]; v[pass][3] = lo[3];
-            v[pass][4] = hi[0]; v[pass][5] = hi[1]; v[pass][6] = hi[2]; v[pass][7] = hi[3];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // patch may be overwritten by the next chunk from here on
 #pragma unroll
         for (int pass = 0; pass < NPASS; ++pass) {
             const int r = pass * RPP + rr;

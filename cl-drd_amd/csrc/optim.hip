@@ -194,6 +194,25 @@ extern "C" int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, fl
     return 0;
 }
 
+// The two halves of cldrd_grad_clip_coef on their own, for a norm taken in pieces: cldrd_sqnorm_partial writes the sums of squares of
+// g[0, n) into partial[0, nblk) (exactly nblk blocks: every slot is written), cldrd_clip_coef turns nblk_total slots into {norm, clip
+// coefficient, non-finite flag}.  The trainer takes the norm of the gradients that are complete early (the query tower, the passage
+// tower's embedding block) on its second stream UNDER the passage tower's weight-gradient launch and only the rest after it.
+extern "C" int cldrd_sqnorm_partial(const float* g, size_t n, float* partial, int nblk, void* stream) {
+    CLDRD_CHECK(n > 0 && n % 4 == 0 && ((uintptr_t)g % 16 == 0), "sqnorm_partial: n must be a multiple of 4, g 16-byte aligned");
+    CLDRD_CHECK(nblk >= 1 && nblk <= 65535 && partial != nullptr, "sqnorm_partial: 1 <= nblk <= 65535 partial sums");
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, n / 4, partial);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_clip_coef(const float* partial, int nblk_total, float max_norm, float* out, void* stream) {
+    CLDRD_CHECK(nblk_total >= 1 && partial != nullptr && out != nullptr, "clip_coef: no partial sums");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk_total, max_norm, out);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
 // Legacy transformers.AdamW (correct_bias=True), step is 1-based.  decay_flags: one byte per 64 parameters.
 // clip: device float[3] from cldrd_grad_clip_coef or null.  shadow: bf16 copy of the updated parameters or null.
 // shadow16 (optional): fp16 copy (RNE, as cldrd_cast_f16) of the updated parameters [h16_begin, h16_end) - the high-precision forward

@@ -457,6 +457,24 @@ class HipEncoder(nn.Module):
             self._t_fresh = False
         self._shadow_version = self.flat_p._version
 
+    def refresh_transposed(self):
+        """Only the transposed bf16 copies (the B operands of the data-gradient GEMMs) from the current bf16 shadow: the trainer makes
+        them at the START of the next step on its second stream - nothing reads them before the backward - instead of after AdamW
+        on the main one (``refresh_shadows(need_transposed=False)`` there)."""
+        if not self.cfg.n_layers:
+            self._t_fresh = True
+            return
+        if self.flat_t is None:
+            self.flat_t = torch.empty(self.layout.t_total, dtype=torch.bfloat16, device=self.flat_p.device)
+        if self._t_desc is None:
+            self._build_t_desc()
+        desc, prefix, nd, tiles = self._t_desc
+        if self._t_desc64 is not None:
+            ops.transpose_bf16_batched(self.flat_h, self.flat_t, desc, self._t_desc64[0], nd, self._t_desc64[1])
+        else:
+            ops.transpose_cast_batched(self.flat_p, self.flat_t, desc, prefix, nd, tiles)
+        self._t_fresh = True
+
     def _shadows_ok(self, need_t):
         return (self.flat_h is not None and self._shadow_version == self.flat_p._version and (not self.needs_h16 or self.flat_h16 is not None) and
                 (not need_t or (self.flat_t is not None and getattr(self, "_t_fresh", False))))

@@ -92,6 +92,21 @@ def write_step_state(seeds, seed0, seed1, hyper, lr, beta1, beta2, adam_step):
          float(beta2), int(adam_step), _stream())
 
 
+def copy_segments(dsts, srcs):
+    """dst[i] <- src[i] for up to 8 pairs of same-sized contiguous device tensors in one launch (bytes are copied: same dtype expected)."""
+    import ctypes as C
+    n = len(dsts)
+    if n != len(srcs) or not 1 <= n <= 8:
+        raise ValueError("copy_segments: 1..8 (dst, src) pairs")
+    for d, s_ in zip(dsts, srcs):
+        if not (d.is_cuda and s_.is_cuda and d.is_contiguous() and s_.is_contiguous() and d.dtype == s_.dtype and d.numel() == s_.numel()):
+            raise ValueError("copy_segments: contiguous device tensors of equal dtype and size")
+    src = (C.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    dst = (C.c_void_p * n)(*[t.data_ptr() for t in dsts])
+    nb = (C.c_size_t * n)(*[t.numel() * t.element_size() for t in srcs])
+    call("cldrd_copy_segments", src, dst, nb, n, _stream())
+
+
 def pad_rows(rows: int) -> int:
     """Activation / gradient buffers are allocated with rows rounded up to 64 (allocation granularity only: no kernel reads the
     rows past M any more - the weight-gradient kernel fetches them from a zero page)."""
@@ -489,6 +504,16 @@ def logit_norm_reg(logits, reg_lambda, loss_out, grad, reg_out=None):
 
 def sqnorm_blocks() -> int:
     return _lib.load().cldrd_sqnorm_blocks()
+
+
+def sqnorm_partial(g, partial, nblk):
+    """partial[0:nblk] <- nblk partial sums of squares of the fp32 vector g (one piece of a norm taken in pieces, see clip_coef)."""
+    call("cldrd_sqnorm_partial", _p(g), g.numel(), _p(partial), int(nblk), _stream())
+
+
+def clip_coef(partial, nblk_total, max_norm, out):
+    """out[3] = {norm, min(1, max_norm / (norm + 1e-6)), non-finite flag} from partial[0:nblk_total] (fixed-order fp64 sum)."""
+    call("cldrd_clip_coef", _p(partial), int(nblk_total), float(max_norm), _p(out), _stream())
 
 
 def grad_clip_coef(g, max_norm, partial, out):

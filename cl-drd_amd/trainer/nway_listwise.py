@@ -161,6 +161,27 @@ class NwayTrainer:
             self._pending.append(work)
         return hook
 
+    def _early_norm_hook(self, main, side):
+        """One GPU: the clip norm is taken in two pieces.  When the passage tower's embedding block is complete (hook -1, called BEFORE
+        its last weight-gradient group is launched) every gradient of the query tower (whose backward is already queued on the second
+        stream) and of that block is final: [0, split) of the joint buffer, two thirds of it.  Their sums of squares are taken on the
+        second stream UNDER the 3-ms weight-gradient launch (HBM reads next to an MFMA-bound kernel); after it only the passage
+        tower's layers are left (`_optimizer_launches`).  Same fp64 reduction of fp32 partial sums as the one-piece norm."""
+        toff = self.model._tower_offsets[-1]
+        split = toff + self.model.towers()[-1].layout.embed_range[1]
+        half = self.norm_partial.numel() // 2
+
+        def hook(layer):
+            if layer != -1 or split % 4 != 0 or split >= self.flat_g.numel():
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                ops.sqnorm_partial(self.flat_g[:split], self.norm_partial, half)
+            self._norm_split = split
+        return hook
+
     def _wait_pending(self):
         """Order every outstanding bucket all-reduce before whatever the CURRENT stream runs next (the gradient norm / optimizer):
         ``Work.wait()`` makes the current stream wait for the collective under ProcessGroupNCCL (no host block) and blocks the host
@@ -182,20 +203,28 @@ class NwayTrainer:
         q, nw = batch["query"], batch["nway_passages"]
         bz, nway, L = nw["input_ids"].shape
         write_once = not model.share_weights and _env_flag("CLDRD_GRAD_ZERO", "") != "full"      # "full": A/B runs
-        if not write_once:
-            self.flat_g.zero_()                 # two tapes accumulate into one tower's gradients
-        else:
-            # every weight / bias / LayerNorm gradient is written exactly once per step (accumulate=False below); only the
-            # embedding tables are scatter-added into and need zeros (2 x 94 MB instead of the whole 531 MB buffer)
-            for tower, toff in zip(model.towers(), model._tower_offsets):
-                a, b = tower.layout.embed_range
-                self.flat_g[toff + a:toff + b].zero_()
         main = torch.cuda.current_stream()
         # The query tower is ~1 % of the FLOPs but dozens of small, latency-bound launches: it runs on its own stream
         # next to the passage tower (forward and backward) instead of in front of it.
         side = self.q_stream if (not model.share_weights and _env_flag("CLDRD_Q_SIDE", "1") != "0") else main      # "0": A/B runs
         if side is not main:
             side.wait_stream(main)
+        # Step preamble that nothing in the passage tower's FORWARD depends on - on the second stream, next to that forward instead of in
+        # front of it (134 us of a 12-ms step on the main stream until round 3, profiles/r03_microbench.txt): the zeros the embedding
+        # tables' scatter-adds need and the transposed weight copies of the data-gradient GEMMs (left stale by the optimizer step).  The
+        # main stream joins the second one after the forward, long before the backward reads either.
+        with torch.cuda.stream(side):
+            if not write_once:
+                self.flat_g.zero_()                 # two tapes accumulate into one tower's gradients
+            else:
+                # every weight / bias / LayerNorm gradient is written exactly once per step (accumulate=False below); only the
+                # embedding tables are scatter-added into and need zeros (2 x 94 MB instead of the whole 531 MB buffer)
+                for tower, toff in zip(model.towers(), model._tower_offsets):
+                    a, b = tower.layout.embed_range
+                    self.flat_g[toff + a:toff + b].zero_()
+            for tower in model.towers():
+                if not getattr(tower, "_t_fresh", False):
+                    tower.refresh_transposed()
         with torch.cuda.stream(side):
             q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True, fp16=model.query_fp16)
         p_cls, p_tape = pe.encode(nw["input_ids"].reshape(bz * nway, L), nw["attention_mask"].reshape(bz * nway, L),
@@ -239,7 +268,11 @@ class NwayTrainer:
             late = side is not main and _env_flag("CLDRD_Q_BWD", "early") == "late"
             if not late:
                 query_backward()
-            pe.backward_from_cls(p_tape, dp, after_layer=self._bucket_hook(1), accumulate=not write_once,
+            self._norm_split = None
+            p_hook = self._bucket_hook(1)
+            if p_hook is None and side is not main and not late and write_once and _env_flag("CLDRD_NORM_SPLIT", "1") != "0":
+                p_hook = self._early_norm_hook(main, side)
+            pe.backward_from_cls(p_tape, dp, after_layer=p_hook, accumulate=not write_once,
                                  before_last_wgrad=query_backward if late else None)
             main.wait_stream(side)
             if self.distributed:
@@ -257,7 +290,15 @@ class NwayTrainer:
     def _optimizer_launches(self, lr, adam_step):
         """The device work of one optimizer step.  Under a captured step (`_state` installed) lr and the bias-corrected step size are
         read from device memory at replay time and the by-value arguments given here are ignored by the kernel."""
-        ops.grad_clip_coef(self.flat_g, self.max_grad_norm, self.norm_partial, self.clip)
+        split = getattr(self, "_norm_split", None)
+        if split:
+            # [0, split) was summed on the second stream during the backward (`_early_norm_hook`; the main stream has joined it since)
+            half = self.norm_partial.numel() // 2
+            ops.sqnorm_partial(self.flat_g[split:], self.norm_partial[half:], half)
+            ops.clip_coef(self.norm_partial, 2 * half, self.max_grad_norm, self.clip)
+            self._norm_split = None
+        else:
+            ops.grad_clip_coef(self.flat_g, self.max_grad_norm, self.norm_partial, self.clip)
         towers = self.model.towers()
         # one AdamW launch over the joint buffer; it also writes the bf16 shadow of every tower
         shadow = self._joint_shadow()
@@ -269,8 +310,11 @@ class NwayTrainer:
             ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, shadow, lr=lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=adam_step, clip=self.clip,
                            shadow16=s16[r16[0]:r16[1]] if fused16 else None, h16_range=r16 if fused16 else None)
+        # the transposed copies wait for the next step's preamble on the second stream (forward_backward) when there is one
+        defer_t = not self.model.share_weights and self.q_stream is not None and _env_flag("CLDRD_Q_SIDE", "1") != "0" \
+            and _env_flag("CLDRD_T_DEFER", "1") != "0"
         for t in towers:
-            t.refresh_shadows(need_transposed=True, cast=False, cast16=not fused16)
+            t.refresh_shadows(need_transposed=not defer_t, cast=False, cast16=not fused16)
 
     def _joint_shadow(self):
         if getattr(self, "_shadow", None) is None:
@@ -379,8 +423,12 @@ class NwayTrainer:
                 torch.cuda.synchronize()
                 return None
         # this step's inputs and state, in stream order in front of the replay
-        for dst, src in zip(entry["inputs"], self._flat_inputs(batch)):
-            dst.copy_(src, non_blocking=True)
+        dsts, srcs = entry["inputs"], self._flat_inputs(batch)
+        if all(s_.is_cuda and s_.is_contiguous() and s_.dtype == d_.dtype and s_.shape == d_.shape for d_, s_ in zip(dsts, srcs)):
+            ops.copy_segments(dsts, srcs)           # one launch instead of five
+        else:
+            for dst, src in zip(dsts, srcs):
+                dst.copy_(src, non_blocking=True)
         self._advance_step_state()
         entry["graph"].replay()
         self.last_logits = entry["logits"]

@@ -184,6 +184,11 @@ int cldrd_lambda_loss_fwd_bwd(const float* y_pred, const float* y_true, float* l
  * (embedding tables: read in fp32 by the embedding kernels). */
 int cldrd_sqnorm_blocks(void);
 int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, float* partial, float* out, void* stream);
+/* The same norm taken in pieces (the trainer takes the part of it whose gradients are complete early on its second stream, under the
+ * last weight-gradient launch): cldrd_sqnorm_partial writes exactly nblk partial sums of squares of g[0, n) to partial[0, nblk);
+ * cldrd_clip_coef reduces nblk_total of them (fixed order, fp64) to out[3] as cldrd_grad_clip_coef does. */
+int cldrd_sqnorm_partial(const float* g, size_t n, float* partial, int nblk, void* stream);
+int cldrd_clip_coef(const float* partial, int nblk_total, float max_norm, float* out, void* stream);
 int cldrd_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,
                      size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                      const float* clip, void* stream);
@@ -262,6 +267,8 @@ int cldrd_add_rows_idx(void* dst, const void* src, int M, int d, const int* idx,
  * makes in front of each replay.  NULL uninstalls; nothing installed = the by-value arguments, as before (bit-identical results). */
 void cldrd_set_seed_base(const unsigned long long* base);
 void cldrd_set_optim_hyper(const float* hyper);
+/* n <= 8 small device-to-device copies in one launch (host arrays of pointers / byte counts): the inputs of a captured step. */
+int cldrd_copy_segments(const void* const* src, void* const* dst, const size_t* bytes, int n, void* stream);
 int cldrd_write_step_state(unsigned long long* seeds, unsigned long long seed0, unsigned long long seed1, float* hyper, float lr,
                            float beta1, float beta2, int adam_step, void* stream);
 

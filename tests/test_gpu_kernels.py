@@ -680,6 +680,43 @@ def test_clip_and_adamw_match_oracle():
     assert clip[2].item() == 1.0 and torch.equal(pd, before)
 
 
+def test_clip_norm_taken_in_two_pieces_matches_the_one_piece_norm_and_the_oracle():
+    """cldrd_sqnorm_partial over [0, split) and [split, n) into the two halves of the partial buffer + cldrd_clip_coef = the norm /
+    coefficient of cldrd_grad_clip_coef over the whole vector (the trainer takes the first piece under the last weight-gradient launch)."""
+    from oracle import optim_ref as O
+    n, split = 64 * 5000, 64 * 1237
+    g = rnd(44, (n,), 0.01)
+    gd = g.to(DEV)
+    nb = ops.sqnorm_blocks()
+    partial = torch.full((nb,), float("nan"), device=DEV)
+    one, two = torch.zeros(3, device=DEV), torch.zeros(3, device=DEV)
+    ops.grad_clip_coef(gd, 1.0, torch.empty(nb, device=DEV), one)
+    ops.sqnorm_partial(gd[:split], partial, nb // 2)
+    ops.sqnorm_partial(gd[split:], partial[nb // 2:], nb // 2)
+    ops.clip_coef(partial, nb, 1.0, two)
+    total, coef = O.clip_coef([g.numpy()], 1.0)
+    assert two[0].item() == pytest.approx(total, rel=1e-6) and two[1].item() == pytest.approx(coef, rel=1e-6) and two[2].item() == 0.0
+    assert two[0].item() == pytest.approx(one[0].item(), rel=1e-6)
+    gd[split + 3] = float("nan")
+    ops.sqnorm_partial(gd[split:], partial[nb // 2:], nb // 2)
+    ops.clip_coef(partial, nb, 1.0, two)
+    assert two[2].item() == 1.0
+
+
+def test_copy_segments_copies_up_to_eight_buffers_in_one_launch():
+    srcs = [torch.arange(8 * 32, device=DEV), torch.arange(256 * 128, device=DEV).view(256, 128) * 3,
+            (torch.arange(256 * 128, device=DEV).view(256, 128) % 2), torch.linspace(-1, 1, 8 * 32, device=DEV).view(8, 32),
+            torch.arange(7, device=DEV, dtype=torch.uint8)]                  # the last one: 7 bytes, the byte-wise path
+    dsts = [torch.zeros_like(t) for t in srcs]
+    ops.copy_segments(dsts, srcs)
+    for d, t in zip(dsts, srcs):
+        assert torch.equal(d, t)
+    with pytest.raises(ValueError):
+        ops.copy_segments(dsts[:1], [srcs[0].float()])
+    with pytest.raises(ValueError):
+        ops.copy_segments([], [])
+
+
 def test_adamw_step_writes_the_fp16_shadow_of_a_sub_range():
     """The fused step leaves the fp16 copy of parameters [lo, hi) (what cast_f16 of the updated parameters gives) and changes
     nothing else: p, m, v and the bf16 shadow are bit-identical to the step without it; a skipped step still refreshes the copy."""

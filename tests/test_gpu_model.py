@@ -172,8 +172,12 @@ def test_trainer_step_matches_oracle_update():
     assert torch.equal(t.flat_h.float()[used], t.flat_p.to(torch.bfloat16).float()[used])
     skip = (tr.decay_flags & 2).repeat_interleave(64).bool()[:t.layout.total]
     assert torch.equal(skip, ~used)
+    # the transposed copies (data-gradient GEMMs) are left stale by the optimizer step and made by the next step's preamble
+    assert not t._t_fresh
+    tr.forward_backward(batch)
+    torch.cuda.synchronize()
     w2 = t.w("transformer.layer.0.ffn.lin2.weight")
-    assert torch.equal(t.ht(0, "f2").float(), w2.T.contiguous().to(torch.bfloat16).float())
+    assert t._t_fresh and torch.equal(t.ht(0, "f2").float(), w2.T.contiguous().to(torch.bfloat16).float())
 
 
 @pytest.mark.parametrize("arch", ["distilbert", "bert"])

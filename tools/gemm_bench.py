@@ -17,9 +17,13 @@ def main():
     torch.manual_seed(0)
     tot = {v: 0.0 for v in variants}
     for name, M, N, K, ep in shapes:
-        A = torch.randn(M, K, device=dev).bfloat16()
+        # ROTATE=n: n sets of (A, output, residual, ...) used in turn, so that no call finds its operands in the 256-MB Infinity Cache
+        # (as in the training step, where every activation is touched once per pass); 1 = the same buffers every call
+        rot = int(os.environ.get("ROTATE", 1))
+        As = [torch.randn(M, K, device=dev).bfloat16() for _ in range(rot)]
         B = (torch.randn(N, K, device=dev) * 0.02).bfloat16()
-        out = torch.empty(M, N, device=dev, dtype=torch.float32 if ep.get("res32") else torch.bfloat16)
+        outs = [torch.empty(M, N, device=dev, dtype=torch.float32 if ep.get("res32") else torch.bfloat16) for _ in range(rot)]
+        A, out = As[0], outs[0]
         kw = {}
         if ep.get("bias"): kw["bias"] = torch.randn(N, device=dev)
         if ep.get("res"): kw["residual"] = torch.randn(M, N, device=dev).bfloat16()
@@ -28,6 +32,7 @@ def main():
         if ep.get("act"): kw["act"] = ep["act"]
         if ep.get("gp"): kw["gelu_pre"] = torch.randn(M, N, device=dev).bfloat16()
         if ep.get("drop"): kw.update(dropout_p=0.1, seed=1234)
+        kws = [kw] + [{k: (v.clone() if torch.is_tensor(v) and v.dim() == 2 else v) for k, v in kw.items()} for _ in range(rot - 1)]
         res = {}
         for rnd in range(3):
             for v in variants:
@@ -35,11 +40,11 @@ def main():
                 os.environ["CLDRD_GEMM_ASYM"] = "0" if v == "ring2s" else "1"          # ring2s: two A slots (the round-2 K-loop schedule)
                 if v.startswith("ring") and len(v) > 4 and v != "ring2s": os.environ["CLDRD_GEMM_TILE"] = v[4:]
                 else: os.environ.pop("CLDRD_GEMM_TILE", None)
-                for _ in range(2): ops.gemm_nt(A, B, out, **kw)
+                for i in range(2): ops.gemm_nt(As[i % rot], B, outs[i % rot], **kws[i % rot])
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                for _ in range(10): ops.gemm_nt(A, B, out, **kw)
+                for i in range(10): ops.gemm_nt(As[i % rot], B, outs[i % rot], **kws[i % rot])
                 e1.record(); torch.cuda.synchronize()
                 res.setdefault(v, []).append(e0.elapsed_time(e1) / 10)
         fl = 2.0 * M * N * K
