@@ -21,6 +21,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("CLDRD_FORCE_DDP", "0") == "1":
+    # before HIP initialises, ranks of a multi-process job only: see cl-drd_amd/__init__.py (two towers on two streams next to RCCL's)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 D, DFF, NL = 768, 3072, 6
@@ -61,7 +64,7 @@ def pmc_traffic(kernel_substr, timeout_s=150):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "r", "--", sys.executable, here,
-                   "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-index", "--no-retrieve", "--no-kernel-events", "--no-pmc", "--no-ragged"]
+                   "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-index", "--no-retrieve", "--no-kernel-events", "--no-pmc", "--no-ragged", "--no-ddp1"]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
@@ -105,10 +108,14 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--no-retrieve", action="store_true")
     ap.add_argument("--no-ragged", action="store_true", help="skip the MSMARCO-shaped (padded / packed) extra legs")
+    ap.add_argument("--no-ddp1", action="store_true", help="skip the child run of the data-parallel code path over RCCL with one rank")
+    ap.add_argument("--ddp1-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--retrieve-rows", type=int, default=1105228, help="index rows per GPU (8 841 823 / 8)")
     ap.add_argument("--retrieve-queries", type=int, default=6980, help="queries searched against the shard (MS MARCO dev: 6980)")
     args = ap.parse_args()
 
+    if args.ddp1_child:
+        return ddp1_child(args)
     import torch                      # counting devices does not initialise the GPU (nothing here may before the ranks are spawned)
     if args.gpus > torch.cuda.device_count():
         # fail fast, on every rank and before any rendezvous: a rank that cannot get its GPU must not leave the others waiting in
@@ -443,6 +450,14 @@ def main():
         except Exception as exc:
             cpu = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
+    # The data-parallel CODE PATH with one rank over the real backend (ProcessGroupNCCL = RCCL): constructor broadcast, per-bucket
+    # all_reduce(async_op=True) from the backward hooks on the communication stream, Work handles, weight gradients flushed every 3 layers,
+    # eager launches.  Not a scaling number (no second GPU exists on this box): the per-rank cost of that path next to the headline's.
+    ddp1 = None
+    if rank == 0 and world == 1 and not args.no_ddp1:
+        torch.cuda.synchronize()
+        ddp1 = ddp1_parent(args)
+
     # roofline.traffic, last (the model and every buffer of this process stay allocated, but nothing of ours runs meanwhile): two
     # rocprofv3 --pmc child runs, rank 0 at N = 1 only
     if rank == 0 and world == 1 and roofline is not None and not args.no_pmc:
@@ -469,12 +484,72 @@ def main():
             "step_mfma_frac_executed": round(samples_per_s * exec_per_sample / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "final_loss": final_loss,
             "msmarco_shaped_train": ragged,
+            "ddp_path_one_rank_rccl": ddp1,
             "index": index, "retrieve": retrieve, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def ddp1_parent(args, timeout_s=240):
+    """Run `bench.py --ddp1-child` (its own process group) and return its JSON, or the reason it did not finish."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", CLDRD_FORCE_DDP="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--ddp1-child", "--batch", str(args.batch), "--nway", str(args.nway), "--seq-len",
+           str(args.seq_len), "--q-len", str(args.q_len), "--loss", args.loss, "--dropout", str(args.dropout), "--steps", "20", "--warmup", "6"]
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s, text=True)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"child rc {r.returncode}: {r.stderr.strip()[-240:]}"}
+        return json.loads(lines[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": f"child did not finish within {timeout_s} s"}
+    except Exception as exc:
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
+def ddp1_child(args):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    import cldrd_amd.synthetic as syn
+    from cldrd_amd.encoder import EncoderConfig
+    from cldrd_amd.models import NwayDualEncoder
+    from cldrd_amd.trainer import NwayTrainer
+    cfg = EncoderConfig(arch="distilbert", dropout=args.dropout, attention_dropout=args.dropout)
+    torch.manual_seed(0)
+    model = NwayDualEncoder(cfg, share_weights=False).to(dev)
+    model.train()
+    trainer = NwayTrainer(model, loss=args.loss, T=1.0, learning_rate=7e-6, warmup_steps=4000, total_steps=100000)
+    if os.environ.get("CLDRD_FORCE_DDP", "0") == "1":
+        assert trainer.distributed and trainer.comm_stream is not None
+    batch = syn.nway_batch(4680, args.batch, args.nway, args.q_len, args.seq_len, ragged=False, label_kind="teacher")
+    batch = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in batch.items()}
+    for _ in range(args.warmup):
+        trainer.train_step(batch)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss_out = trainer.train_step(batch)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"samples_per_s": round(args.batch * args.steps / dt, 2), "ms_per_step": round(1e3 * dt / args.steps, 3), "steps": args.steps,
+                      "backend": dist.get_backend(), "world_size": 1, "ddp_path": bool(trainer.distributed), "buckets": len(trainer.buckets), "step_launch": "eager",
+                      "final_loss": float(loss_out[0].item())}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 def spawn_ranks(n: int) -> int:

@@ -85,13 +85,16 @@ class NwayTrainer:
         self.global_step = 0
         self.adam_step = 0          # bias-correction step of AdamW: differs from global_step only after resuming a reference fp16
                                     # checkpoint whose GradScaler skipped steps (state["step"] < global_step there)
-        self.distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # CLDRD_FORCE_DDP=1: take the data-parallel path (constructor broadcast, bucket hooks, communication stream, Work handles) with a
+        # process group of ONE rank too - the only way to run it over RCCL (ProcessGroupNCCL) on a one-GPU box (tests/test_gpu_ddp.py)
+        self.distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _env_flag("CLDRD_FORCE_DDP", "0") == "1")
         self.world = dist.get_world_size() if self.distributed else 1
         self.flat_p, self.flat_g = model.fuse_flat()
         # deferred weight gradients: one group launch per tower at the end of the backward on one GPU; with RCCL every
         # ceil(layers / 2) layers, so the first half of the buckets is all-reduced while the rest of the backward still runs
+        flush_env = _env_flag("CLDRD_WGRAD_FLUSH", "")              # experiments: layers per weight-gradient group under torch.distributed
         for t in model.towers():
-            t.wgrad_flush_layers = max(1, -(-t.cfg.n_layers // 2)) if self.distributed else 0
+            t.wgrad_flush_layers = (int(flush_env) if flush_env != "" else max(1, -(-t.cfg.n_layers // 2))) if self.distributed else 0
         dev = self.flat_p.device
         self._require_gpu(dev)
         n = self.flat_p.numel()
@@ -157,6 +160,8 @@ class NwayTrainer:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
+                if _env_flag("CLDRD_DDP_NOCOMM", "0") == "1":       # experiments only: what the hooks cost without the collective
+                    return
                 work = dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, async_op=True)
             self._pending.append(work)
         return hook

@@ -81,3 +81,69 @@ def test_ddp_bucket_hooks_world2_on_one_gpu(tmp_path, share):
     out = str(tmp_path / "ok")
     mp.spawn(_worker, args=(2, _free_port(), out, share), nprocs=2, join=True)
     assert open(out).read().startswith("ok")
+
+
+def _rccl_worker(rank, port, out):
+    """ONE rank over the real backend: `init_process_group("nccl")` is RCCL on ROCm.  With CLDRD_FORCE_DDP=1 the trainer takes its
+    data-parallel path although world_size is 1, so everything that path does with ProcessGroupNCCL runs on the GPU for real: the
+    constructor broadcast, the per-bucket `all_reduce(async_op=True)` issued from the backward hooks on the communication stream behind an
+    event of the compute stream, the Work handles waited for in `_wait_pending`, MIN over ranks of the step count.  An all-reduce over
+    one rank is the identity, so gradients and updated weights must equal the plain single-process trainer's."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CLDRD_FORCE_DDP="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", GPU_MAX_HW_QUEUES="8")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    assert dist.get_backend() == "nccl"
+    import cldrd_amd.synthetic as syn
+    import selftest
+    from cldrd_amd.encoder import EncoderConfig
+    from cldrd_amd.trainer import NwayTrainer
+    from cldrd_amd.trainer.nway_listwise import common_steps_per_epoch
+
+    cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=3,
+                        max_position_embeddings=64, dropout=0.0, attention_dropout=0.0)
+    batch = syn.nway_batch(4680, 4, 5, 10, 40, vocab=cfg.vocab_size, ragged=True)
+    model = selftest.build_tiny_model(cfg, seed=3).cuda()
+    model.train()
+    tr = NwayTrainer(model, loss="margin_mse", learning_rate=1e-3, warmup_steps=0, total_steps=10)
+    assert tr.distributed and tr.world == 1 and tr.comm_stream is not None
+    assert common_steps_per_epoch(7, True, torch.device("cuda", 0)) == 7          # all_reduce(MIN) of a device tensor over RCCL
+    tr.flat_g.fill_(77.0)
+    tr.forward_backward(batch)
+    assert not tr._pending, "bucket all-reduces left unwaited"
+    torch.cuda.synchronize()
+    g_ddp = tr.flat_g.clone()
+    os.environ["CLDRD_FORCE_DDP"] = "0"
+    plain_model = selftest.build_tiny_model(cfg, seed=3).cuda()
+    plain_model.train()
+    plain = NwayTrainer(plain_model, loss="margin_mse", learning_rate=1e-3, warmup_steps=0, total_steps=10)
+    assert not plain.distributed
+    plain.forward_backward(batch)
+    torch.cuda.synchronize()
+    scale = plain.flat_g.abs().max().item()
+    err = (g_ddp - plain.flat_g).abs().max().item()
+    # same kernels; the weight-gradient groups are flushed every 2 layers instead of once (other token splits) and the embedding atomics race
+    assert err <= 2e-3 * scale, f"gradient through the RCCL path differs: {err:.3e} vs scale {scale:.3e}"
+    p0 = plain.flat_p.clone()
+    for _ in range(3):                                     # whole steps: hooks + clip + AdamW, eager (never a graph under torch.distributed)
+        tr.train_step(batch)
+        plain.train_step(batch)
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.flat_p).all().item()
+    # AdamW turns a last-bit gradient difference on a near-zero gradient (k_lin.bias: mathematically zero) into +-lr, so single
+    # weights may differ by a few lr; the UPDATE as a whole must agree
+    upd, upd_ref = (tr.flat_p - p0).double(), (plain.flat_p - p0).double()
+    dp = ((upd - upd_ref).norm() / upd_ref.norm()).item()
+    assert upd_ref.norm().item() > 0 and dp <= 0.05, f"update after 3 steps differs: relative {dp:.3e}"
+    open(out, "w").write(f"ok {err / scale:.2e} {dp:.2e}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_path_over_rccl_with_one_rank(tmp_path):
+    """What one GPU can prove about the RCCL path (tests above: two ranks over gloo): ProcessGroupNCCL itself, world_size 1."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok")
+    mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert open(out).read().startswith("ok")

@@ -3,7 +3,7 @@
 # section HBM); both counters are in KiB.  Output: gpurun_out/pmc_train/traffic.json (copy to profiles/).
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_train/$c -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-index --no-retrieve --no-kernel-events --no-ragged --steps 4 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/pmc_train_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_train/$c -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-index --no-retrieve --no-kernel-events --no-ragged --no-ddp1 --steps 4 --warmup 2 > $GRAFT_REPO_ROOT/gpurun_out/pmc_train_$c.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 for side in 1 0; do
   export CLDRD_Q_SIDE=$side
-  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_side$side -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-index --no-retrieve --no-kernel-events --no-ragged --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/gpurun_out/prof_side$side.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_side$side -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-index --no-retrieve --no-kernel-events --no-ragged --no-ddp1 --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/gpurun_out/prof_side$side.log 2>&1
   tail -1 $GRAFT_REPO_ROOT/gpurun_out/prof_side$side.log | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('Q_SIDE=$side', d['value'], d['ms_per_step'])"
 done
 cd $GRAFT_REPO_ROOT

@@ -1,7 +1,7 @@
 # kernel trace of a few training steps; prints one step (AdamW to AdamW) around its boundaries: tools/step_trace.sh [first n / last n rows]
 cd /tmp && export TMPDIR=/tmp
 export CLDRD_GRAPH=${TRACE_GRAPH:-0}   # rocprofv3 serialises the branches of a replayed graph: trace the eager step
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_trace -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-index --no-retrieve --no-kernel-events --no-ragged --steps 12 --warmup 6 > $GRAFT_REPO_ROOT/gpurun_out/prof_trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_trace -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-index --no-retrieve --no-kernel-events --no-ragged --no-ddp1 --steps 12 --warmup 6 > $GRAFT_REPO_ROOT/gpurun_out/prof_trace.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob
