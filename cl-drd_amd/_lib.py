@@ -31,15 +31,15 @@ SIGNATURES = {
     "cldrd_attention_bwd_bits": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp, vp]),
     "cldrd_attention_cls_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
     "cldrd_attention_cls_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
-    "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, vp]),
+    "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_ln_partial_blocks": (ci, [ci]),
     "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, ci, vp, vp, vp]),
-    "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp, vp]),
+    "cldrd_embed_ln_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cull, ci, vp, ci, vp, vp]),
     "cldrd_layernorm_fwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, cf, vp, ci, ci, vp, ci, vp, vp]),
-    "cldrd_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cull, ci, ci, vp]),
+    "cldrd_layernorm_bwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cull, ci, ci, vp, vp]),
     "cldrd_ln_reduce_group": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, vp]),
     "cldrd_colsum_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
-    "cldrd_scatter_cls_grad": (ci, [vp, vp, ci, ci, ci, ci, vp]),
+    "cldrd_scatter_cls_grad": (ci, [vp, vp, ci, ci, ci, ci, ci, vp]),
     "cldrd_score_fwd": (ci, [vp, vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_score_bwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_loss_fwd_bwd": (ci, [ci, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, ci, vp]),
@@ -69,8 +69,8 @@ SIGNATURES = {
     "cldrd_gather_cast_rows": (ci, [vp, vp, csz, csz, ci, vp]),
     "cldrd_unpack_rows16": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "cldrd_gather_rows": (ci, [vp, vp, vp, ci, ci, vp]),
-    "cldrd_scatter_cls_grad_idx": (ci, [vp, vp, ci, ci, vp, ci, vp]),
-    "cldrd_add_rows_idx": (ci, [vp, vp, ci, ci, vp, vp]),
+    "cldrd_scatter_cls_grad_idx": (ci, [vp, vp, ci, ci, vp, ci, ci, vp]),
+    "cldrd_add_rows_idx": (ci, [vp, vp, ci, ci, vp, ci, vp]),
     "cldrd_set_seed_base": (None, [vp]),
     "cldrd_set_optim_hyper": (None, [vp]),
     "cldrd_write_step_state": (ci, [vp, cull, cull, vp, cf, cf, cf, ci, vp]),

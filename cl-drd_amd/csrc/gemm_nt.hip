@@ -345,6 +345,7 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
         case EPI_GELUGRAD: return launch_nt<EPI_GELUGRAD>(a, (hipStream_t)stream);
         case EPI_RESIDUAL: return launch_nt<EPI_RESIDUAL>(a, (hipStream_t)stream);
         case EPI_F32: return launch_nt<EPI_F32>(a, (hipStream_t)stream);
+        case EPI_RESIDUAL | EPI_RES32 | EPI_F32: return launch_nt<EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);     // fp32 gradient stream
         case EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32: return launch_nt<EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
         case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
             return launch_nt<EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);

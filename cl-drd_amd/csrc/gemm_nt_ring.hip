@@ -18,6 +18,8 @@ int launch_ring(const GemmNtArgs& a, hipStream_t st) {
         case EPI_GELUGRAD: return launch_ring_epi<BN, EPI_GELUGRAD>(a, st);
         case EPI_RESIDUAL: return launch_ring_epi<BN, EPI_RESIDUAL>(a, st);
         case EPI_F32: return launch_ring_epi<BN, EPI_F32>(a, st);
+        // data gradients of the fp32 gradient stream: fp32 residual (the LayerNorm backward's dx) in, fp32 sum out
+        case EPI_RESIDUAL | EPI_RES32 | EPI_F32: return launch_ring_epi<BN, EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, st);
         case EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32: return launch_ring_epi<BN, EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, st);
         case EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
             return launch_ring_epi<BN, EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, st);

@@ -267,12 +267,18 @@ __device__ __forceinline__ void block_partials(float* smem, RowF& a, RowF& b, Ro
 //   dx  = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))                       -> dx (residual path)
 //   dx2 = dropout-masked dx (the branch that went through dropout before the residual add), or null
 //   partial[blk] = { sum dy*xhat (dgamma), sum dy (dbeta), sum dx2-or-dx (bias grad of the preceding Linear) }
-template <int DC, bool DROP, bool X32>
-__global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const void* __restrict__ x,
+// G32 (round 3): the gradient STREAM is fp32 - dy is read and dx written as fp32 rows; dx2, the MFMA operand of the next data-gradient
+// GEMM, stays bf16 (and is then written without dropout too).  The stream is rounded to 16 bits nowhere between the loss and the embeddings.
+// dy_branch (optional, bf16): the output of the data-gradient GEMM of the branch that joins the stream here (FFN / attention), added on
+// load: dy = stream + branch.  That GEMM then has a plain bf16 epilogue (no fp32 residual in, no fp32 sum out: 200 MB less per GEMM at
+// T = 32768 than adding in its epilogue) and only the branch's own contribution is rounded, once, like any MFMA operand.
+template <int DC, bool DROP, bool X32, bool G32 = false>
+__global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy_v, const void* __restrict__ x,
                                                       const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
-                                                      const float* __restrict__ gamma, bf16_t* __restrict__ dx,
+                                                      const float* __restrict__ gamma, void* __restrict__ dx_v,
                                                       bf16_t* __restrict__ dx2, float* __restrict__ partial, int T, int d_rt,
-                                                      uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+                                                      uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
+                                                      const bf16_t* __restrict__ dy_branch) {
     const uint64_t seed = seed_a.get();
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     extern __shared__ __attribute__((aligned(16))) float lsm[];
@@ -285,7 +291,19 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ 
     const int wpb = blockDim.x >> 6;      // waves per block: 8 -> 16 waves per CU keep enough loads in flight
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < T; row += gridDim.x * wpb) {
         RowF g, xr;
-        load_row_bf16(dy + (size_t)row * d, d, lane, g);
+        if (G32) {
+            load_row_f32_stream((const float*)dy_v + (size_t)row * d, d, lane, g);
+            if (dy_branch) {       // dy = fp32 stream + the bf16 output of the branch's data-gradient GEMM, added here instead of in its epilogue
+                RowF br;
+                load_row_bf16(dy_branch + (size_t)row * d, d, lane, br);
+#pragma unroll
+                for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g.v[it][j] += br.v[it][j];
+            }
+        } else {
+            load_row_bf16((const bf16_t*)dy_v + (size_t)row * d, d, lane, g);
+        }
         if (X32) load_row_f32_stream((const float*)x + (size_t)row * d, d, lane, xr);
         else load_row_bf16((const bf16_t*)x + (size_t)row * d, d, lane, xr);
         const float mean = mean_i[row], rstd = rstd_i[row];
@@ -324,7 +342,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 dbias.v[it][j] += v;
             }
         }
-        store_row_bf16(dx + (size_t)row * d, d, lane, g);
+        if (G32) store_row_f32((float*)dx_v + (size_t)row * d, d, lane, g);
+        else store_row_bf16((bf16_t*)dx_v + (size_t)row * d, d, lane, g);
         if (dx2) store_row_bf16(dx2 + (size_t)row * d, d, lane, o2);
     }
     block_partials(lsm, dg, db, dbias, d, lane, partial);
@@ -333,15 +352,15 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const bf16_t* __restrict__ 
 // Embedding backward: dy -> (dropout) -> LN backward (statistics saved, input recomputed from the tables)
 // -> scatter-add into the word / position tables (fp32 atomics); LN-parameter and token-type gradients go
 // through per-block partials {dgamma, dbeta, dtype}.
-template <int DC, bool DROP>
-__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restrict__ dy, const int64_t* __restrict__ ids,
+template <int DC, bool DROP, bool G32 = false>
+__global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const void* __restrict__ dy_v, const int64_t* __restrict__ ids,
                                                             const float* __restrict__ word, const float* __restrict__ pos,
                                                             const float* __restrict__ type0, const float* __restrict__ gamma,
                                                             const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                             float* __restrict__ dword, float* __restrict__ dpos,
                                                             float* __restrict__ partial, int T, int L, int d_rt, int vocab,
                                                             uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int pos_uniform,
-                                                            const int* __restrict__ pos_idx) {
+                                                            const int* __restrict__ pos_idx, const bf16_t* __restrict__ dy_branch) {
     const uint64_t seed = seed_a.get();
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     extern __shared__ __attribute__((aligned(16))) float lsm[];
@@ -359,7 +378,19 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const bf16_t* __restr
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const int l = pos_idx ? pos_idx[row] : row % L;
         RowF g, xr, p;
-        load_row_bf16_i(dy + (size_t)row * d, d, lane, g);
+        if (G32) {
+            load_row_f32_i((const float*)dy_v + (size_t)row * d, d, lane, g);
+            if (dy_branch) {       // + the bf16 output of layer 0's last data-gradient GEMM (see ln_bwd_kernel)
+                RowF br;
+                load_row_bf16_i(dy_branch + (size_t)row * d, d, lane, br);
+#pragma unroll
+                for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g.v[it][j] += br.v[it][j];
+            }
+        } else {
+            load_row_bf16_i((const bf16_t*)dy_v + (size_t)row * d, d, lane, g);
+        }
         {   // a row whose incoming gradient is exactly zero (padded positions: nothing attends to them) contributes exactly
             // zero to every sum below: skip it, and with it the atomics of all pad tokens onto the one [PAD] table row
             float amax = 0.f;
@@ -469,9 +500,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 }
 
 // g[T, d] = 0 except rows r*stride <- dcls[r] (gradient of the CLS pooling)
-__global__ void scatter_cls_kernel(const float* __restrict__ dcls, bf16_t* __restrict__ g, int R, int d, int stride) {
+template <bool F32>
+__global__ void scatter_cls_kernel(const float* __restrict__ dcls, void* __restrict__ g, int R, int d, int stride) {
     const int r = blockIdx.x;
-    for (int c = threadIdx.x; c < d; c += blockDim.x) g[(size_t)r * stride * d + c] = f2bf(dcls[(size_t)r * d + c]);
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+        if (F32) ((float*)g)[(size_t)r * stride * d + c] = dcls[(size_t)r * d + c];
+        else ((bf16_t*)g)[(size_t)r * stride * d + c] = f2bf(dcls[(size_t)r * d + c]);
+    }
 }
 
 }  // namespace
@@ -569,20 +604,28 @@ static int launch_reduce(const float* partial, int nblk, int d, float* o0, float
 // All three null: the reduction is deferred - `partial` keeps the per-block sums for a later cldrd_ln_reduce_group call.
 extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                                    void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
-                                   int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, void* stream) {
+                                   int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, const void* dy_branch, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_bwd: need 0 < d <= 1024, d % 4 == 0");
+    CLDRD_CHECK(dy_branch == nullptr || (x_f32 & 2), "layernorm_bwd: dy_branch goes with the fp32 gradient stream (x_f32 bit 1)");
+    // x_f32: bit 0 = x holds fp32 pre-LN sums; bit 1 = dy and dx are fp32 rows (fp32 gradient stream; dx_dropped stays bf16 and is required:
+    // it is the MFMA operand of the next data-gradient GEMM)
+    const bool g_f32 = (x_f32 & 2) != 0;
+    CLDRD_CHECK(!g_f32 || ((x_f32 & 1) && dx_dropped != nullptr), "layernorm_bwd: the fp32 gradient stream needs fp32 x and the bf16 operand copy (dx_dropped)");
     const int nb = ln_bwd_blocks(T);
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
         constexpr int DCV = decltype(dc)::value;
         constexpr bool DRV = decltype(dr)::value;
         const size_t lds = (512 / 128) * 3 * MAX_IT * 64 * sizeof(float4);
-        if (x_f32)
-            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true>), dim3(nb), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dy, x, mean, rstd, gamma,
-                               (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
+        const float sc = 1.0f / (1.0f - dropout_p);
+        hipStream_t st = (hipStream_t)stream;
+        bf16_t* d2 = (bf16_t*)dx_dropped;
+        if (g_f32)          // fp32 gradient stream: only with the fp32 pre-LN sums of the fp32 residual stream
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true, true>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)dy_branch);
+        else if (x_f32 & 1)
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)nullptr);
         else
-            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, false>), dim3(nb), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dy, x, mean, rstd, gamma,
-                               (bf16_t*)dx, (bf16_t*)dx_dropped, partial, T, d, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, false>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)nullptr);
     });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dbias, accumulate, (hipStream_t)stream);
@@ -611,8 +654,10 @@ extern "C" int cldrd_ln_reduce_group(const float* const* partial, const int* T, 
 extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,
                                   const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
                                   float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,
-                                  float dropout_p, unsigned long long seed, int accumulate, const int* pos_idx, void* stream) {
+                                  float dropout_p, unsigned long long seed, int accumulate, const int* pos_idx, int dy_f32, const void* dy_branch,
+                                  void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_bwd: bad shape");
+    CLDRD_CHECK(dy_branch == nullptr || dy_f32, "embed_ln_bwd: dy_branch goes with an fp32 dy");
     int nb = ln_bwd_blocks(T);                      // the caller sized `partial` for this many blocks; fewer is fine
     int g4 = 4, r = L;                              // gcd(4, L)
     while (r) { const int t = g4 % r; g4 = r; r = t; }
@@ -621,9 +666,15 @@ extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const fl
     if (pos_uniform) nb = (nb / step) * step;
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
-        hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3(nb), dim3(256), (256 / 128) * 3 * MAX_IT * 64 * sizeof(float4),
-                           (hipStream_t)stream, (const bf16_t*)dy, (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial,
-                           T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx);
+        const size_t lds = (256 / 128) * 3 * MAX_IT * 64 * sizeof(float4);
+        if (dy_f32)
+            hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value, true>), dim3(nb), dim3(256), lds,
+                               (hipStream_t)stream, dy, (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial,
+                               T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx, (const bf16_t*)dy_branch);
+        else
+            hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3(nb), dim3(256), lds,
+                               (hipStream_t)stream, dy, (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial,
+                               T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx, (const bf16_t*)nullptr);
     });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dtype0, accumulate, (hipStream_t)stream);
@@ -642,10 +693,11 @@ extern "C" int cldrd_colsum_bf16(const void* x, float* out, float* partial, int 
     return 0;
 }
 
-extern "C" int cldrd_scatter_cls_grad(const float* dcls, void* g, int R, int d, int stride, int T, void* stream) {
+extern "C" int cldrd_scatter_cls_grad(const float* dcls, void* g, int R, int d, int stride, int T, int g_f32, void* stream) {
     CLDRD_CHECK(R > 0 && d > 0 && stride > 0 && (long long)R * stride <= (long long)T + stride - 1, "scatter_cls_grad: bad shape");
-    if (hipMemsetAsync(g, 0, (size_t)T * d * sizeof(bf16_t), (hipStream_t)stream) != hipSuccess) return cldrd_set_error("scatter_cls_grad: memset failed");
-    hipLaunchKernelGGL(scatter_cls_kernel, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, (bf16_t*)g, R, d, stride);
+    if (hipMemsetAsync(g, 0, (size_t)T * d * (g_f32 ? sizeof(float) : sizeof(bf16_t)), (hipStream_t)stream) != hipSuccess) return cldrd_set_error("scatter_cls_grad: memset failed");
+    if (g_f32) hipLaunchKernelGGL(scatter_cls_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, R, d, stride);
+    else hipLaunchKernelGGL(scatter_cls_kernel<false>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, R, d, stride);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

@@ -290,8 +290,10 @@ def attention_cls_bwd(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p=0.0, 
 
 
 def add_rows_strided(dst, src, M, stride_rows):
-    _chk(dst, BF16, "dst", 2), _chk(src, BF16, "src", 2)
-    call("cldrd_add_rows_strided", _p(dst), _p(src), M, src.shape[1], stride_rows, _stream())
+    """dst[m * stride_rows] += src[m]: bf16 rows (fp32 add, one rounding), or fp32 rows (fp32 gradient stream)."""
+    dt = F32 if dst.dtype == F32 else BF16
+    _chk(dst, dt, "dst", 2), _chk(src, dt, "src", 2)
+    call("cldrd_add_rows_strided", _p(dst), _p(src), M, src.shape[1], stride_rows, 1 if dt == F32 else 0, _stream())
 
 
 def ln_partial_elems(T, d) -> int:
@@ -312,13 +314,17 @@ def embed_ln_fwd(ids, word, pos, type0, gamma, beta, out, mean, rstd, T, L, eps,
 
 
 def embed_ln_bwd(dy, ids, word, pos, type0, gamma, mean, rstd, dword, dpos, dtype0, dgamma, dbeta, partial, T, L,
-                 dropout_p=0.0, seed=0, accumulate=True, pos_idx=None):
+                 dropout_p=0.0, seed=0, accumulate=True, pos_idx=None, dy_branch=None):
     d = word.shape[1]
     if pos_idx is not None:
         _chk(pos_idx, torch.int32, "pos_idx", 1)
+    if dy.dtype not in (BF16, F32):
+        raise TypeError("embed_ln_bwd: dy must be bf16, or fp32 (fp32 gradient stream)")
+    if dy_branch is not None and (dy.dtype != F32 or dy_branch.dtype != BF16 or dy_branch.shape[1] != dy.shape[1] or dy_branch.shape[0] < T):
+        raise ValueError("embed_ln_bwd: dy_branch (bf16 [>= T, d]) goes with an fp32 dy")
     call("cldrd_embed_ln_bwd", _p(dy), _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(mean), _p(rstd), _p(dword),
          _p(dpos), _p(dtype0), _p(dgamma), _p(dbeta), _p(partial), T, L, d, word.shape[0], dropout_p, seed,
-         1 if accumulate else 0, _p(pos_idx), _stream())
+         1 if accumulate else 0, _p(pos_idx), 1 if dy.dtype == F32 else 0, _p(dy_branch), _stream())
 
 
 # ---- variable-length packing (csrc/pack.hip) ---------------------------------------------------------------------------------------
@@ -346,13 +352,14 @@ def gather_rows(src, idx, dst, n=None):
 
 
 def scatter_cls_grad_idx(dcls, g, idx, T):
-    _chk(dcls, F32, "dcls", 2), _chk(g, BF16, "g", 2), _chk(idx, torch.int32, "idx", 1)
-    call("cldrd_scatter_cls_grad_idx", _p(dcls), _p(g), dcls.shape[0], dcls.shape[1], _p(idx), T, _stream())
+    _chk(dcls, F32, "dcls", 2), _chk(g, F32 if g.dtype == F32 else BF16, "g", 2), _chk(idx, torch.int32, "idx", 1)
+    call("cldrd_scatter_cls_grad_idx", _p(dcls), _p(g), dcls.shape[0], dcls.shape[1], _p(idx), T, 1 if g.dtype == F32 else 0, _stream())
 
 
 def add_rows_idx(dst, src, idx, M):
-    _chk(dst, BF16, "dst", 2), _chk(src, BF16, "src", 2), _chk(idx, torch.int32, "idx", 1)
-    call("cldrd_add_rows_idx", _p(dst), _p(src), M, src.shape[1], _p(idx), _stream())
+    dt = F32 if dst.dtype == F32 else BF16
+    _chk(dst, dt, "dst", 2), _chk(src, dt, "src", 2), _chk(idx, torch.int32, "idx", 1)
+    call("cldrd_add_rows_idx", _p(dst), _p(src), M, src.shape[1], _p(idx), 1 if dt == F32 else 0, _stream())
 
 
 def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_stride=0, out32=None, out_copy=None):
@@ -401,11 +408,27 @@ class LnReduceQueue:
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_dropped, dgamma, dbeta, dbias, partial, T, dropout_p=0.0, seed=0,
-                  accumulate=True, defer=None):
+                  accumulate=True, defer=None, dy_branch=None):
     """``defer`` (an LnReduceQueue): dgamma / dbeta / dbias are not produced by this call but by the queue's next ``flush``;
-    ``partial`` is then a buffer of this call's own (ln_partial_elems(T, d) floats) that the queue keeps alive."""
+    ``partial`` is then a buffer of this call's own (ln_partial_elems(T, d) floats) that the queue keeps alive.
+    fp32 ``dy`` = the fp32 gradient stream: ``dx`` fp32, ``dx_dropped`` (bf16, required) the MFMA operand copy; ``dy_branch`` (bf16,
+    optional) is added to dy on load (the branch's data-gradient GEMM output, instead of a residual add in that GEMM's epilogue)."""
     x_f32 = 1 if x.dtype == F32 else 0
-    _chk(dy, BF16, "dy", 2), _chk(x, F32 if x_f32 else BF16, "x", 2), _chk(dx, BF16, "dx", 2)
+    g_f32 = dy.dtype == F32               # fp32 gradient stream: dy and dx fp32, dx_dropped (the bf16 MFMA operand) required
+    if g_f32:
+        if not x_f32 or dx_dropped is None:
+            raise ValueError("layernorm_bwd: an fp32 dy needs fp32 x and the bf16 operand copy dx_dropped")
+        _chk(dx, F32, "dx", 2), _chk(dx_dropped, BF16, "dx_dropped", 2)
+        if dy_branch is not None:
+            _chk(dy_branch, BF16, "dy_branch", 2)
+            if dy_branch.shape[1] != dy.shape[1] or dy_branch.shape[0] < T:
+                raise ValueError("layernorm_bwd: dy_branch must be [>= T, d]")
+        x_f32 |= 2
+    else:
+        if dy_branch is not None:
+            raise ValueError("layernorm_bwd: dy_branch goes with an fp32 dy")
+        _chk(dy, BF16, "dy", 2), _chk(dx, BF16, "dx", 2)
+    _chk(x, F32 if x_f32 else BF16, "x", 2)
     d = x.shape[1]
     if defer is not None:
         for t, nme in ((dgamma, "dgamma"), (dbeta, "dbeta"), (dbias, "dbias")):
@@ -414,11 +437,11 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_dropped, dgamma, dbeta, dbias
         if partial.numel() < ln_partial_elems(T, d):
             raise ValueError("layernorm_bwd: deferred reduction needs a partial buffer of ln_partial_elems(T, d) floats")
         call("cldrd_layernorm_bwd", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dx_dropped), None, None, None,
-             _p(partial), T, d, dropout_p, seed, 1 if accumulate else 0, x_f32, _stream())
+             _p(partial), T, d, dropout_p, seed, 1 if accumulate else 0, x_f32, _p(dy_branch), _stream())
         defer.jobs.append((partial, dgamma, dbeta, dbias, int(T), int(d)))
         return
     call("cldrd_layernorm_bwd", _p(dy), _p(x), _p(mean), _p(rstd), _p(gamma), _p(dx), _p(dx_dropped), _p(dgamma),
-         _p(dbeta), _p(dbias), _p(partial), T, d, dropout_p, seed, 1 if accumulate else 0, x_f32, _stream())
+         _p(dbeta), _p(dbias), _p(partial), T, d, dropout_p, seed, 1 if accumulate else 0, x_f32, _p(dy_branch), _stream())
 
 
 def colsum(x, out, partial, T, accumulate=True):
@@ -427,8 +450,9 @@ def colsum(x, out, partial, T, accumulate=True):
 
 
 def scatter_cls_grad(dcls, g, R, stride, T):
-    _chk(dcls, F32, "dcls", 2), _chk(g, BF16, "g", 2)
-    call("cldrd_scatter_cls_grad", _p(dcls), _p(g), R, dcls.shape[1], stride, T, _stream())
+    """g[T, d] (bf16, or fp32 for the fp32 gradient stream) = 0 except rows r * stride <- dcls[r]."""
+    _chk(dcls, F32, "dcls", 2), _chk(g, F32 if g.dtype == F32 else BF16, "g", 2)
+    call("cldrd_scatter_cls_grad", _p(dcls), _p(g), R, dcls.shape[1], stride, T, 1 if g.dtype == F32 else 0, _stream())
 
 
 def score_fwd(q, p, logits, B, N, mode=0):

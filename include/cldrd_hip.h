@@ -114,7 +114,7 @@ int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mas
                             int H, float dropout_p, unsigned long long seed, int io_f16, void* stream);
 int cldrd_attention_cls_bwd(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
                             int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
-int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, void* stream);
+int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, int f32, void* stream);   /* f32: fp32 rows (fp32 gradient stream) */
 
 /* ---- embeddings + LayerNorm (HF Embeddings.forward, sa_layer_norm / output_layer_norm) --------------------
  * d <= 1024, d % 4 == 0.  `partial` scratch: cldrd_ln_partial_blocks(T) * 3 * d floats. */
@@ -126,7 +126,8 @@ int cldrd_embed_ln_fwd(const long long* ids, const float* word, const float* pos
 int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const float* word, const float* pos, const float* type0,
                        const float* gamma, const float* mean, const float* rstd, float* dword, float* dpos,
                        float* dtype0, float* dgamma, float* dbeta, float* partial, int T, int L, int d, int vocab,
-                       float dropout_p, unsigned long long seed, int accumulate, const int* pos_idx, void* stream);
+                       float dropout_p, unsigned long long seed, int accumulate, const int* pos_idx, int dy_f32, const void* dy_branch,
+                       void* stream);
 /* out = LN(x)*gamma+beta (bf16); cls_out (fp32 [T/cls_stride, d], optional) receives rows r % cls_stride == 0:
  * the `[0][:, 0, :]` CLS pooling of models/nway_dual_encoder.py:52,56,64.
  * x_f32 != 0: x is fp32 (the pre-LN sum of the fp32 residual stream) and out32 (optional) receives the fp32 output next to
@@ -137,10 +138,14 @@ int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
                         int T, int d, float eps, float* cls_out, int cls_stride, int x_f32, float* out32, int out_f16,
                         void* out_bf16_copy, void* stream);
 /* dx = LN backward of dy; dx_dropped (optional) = dropout-masked dx for the branch that passed through dropout;
- * dgamma/dbeta/dbias (each optional) receive sum(dy*xhat), sum(dy), sum(dx_dropped or dx). */
+ * dgamma/dbeta/dbias (each optional) receive sum(dy*xhat), sum(dy), sum(dx_dropped or dx).
+ * x_f32: bit 0 = x holds fp32 pre-LN sums; bit 1 = fp32 GRADIENT STREAM: dy is read and dx written as fp32 rows, dx_dropped (bf16, then
+ * required and written without dropout too) is the MFMA operand of the next data-gradient GEMM, and dy_branch (bf16, optional) is added to dy
+ * on load - the output of the data-gradient GEMM of the branch that joins the residual path here.  cldrd_embed_ln_bwd: dy_f32 / dy_branch
+ * likewise. */
 int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
-                        int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, void* stream);
+                        int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, const void* dy_branch, void* stream);
 /* Deferred form: call cldrd_layernorm_bwd with dgamma = dbeta = dbias = NULL (its `partial` then keeps the per-block sums and must
  * stay untouched), and reduce the scratch buffers of n such calls in ONE launch afterwards.  T[i] = the T of call i; outputs as
  * above, bit-identical to the immediate form.  (The parameter gradients of a LayerNorm are not on the backward's critical path.) */
@@ -149,7 +154,7 @@ int cldrd_ln_reduce_group(const float* const* partial, const int* T, float* cons
 /* out[N] (+)= column sums of bf16 x[T,N] (bias gradients).  partial: ceil(T/128) * N floats. */
 int cldrd_colsum_bf16(const void* x, float* out, float* partial, int T, int N, int ld, int accumulate, void* stream);
 /* g = zeros(bf16 [T,d]); g[r*stride] = dcls[r]  (gradient of the CLS pooling). */
-int cldrd_scatter_cls_grad(const float* dcls, void* g, int R, int d, int stride, int T, void* stream);
+int cldrd_scatter_cls_grad(const float* dcls, void* g, int R, int d, int stride, int T, int g_f32, void* stream);   /* g_f32: g holds fp32 rows */
 
 /* ---- N-way scoring (models/nway_dual_encoder.py:30-47) ----------------------------------------------------
  * mode 0: logits[B,N]; 1: in-batch, all negatives [B,B*N]; 2: in-batch, next sample's N [B,2N]. fp32. */
@@ -256,8 +261,8 @@ int cldrd_gather_cast_rows(const float* src, void* dst, size_t n_out, size_t str
  *   (rows of row_bytes bytes: packing, CLS rows);  scatter_cls_grad_idx: g = 0, g[idx[r]] = bf16(dcls[r]);  add_rows_idx: dst[idx[m]] += src[m]. */
 int cldrd_unpack_rows16(const void* src_packed, void* dst_padded, const int* cu, int nseq, int L, int w, void* stream);
 int cldrd_gather_rows(const void* src, const int* idx, void* dst, int n, int row_bytes, void* stream);
-int cldrd_scatter_cls_grad_idx(const float* dcls, void* g, int R, int d, const int* idx, int T, void* stream);
-int cldrd_add_rows_idx(void* dst, const void* src, int M, int d, const int* idx, void* stream);
+int cldrd_scatter_cls_grad_idx(const float* dcls, void* g, int R, int d, const int* idx, int T, int g_f32, void* stream);
+int cldrd_add_rows_idx(void* dst, const void* src, int M, int d, const int* idx, int f32, void* stream);
 
 /* ---- per-step state in device memory: what lets a whole training step be captured into a HIP graph and replayed -------------------
  * Kernel arguments are frozen at capture; a dropout seed and the optimizer's lr / bias-corrected step size change every step.  With a

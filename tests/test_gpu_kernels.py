@@ -507,6 +507,89 @@ def test_layernorm_fwd_bwd(T, d):
     close(dbias, dx.float().sum(0), 2e-2, 2e-2 * dx.float().sum(0).abs().max().item() + 1e-2, "ln dbias")
 
 
+@pytest.mark.parametrize("T,d,p", [(1000, 768, 0.0), (130, 1024, 0.1), (64, 256, 0.1), (4097, 768, 0.1)])
+def test_layernorm_bwd_fp32_gradient_stream(T, d, p):
+    """fp32 dy in, fp32 dx out (the gradient stream is rounded nowhere), bf16 dx_dropped next to it (the MFMA operand of the next
+    data-gradient GEMM): dx against the fp64 formula at fp32 accuracy, dx_dropped = bf16(masked dx) with the bf16-stream kernel's mask,
+    parameter gradients as before."""
+    x = rnd(113, (T, d), 2.0) + 0.5
+    gamma = 1 + rnd(114, (d,), 0.1)
+    dy = rnd(116, (T, d)) * 1e-3
+    xr = x.double().requires_grad_(True)
+    gr, br = gamma.double().requires_grad_(True), torch.zeros(d, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-12).backward(dy.double())
+    mean = x.mean(1).to(DEV)
+    rstd = (1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-12)).to(DEV)
+    dx = torch.full((T, d), float("nan"), dtype=torch.float32, device=DEV)
+    dxm = torch.full((T, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dg, db, dbias = (torch.zeros(d, device=DEV) for _ in range(3))
+    partial = torch.empty(ops.ln_partial_elems(T, d), device=DEV)
+    ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), dx, dxm, dg, db, dbias, partial, T, dropout_p=p, seed=77, accumulate=False)
+    scale = xr.grad.abs().max().item()
+    close(dx, xr.grad, 1e-4, 1e-5 * scale, "ln dx fp32")
+    close(dg, gr.grad, 1e-3, 1e-3 * gr.grad.abs().max().item(), "ln dgamma")
+    close(db, br.grad, 1e-3, 1e-3 * br.grad.abs().max().item(), "ln dbeta")
+    # the same call on the bf16 stream gives the mask: where its dropped copy is zero and its dx is not
+    dx16, dxm16 = torch.empty(T, d, dtype=torch.bfloat16, device=DEV), torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_bwd(bf(dy).to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), dx16, dxm16, None, None, None, partial, T, dropout_p=p, seed=77)
+    keep = ~((dxm16.float() == 0) & (dx16.float() != 0))
+    want = torch.where(keep, dx / (1.0 - p), torch.zeros_like(dx))
+    close(dxm, want, 1 / 128, 1e-6 * scale, "dx_dropped = bf16(mask * dx / (1 - p))")
+    assert torch.equal(dxm.float() == 0, want == 0), "dropout mask differs from the bf16-stream kernel's"
+    close(dbias, want.sum(0), 1e-3, 1e-4 * scale * T ** 0.5, "ln dbias")
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd(dy.to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), dx, None, dg, db, dbias, partial, T)       # operand copy required
+    # dy = fp32 stream + bf16 branch, added on load: the same results as the sum handed over in one tensor
+    branch = bf(rnd(117, (T, d)) * 1e-3)
+    dxb = torch.empty_like(dx); dxmb = torch.empty_like(dxm)
+    g3 = [torch.zeros(d, device=DEV) for _ in range(3)]
+    ops.layernorm_bwd((dy - branch).to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), dxb, dxmb, g3[0], g3[1], g3[2], partial, T, dropout_p=p, seed=77,
+                      accumulate=False, dy_branch=branch.to(DEV))
+    close(dxb, dx, 1e-4, 2e-6 * scale, "ln dx (stream + branch)")
+    close(g3[0], dg, 1e-4, 1e-5 * dg.abs().max().item(), "ln dgamma (stream + branch)")
+    close(g3[1], db, 1e-4, 1e-5 * db.abs().max().item() + 1e-9, "ln dbeta (stream + branch)")
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd(bf(dy).to(DEV), x.to(DEV), mean, rstd, gamma.to(DEV), dx16, dxm16, None, None, None, partial, T, dy_branch=branch.to(DEV))
+
+
+def test_stream_row_ops_on_fp32_rows():
+    """scatter_cls_grad(_idx) / add_rows_strided / add_rows_idx with fp32 rows (fp32 gradient stream): exact."""
+    R, d, L = 5, 128, 16
+    dcls = rnd(128, (R, d)).to(DEV)
+    g = torch.full((ops.pad_rows(R * L), d), 3.0, dtype=torch.float32, device=DEV)
+    ops.scatter_cls_grad(dcls, g, R, L, R * L)
+    ref = torch.zeros(R * L, d, device=DEV)
+    ref[::L] = dcls
+    assert torch.equal(g[: R * L], ref)
+    idx = torch.tensor([0, 7, 19, 30, 41], dtype=torch.int32, device=DEV)
+    g2 = torch.full((64, d), 3.0, dtype=torch.float32, device=DEV)
+    ops.scatter_cls_grad_idx(dcls, g2, idx, 50)
+    ref2 = torch.zeros(50, d, device=DEV)
+    ref2[idx.long()] = dcls
+    assert torch.equal(g2[:50], ref2)
+    add = rnd(129, (R, d)).to(DEV)
+    ops.add_rows_strided(g, add, R, L)
+    ref[::L] += add
+    assert torch.equal(g[: R * L], ref)
+    ops.add_rows_idx(g2, add, idx, R)
+    ref2[idx.long()] += add
+    assert torch.equal(g2[:50], ref2)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 768, 3072), (2048, 768, 2304), (240, 768, 768), (256, 768, 3072)])
+def test_gemm_fp32_residual_in_fp32_sum_out_without_bias(M, N, K):
+    """The data-gradient flavour of the fp32 gradient stream: out fp32 = A @ B^T + fp32 residual (ring kernel and the small-M kernel)."""
+    A, B = bf(rnd(130, (M, K))), bf(rnd(131, (N, K), 0.05))
+    res = rnd(132, (M, N))
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out, M, residual=res.to(DEV))
+    ref = A.double() @ B.double().T + res.double()
+    close(out, ref, 1e-4, 1e-4 * ref.abs().max().item(), "gemm res32 -> f32")
+    out2 = torch.full((M, N), float("nan"), dtype=torch.float32, device=DEV)
+    ops.gemm_nt(A.to(DEV), B.to(DEV), out2, M)                                # no residual: EPI_F32
+    close(out2, A.double() @ B.double().T, 1e-4, 1e-4 * ref.abs().max().item(), "gemm -> f32")
+
+
 @pytest.mark.parametrize("accumulate", [False, True])
 def test_layernorm_bwd_deferred_group_reduction_is_bit_identical(accumulate):
     """Parameter gradients parked in per-call scratch buffers and reduced by ONE cldrd_ln_reduce_group launch (hip_ops.LnReduceQueue)
@@ -563,6 +646,20 @@ def test_embed_ln_fwd_bwd(V, P, d, M, L):
     for got, ref, name in ((dword, w.grad, "dword"), (dpos, p_.grad, "dpos"), (dtyp, t_.grad, "dtype"), (dg, g_.grad, "dgamma"),
                            (db, b_.grad, "dbeta")):
         close(got, ref, 1e-3, 1e-3 * ref.abs().max().item(), name)
+    # the same from an fp32 dy (fp32 gradient stream): identical values here (dy is bf16-representable), so identical sums up to the atomics' order
+    dword2, dpos2, dtyp2 = torch.zeros_like(wd), torch.zeros_like(pd), torch.zeros_like(td)
+    dg2, db2 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    ops.embed_ln_bwd(dy.float().to(DEV), ids.to(DEV), wd, pd, td[0], gd, mean, rstd, dword2, dpos2, dtyp2[0], dg2, db2, partial, T, L)
+    for got, ref, name in ((dword2, dword, "dword32"), (dpos2, dpos, "dpos32"), (dtyp2, dtyp, "dtype32"), (dg2, dg, "dgamma32"), (db2, db, "dbeta32")):
+        close(got, ref, 1e-5, 1e-5 * ref.abs().max().item(), name)
+    # ... and from an fp32 stream + a bf16 branch term that add up to the same dy
+    half = bf(dy.float() * 0.5)
+    dword3, dpos3, dtyp3 = torch.zeros_like(wd), torch.zeros_like(pd), torch.zeros_like(td)
+    dg3, db3 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    ops.embed_ln_bwd((dy.float() - half.float()).to(DEV), ids.to(DEV), wd, pd, td[0], gd, mean, rstd, dword3, dpos3, dtyp3[0], dg3, db3, partial, T, L,
+                     dy_branch=half.to(DEV))
+    for got, ref, name in ((dword3, dword, "dword (stream + branch)"), (dpos3, dpos, "dpos"), (dg3, dg, "dgamma"), (db3, db, "dbeta")):
+        close(got, ref, 1e-4, 1e-5 * ref.abs().max().item(), name)
 
 
 def test_colsum_and_scatter():

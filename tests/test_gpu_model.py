@@ -339,15 +339,14 @@ def test_full_size_configs_match_reference_goldens(name):
             assert e_our <= max(e_amp, 1e-6 * np.abs(dref).max()) and cos_dl >= (0.99 if loss_kind == "lambda_mrr" else 0.999)
         # gradient DIRECTIONS against stored fp32 reference gradients (tests/golden/make_full_golden_r3.py): the first 16 rows of the four
         # weight matrices of layers 0 and 5 and of the position embeddings, every 1-D parameter of layers 0, 2, 5 and the embedding LayerNorm.
-        #   weight matrices (99.9 % of the parameters): the survey's bar is cosine >= 0.999; the reference's OWN
-        #   bf16-autocast backward reaches 0.9987 on these slices (16 rows each), this backward 0.9979 - 0.99999 (median 0.99995): asserted
-        #   >= 0.997 and reported next to the reference's;
-        #   biases, LayerNorm parameters and position-embedding rows: their gradient is a plain SUM over all tokens (all sequences) of an
-        #   activation gradient whose terms nearly cancel (|sum| ~ 1e-4 of the summed magnitudes), so its direction is set by the
-        #   rounding noise of that tensor.  The
-        #   reference's bf16 autocast keeps the residual-stream gradient in fp32 (only matmul operands are rounded) and lands at 0.997-0.998;
-        #   this backward stores the stream gradient in bf16 between kernels (it is not an MFMA operand: an fp32 stream gradient would
-        #   cost ~4 % of the step) and lands at 0.987-0.992: asserted >= 0.985 and reported next to the reference's.
+        #   weight matrices (99.9 % of the parameters): the survey's bar is cosine >= 0.999, asserted as such.  With
+        #   the fp32 gradient stream (the default since round 3) this backward reaches 0.99909 - 0.99999 (median 0.99997); the reference's OWN
+        #   bf16-autocast backward 0.99874 on the same slices.  (CLDRD_GRAD_STREAM=bf16, the round-2 backward: 0.9979, bar 0.997.)
+        #   biases, LayerNorm parameters and position-embedding rows: their gradient is a plain SUM over all tokens of an activation
+        #   gradient whose terms nearly cancel (|sum| ~ 1e-4 of the summed magnitudes), so its direction is set by the rounding noise of
+        #   that tensor.  What reads the fp32 stream (LayerNorm parameters, the biases in front of a LayerNorm, position rows) is now at
+        #   >= 0.9997; the worst ones left - q/k/v and FFN1 biases, 0.9950 - 0.9959 - are column sums of a bf16 MFMA operand (dqkv, dpre),
+        #   exactly where the reference's bf16 autocast lands on the same tensors (0.9952 / 0.9959).  Asserted >= 0.994 (bf16 stream: 0.985).
         nkey = f"gslice_names_{gk}"
         if nkey in g.files:
             def cosine(a, b):
@@ -368,8 +367,10 @@ def test_full_size_configs_match_reference_goldens(name):
                 print(f"{name}/{loss_kind}: gradient cosine of {len(sub)} {label}: min {sub[0][0]:.5f} ({sub[0][2]}; the reference's bf16-autocast "
                       f"backward: {sub[0][1]:.5f}), median {sub[len(sub) // 2][0]:.5f}; reference autocast min {min(r[1] for r in sub):.5f}")
             assert len(rows) >= 40
+            gs32 = os.environ.get("CLDRD_GRAD_STREAM", "fp32") != "bf16" and os.environ.get("CLDRD_RESIDUAL", "fp32") != "bf16"
+            bar2, bar1 = (0.999, 0.994) if gs32 else (0.997, 0.985)
             for c, c_amp, n, dim in rows:
-                assert c >= (0.997 if dim == 2 else 0.985), f"{name}/{loss_kind}: gradient of {n}: cosine {c:.5f} (reference autocast {c_amp:.5f})"
+                assert c >= (bar2 if dim == 2 else bar1), f"{name}/{loss_kind}: gradient of {n}: cosine {c:.5f} (reference autocast {c_amp:.5f})"
         del tr
 
 
