@@ -6,6 +6,8 @@
 // by LDS-DMA.  The 16-B slot index is XOR-swizzled with f(m) = 2*((m&3) | ((m>>3)&1)<<2) (on the DMA source address
 // and on the read address): every transposed read then touches all 64 banks exactly once.
 //
+// (Round 3: the NT kernel's third A slot / separate operand rings were tried here too and removed again - nothing for the step, and the
+// restructured K loop read 7.4 instead of 5.9 GB per passage-tower group: profiles/r03_microbench.txt.)
 // Tile 256 (n1) x 128 (n2), 512 threads = 4 x 2 waves of 64 x 64, MFMA 16x16x32; 64-token K tiles in two LDS slots.
 // Same software pipeline as gemm_nt_ring.hip: per 32-token k-step the A fragments are refilled in place as soon as
 // their last MFMA has issued, the B fragments are double-buffered, reads are threaded between the MFMAs
@@ -43,7 +45,6 @@ struct TnProblem {
 };
 struct TnGroupArgs {
     int n, splits, accumulate, stagger;
-    int asym;                          // 256 x 192 tile: third A slot, A requested two K tiles ahead (0: two slots each, the round-2 schedule)
     float* slabs;
     TnProblem p[MAXP];
 };
@@ -96,11 +97,6 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
     constexpr int APW = A_BYTES / 1024 / NW, BPW = B_BYTES / 1024 / NW;     // pieces per wave
     constexpr int NSLOT = 3 * SLOT <= 160 * 1024 ? 3 : 2;                   // 3: K tiles kt+1 and kt+2 stay in flight
     constexpr int G = APW + BPW;                        // LDS-DMA instructions per wave per K tile
-    // LDS = [NA A slots | NSLOT B slots].  Where only two whole K tiles fit (256 x 192: 2 x 56 KiB) the A operand gets a third slot
-    // (3 x 32 + 2 x 24 = 144 KiB) and is requested two K tiles ahead, as in gemm_nt_ring_kernel.h (ga.asym; 0 = two slots each).
-    constexpr int NA_MAX = (NSLOT == 2 && 3 * A_BYTES + 2 * B_BYTES <= 160 * 1024) ? 3 : NSLOT;
-    constexpr int BRING = NA_MAX * A_BYTES;
-    const int na_ = (NA_MAX > NSLOT && ga.asym != 0) ? NA_MAX : NSLOT;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int id = xcd_remap(blockIdx.x, gridDim.x);
@@ -136,44 +132,31 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
         const int r = byte / (T2 * 2), pos = (byte % (T2 * 2)) / 16;
         ob[i] = (uint32_t)r * (uint32_t)(ldb * 2) + (uint32_t)(c2 * 2) + (uint32_t)(chunk_pos<T2 * 2>(pos, r) * 16);
     }
-    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(smem);
-    auto stageA = [&](int slot, int kt) {
+    auto stage = [&](int slot, int kt) {
+        char* base = smem + slot * SLOT;
         const char* pa = (const char*)A + (size_t)(kbeg + kt) * BK * lda * 2;
+        const char* pb = (const char*)B + (size_t)(kbeg + kt) * BK * ldb * 2;
         if (mtail != 0 && kbeg + kt == ktotal - 1) {
             // last, partial K tile: token rows >= M come from the zero page (once per workgroup at most; rows recomputed here
             // instead of being kept in registers)
             const char* zp = (const char*)g_zero_page + lane * 16;
-            char* base = smem + slot * A_BYTES;
 #pragma unroll
             for (int i = 0; i < APW; ++i) {
                 const int r = RA * (APW * wid + i) + lane / LPR_A;
                 __builtin_amdgcn_global_load_lds(GLOBAL_PTR(r < mtail ? pa + oa[i] : zp), LDS_PTR(base + (APW * wid + i) * 1024), 16, 0, 0);
             }
-            return;
-        }
-#pragma unroll
-        for (int i = 0; i < APW; ++i) tn_dma16(lds0 + slot * A_BYTES + (APW * wid + i) * 1024, oa[i], pa);
-    };
-    auto stageB = [&](int slot, int kt) {
-        const char* pb = (const char*)B + (size_t)(kbeg + kt) * BK * ldb * 2;
-        if (mtail != 0 && kbeg + kt == ktotal - 1) {
-            const char* zp = (const char*)g_zero_page + lane * 16;
-            char* base = smem + BRING + slot * B_BYTES;
 #pragma unroll
             for (int i = 0; i < BPW; ++i) {
                 const int r = ((BPW * wid + i) * 1024 + lane * 16) / (T2 * 2);
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(r < mtail ? pb + ob[i] : zp), LDS_PTR(base + (BPW * wid + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(r < mtail ? pb + ob[i] : zp), LDS_PTR(base + A_BYTES + (BPW * wid + i) * 1024), 16, 0, 0);
             }
             return;
         }
+        const uint32_t lbase = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * SLOT;
 #pragma unroll
-        for (int i = 0; i < BPW; ++i) tn_dma16(lds0 + BRING + slot * B_BYTES + (BPW * wid + i) * 1024, ob[i], pb);
-    };
-    // the requests a slot recycle at the barrier of K tile kt makes: B of K tile kt + NSLOT into tile kt's B slot, then A of K tile kt + na
-    // into its A slot.  B first: the wait for K tile kt+1 then leaves exactly the youngest requests - A(kt+2) - in flight.
-    auto recycle = [&](int slotA, int slotB, int kt) {
-        if (kt + NSLOT < nk) stageB(slotB, kt + NSLOT);
-        if (kt + na_ < nk) stageA(slotA, kt + na_);
+        for (int i = 0; i < APW; ++i) tn_dma16(lbase + (APW * wid + i) * 1024, oa[i], pa);
+#pragma unroll
+        for (int i = 0; i < BPW; ++i) tn_dma16(lbase + A_BYTES + (BPW * wid + i) * 1024, ob[i], pb);
     };
 
     // ---- transposed-read addressing: 16-lane group g reads token rows 8g+q (+4); lane (4q+pp) supplies cols 4pp..4pp+3.
@@ -190,7 +173,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
 #pragma unroll
     for (int t = 0; t < NBF; ++t) {
         const int cb = wn * (16 * NBF) + t * 16 + 4 * pp;
-        rb[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + BRING + m0 * (T2 * 2) + chunk_pos<T2 * 2>(cb >> 3, m0) * 16 + (cb & 7) * 2;
+        rb[t] = (uint32_t)(uintptr_t)LDS_PTR(smem) + A_BYTES + m0 * (T2 * 2) + chunk_pos<T2 * 2>(cb >> 3, m0) * 16 + (cb & 7) * 2;
     }
 
     f32x4 acc[FA][NBF];
@@ -229,7 +212,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
     // MFMA pipe at the same time (measured on the NT kernel: +2..9 %)
     const bool late_wave = NW == 8 && wid >= 4 && stagger;
     // one 32-token k-step over (af, bc); the next fragments come from slot offset noff, k-step NKS of that slot
-    auto kstep = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t noffA, uint32_t noffB, auto nks_tag, bool sync, int slot, int kt) {
+    auto kstep = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
         constexpr int NKS = decltype(nks_tag)::value;
         constexpr int OA = NKS * 32 * T1 * 2, OB = NKS * 32 * T2 * 2;
         wait_row0(bc);
@@ -242,15 +225,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (!late_wave) recycle(slot, slot, kt);       // slots of K tile kt: every wave holds its fragments in registers
+            if (!late_wave && kt + NSLOT < nk) stage(slot, kt + NSLOT);  // slot of K tile kt: every wave holds its fragments in registers
             __builtin_amdgcn_sched_barrier(0);
-        } else if (late_wave && slot >= 0) {
-            recycle(slot, slot, kt);                       // postponed from the previous K tile's barrier (see gemm_nt_ring.hip)
+        } else if (late_wave && slot >= 0 && kt + NSLOT < nk) {
+            stage(slot, kt + NSLOT);                       // postponed from the previous K tile's barrier (see gemm_nt_ring.hip)
             __builtin_amdgcn_sched_barrier(0);
         }
-        tr_issue<OA, 4 * T1 * 2>(af[0], ra[0] + noffA);
+        tr_issue<OA, 4 * T1 * 2>(af[0], ra[0] + noff);
 #pragma unroll
-        for (int t = 0; t < NBF; ++t) tr_issue<OB, 4 * T2 * 2>(bn[t], rb[t] + noffB);
+        for (int t = 0; t < NBF; ++t) tr_issue<OB, 4 * T2 * 2>(bn[t], rb[t] + noff);
 #pragma unroll
         for (int t1 = 1; t1 < FA; ++t1) {
             __builtin_amdgcn_sched_barrier(0);
@@ -258,7 +241,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
             __builtin_amdgcn_sched_barrier(0);
             mfma_row(t1, bc);
             __builtin_amdgcn_sched_barrier(0);
-            tr_issue<OA, 4 * T1 * 2>(af[t1], ra[t1] + noffA);
+            tr_issue<OA, 4 * T1 * 2>(af[t1], ra[t1] + noff);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -285,16 +268,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
                          "+v"(bc[1].hi), "+v"(bc[2].lo), "+v"(bc[2].hi) : "n"(WLO));
     };
     // one 32-token k-step; current fragments at slot offset coff / k-step CKS, the next k-step's at noff / NKS
-    auto kstep8 = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t coff, auto cks_tag, uint32_t noff, uint32_t noffB, auto nks_tag, bool sync,
-                      int slot, int slotB, int kt) {
+    auto kstep8 = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t coff, auto cks_tag, uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
         constexpr int CKS = decltype(cks_tag)::value, NKS = decltype(nks_tag)::value;
         constexpr int COA = CKS * 32 * T1 * 2, NOA = NKS * 32 * T1 * 2, NOB = NKS * 32 * T2 * 2;
         wait_row0_lag(bc);
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(0, bc);
         __builtin_amdgcn_sched_barrier(0);
-        if (!sync && late_wave && slot >= 0) {
-            recycle(slot, slotB, kt);                      // postponed from the previous K tile's barrier (see gemm_nt_ring.hip)
+        if (!sync && late_wave && slot >= 0 && kt + NSLOT < nk) {
+            stage(slot, kt + NSLOT);                       // postponed from the previous K tile's barrier (see gemm_nt_ring.hip)
             __builtin_amdgcn_sched_barrier(0);
         }
         tr_issue<COA, 4 * T1 * 2>(af[4], ra[4] + coff);
@@ -313,17 +295,15 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
         mfma_row(4, bc);
         __builtin_amdgcn_sched_barrier(0);
         if (sync) {
-            // every read of this K tile's slots has been issued (and is waited for here); K tile kt+1 must have landed - with the
-            // third A slot the youngest requests, A of K tile kt+2, stay in flight
-            if (na_ == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(APW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            // every read of this K tile's slot has been issued (and is waited for here); K tile kt+1 must have landed
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (!late_wave) recycle(slot, slotB, kt);
+            if (!late_wave && kt + NSLOT < nk) stage(slot, kt + NSLOT);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int t = 0; t < NBF; ++t) tr_issue<NOB, 4 * T2 * 2>(bn[t], rb[t] + noffB);
+        for (int t = 0; t < NBF; ++t) tr_issue<NOB, 4 * T2 * 2>(bn[t], rb[t] + noff);
         tr_issue<NOA, 4 * T1 * 2>(af[0], ra[0] + noff);
 #pragma unroll
         for (int t1 = 5; t1 < 8; ++t1) {
@@ -339,41 +319,25 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
 
     if constexpr (FA == 8) {
         if (nk > 0) {
-            // every slot is free: K tiles 0 and 1 (and A of K tile 2) are requested back to back, only tile 0 is waited for
-            // (request order A0 B0 | B1 A1 | A2 - what the waits count on)
-            stageA(0, 0);
-            stageB(0, 0);
-            const bool early = na_ == 3 && nk > 1;
-            if (early) {
-                stageB(1, 1);
-                stageA(1, 1);
-                if (nk > 2) {
-                    stageA(2, 2);
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G + APW) : "memory");
-                } else {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
-                }
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            stage(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (nk > 1 && !early) { stageB(1, 1); stageA(1, 1); }
+            if (nk > 1) stage(1, 1);
 #pragma unroll
             for (int t = 0; t < NBF; ++t) tr_issue<0, 4 * T2 * 2>(b0[t], rb[t]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) tr_issue<0, 4 * T1 * 2>(af[t], ra[t]);
-            int csA = 0, csB = 0, psA = -1, psB = -1;          // A / B slots of K tiles kt and kt-1
+            int cs = 0, ps = -1;                               // slots of K tiles kt and kt-1
             for (int kt = 0; kt + 1 < nk; ++kt) {
-                const int nsA = csA == na_ - 1 ? 0 : csA + 1, nsB = csB ^ 1;
-                kstep8(b0, b1, (uint32_t)(csA * A_BYTES), KS0{}, (uint32_t)(csA * A_BYTES), (uint32_t)(csB * B_BYTES), KS1{}, false, psA, psB, kt - 1);
-                kstep8(b1, b0, (uint32_t)(csA * A_BYTES), KS1{}, (uint32_t)(nsA * A_BYTES), (uint32_t)(nsB * B_BYTES), KS0{}, true, csA, csB, kt);
-                psA = csA; psB = csB;
-                csA = nsA; csB = nsB;
+                const int ns = cs ^ 1;
+                kstep8(b0, b1, (uint32_t)(cs * SLOT), KS0{}, (uint32_t)(cs * SLOT), KS1{}, false, ps, kt - 1);
+                kstep8(b1, b0, (uint32_t)(cs * SLOT), KS1{}, (uint32_t)(ns * SLOT), KS0{}, true, cs, kt);
+                ps = cs;
+                cs = ns;
             }
-            kstep8(b0, b1, (uint32_t)(csA * A_BYTES), KS0{}, (uint32_t)(csA * A_BYTES), (uint32_t)(csB * B_BYTES), KS1{}, false, psA, psB, nk - 2);
-            // its next-k-step requests read stale LDS: unused
-            kstep8(b1, b0, (uint32_t)(csA * A_BYTES), KS1{}, (uint32_t)(csA * A_BYTES), (uint32_t)(csB * B_BYTES), KS0{}, false, -1, -1, nk);
+            kstep8(b0, b1, (uint32_t)(cs * SLOT), KS0{}, (uint32_t)(cs * SLOT), KS1{}, false, ps, nk - 2);
+            kstep8(b1, b0, (uint32_t)(cs * SLOT), KS1{}, (uint32_t)(cs * SLOT), KS0{}, false, -1, nk);      // its next-k-step requests read stale LDS: unused
             // drain them: an outstanding read lands in its destination register whatever the register holds by then
             if constexpr (NBF == 4)
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(af[1].lo), "+v"(af[1].hi), "+v"(af[2].lo), "+v"(af[2].hi),
@@ -386,19 +350,16 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
         }
     } else
     if (nk > 0) {
-        // (na_ == NSLOT for these tiles: A and B slots advance together; request order B then A inside a K tile)
-        stageB(0, 0);
-        stageA(0, 0);
+        stage(0, 0);
         if (NSLOT == 3 && nk > 1) {
-            stageB(1, 1);
-            stageA(1, 1);
+            stage(1, 1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (NSLOT == 3) { if (nk > 2) { stageB(2, 2); stageA(2, 2); } } else { if (nk > 1) { stageB(1, 1); stageA(1, 1); } }
+        if (NSLOT == 3) { if (nk > 2) stage(2, 2); } else { if (nk > 1) stage(1, 1); }
         tr_issue<0, 4 * T1 * 2>(af[0], ra[0]);
 #pragma unroll
         for (int t = 0; t < NBF; ++t) tr_issue<0, 4 * T2 * 2>(b0[t], rb[t]);
@@ -407,12 +368,12 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
         int cs = 0, ps = -1;                               // slots of K tiles kt and kt-1
         for (int kt = 0; kt + 1 < nk; ++kt) {
             const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
-            kstep(b0, b1, (uint32_t)(cs * A_BYTES), (uint32_t)(cs * B_BYTES), KS1{}, false, ps, kt - 1);
-            kstep(b1, b0, (uint32_t)(ns * A_BYTES), (uint32_t)(ns * B_BYTES), KS0{}, true, cs, kt);
+            kstep(b0, b1, (uint32_t)(cs * SLOT), KS1{}, false, ps, kt - 1);
+            kstep(b1, b0, (uint32_t)(ns * SLOT), KS0{}, true, cs, kt);
             ps = cs;
             cs = ns;
         }
-        kstep(b0, b1, (uint32_t)(cs * A_BYTES), (uint32_t)(cs * B_BYTES), KS1{}, false, ps, nk - 2);
+        kstep(b0, b1, (uint32_t)(cs * SLOT), KS1{}, false, ps, nk - 2);
         wait_row0(b1);
         __builtin_amdgcn_sched_barrier(0);
         mfma_row(0, b1);
@@ -572,8 +533,8 @@ static inline int wgrad_stagger() {
 
 template <int T1, int T2, int NW>
 static int launch_tn_group(const TnGroupArgs& g, int items, hipStream_t st) {
-    constexpr int abytes = BK * T1 * 2, bbytes = BK * T2 * 2, nslot = 3 * (abytes + bbytes) <= 160 * 1024 ? 3 : 2;
-    constexpr int lds = ((nslot == 2 && 3 * abytes + 2 * bbytes <= 160 * 1024) ? 3 : nslot) * abytes + nslot * bbytes;
+    constexpr int slot = BK * (T1 + T2) * 2;
+    constexpr int lds = (3 * slot <= 160 * 1024 ? 3 : 2) * slot;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T1, T2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -628,8 +589,6 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
         const int m = n - lo < MAXP ? n - lo : MAXP;
         TnGroupArgs g;
         g.n = m; g.splits = splits; g.accumulate = accumulate; g.stagger = wgrad_stagger(); g.slabs = workspace;
-        // third A slot: +2..5 % on the long encoder problems alone, -3 % at 4096^3, nothing on the training step (profiles/r03_microbench.txt): opt-in
-        { const char* e = getenv("CLDRD_WGRAD_ASYM"); g.asym = e ? atoi(e) : 0; }
         int items = 0;
         for (int i = 0; i < m; ++i) {
             TnProblem& P = g.p[i];
