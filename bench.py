@@ -570,7 +570,7 @@ def spawn_ranks(n: int) -> int:
 def cpu_baseline(N, L, Lq):
     """The CPU oracle (oracle/, a port of the reference path pinned to it by tests/golden) timed on this box's host cores: fp32
     training steps (forward + loss + backward + clip + AdamW) of the same workload (cfg2: N=32, L=128, kl_div) at B=2 - one untimed
-    warm-up step, then two timed ones: a bounded sample (~10-20 s of CPU work), all cores the process may use."""
+    warm-up step, then four timed ones: a bounded sample (~10-20 s of CPU work), all cores the process may use."""
     import numpy as np
     import torch
     from oracle import encoder_ref as E
@@ -580,7 +580,7 @@ def cpu_baseline(N, L, Lq):
     # steps took 496 s on 256 torch threads and 6.8 s on 32 - beyond that torch-CPU's intra-op parallelism only adds contention.
     cores = min(len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(cores)
-    Bc, timed = 2, 2
+    Bc, timed = 2, 4          # ~11 s on the MI355X host at 32 threads (the prescribed bounded sample is 10-30 s of CPU work)
     cfg = E.RefConfig()
     shapes = E.param_shapes(cfg)
     g = torch.Generator().manual_seed(0)
