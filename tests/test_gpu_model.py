@@ -389,6 +389,31 @@ def test_bf16_residual_stream_option_drift(monkeypatch):
     assert 1.0 < err / amp_err <= 3.0
 
 
+@pytest.mark.parametrize("arch", ["distilbert", "bert"])
+def test_bf16_gradient_stream_option_still_runs_and_differs_only_by_rounding(arch):
+    """`grad_stream32` off (CLDRD_GRAD_STREAM=bf16, the round-2 backward: stream gradient stored in bf16, residual added in the data-gradient
+    GEMM's epilogue) stays available as the fast mode: same forward, gradients equal to the fp32-stream ones up to bf16 rounding (the
+    switch is alive: they are not bit-identical)."""
+    cfg = small_cfg(arch=arch, layers=3)
+    batch = syn.nway_batch(4680, 3, 4, 10, 32, vocab=cfg.vocab_size, ragged=True)
+    grads, logits = {}, {}
+    for mode in (True, False):
+        model = selftest.build_tiny_model(cfg).cuda()
+        model.train()
+        for t in model.towers():
+            assert t.grad_stream32                  # the default
+            t.grad_stream32 = mode
+        tr = NwayTrainer(model, loss="margin_mse")
+        _, lg = tr.forward_backward(batch)
+        torch.cuda.synchronize()
+        grads[mode], logits[mode] = tr.flat_g.double().clone(), lg.clone()
+    assert torch.equal(logits[True], logits[False])
+    a, b = grads[True], grads[False]
+    assert torch.isfinite(b).all().item() and not torch.equal(a, b)
+    c = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
+    assert c > 0.9995 and abs((b.norm() / a.norm()).item() - 1.0) < 5e-3, (c, (b.norm() / a.norm()).item())
+
+
 def test_torch_optimizer_loop_sees_fresh_weights():
     """Reference-style loop (nway_listwise_1.py:328-367 with a torch optimizer): the bf16 weight shadows must follow
     optimizer.step() and load_state_dict (parameters share flat_p's version counter now)."""
