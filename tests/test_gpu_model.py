@@ -636,6 +636,39 @@ def test_packed_batch_equals_padded_batch(arch, layers, monkeypatch):
     assert torch.isfinite(out[0]).item() and torch.isfinite(tr2.flat_p).all().item()
 
 
+@pytest.mark.parametrize("arch", ["distilbert", "bert"])
+@pytest.mark.parametrize("packed", [False, True])
+def test_full_last_layer_equals_the_cls_only_last_layer(arch, packed, monkeypatch):
+    """`cls_only_last = False` (CLDRD_CLS_ONLY=0: the last layer computed for every token, as the reference does) against the default
+    that computes only the CLS row after the K / V projection: same logits and gradients up to rounding, on padded and packed batches
+    (the packed full layer scatters dL/dCLS to the rows `cu[m]`, not to `m * L`)."""
+    cfg = small_cfg(arch, 3)
+    B, N, Lq, Lp = 3, 5, 8, 40
+    batch, lens = _ragged_batch(cfg, 654, B, N, Lq, Lp)
+    dev = lambda b: {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in b.items()}
+    monkeypatch.setenv("CLDRD_GRAPH", "0")
+    out = {}
+    for cls_only in (True, False):
+        model = selftest.build_tiny_model(cfg).cuda().train()
+        for t in model.towers():
+            t.cls_only_last = cls_only
+        tr = NwayTrainer(model, loss="margin_mse")
+        b = dev(batch)
+        if packed:
+            b["nway_passages"]["lengths"] = torch.from_numpy(lens)
+        _, logits = tr.forward_backward(b)
+        torch.cuda.synchronize()
+        out[cls_only] = (logits.double().clone(), tr.flat_g.double().clone())
+    (l1, g1), (l0, g0) = out[True], out[False]
+    rel = (l1 - l0).abs().max().item() / l1.abs().max().item()
+    c = torch.nn.functional.cosine_similarity(g1, g0, dim=0).item()
+    ratio = (g0.norm() / g1.norm()).item()
+    print(f"full vs CLS-only last layer ({arch}, packed={packed}): max logit diff {rel:.2e} of the logit scale, gradient cosine {c:.6f}, norm ratio {ratio:.5f}")
+    # the two paths round at different points (the CLS path keeps its attention probabilities in fp32, the full kernel feeds bf16 P to the
+    # MFMA) and the tiny models' weights are 10x the HF init: bf16-level differences
+    assert rel <= 1e-2 and c >= 0.9995 and abs(ratio - 1.0) <= 5e-3, (rel, c, ratio)
+
+
 def test_packed_index_encode_matches_padded(monkeypatch):
     """The index path packs by default (retrieval_utils.batch_to_device takes the token counts from the host-side mask):
     get_embeddings_from_scratch on ragged batches against the same call with packing off."""
