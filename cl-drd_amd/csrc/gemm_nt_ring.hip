@@ -45,9 +45,7 @@ int cldrd_gemm_nt_ring16_launch(const GemmNtArgs& a, int bn, hipStream_t st);   
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_t st) {
     GemmNtArgs a = a_in;
     int gn_force;
-    static int stagger = -1;
-    if (stagger < 0) { const char* e = getenv("CLDRD_GEMM_STAGGER"); stagger = e ? atoi(e) : 1; }
-    a.stagger = stagger;
+    { const char* e = getenv("CLDRD_GEMM_STAGGER"); a.stagger = e ? atoi(e) : 1; }      // read per call, like the two below: tests flip them in-process
     { const char* e = getenv("CLDRD_GEMM_EARLY1"); a.early1 = e ? atoi(e) : 1; }
     { const char* e = getenv("CLDRD_GEMM_ASYM"); a.asym = e ? atoi(e) : 1; }
     static int gn_env = -2;

@@ -190,6 +190,37 @@ def test_gemm_nt_dropout_is_deterministic_and_unbiased():
     assert not torch.equal(out1, out2)
 
 
+@pytest.mark.parametrize("M,N,K,kw", [(2048, 768, 3072, "res32"), (4100, 2304, 768, "bias"), (1536, 3072, 768, "gelu"), (3000, 768, 768, "plain"),
+                                      (1024, 768, 128, "plain")])
+def test_ring_gemm_schedule_switches_are_bit_identical(M, N, K, kw, monkeypatch):
+    """CLDRD_GEMM_ASYM (third A slot, A requested two K tiles ahead), CLDRD_GEMM_EARLY1 (K tile 1 requested with K tile 0) and
+    CLDRD_GEMM_STAGGER (waves 4..7 issue their LDS-DMA one k-step later) change WHEN operands are requested, never what is computed:
+    every combination must give the bits of the default (read per call, so they are flipped in-process).  K = 128: two K tiles only."""
+    A, B = bf(rnd(140, (M, K))).to(DEV), bf(rnd(141, (N, K), 0.05)).to(DEV)
+    args = {}
+    out_dt = torch.bfloat16
+    if kw == "bias":
+        args["bias"] = rnd(142, (N,)).to(DEV)
+    elif kw == "res32":
+        args["bias"], args["residual"], out_dt = rnd(142, (N,)).to(DEV), rnd(143, (M, N)).to(DEV), torch.float32
+    elif kw == "gelu":
+        args["bias"], args["act"] = rnd(142, (N,)).to(DEV), 1
+    outs = {}
+    for asym in ("1", "0"):
+        for early in ("1", "0"):
+            for stagger in ("1", "0"):
+                monkeypatch.setenv("CLDRD_GEMM_ASYM", asym)
+                monkeypatch.setenv("CLDRD_GEMM_EARLY1", early)
+                monkeypatch.setenv("CLDRD_GEMM_STAGGER", stagger)
+                out = torch.full((M, N), float("nan"), dtype=out_dt, device=DEV)
+                ops.gemm_nt(A, B, out, M, **args)
+                outs[(asym, early, stagger)] = out
+    base = outs[("1", "1", "1")]
+    assert torch.isfinite(base.float()).all().item()
+    for k, o in outs.items():
+        assert torch.equal(o, base), f"schedule switches {k} change the result"
+
+
 # The persistent large-M kernel (gemm_nt_pers.hip): every compiled epilogue flavour, BN = 192 and 256, more tiles than CUs (a
 # workgroup walks 2-3 tiles: next-tile DMA issued before the epilogue, stores left in flight under a counted vmcnt), a partial
 # last M tile (predicated epilogue + drain), against torch fp32 on the same bf16 inputs; the one-tile-per-workgroup ring kernel

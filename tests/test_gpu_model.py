@@ -669,6 +669,42 @@ def test_full_last_layer_equals_the_cls_only_last_layer(arch, packed, monkeypatc
     assert rel <= 1e-2 and c >= 0.9995 and abs(ratio - 1.0) <= 5e-3, (rel, c, ratio)
 
 
+@pytest.mark.parametrize("switch,kind", [("CLDRD_Q_SIDE=0", "exec"), ("CLDRD_T_DEFER=0", "exec"), ("CLDRD_NORM_SPLIT=0", "exec"),
+                                         ("CLDRD_GRAD_ZERO=full", "exec"),
+                                         ("CLDRD_LN_ON_THE_FLY=0", "numerics"),        # also turns the fp16-operand FFN GEMMs off
+                                         ("CLDRD_FFN_FP16=0", "numerics"), ("CLDRD_QKV_FP16=1", "numerics"), ("CLDRD_QUERY_FP16=0", "numerics")])
+def test_switches_of_the_training_step(switch, kind, monkeypatch):
+    """Every A/B switch of the step keeps working: two training steps (dropout off) under the switch against the default.
+    Execution switches (where / when things run) give the same logits bit for bit and the same update up to the float atomics of the
+    embedding gradients and the grouping of the clip norm; numerics switches (operand formats) stay within bf16 rounding of it."""
+    cfg = small_cfg("bert", 3)
+    batch = syn.nway_batch(4680, 3, 4, 10, 32, vocab=cfg.vocab_size, ragged=True)
+    monkeypatch.setenv("CLDRD_GRAPH", "0")
+    res = {}
+    for on in (False, True):
+        if on:
+            k, v = switch.split("=")
+            monkeypatch.setenv(k, v)
+        model = selftest.build_tiny_model(cfg).cuda().train()
+        tr = NwayTrainer(model, loss="margin_mse", learning_rate=1e-4, warmup_steps=0, total_steps=10)
+        p0 = tr.flat_p.clone()
+        tr.train_step(batch)
+        l1 = tr.last_logits.clone()
+        tr.train_step(batch)
+        torch.cuda.synchronize()
+        res[on] = (l1, tr.last_logits.clone(), (tr.flat_p - p0).double())
+    (a1, a2, ua), (b1, b2, ub) = res[False], res[True]
+    assert torch.isfinite(b2).all().item() and torch.isfinite(ub).all().item()
+    rel_upd = ((ua - ub).norm() / ua.norm()).item()
+    if kind == "exec":
+        assert torch.equal(a1, b1), f"{switch}: first-step logits differ"
+        assert rel_upd <= 2e-2, f"{switch}: update differs by {rel_upd:.2e}"
+    else:
+        assert not torch.equal(a1, b1), f"{switch}: the switch is dead (bit-identical logits)"
+        assert (a1 - b1).abs().max().item() <= 2e-2 * a1.abs().max().item(), f"{switch}: logits moved by more than rounding"
+        assert rel_upd <= 0.2, f"{switch}: update differs by {rel_upd:.2e}"
+
+
 def test_packed_index_encode_matches_padded(monkeypatch):
     """The index path packs by default (retrieval_utils.batch_to_device takes the token counts from the host-side mask):
     get_embeddings_from_scratch on ragged batches against the same call with packing off."""
