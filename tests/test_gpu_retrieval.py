@@ -116,6 +116,31 @@ def test_flat_ip_search_matches_oracle(n, d, nq, k):
     assert st["exhaustive"] or st["scans"] >= (nq + index.query_tile - 1) // index.query_tile
 
 
+@pytest.mark.parametrize("env", [{}, {"CLDRD_TOPK_PROBE": "0"}, {"CLDRD_QUERY_TILE": "128"}])
+def test_multi_pass_search_switches_give_the_same_answer(env, monkeypatch):
+    """A search of several passes (more than two query tiles) with the probe pass off / with 128-query tiles: the exact result cannot
+    depend on how the thresholds were found or how the queries were tiled - scores and ids against the oracle, and equal to the default's."""
+    n, d, nq, k = 60000, 768, 700, 100
+    emb = syn.corpus_embeddings(21, n, d)
+    q = syn.corpus_embeddings(22, nq, d)
+    ids = np.arange(n, dtype=np.int64)
+    for kk, vv in env.items():
+        monkeypatch.setenv(kk, vv)
+    index = RU.construct_flatindex_from_embeddings(emb, ids)
+    RU.convert_index_to_gpu(index, 0, False)
+    D, I = index.search(q, k)
+    st = dict(index.last_stats)
+    assert not st["exhaustive"] and st["scans"] >= 3
+    Dr, Ir = R.flat_ip_search(emb, ids, q[:64], k)
+    same_ranking(D[:64], I[:64], Dr, Ir)
+    for kk in env:
+        monkeypatch.delenv(kk)
+    index2 = RU.construct_flatindex_from_embeddings(emb, ids)
+    RU.convert_index_to_gpu(index2, 0, False)
+    D2, I2 = index2.search(q, k)
+    assert np.array_equal(D, D2) and np.array_equal(I, I2)
+
+
 def test_duplicate_rows_tie_break_and_no_ids():
     emb = syn.corpus_embeddings(13, 4096, 128)
     emb[100] = emb[7]
