@@ -705,6 +705,28 @@ def test_switches_of_the_training_step(switch, kind, monkeypatch):
         assert rel_upd <= 0.2, f"{switch}: update differs by {rel_upd:.2e}"
 
 
+@pytest.mark.parametrize("arch,L", [("bert", 200), ("distilbert", 96)])
+def test_bert_large_widths_and_sequences_over_128_tokens(arch, L):
+    """dim 1024 / 16 heads / FFN 4096 (the LayerNorm kernels' widest row, N = 1024 / 3072 / 4096 GEMM tilings) and L = 200 (the
+    non-persistent attention kernels: L > 128) through the whole step, weights at the HF init scale: logits against the oracle at
+    the full-size bar (5e-3 of the logit scale), gradient direction, and a finite update."""
+    cfg = EncoderConfig(arch=arch, vocab_size=1000, dim=1024, n_heads=16, hidden_dim=4096, n_layers=2, max_position_embeddings=256,
+                        dropout=0.0, attention_dropout=0.0)
+    model = selftest.build_tiny_model(cfg, std=0.02).cuda().train()
+    batch = syn.nway_batch(4680, 2, 3, 12, L, vocab=cfg.vocab_size, ragged=True)
+    tr = NwayTrainer(model, loss="margin_mse")
+    _, logits = tr.forward_backward(batch)
+    ref_logits, _, qp, pp = oracle_run(model, cfg, batch, "margin_mse")
+    err = np.abs(logits.cpu().numpy() - ref_logits).max() / np.abs(ref_logits).max()
+    assert err <= 5e-3, err
+    got = torch.cat([p.grad.detach().reshape(-1) for _, p in model.passage_encoder.named_flat()]).double().cpu()
+    want = torch.cat([pp[k].grad.reshape(-1) for k, _ in model.passage_encoder.named_flat()]).double()
+    c = torch.nn.functional.cosine_similarity(got, want, dim=0).item()
+    assert c >= 0.999 and abs((got.norm() / want.norm()).item() - 1.0) <= 2e-2, (c, (got.norm() / want.norm()).item())
+    out = tr.train_step(batch)
+    assert torch.isfinite(out[0]).item() and torch.isfinite(tr.flat_p).all().item()
+
+
 def test_packed_index_encode_matches_padded(monkeypatch):
     """The index path packs by default (retrieval_utils.batch_to_device takes the token counts from the host-side mask):
     get_embeddings_from_scratch on ragged batches against the same call with packing off."""
