@@ -727,6 +727,32 @@ def test_bert_large_widths_and_sequences_over_128_tokens(arch, L):
     assert torch.isfinite(out[0]).item() and torch.isfinite(tr.flat_p).all().item()
 
 
+@pytest.mark.parametrize("B,N,Lq,Lp,lens,loss", [(1, 1, 4, 8, None, "margin_mse"), (1, 2, 4, 8, None, "kl_div"), (2, 3, 1, 1, None, "margin_mse"),
+                                                  (2, 3, 4, 8, [1] * 6, "margin_mse"), (2, 3, 4, 8, [1, 8, 3, 1, 8, 2], "kl_div")])
+def test_degenerate_batch_shapes_train(B, N, Lq, Lp, lens, loss):
+    """One query, one passage, one-token sequences, packed batches whose rows are single [CLS] tokens: two training steps with dropout
+    run and leave finite weights; the first step's logits equal the oracle's."""
+    cfg = small_cfg("distilbert", 2)
+    model = selftest.build_tiny_model(cfg).cuda().train()
+    batch = syn.nway_batch(1, B, N, Lq, Lp, vocab=cfg.vocab_size, ragged=False)
+    if lens is not None:
+        m = batch["nway_passages"]["attention_mask"].view(-1, Lp)
+        for i, l in enumerate(lens):
+            m[i, l:] = 0
+        batch["nway_passages"]["lengths"] = torch.tensor(lens)
+    tr = NwayTrainer(model, loss=loss)
+    _, logits = tr.forward_backward(batch)
+    ref = oracle_run(model, cfg, {k: v for k, v in batch.items()}, loss)[0]
+    # (one-token sequences: every CLS vector is the same, the logits are small next to |q| |p| (~20) and carry its rounding: + 0.1)
+    assert np.abs(logits.cpu().numpy() - ref).max() <= 3e-2 * np.abs(ref).max() + 0.1
+    cfg.dropout = cfg.attention_dropout = 0.1
+    m2 = selftest.build_tiny_model(cfg).cuda().train()
+    tr2 = NwayTrainer(m2, loss=loss)
+    for _ in range(2):
+        out = tr2.train_step(batch)
+    assert torch.isfinite(out[0]).item() and torch.isfinite(tr2.flat_p).all().item()
+
+
 def test_packed_index_encode_matches_padded(monkeypatch):
     """The index path packs by default (retrieval_utils.batch_to_device takes the token counts from the host-side mask):
     get_embeddings_from_scratch on ragged batches against the same call with packing off."""

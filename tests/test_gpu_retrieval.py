@@ -141,6 +141,22 @@ def test_multi_pass_search_switches_give_the_same_answer(env, monkeypatch):
     assert np.array_equal(D, D2) and np.array_equal(I, I2)
 
 
+@pytest.mark.parametrize("nq,k,rows", [(1, 1, 50), (3, 100, 50), (0, 10, 50), (2, 5, 1)])
+def test_degenerate_searches(nq, k, rows):
+    """One query, k = 1, k larger than the index, no queries at all (faiss returns empty [0, k] arrays), an index of one row."""
+    emb = syn.corpus_embeddings(3, 50, 128)[:rows]
+    ids = np.arange(rows, dtype=np.int64) + 7
+    index = RU.construct_flatindex_from_embeddings(emb, ids)
+    RU.convert_index_to_gpu(index, 0, False)
+    q = syn.corpus_embeddings(4, max(nq, 1), 128)[:nq]
+    D, I = index.search(q, k)
+    assert D.shape == (nq, k) and I.shape == (nq, k)
+    if nq:
+        Dr, Ir = R.flat_ip_search(emb, ids, q, k)
+        same_ranking(D, I, Dr, Ir)
+        assert np.all(I[:, min(k, rows):] == -1)
+
+
 def test_duplicate_rows_tie_break_and_no_ids():
     emb = syn.corpus_embeddings(13, 4096, 128)
     emb[100] = emb[7]
