@@ -1166,8 +1166,33 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
         }
     }
     __syncthreads();
+    // ctx = P V.  Eight lanes share a key row (16 bytes = 8 features each), eight keys per instruction: L / 8 row-block loads instead of
+    // the L dependent 2-byte-per-lane loads this loop was until round 3 (24 of the kernel's 34 us at L = 128: pure load latency, on the
+    // step's critical path between the last K / V projection and the loss).  The eight key groups are combined through LDS.
+    const int c8 = lane & 7, g = lane >> 3;
+    float o8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o8[j] = 0.f;
+    for (int k0 = 0; k0 < L; k0 += 8) {
+        const int key = k0 + g;
+        if (key < L) {
+            const float pk = sp[key];
+            const uint4 u = *(const uint4*)(vb + (size_t)key * 2 * dm + c8 * 8);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o8[2 * j] += pk * x2f<F16>((bf16_t)(w[j] & 0xFFFFu));
+                o8[2 * j + 1] += pk * x2f<F16>((bf16_t)(w[j] >> 16));
+            }
+        }
+    }
+    __shared__ float so[8][64];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) so[g][c8 * 8 + j] = o8[j];
+    __syncthreads();
     float o = 0.f;
-    for (int key = 0; key < L; ++key) o += sp[key] * x2f<F16>(vb[(size_t)key * 2 * dm + lane]);
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) o += so[gg][lane];
     ctx[(size_t)seq * dm + hd * 64 + lane] = f2x<F16>(o);
 }
 
@@ -1219,15 +1244,42 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
         if (key < L) sds[key] = p[i] * (dp[i] - dot) * scale;
     }
     __syncthreads();
-    // lane = feature: dq = sum_key ds[key] K[key]; dK[key] = ds[key] q; dV[key] = p_drop[key] dO
+    // dq = sum_key ds[key] K[key]; dK[key] = ds[key] q; dV[key] = p_drop[key] dO.  Eight lanes per key row (16 bytes = 8 features
+    // each), eight keys per instruction (see attn_cls_fwd_kernel): L / 8 row-block loads and 2 L / 8 row-block stores instead of L + 2 L
+    // two-byte-per-lane accesses; the eight key groups' dq partial sums are combined through LDS.
+    __shared__ float sqd[64];
+    sqd[lane] = qd;
+    __syncthreads();
     bf16_t* dkb = dkv + (size_t)seq * L * 2 * dm + hd * 64;
-    float dq = 0.f;
-    for (int key = 0; key < L; ++key) {
-        const float ds = sds[key];
-        dq += ds * bf2f(kb[(size_t)key * 2 * dm + lane]);
-        dkb[(size_t)key * 2 * dm + lane] = f2bf(ds * qd);
-        dkb[(size_t)key * 2 * dm + dm + lane] = f2bf(spd[key] * sdo[lane]);
+    const int c8 = lane & 7, g = lane >> 3;
+    float q8[8], do8[8], dq8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { q8[j] = sqd[c8 * 8 + j]; do8[j] = sdo[c8 * 8 + j]; dq8[j] = 0.f; }
+    for (int k0 = 0; k0 < L; k0 += 8) {
+        const int key = k0 + g;
+        if (key < L) {
+            const float ds = sds[key], pd = spd[key];
+            const uint4 u = *(const uint4*)(kb + (size_t)key * 2 * dm + c8 * 8);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+            uint32_t ok[4], ov[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dq8[2 * j] += ds * __uint_as_float(w[j] << 16);
+                dq8[2 * j + 1] += ds * __uint_as_float(w[j] & 0xFFFF0000u);
+                ok[j] = (uint32_t)f2bf(ds * q8[2 * j]) | ((uint32_t)f2bf(ds * q8[2 * j + 1]) << 16);
+                ov[j] = (uint32_t)f2bf(pd * do8[2 * j]) | ((uint32_t)f2bf(pd * do8[2 * j + 1]) << 16);
+            }
+            *(uint4*)(dkb + (size_t)key * 2 * dm + c8 * 8) = make_uint4(ok[0], ok[1], ok[2], ok[3]);
+            *(uint4*)(dkb + (size_t)key * 2 * dm + dm + c8 * 8) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+        }
     }
+    __shared__ float sdq[8][64];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sdq[g][c8 * 8 + j] = dq8[j];
+    __syncthreads();
+    float dq = 0.f;
+#pragma unroll
+    for (int gg = 0; gg < 8; ++gg) dq += sdq[gg][lane];
     dqc[(size_t)seq * dm + hd * 64 + lane] = f2bf(dq);
 }
 
