@@ -72,6 +72,19 @@ __device__ __forceinline__ void load_row_f32_i(const float* row, int d, int lane
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const int c = icol(it, j, lane); r.v[it][j] = c < d ? row[c] : 0.f; }
 }
+// the same with non-temporal stores: a tape copy nobody reads before the backward's weight-gradient launch (~10 ms later) should not
+// push the operands of the next GEMM out of the Infinity Cache
+__device__ __forceinline__ void store_row_bf16_stream(bf16_t* row, int d, int lane, const RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+            const u32x2_t u = {pack2bf(r.v[it][0], r.v[it][1]), pack2bf(r.v[it][2], r.v[it][3])};
+            __builtin_nontemporal_store(u, (u32x2_t*)(row + c));
+        }
+    }
+}
 __device__ __forceinline__ void store_row_bf16(bf16_t* row, int d, int lane, const RowF& r) {
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
@@ -152,7 +165,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ x,
     }
     if (out_f16) store_row_f16(out + (size_t)row * d, d, lane, r);
     else store_row_bf16(out + (size_t)row * d, d, lane, r);
-    if (out_copy) store_row_bf16(out_copy + (size_t)row * d, d, lane, r);       // fp16 `out` for the forward GEMM + the bf16 tape copy
+    if (out_copy) store_row_bf16_stream(out_copy + (size_t)row * d, d, lane, r);       // fp16 `out` for the forward GEMM + the bf16 tape copy
     if (X32 && out32) store_row_f32(out32 + (size_t)row * d, d, lane, r);
     if (lane == 0) { if (mean_o) mean_o[row] = mean; if (rstd_o) rstd_o[row] = rstd; }
 }
