@@ -27,9 +27,9 @@ SIGNATURES = {
     "cldrd_attention_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
     "cldrd_attention_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
     "cldrd_attention_bits_words": (C.c_longlong, [ci, ci, ci, cf]),
-    "cldrd_attention_fwd_bits": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp]),
+    "cldrd_attention_fwd_bits": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp, vp]),
     "cldrd_attention_bwd_bits": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp, vp]),
-    "cldrd_attention_cls_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
+    "cldrd_attention_cls_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp]),
     "cldrd_attention_cls_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
     "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_ln_partial_blocks": (ci, [ci]),

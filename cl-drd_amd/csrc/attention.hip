@@ -83,7 +83,8 @@ __device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld,
 template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
-                                                        float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+                                                        float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
+                                                        bf16_t* __restrict__ ctx16) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -178,7 +179,11 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int qq = qb * 32 + rowmap(t, h);
-                if (qq < L) ctx[((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r] = f2x<F16>(O[dt][t]);
+                if (qq < L) {       // ctx: the kernel's own format (may be absent); ctx16: an fp16 copy of a bf16 pass (out-projection operand)
+                    const size_t o = ((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r;
+                    if (ctx) ctx[o] = f2x<F16>(O[dt][t]);
+                    if (ctx16) ctx16[o] = f2x<true>(O[dt][t]);
+                }
             }
     }
 }
@@ -193,7 +198,7 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                          bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                          float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
-                                                         uint32_t* __restrict__ bits_out) {
+                                                         uint32_t* __restrict__ bits_out, bf16_t* __restrict__ ctx16) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -352,7 +357,11 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int qq = qb * 32 + rowmap(t, h);
-                if (qq < L) ctx[((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r] = f2x<F16>(O[dt][t]);
+                if (qq < L) {       // ctx: the kernel's own format (may be absent); ctx16: an fp16 copy of a bf16 pass (out-projection operand)
+                    const size_t o = ((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r;
+                    if (ctx) ctx[o] = f2x<F16>(O[dt][t]);
+                    if (ctx16) ctx16[o] = f2x<true>(O[dt][t]);
+                }
             }
             }
         __syncthreads();          // the other buffer is complete, and nobody reads this one any more
@@ -370,7 +379,8 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
 template <int NKB, bool DROP>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
-                                                        float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+                                                        float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
+                                                        bf16_t* __restrict__ ctx16) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -453,15 +463,24 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
         if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (m + __log2f(l)) * LN2;
         const float inv = (DROP ? drop_scale : 1.0f) / l;
         if (q < L) {
-            bf16_t* orow = ctx + ((size_t)seq * L + q) * dm + hd * 64;
+            const size_t orow = ((size_t)seq * L + q) * dm + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    uint2 o;
-                    o.x = pack2bf(O[dt][4 * u] * inv, O[dt][4 * u + 1] * inv);
-                    o.y = pack2bf(O[dt][4 * u + 2] * inv, O[dt][4 * u + 3] * inv);
-                    *(uint2*)(orow + dt * 32 + 8 * u + 4 * h) = o;
+                    const float v0 = O[dt][4 * u] * inv, v1 = O[dt][4 * u + 1] * inv, v2 = O[dt][4 * u + 2] * inv, v3 = O[dt][4 * u + 3] * inv;
+                    if (ctx) {
+                        uint2 o;
+                        o.x = pack2bf(v0, v1);
+                        o.y = pack2bf(v2, v3);
+                        *(uint2*)(ctx + orow + dt * 32 + 8 * u + 4 * h) = o;
+                    }
+                    if (ctx16) {       // fp16 copy (out-projection operand)
+                        uint2 o;
+                        o.x = (uint32_t)f2x<true>(v0) | ((uint32_t)f2x<true>(v1) << 16);
+                        o.y = (uint32_t)f2x<true>(v2) | ((uint32_t)f2x<true>(v3) << 16);
+                        *(uint2*)(ctx16 + orow + dt * 32 + 8 * u + 4 * h) = o;
+                    }
                 }
         }
     }
@@ -927,11 +946,11 @@ bool attn_fwd2_enabled(int nseq, int L, int H);
 
 template <int NKB, bool DROP>
 int launch_fwd_f16(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-                   unsigned long long seed, hipStream_t st) {
+                   unsigned long long seed, hipStream_t st) {      // fp16 in, fp16 out: no second copy
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
     (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP, true>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed));
+                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)nullptr);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -944,7 +963,7 @@ int launch_fwd_h(const void* qkv, const long long* mask, void* ctx, float* lse, 
 
 template <int NKB, bool DROP>
 int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-                 unsigned long long seed, uint32_t* bits_out, hipStream_t st) {
+                 unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st) {
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
     if constexpr (NKB <= 4) {
         // many items: the persistent loader / compute kernel (CLDRD_ATTN_FWD2=0 keeps the one-item-per-workgroup kernel: A/B runs and tests)
@@ -954,26 +973,26 @@ int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, 
             (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipLaunchKernelGGL((attn_fwd2_kernel<NKB, DROP>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems,
-                               bits_out);
+                               bits_out, (bf16_t*)ctx16);
             CLDRD_LAUNCH_CHECK();
             return 0;
         }
         (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed));
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16);
     } else {
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(512), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed));
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16);
     }
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 template <int NKB>
 int launch_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-               unsigned long long seed, uint32_t* bits_out, hipStream_t st) {
-    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, bits_out, st)
-                                              : launch_fwd_d<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, nullptr, st);
+               unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st) {
+    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, bits_out, ctx16, st)
+                                              : launch_fwd_d<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, nullptr, ctx16, st);
 }
 int attn_num_cus() {
     static int n = 0;
@@ -1044,15 +1063,21 @@ extern "C" long long cldrd_attention_bits_words(int nseq, int L, int H, float dr
 }
 
 extern "C" int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
-                                        float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* stream);
+                                        float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy,
+                                        void* stream);
 extern "C" int cldrd_attention_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
                                    float dropout_p, unsigned long long seed, int io_f16, void* stream) {
-    return cldrd_attention_fwd_bits(qkv, mask, ctx, lse, nseq, L, H, dropout_p, seed, io_f16, nullptr, stream);
+    return cldrd_attention_fwd_bits(qkv, mask, ctx, lse, nseq, L, H, dropout_p, seed, io_f16, nullptr, nullptr, stream);
 }
 // drop_bits_out (optional, cldrd_attention_bits_words() words): receives the dropout keep bits for cldrd_attention_bwd_bits.
+// ctx_f16_copy (optional, bf16 pass only): the same context in fp16 - the operand of an fp16 out-projection GEMM; ctx itself may then be null
+// (an evaluation forward keeps no bf16 tape).
 extern "C" int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
-                                        float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* stream) {
+                                        float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy,
+                                        void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_fwd: need 0 < L <= 256");
+    CLDRD_CHECK(ctx != nullptr || ctx_f16_copy != nullptr, "attention_fwd: no output");
+    CLDRD_CHECK(!(io_f16 && (ctx_f16_copy != nullptr || ctx == nullptr)), "attention_fwd: the fp16 pass writes ctx only");
     const float scale = 0.125f;   // 1 / sqrt(64)
     const int nkb = (L + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
@@ -1066,14 +1091,14 @@ extern "C" int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, 
         }
     }
     switch (nkb) {
-        case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
-        case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
-        case 3: return launch_fwd<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
-        case 4: return launch_fwd<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
-        case 5: return launch_fwd<5>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
-        case 6: return launch_fwd<6>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
-        case 7: return launch_fwd<7>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
-        default: return launch_fwd<8>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, st);
+        case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
+        case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
+        case 3: return launch_fwd<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
+        case 4: return launch_fwd<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
+        case 5: return launch_fwd<5>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
+        case 6: return launch_fwd<6>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
+        case 7: return launch_fwd<7>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
+        default: return launch_fwd<8>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
     }
 }
 
@@ -1116,7 +1141,7 @@ template <bool F16>
 __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
                                                            const int64_t* __restrict__ mask, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ probs, int L, int H, float scale,
-                                                           uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+                                                           uint32_t drop_thresh, float drop_scale, SeedArg seed_a, bf16_t* __restrict__ ctx16) {
     const uint64_t seed = seed_a.get();
     __shared__ float sp[256];
     __shared__ float sq[64];
@@ -1193,7 +1218,8 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
     float o = 0.f;
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) o += so[gg][lane];
-    ctx[(size_t)seq * dm + hd * 64 + lane] = f2x<F16>(o);
+    if (ctx) ctx[(size_t)seq * dm + hd * 64 + lane] = f2x<F16>(o);
+    if (ctx16) ctx16[(size_t)seq * dm + hd * 64 + lane] = f2x<true>(o);       // fp16 copy of a bf16 pass (out-projection operand)
 }
 
 __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
@@ -1299,15 +1325,16 @@ __global__ __launch_bounds__(256) void add_rows_strided_kernel(void* __restrict_
 
 // qc: bf16 [nseq, H*64] (CLS queries); kv: bf16 [nseq*L, 2*H*64] = K | V; ctx: bf16 [nseq, H*64]; probs: fp32 [nseq, H, L]
 extern "C" int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L,
-                                       int H, float dropout_p, unsigned long long seed, int io_f16, void* stream) {
+                                       int H, float dropout_p, unsigned long long seed, int io_f16, void* ctx_f16_copy, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0 && probs != nullptr, "attention_cls_fwd: need 0 < L <= 256 and a probs buffer");
+    CLDRD_CHECK((ctx != nullptr || ctx_f16_copy != nullptr) && !(io_f16 && (ctx_f16_copy != nullptr || ctx == nullptr)), "attention_cls_fwd: outputs");
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     if (io_f16)
         hipLaunchKernelGGL(attn_cls_fwd_kernel<true>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
-                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
+                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), (bf16_t*)nullptr);
     else
         hipLaunchKernelGGL(attn_cls_fwd_kernel<false>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
-                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
+                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), (bf16_t*)ctx_f16_copy);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

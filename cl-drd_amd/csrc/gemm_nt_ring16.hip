@@ -1,5 +1,6 @@
 // fp16-operand instantiations of gemm_nt_ring_kernel: the forward FFN GEMMs of the encoder (HF ffn.lin1 / ffn.lin2, intermediate.dense /
-// output.dense; reference call sites models/nway_dual_encoder.py:52,56,64) and its QKV projection (fp16 operands, bf16 result).
+// output.dense; reference call sites models/nway_dual_encoder.py:52,56,64), its out-projection (round 3: fp16 context from the attention kernel)
+// and its QKV projection (fp16 operands, bf16 result).
 //
 // Why these two GEMMs: of all 16-bit rounding points of a layer the operands of the FFN GEMMs carry the logit drift (CPU emulation on the
 // cfg1 golden, DESIGN.md section 2: every operand bf16 0.234, FFN operands fp16 and the rest bf16 0.051, everything fp16 0.024, against
@@ -18,6 +19,11 @@ int launch_ring16(const GemmNtArgs& a, hipStream_t st) {
         case EPI_F16IN | EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU:
             return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS | EPI_PREACT | EPI_GELU | EPI_DGELU>(a, st);
         case EPI_F16IN | EPI_BIAS | EPI_GELU: return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS | EPI_GELU>(a, st);
+        // out-projection of the first layer (its residual is the embedding block's fp32 output: no LayerNorm still to apply)
+        case EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
+            return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, st);
+        case EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32:
+            return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, st);
         case EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN:
             return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN>(a, st);
         case EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN:

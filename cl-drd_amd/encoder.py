@@ -650,12 +650,13 @@ class HipEncoder(nn.Module):
         res_ln = None                                        # LayerNorm still to be applied to x32 (None: x32 is the value itself)
         LNF = S32 and _env_flag("CLDRD_LN_ON_THE_FLY", "1") != "0"          # "0": store every fp32 LayerNorm output (A/B runs)
         FFN16 = self.ffn_fp16 and S32 and not fp16                           # a bf16 pass whose FFN GEMMs read fp16 operands
+        OUT16 = FFN16 and LNF and _env_flag("CLDRD_OUT_FP16", "1") != "0"    # ... and whose out-projection does (fp16 context from the attention kernel)
         for i in range(cfg.n_layers):
             W = self._layer_weights(i, fp16)
             W16 = self._layer_weights(i, True) if FFN16 else None
             s_l = seed + 7919 * (i + 1)
             if i == cfg.n_layers - 1 and self.cls_only_last:
-                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16, W16, pk, xh)
+                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16, W16, pk, xh, out16=OUT16)
                 break
             qkv = self._buf(T, 3 * d, dev, dt16)
             if QKV16:
@@ -665,21 +666,33 @@ class HipEncoder(nn.Module):
             lse = torch.empty(M, H, L, **f32) if save else None
             dbits = ops.attention_drop_bits(M, L, H, p_a, dev) if (save and dt16 == torch.bfloat16) else None      # dropout keep bits for the backward
             ctx_pad = None
+            # OUT16: the out-projection on fp16 operands too - the attention kernel leaves its context in fp16 next to (training) or
+            # instead of (evaluation) the bf16 tensor the backward's MFMAs read.  With the FFN pair already on fp16 operands this is the
+            # rounding point that carries most of what is left of the logit drift (CPU emulation on the goldens, DESIGN.md section 2:
+            # BERT-base 5.25e-3 -> 2.08e-3 of the logit scale, DistilBERT 2.98e-3 -> 2.05e-3).
+            ctx16 = self._buf(T, d, dev, torch.float16) if OUT16 else None
             if pk is None:
-                ctx = self._buf(T, d, dev, dt16)
-                ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits)
+                ctx = self._buf(T, d, dev, dt16) if (save or not OUT16) else None
+                ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16)
             else:
                 # packed batch: attention works on the padded [M * L, .] layout (one item = one sequence x head, keys >= len masked): move
                 # the rows there (zeros in the padding: a masked key contributes exp(-inf) * v = 0 only for finite v) and the context back
                 qkv_p, qkv = qkv, self._buf(TP, 3 * d, dev, dt16)
                 ops.unpack_rows16(qkv_p, qkv, pk.cu, M, L)
-                ctx_pad = self._buf(TP, d, dev, dt16)
-                ops.attention_fwd(qkv, mask, ctx_pad, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits)
-                ctx = self._buf(T, d, dev, dt16)
-                ops.gather_rows(ctx_pad, pk.tok_idx, ctx, T)
-                del qkv_p
+                ctx_pad = self._buf(TP, d, dev, dt16) if (save or not OUT16) else None
+                ctx16_pad = self._buf(TP, d, dev, torch.float16) if OUT16 else None
+                ops.attention_fwd(qkv, mask, ctx_pad, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16_pad)
+                ctx = None
+                if ctx_pad is not None:
+                    ctx = self._buf(T, d, dev, dt16)
+                    ops.gather_rows(ctx_pad, pk.tok_idx, ctx, T)
+                if OUT16:
+                    ops.gather_rows(ctx16_pad, pk.tok_idx, ctx16, T)
+                del qkv_p, ctx16_pad
             s1 = self._buf(T, d, dev, sdt)
-            ops.gemm_nt(ctx, W["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out, seed=s_l + 2, residual_ln=res_ln)
+            ops.gemm_nt(ctx16 if OUT16 else ctx, (W16 if OUT16 else W)["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out,
+                        seed=s_l + 2, residual_ln=res_ln)
+            del ctx16
             mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
             x1_32 = self._buf(T, d, dev, torch.float32) if (S32 and not LNF) else None
             F16 = FFN16 and LNF                                  # the FFN pair on fp16 operands (the fp16 FFN2 flavours add LayerNorm on the fly)
@@ -725,7 +738,8 @@ class HipEncoder(nn.Module):
         return (cls, tape) if save else cls
 
     # ------------------------------------------------------------------ last layer, CLS row only
-    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16=torch.bfloat16, W16=None, pk=None, xh=None):
+    def _last_layer_cls_fwd(self, x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16=torch.bfloat16, W16=None, pk=None, xh=None,
+                            out16=False):
         """Only ``last_hidden_state[:, 0, :]`` is consumed (reference models/nway_dual_encoder.py:52,56,64), so the last
         layer projects K and V for every token but Q, attention, out-proj, FFN and both LayerNorms for token 0 only:
         identical CLS output, ~1/6 of the layer's FLOPs."""
@@ -767,11 +781,14 @@ class HipEncoder(nn.Module):
             ops.gemm_nt(xch, W16["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
         else:
             ops.gemm_nt(xc, W["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
-        ctxc = self._buf(M, d, dev, dt16)
+        out16 = out16 and W16 is not None and S32            # out-projection on fp16 operands (see _encode)
+        ctxc = self._buf(M, d, dev, dt16) if (save or not out16) else None
+        ctxc16 = self._buf(M, d, dev, torch.float16) if out16 else None
         probs = torch.empty(M, H, L, **f32)
-        ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1)
+        ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1, ctx16=ctxc16)
         s1 = self._buf(M, d, dev, sdt)
-        ops.gemm_nt(ctxc, W["Wo"], s1, M, bias=W["bo"], residual=xc32 if S32 else xc, dropout_p=p_out, seed=s_l + 2)
+        ops.gemm_nt(ctxc16 if out16 else ctxc, (W16 if out16 else W)["Wo"], s1, M, bias=W["bo"], residual=xc32 if S32 else xc, dropout_p=p_out,
+                    seed=s_l + 2)
         x1_32 = self._buf(M, d, dev, torch.float32) if S32 else None
         mean1, rstd1 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
         if W16 is not None and S32:         # the FFN pair on fp16 operands, as in the full layers (bf16 copies for the backward)

@@ -240,9 +240,22 @@ def attention_drop_bits(nseq, L, H, dropout_p, device):
     return torch.empty(n, dtype=torch.int32, device=device) if n > 0 else None
 
 
-def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None):
+def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, ctx16=None):
+    """``ctx16`` (fp16, bf16 pass only): the same context in fp16, for an fp16-operand out-projection; ``ctx`` may then be None."""
     io_f16 = _fmt16(qkv, "qkv")
-    _chk(qkv, F16 if io_f16 else BF16, "qkv", 2), _chk(ctx, F16 if io_f16 else BF16, "ctx", 2)
+    _chk(qkv, F16 if io_f16 else BF16, "qkv", 2)
+    if ctx16 is not None:
+        if io_f16:
+            raise ValueError("attention_fwd: ctx16 goes with a bf16 pass")
+        _chk(ctx16, F16, "ctx16", 2)
+        if ctx16.shape[1] != H * 64 or not ctx16.is_contiguous():
+            raise ValueError("attention: ctx16 must be contiguous [T, H*64]")
+        if ctx is None:
+            if mask is not None:
+                _chk(mask, torch.int64, "mask", 2)
+            call("cldrd_attention_fwd_bits", _p(qkv), _p(mask), None, _p(lse), nseq, L, H, dropout_p, seed, 0, _p(drop_bits), _p(ctx16), _stream())
+            return ctx16
+    _chk(ctx, F16 if io_f16 else BF16, "ctx", 2)
     if mask is not None:
         _chk(mask, torch.int64, "mask", 2)
         if not mask.is_contiguous() or tuple(mask.shape) != (nseq, L):
@@ -255,7 +268,7 @@ def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_b
         _chk(drop_bits, torch.int32, "drop_bits", 1)
         if drop_bits.numel() != _lib.load().cldrd_attention_bits_words(nseq, L, H, dropout_p):
             raise ValueError("attention_fwd: drop_bits must come from attention_drop_bits() for the same shape")
-    call("cldrd_attention_fwd_bits", _p(qkv), _p(mask), _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _p(drop_bits), _stream())
+    call("cldrd_attention_fwd_bits", _p(qkv), _p(mask), _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _p(drop_bits), _p(ctx16), _stream())
     return ctx
 
 
@@ -272,13 +285,21 @@ def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, se
     return dqkv
 
 
-def attention_cls_fwd(qc, kv, mask, ctx, probs, nseq, L, H, dropout_p=0.0, seed=0):
+def attention_cls_fwd(qc, kv, mask, ctx, probs, nseq, L, H, dropout_p=0.0, seed=0, ctx16=None):
     io_f16 = _fmt16(qc, "qc")
     dt16 = F16 if io_f16 else BF16
-    _chk(qc, dt16, "qc", 2), _chk(kv, dt16, "kv", 2), _chk(ctx, dt16, "ctx", 2), _chk(probs, F32, "probs")
-    if kv.shape[1] != 2 * H * 64 or not kv.is_contiguous() or not qc.is_contiguous() or not ctx.is_contiguous():
+    _chk(qc, dt16, "qc", 2), _chk(kv, dt16, "kv", 2), _chk(probs, F32, "probs")
+    if ctx is not None:
+        _chk(ctx, dt16, "ctx", 2)
+    if ctx16 is not None:
+        if io_f16:
+            raise ValueError("attention_cls_fwd: ctx16 goes with a bf16 pass")
+        _chk(ctx16, F16, "ctx16", 2)
+    if ctx is None and ctx16 is None:
+        raise ValueError("attention_cls_fwd: no output")
+    if kv.shape[1] != 2 * H * 64 or not kv.is_contiguous() or not qc.is_contiguous() or any(t is not None and not t.is_contiguous() for t in (ctx, ctx16)):
         raise ValueError("attention_cls: kv must be contiguous [T, 2*H*64]")
-    call("cldrd_attention_cls_fwd", _p(qc), _p(kv), _p(mask), _p(ctx), _p(probs), nseq, L, H, dropout_p, seed, io_f16, _stream())
+    call("cldrd_attention_cls_fwd", _p(qc), _p(kv), _p(mask), _p(ctx), _p(probs), nseq, L, H, dropout_p, seed, io_f16, _p(ctx16), _stream())
 
 
 def attention_cls_bwd(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p=0.0, seed=0):

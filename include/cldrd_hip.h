@@ -100,8 +100,10 @@ int cldrd_attention_bwd(const void* qkv, const long long* mask, const void* ctx,
  * the backward for the same (nseq, L, H, dropout_p, seed) then reads them instead of hashing again.  cldrd_attention_bits_words()
  * says how many 32-bit words that is for a shape (0: this shape does not produce bits - pass null and the backward re-hashes). */
 long long cldrd_attention_bits_words(int nseq, int L, int H, float dropout_p);
+/* ctx_f16_copy (optional, bf16 pass only): the same context vectors in fp16 - the A operand of an fp16-operand out-projection GEMM (round 3:
+ * the out-projection's operands carry most of the remaining logit drift of a 12-layer tower); ctx may then be NULL (no bf16 tape wanted). */
 int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
-                             float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* stream);
+                             float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy, void* stream);
 int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                              void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
                              void* stream);
@@ -111,7 +113,7 @@ int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, const void*
  * probs: fp32 [nseq, H, L] (softmax row, saved for the backward); dkv: bf16 [nseq*L, 2*H*64] (every row written).
  * cldrd_add_rows_strided: dst[m * stride_rows] += src[m] for bf16 rows of d elements (puts the CLS-row gradients back). */
 int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L,
-                            int H, float dropout_p, unsigned long long seed, int io_f16, void* stream);
+                            int H, float dropout_p, unsigned long long seed, int io_f16, void* ctx_f16_copy, void* stream);
 int cldrd_attention_cls_bwd(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
                             int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
 int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, int f32, void* stream);   /* f32: fp32 rows (fp32 gradient stream) */

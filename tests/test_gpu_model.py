@@ -291,9 +291,13 @@ def test_full_size_configs_match_reference_goldens(name):
             print(f"{name}/{loss_kind}: the reference's fp16-autocast drift is max {a16.max():.4f} rms {np.sqrt(np.mean(a16 ** 2)):.4f}: ours = "
                   f"{err / a16.max():.2f} x / {rms / np.sqrt(np.mean(a16 ** 2)):.2f} x; relative to max|logit|: {err / np.abs(ref).max():.2e}")
         if model.passage_encoder.ffn_fp16:
-            # GPU vs fp32 oracle, logits <= 5e-3 relative (met since the FFN GEMMs read fp16 operands)
-            rel_bar = 5e-3 if arch == "distilbert" else 7.5e-3     # BERT-base at L = 256: 5.5e-3 measured (the out-projection's operands)
+            # GPU vs fp32 oracle, logits <= 5e-3 relative - every config, BERT-base at L = 256 included since the
+            # out-projection reads fp16 operands too (measured 2.2e-3 - 3.0e-3: asserted at 4e-3), and within 1.5 x of the drift of the
+            # reference's OWN fp16 autocast (measured 0.96 x - 1.36 x)
+            rel_bar = 4e-3
             assert err <= rel_bar * np.abs(ref).max(), f"{name}: max|dlogit| {err:.4f} above {rel_bar:g} x max|logit| = {rel_bar * np.abs(ref).max():.4f}"
+            if "logits_autocast_fp16" in g.files and os.environ.get("CLDRD_OUT_FP16", "1") != "0":
+                assert err <= 1.5 * a16.max() and rms <= 1.5 * np.sqrt(np.mean(a16 ** 2)), f"{name}: more than 1.5 x the reference's fp16-autocast drift"
         if "loss" in g.files:                                # cfg1 golden (round 1 layout)
             ref_loss, names, vals = float(g["loss"]), [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]
             amp_loss, _ = ORACLE_LOSS[gk](g["logits_autocast_bf16"], batch["labels"].numpy())
