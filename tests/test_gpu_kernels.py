@@ -426,6 +426,43 @@ def test_attention_fwd_bwd(nseq, L, H, masked):
     close(dqkv, g, 1 / 32, 2e-2 * scale, f"attention bwd L={L}")
 
 
+@pytest.mark.parametrize("nseq,L,H,fwd2", [(64, 128, 12, "1"), (64, 128, 12, "0"), (3, 40, 2, "1"), (2, 200, 2, "1"), (1, 256, 3, "1")])
+def test_attention_fwd_writes_an_fp16_copy_of_its_context(nseq, L, H, fwd2, monkeypatch):
+    """`ctx16`: the context of a bf16 pass a second time in fp16 (the out-projection's operand), from the persistent kernel, the
+    one-item-per-workgroup kernel (CLDRD_ATTN_FWD2=0), the streaming kernel (L > 128) and the CLS-only kernel; with `ctx = None` only the
+    fp16 tensor is written.  Both are roundings of the same fp32 value: the bf16 one is unchanged bit for bit, the fp16 one 8x closer."""
+    monkeypatch.setenv("CLDRD_ATTN_FWD2", fwd2)
+    d, T = H * 64, nseq * L
+    qkv = bf(rnd(150, (T, 3 * d), 1.0)).to(DEV)
+    lens = np.clip(syn.msmarco_lengths(151, nseq, L), 2, L)
+    lens[0] = L
+    mask = torch.from_numpy((np.arange(L)[None, :] < lens[:, None]).astype(np.int64)).to(DEV)
+    ref, _ = attn_ref(qkv.cpu().double(), mask.cpu(), nseq, L, H)
+    plain = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    ops.attention_fwd(qkv, mask, plain, None, nseq, L, H)
+    ctx = torch.full((T, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    c16 = torch.full((T, d), float("nan"), dtype=torch.float16, device=DEV)
+    ops.attention_fwd(qkv, mask, ctx, None, nseq, L, H, ctx16=c16)
+    assert torch.equal(ctx, plain)
+    close(c16, ref, 1 / 64, 2e-2, "fp16 context copy")                       # P still goes through bf16
+    assert (c16.float() - ctx.float()).abs().max().item() <= 2.0 ** -7 * ctx.float().abs().max().item()
+    only = torch.full((T, d), float("nan"), dtype=torch.float16, device=DEV)
+    ops.attention_fwd(qkv, mask, None, None, nseq, L, H, ctx16=only)
+    assert torch.equal(only, c16)
+    # CLS-only form
+    kv = qkv[:, d:].contiguous()
+    qc = qkv.view(nseq, L, 3 * d)[:, 0, :d].contiguous()
+    probs = torch.empty(nseq, H, L, dtype=torch.float32, device=DEV)
+    cb, ch = torch.empty(nseq, d, dtype=torch.bfloat16, device=DEV), torch.full((nseq, d), float("nan"), dtype=torch.float16, device=DEV)
+    ops.attention_cls_fwd(qc, kv, mask, cb, probs, nseq, L, H, ctx16=ch)
+    close(ch, ref.view(nseq, L, d)[:, 0], 1 / 256, 5e-3, "fp16 CLS context copy")
+    ch2 = torch.full((nseq, d), float("nan"), dtype=torch.float16, device=DEV)
+    ops.attention_cls_fwd(qc, kv, mask, None, probs, nseq, L, H, ctx16=ch2)
+    assert torch.equal(ch, ch2)
+    with pytest.raises(ValueError):
+        ops.attention_fwd(qkv.to(torch.float16), mask, torch.empty(T, d, dtype=torch.float16, device=DEV), None, nseq, L, H, ctx16=c16)
+
+
 @pytest.mark.parametrize("nseq,L,H,p", [(48, 128, 12, 0.0), (48, 128, 12, 0.1), (90, 100, 6, 0.1), (200, 30, 3, 0.0), (70, 64, 8, 0.1),
                                          (43, 96, 12, 0.0)])
 def test_attention_bwd_persistent_two_role_kernel(nseq, L, H, p):

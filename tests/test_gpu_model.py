@@ -676,7 +676,8 @@ def test_full_last_layer_equals_the_cls_only_last_layer(arch, packed, monkeypatc
 @pytest.mark.parametrize("switch,kind", [("CLDRD_Q_SIDE=0", "exec"), ("CLDRD_T_DEFER=0", "exec"), ("CLDRD_NORM_SPLIT=0", "exec"),
                                          ("CLDRD_GRAD_ZERO=full", "exec"), ("CLDRD_Q_BWD=late", "exec"), ("CLDRD_ADAM_H16=0", "exec"),
                                          ("CLDRD_LN_ON_THE_FLY=0", "numerics"),        # also turns the fp16-operand FFN GEMMs off
-                                         ("CLDRD_FFN_FP16=0", "numerics"), ("CLDRD_QKV_FP16=1", "numerics"), ("CLDRD_QUERY_FP16=0", "numerics")])
+                                         ("CLDRD_FFN_FP16=0", "numerics"), ("CLDRD_QKV_FP16=1", "numerics"), ("CLDRD_QUERY_FP16=0", "numerics"),
+                                         ("CLDRD_OUT_FP16=0", "numerics")])
 def test_switches_of_the_training_step(switch, kind, monkeypatch):
     """Every A/B switch of the step keeps working: two training steps (dropout off) under the switch against the default.
     Execution switches (where / when things run) give the same logits bit for bit and the same update up to the float atomics of the
