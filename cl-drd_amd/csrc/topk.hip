@@ -104,7 +104,10 @@ __global__ __launch_bounds__(1024) void kth_largest_kernel(const float* __restri
     if (threadIdx.x == 0) thr[blockIdx.x] = from_orderable(sel_prefix);
 }
 
-// exact fp32 re-score: one wave per candidate, fixed summation order (lane-strided partial sums, then a butterfly)
+// exact re-score: one wave per candidate, fixed summation order (lane-strided partial sums, then a butterfly), accumulated in fp64 and
+// rounded to fp32 ONCE - the oracle's (and the retrieval contract's) definition of a score, whatever the data.  (Until round 3 the sums
+// were fp32 FMAs: fine for embeddings, but on rows with heavy-tailed norms a low-ranked score of 2.3 next to |q||p| ~ 1e4 came out 1.4e-4
+// off, tools/search_fuzz.py.  768 fp64 FMAs per candidate are nothing next to fetching its 3-KiB row.)
 __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ q, const float* __restrict__ P, int d,
                                                        const int* __restrict__ counts, const int* __restrict__ cand_rows,
                                                        float* __restrict__ cand_scores, int cap) {
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
     const float* qr = q + (size_t)qi * d;
     for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < n; c += gridDim.x * 4) {
         const float* pr = P + (size_t)cand_rows[(size_t)qi * cap + c] * d;
-        float s = 0.f;
+        double s = 0.0;
         for (int j = lane * 4; j < d; j += 256) {
             const float4 a = *(const float4*)(qr + j);
 #if CLDRD_SCAN_NT
@@ -123,10 +126,12 @@ __global__ __launch_bounds__(256) void rescore_kernel(const float* __restrict__ 
 #else
             const float4 b = *(const float4*)(pr + j);
 #endif
-            s = fmaf(a.x, b.x, s); s = fmaf(a.y, b.y, s); s = fmaf(a.z, b.z, s); s = fmaf(a.w, b.w, s);
+            s = fma((double)a.x, (double)b.x, s); s = fma((double)a.y, (double)b.y, s);
+            s = fma((double)a.z, (double)b.z, s); s = fma((double)a.w, (double)b.w, s);
         }
-        s = wave_sum(s);
-        if (lane == 0) cand_scores[(size_t)qi * cap + c] = s;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) cand_scores[(size_t)qi * cap + c] = (float)s;
     }
 }
 

@@ -357,6 +357,22 @@ def _device_fp64_topk(P32, q32, k, chunk=1 << 19):
     return np.take_along_axis(s, order, 1).astype(np.float32), np.take_along_axis(i, order, 1)
 
 
+@pytest.mark.parametrize("rows,d,nq,k", [(2873, 128, 128, 1000), (9000, 128, 64, 1000), (60000, 768, 40, 100)])
+def test_scores_are_the_correctly_rounded_inner_products_on_heavy_tailed_rows(rows, d, nq, k):
+    """Rows whose norms spread over two orders of magnitude: a low-ranked score of ~2 sits next to |q| |p| ~ 1e4, where an fp32-accumulated
+    inner product is 1e-4 off (tools/search_fuzz.py found it).  The re-score accumulates in fp64 and rounds once, so D equals the fp64
+    reference rounded to fp32 BIT FOR BIT and I follows (score desc, row asc) exactly - on the exhaustive and on the scanned path."""
+    g = torch.Generator(device=DEV).manual_seed(3)
+    P = torch.randn(rows, d, device=DEV, generator=g) * torch.exp(1.5 * torch.randn(rows, 1, device=DEV, generator=g))
+    Q = torch.randn(nq, d, device=DEV, generator=g)
+    index = RU.construct_flatindex_from_embeddings(P.cpu().numpy(), np.arange(rows, dtype=np.int64))
+    RU.convert_index_to_gpu(index, 0, False)
+    D, I = index.search(Q.cpu().numpy(), k)
+    Dg, Ig = _device_fp64_topk(P, Q, k)
+    assert np.array_equal(D, Dg), f"max relative score difference {np.max(np.abs(D - Dg) / (np.abs(Dg) + 1e-30)):.2e}"
+    assert np.array_equal(I, Ig)
+
+
 def test_cfg5_shard_search_matches_oracle_at_full_size():
     """BASELINE.json configs[4], one shard: 1 105 228 x 768 rows (8 841 823 / 8), 6 980 queries, k = 1000 (reference loop
     retriever/retrieval_utils.py:131-153).  The first 128-query batch is checked against the CPU oracle (oracle/retrieval_ref.py),
