@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Randomised model-level checks: small random encoders (arch, layers, heads) x random batch shapes (B, N, Lq, Lp) with random right-padded
+lengths: logits against the oracle, packed == padded (logits bit for bit, gradient cosine), and a two-step training run with shapes changing
+between steps (graph cache + eager fall-back).  usage: tools/model_fuzz.py [cases] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import cldrd_amd.synthetic as syn, selftest
+from cldrd_amd.encoder import EncoderConfig
+from cldrd_amd.trainer import NwayTrainer
+from oracle import encoder_ref as E
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+bad = 0
+dev = lambda b: {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in b.items()}
+for c in range(cases):
+    arch = str(rng.choice(["distilbert", "bert"])); layers = int(rng.integers(1, 5)); H = int(rng.choice([2, 4, 6]))
+    cfg = EncoderConfig(arch=arch, vocab_size=400, dim=64 * H, n_heads=H, hidden_dim=int(rng.choice([128, 256, 512])), n_layers=layers,
+                        max_position_embeddings=160, dropout=0.0, attention_dropout=0.0)
+    share = bool(rng.random() < 0.2)
+    model = selftest.build_tiny_model(cfg, share_weights=share, std=0.05).cuda().train()
+    B, N, Lq, Lp = int(rng.integers(1, 6)), int(rng.integers(1, 12)), int(rng.integers(1, 20)), int(rng.choice([1, 5, 31, 32, 33, 64, 100, 129, 150]))
+    loss = str(rng.choice(["margin_mse", "kl_div", "lambda_mrr", "ranknet"]))
+    batch = syn.nway_batch(int(rng.integers(1 << 20)), B, N, Lq, Lp, vocab=cfg.vocab_size, ragged=False,
+                           label_kind="teacher" if loss in ("margin_mse", "kl_div") else "mode9")
+    lens = rng.integers(1, Lp + 1, B * N)
+    m = batch["nway_passages"]["attention_mask"].view(-1, Lp)
+    for i, l in enumerate(lens): m[i, l:] = 0
+    tag = f"case {c}: {arch} x{layers} H{H} share {share} B {B} N {N} Lq {Lq} Lp {Lp} {loss}"
+    try:
+        os.environ["CLDRD_GRAPH"] = "0"
+        tr = NwayTrainer(model, loss=loss)
+        _, lp = tr.forward_backward(dev(batch)); gp = tr.flat_g.double().clone()
+        pk = dev(batch); pk["nway_passages"]["lengths"] = torch.from_numpy(lens)
+        _, lk = tr.forward_backward(pk); gk = tr.flat_g.double().clone()
+        qp, pp = selftest.oracle_params(model)
+        ref = E.nway_forward(qp, pp, selftest.oracle_cfg(cfg), batch["query"], batch["nway_passages"]).detach().numpy()
+        err = np.abs(lp.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3)
+        cos = torch.nn.functional.cosine_similarity(gp, gk, dim=0).item() if gp.norm() > 0 else 1.0
+        ok = err <= 2e-2 and torch.equal(lp, lk) and cos >= 0.9999
+        os.environ["CLDRD_GRAPH"] = "1"
+        tr2 = NwayTrainer(selftest.build_tiny_model(cfg, share_weights=share, std=0.05).cuda().train(), loss=loss)
+        for s in range(6):
+            out = tr2.train_step(dev(batch) if s % 3 else pk)
+        ok = ok and bool(torch.isfinite(tr2.flat_p).all())
+        if not ok:
+            bad += 1
+            print(f"MISMATCH {tag}: logit err {err:.2e}, packed logits equal {torch.equal(lp, lk)}, gradient cosine {cos:.7f}", flush=True)
+    except Exception as e:
+        bad += 1
+        print(f"EXC {tag}: {type(e).__name__} {str(e)[:160]}", flush=True)
+print(f"{cases} cases, {bad} mismatches")
+sys.exit(1 if bad else 0)
