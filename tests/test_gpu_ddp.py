@@ -130,6 +130,9 @@ def _rccl_worker(rank, port, out):
         tr.train_step(batch)
         plain.train_step(batch)
     torch.cuda.synchronize()
+    # the clip norm is the norm of the reduced gradient
+    assert abs(tr.clip[0].item() - tr.flat_g.double().norm().item()) <= 1e-5 * tr.clip[0].item()
+    assert abs(tr.clip[0].item() - plain.clip[0].item()) <= 2e-3 * plain.clip[0].item()
     assert torch.isfinite(tr.flat_p).all().item()
     # AdamW turns a last-bit gradient difference on a near-zero gradient (k_lin.bias: mathematically zero) into +-lr, so single
     # weights may differ by a few lr; the UPDATE as a whole must agree
