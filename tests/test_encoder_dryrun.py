@@ -52,11 +52,14 @@ def cfg_of(arch, layers):
 
 
 @pytest.mark.parametrize("arch,layers", [("distilbert", 3), ("bert", 2), ("distilbert", 1)])
-@pytest.mark.parametrize("ffn16,qkv16", [("1", "1"), ("1", "0"), ("1", "auto"), ("0", "0")])
+@pytest.mark.parametrize("ffn16,qkv16,out16", [("1", "1", "1"), ("1", "0", "1"), ("1", "auto", "0"), ("0", "0", "1")])
 @pytest.mark.parametrize("packed", [False, True])
-def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, ffn16, qkv16, packed):
+@pytest.mark.parametrize("gs", ["fp32", "bf16"])
+def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, ffn16, qkv16, out16, packed, gs):
     monkeypatch.setenv("CLDRD_FFN_FP16", ffn16)
     monkeypatch.setenv("CLDRD_QKV_FP16", qkv16)
+    monkeypatch.setenv("CLDRD_OUT_FP16", out16)
+    monkeypatch.setenv("CLDRD_GRAD_STREAM", gs)
     enc = HipEncoder(cfg_of(arch, layers), seed=1)
     M, L = 6, 24
     lens = np.array([24, 3, 10, 17, 5, 8])
