@@ -6,7 +6,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("CLDRD_LIB") or os.path.join(_HERE, "libcldrd_hip.so")      # CLDRD_LIB: A/B runs of two builds
+# CLDRD_LIB selects another BUILD of the library (tools/build_dev.py: the development build with the experiments' knobs); the product
+# library itself reads no environment variable
+LIB_PATH = os.environ.get("CLDRD_LIB") or os.path.join(_HERE, "libcldrd_hip.so")
 
 _lib = None
 
@@ -16,6 +18,7 @@ SIGNATURES = {
     "cldrd_last_error": (C.c_char_p, []),
     "cldrd_version": (ci, []),
     "cldrd_device_ok": (ci, []),
+    "cldrd_set_tuning": (ci, [C.c_char_p, ci]),
     "cldrd_gemm_nt_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp]),
     "cldrd_gemm_nt_bf16_ln": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp, vp, vp, vp, vp]),
     "cldrd_gemm_nt_splitk_workspace": (csz, [ci, ci, ci]),

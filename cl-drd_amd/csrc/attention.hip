@@ -1005,18 +1005,16 @@ int attn_num_cus() {
 }
 
 bool attn_fwd2_enabled(int nseq, int L, int H) {
-    const char* e = getenv("CLDRD_ATTN_FWD2");
-    return L <= 128 && nseq * H >= 2 * attn_num_cus() && !(e && atoi(e) == 0);
+    return L <= 128 && nseq * H >= 2 * attn_num_cus() && g_cldrd_tune_attn_fwd2 != 0;
 }
 
 template <int NKB, bool DROP>
 int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
                  int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st) {
     if constexpr (NKB <= 4) {
-        // many items: the persistent two-role kernel (CLDRD_ATTN_BWD2=0 keeps the one-item-per-workgroup kernel: A/B runs and tests)
-        const char* e = getenv("CLDRD_ATTN_BWD2");
+        // many items: the persistent two-role kernel (cldrd_set_tuning("attn_bwd2", 0) keeps the one-item-per-workgroup kernel: tests)
         const int nitems = nseq * H, cus = attn_num_cus();
-        if (nitems >= 2 * cus && !(e && atoi(e) == 0)) {
+        if (nitems >= 2 * cus && g_cldrd_tune_attn_bwd2 != 0) {
             const size_t lds1 = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
             if (DROP && drop_bits) {
                 const size_t lds2 = 2 * (lds1 + 32 * NKB * NKB * sizeof(uint32_t));

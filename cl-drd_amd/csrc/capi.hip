@@ -12,6 +12,21 @@ int cldrd_set_error(const char* msg) {
 }
 
 extern "C" const char* cldrd_last_error(void) { return g_err; }
+
+#ifdef CLDRD_DEV_BUILD
+#include <stdlib.h>
+int cldrd_dev_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#endif
+int g_cldrd_tune_splitk = 0, g_cldrd_tune_attn_fwd2 = 1, g_cldrd_tune_attn_bwd2 = 1;
+// key: "gemm_splitk" | "attn_fwd2" | "attn_bwd2" (meanings: common.h).  Every choice computes the same function; tests use it to
+// reach the alternative kernels.  Process-wide, not thread-safe against concurrent launches.
+extern "C" int cldrd_set_tuning(const char* key, int value) {
+    CLDRD_CHECK(key != nullptr, "set_tuning: null key");
+    if (!strcmp(key, "gemm_splitk")) { CLDRD_CHECK(value >= 0, "set_tuning: gemm_splitk >= 0"); g_cldrd_tune_splitk = value; return 0; }
+    if (!strcmp(key, "attn_fwd2")) { g_cldrd_tune_attn_fwd2 = value != 0; return 0; }
+    if (!strcmp(key, "attn_bwd2")) { g_cldrd_tune_attn_bwd2 = value != 0; return 0; }
+    return cldrd_set_error("set_tuning: unknown key");
+}
 extern "C" int cldrd_version(void) { return 100; }
 extern "C" int cldrd_device_ok(void) {
     int n = 0;

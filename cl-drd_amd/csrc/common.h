@@ -125,5 +125,19 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
 }
 
 int cldrd_set_error(const char* msg);
+
+// The PRODUCT library reads no environment variable: an inherited variable must not change what a run computes, or how.  Tuning and
+// ablation knobs of the experiments (tools/) exist only in the development build (tools/build_dev.py: -DCLDRD_DEV_BUILD ->
+// libcldrd_hip_dev.so, selected with CLDRD_LIB=...); in the product build CLDRD_DEV_INT(name, default) IS the default, at compile time.
+#ifdef CLDRD_DEV_BUILD
+int cldrd_dev_int(const char* name, int dflt);
+#define CLDRD_DEV_INT(name, dflt) cldrd_dev_int(name, dflt)
+#else
+#define CLDRD_DEV_INT(name, dflt) (dflt)
+#endif
+// Kernel choices that tests flip IN PROCESS go through cldrd_set_tuning (capi.hip), never through the environment.
+extern int g_cldrd_tune_splitk;        // 0: heuristic, 1: never split K, n > 1: n splits (small-M NT GEMM)
+extern int g_cldrd_tune_attn_fwd2;     // 1: persistent attention forward where it applies, 0: one item per workgroup
+extern int g_cldrd_tune_attn_bwd2;     // the same for the backward
 #define CLDRD_CHECK(cond, msg) do { if (!(cond)) return cldrd_set_error(msg); } while (0)
 #define CLDRD_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return cldrd_set_error(hipGetErrorString(e_)); } while (0)

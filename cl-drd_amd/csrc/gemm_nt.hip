@@ -172,8 +172,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmNtArgs p) {
 // K splits of the small-M kernel for a shape (1: one pass).  The 128 x 128 kernel holds two workgroups per CU: aim at ~1.5 per CU with
 // at least 4 K tiles each, only where the one-pass grid leaves most of the chip idle.
 static int splitk_choice(int M, int N, int K) {
-    const char* e = getenv("CLDRD_GEMM_SPLITK");        // 1: never split, n > 1: n splits (read per call: tests flip it in-process)
-    const int force = e ? atoi(e) : 0;
+    const int force = g_cldrd_tune_splitk;              // 1: never split, n > 1: n splits (cldrd_set_tuning: tests flip it in-process)
     if (force == 1) return 1;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN), nk = K / BK;
     if (M >= 1024 || tiles >= 128 || nk < 8) return 1;
@@ -326,9 +325,8 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
             default: return cldrd_set_error("gemm_nt: this epilogue combination is not built for the fp16 format");
         }
     }
-    // large-M shapes go to the 256-row ring kernel; CLDRD_GEMM_TILE=128|192|256 forces a variant (experiments)
-    const char* env_tile = getenv("CLDRD_GEMM_TILE");
-    const int force = env_tile ? atoi(env_tile) : 0;
+    // large-M shapes go to the 256-row ring kernel; development build: CLDRD_GEMM_TILE=128|192|256 forces a variant
+    const int force = CLDRD_DEV_INT("CLDRD_GEMM_TILE", 0);
     if (force != 128) {
         const int rc = cldrd_gemm_nt_ring_dispatch(a, force, (hipStream_t)stream);
         if (rc >= 0) return rc;
@@ -371,13 +369,11 @@ static int scan_filter_impl(const void* Q, const void* P, int nq, long long rows
     a.drop_thresh = 0; a.drop_scale = 1.0f; a.seed = 0; a.out_f32 = 0;
     a.thr = thr; a.counts = counts; a.cand_rows = cand_rows; a.cand_scores = cand_scores; a.cap = cap;
     a.in_f16 = f16 ? 1 : 0;
-    const char* env_scan = getenv("CLDRD_SCAN");          // "gemm" forces the tiled-GEMM scan (A/B experiments)
-    if (!tiled && !(env_scan && env_scan[0] == 'g')) {
+    if (!tiled && !CLDRD_DEV_INT("CLDRD_SCAN_GEMM", 0)) {          // development build: 1 forces the tiled-GEMM scan (A/B experiments)
         const int rc = cldrd_topk_scan_stream(Q, P, nq, rows, d, thr, counts, cand_rows, cand_scores, cap, f16, (hipStream_t)stream);
         if (rc >= 0) return rc;
     }
-    const char* env_tile = getenv("CLDRD_GEMM_TILE");
-    if (rows >= 4096 && nq <= 128 && !(env_tile && atoi(env_tile) == 128) && (double)rows * d * 2.0 < 4.0e9) {
+    if (rows >= 4096 && nq <= 128 && CLDRD_DEV_INT("CLDRD_GEMM_TILE", 0) != 128 && (double)rows * d * 2.0 < 4.0e9) {
         // large shard: index rows are the M dimension of the 256-row ring kernel, the (<= 128) queries its N tile
         a.A = (const bf16_t*)P; a.B = (const bf16_t*)Q; a.M = (int)rows; a.N = nq;
         return cldrd_gemm_nt_ring_scan(a, (hipStream_t)stream);

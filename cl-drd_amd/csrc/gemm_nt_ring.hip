@@ -38,19 +38,16 @@ int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st) {
     return a.in_f16 ? launch_ring_epi<128, EPI_FILTER | EPI_F16IN>(a, st) : launch_ring_epi<128, EPI_FILTER>(a, st);
 }
 
-int cldrd_gemm_nt_pers_dispatch(const GemmNtArgs& a, int bn, hipStream_t st);    // gemm_nt_pers.hip
 int cldrd_gemm_nt_ring16_launch(const GemmNtArgs& a, int bn, hipStream_t st);    // gemm_nt_ring16.hip
 
 // Returns -1 if this variant does not apply (caller falls back to the 128x128 kernel), else the launch status.
 int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_t st) {
     GemmNtArgs a = a_in;
     int gn_force;
-    { const char* e = getenv("CLDRD_GEMM_STAGGER"); a.stagger = e ? atoi(e) : 1; }      // read per call, like the two below: tests flip them in-process
-    { const char* e = getenv("CLDRD_GEMM_EARLY1"); a.early1 = e ? atoi(e) : 1; }
-    { const char* e = getenv("CLDRD_GEMM_ASYM"); a.asym = e ? atoi(e) : 1; }
-    static int gn_env = -2;
-    if (gn_env == -2) { const char* e = getenv("CLDRD_GEMM_GN"); gn_env = e ? atoi(e) : -1; }
-    gn_force = gn_env;
+    a.stagger = CLDRD_DEV_INT("CLDRD_GEMM_STAGGER", 1);      // settled A/B pairs (profiles/r02, r03_microbench.txt): live in the development build only
+    a.early1 = CLDRD_DEV_INT("CLDRD_GEMM_EARLY1", 1);
+    a.asym = CLDRD_DEV_INT("CLDRD_GEMM_ASYM", 1);
+    gn_force = CLDRD_DEV_INT("CLDRD_GEMM_GN", -1);
     if (a.K % BK != 0) return -1;
     if ((double)a.M * a.lda * 2.0 >= 4.0e9 || (double)a.N * a.ldb * 2.0 >= 4.0e9) return -1;   // 32-bit DMA offsets
     int bn = force_bn;
@@ -73,16 +70,9 @@ int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_
     // group pass would re-read the A panels - PMC: 436 MB instead of 293 MB for N = 768, K = 2304 / 3072)
     a.gn = gn_force >= 0 ? gn_force : (a.K <= 1024 ? (int)(2.0e6 / ((double)bn * a.K * 2.0) + 0.5) : 0);
     if (a.gn < 0) a.gn = 0;
-    // Persistent form (gemm_nt_pers.hip: one workgroup per CU walks its tiles, register epilogue, stores left in flight), opt-in with
-    // CLDRD_GEMM_PERSIST=1: measured equal to this kernel within 1 % on the encoder shapes and in the training step
-    // (profiles/r02_microbench.txt) - the K loop sits at the CU's L2 -> LDS rate either way and the epilogues that hurt are VALU-
-    // bound (GELU) or HBM-bound (fp32 residual stream), which a tile walk does not change.  Read per call: tests flip it in-process.
+    // (A persistent tile walk with a register epilogue - gemm_nt_pers.hip of rounds 2-3 - measured equal to this kernel within 1 % on
+    // the encoder shapes and in the training step, profiles/r02_microbench.txt, and was removed in round 4.)
     if (a.in_f16) return cldrd_gemm_nt_ring16_launch(a, bn, st);       // fp16 operands: the forward FFN flavours, or -1
-    const char* pe = getenv("CLDRD_GEMM_PERSIST");
-    if (pe && atoi(pe) != 0) {
-        const int rc = cldrd_gemm_nt_pers_dispatch(a, bn, st);
-        if (rc >= 0) return rc;
-    }
     if (bn == 256 && a.N % 256 == 0) return launch_ring<256>(a, st);
     if (bn == 192 && a.N % 192 == 0) return launch_ring<192>(a, st);
     return -1;

@@ -281,10 +281,9 @@ int launch_ring_abl(const GemmNtArgs& a, hipStream_t st) {
 
 template <int BN, int EPI>
 int launch_ring_epi(const GemmNtArgs& a, hipStream_t st) {
+#ifdef CLDRD_DEV_BUILD                                 // timing-only ablations (WRONG results): development build only, never in the product library
     if (EPI == 0 && BN == 192) {                       // ablations exist for the plain BN = 192 instance only
-        static int abl = -1;
-        if (abl < 0) { const char* e = getenv("CLDRD_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
-        switch (abl) {
+        switch (cldrd_dev_int("CLDRD_GEMM_ABLATE", 0)) {
             case 1: return launch_ring_abl<192, 1>(a, st);
             case 2: return launch_ring_abl<192, 2>(a, st);
             case 3: return launch_ring_abl<192, 3>(a, st);
@@ -295,6 +294,7 @@ int launch_ring_epi(const GemmNtArgs& a, hipStream_t st) {
             default: break;
         }
     }
+#endif
     constexpr int lds = ring_lds_bytes<BN>();
     static bool attr_set = false;
     if (!attr_set) {

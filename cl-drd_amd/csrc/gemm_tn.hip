@@ -458,8 +458,7 @@ struct WgradTile { int t1, t2; };
 // BN = 192) when every problem allows it, else 256 x 128 (8 waves of 64 x 64), else 128 x 128 (4 waves).  The 256 x 256 tile of
 // round 1 (all 256 VGPRs, spills, two LDS slots: 430-480 TF/s against 690-810) is gone.  CLDRD_WGRAD_TILE=128|192 forces one.
 static WgradTile wgrad_tile_group(const int* N1, const int* N2, int n) {
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("CLDRD_WGRAD_TILE"); force = e ? atoi(e) : 0; }
+    const int force = CLDRD_DEV_INT("CLDRD_WGRAD_TILE", 0);
     bool ok192 = true, ok128w = true;
     for (int i = 0; i < n; ++i) {
         ok192 = ok192 && N1[i] % 256 == 0 && N2[i] % 192 == 0;
@@ -490,17 +489,14 @@ static int wgrad_splits_group(const int* M, const int* N1, const int* N2, int n,
         tiles_all += (long)(N1[i] / t.t1) * (N2[i] / t.t2);
     }
     if (tiles_all <= 0) return 1;
-    static int overhead = -1;
-    if (overhead < 0) { const char* e = getenv("CLDRD_WGRAD_OVERHEAD"); overhead = e ? atoi(e) : 6; }
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("CLDRD_WGRAD_SPLITS"); force = e ? atoi(e) : 0; }
+    const int overhead = 6;
+    const int force = CLDRD_DEV_INT("CLDRD_WGRAD_SPLITS", 0);
     if (force > 0) return force < ktotal ? force : ktotal;
     // Workgroups of one XCD share A / B panels through its 4-MiB L2 only while they sweep the same token range at about the same
     // time; nothing synchronises them, so over a long sweep they drift apart and every one of them streams its operands from HBM
     // (measured at cfg2: 512 K tiles per item, no split: 3.2 ms for the passage tower's group; 2 splits of 256: 2.9 ms + 0.1 ms of
     // slabs).  Items are therefore capped at MAXK K tiles.
-    static int maxk = -1;
-    if (maxk < 0) { const char* e = getenv("CLDRD_WGRAD_MAXK"); maxk = e ? atoi(e) : 256; if (maxk < 1) maxk = 256; }
+    const int maxk = CLDRD_DEV_INT("CLDRD_WGRAD_MAXK", 256) < 1 ? 256 : CLDRD_DEV_INT("CLDRD_WGRAD_MAXK", 256);
     const int sp_min = (ktotal + maxk - 1) / maxk;
     int best = sp_min;
     double best_cost = -1.0;
@@ -525,11 +521,7 @@ extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
     return wgrad_splits_group(&M, &N1, &N2, 1, wgrad_tile_group(&N1, &N2, 1));
 }
 
-static inline int wgrad_stagger() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("CLDRD_GEMM_STAGGER"); v = e ? atoi(e) : 1; }
-    return v;
-}
+static inline int wgrad_stagger() { return 1; }
 
 template <int T1, int T2, int NW>
 static int launch_tn_group(const TnGroupArgs& g, int items, hipStream_t st) {
@@ -582,8 +574,7 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
         for (int i = 0; i < n; ++i) need += (size_t)splits * ((size_t)N1[i] * N2[i] + (size_t)N1[i]);
         CLDRD_CHECK(workspace != nullptr && ((uintptr_t)workspace % 16 == 0) && workspace_bytes >= need * sizeof(float), "wgrad: workspace too small");
     }
-    static int env_order = -2;
-    if (env_order == -2) { const char* e = getenv("CLDRD_WGRAD_N1FAST"); env_order = e ? atoi(e) : -1; }      // 0 / 1 force, default: per problem
+    const int env_order = -1;       // tile order per problem (below)
     size_t slab_off = 0;
     for (int lo = 0; lo < n; lo += MAXP) {
         const int m = n - lo < MAXP ? n - lo : MAXP;

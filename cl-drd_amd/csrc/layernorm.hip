@@ -535,8 +535,7 @@ static void ln_dispatch(int d, bool drop, F&& f) {
 }
 
 static inline int ln_bwd_blocks(int T) {
-    static int cap = 0;
-    if (!cap) { const char* e = getenv("CLDRD_LN_BLOCKS"); cap = e ? atoi(e) : 512; if (cap < 1) cap = 512; }
+    const int cap = 512;
     int b = (T + 7) / 8;
     return b < cap ? (b ? b : 1) : cap;
 }

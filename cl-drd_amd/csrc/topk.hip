@@ -623,23 +623,25 @@ int launch_scan_stream_abl(const void* Q, const void* P, int nq, long long rows,
 template <int KS>
 int launch_scan_stream(const void* Q, const void* P, int nq, long long rows, const float* thr, int* counts, int* cand_rows,
                        float* cand_scores, int cap, bool f16, hipStream_t st) {
+#ifdef CLDRD_DEV_BUILD                                 // timing-only ablations (WRONG results): development build only, never in the product library
     if (KS == 24 && !f16) {                            // ablations exist for the d = 768 bf16 instance only
-        const char* ab = getenv("CLDRD_SCAN_ABLATE");
-        switch (ab ? atoi(ab) : 0) {
+        switch (cldrd_dev_int("CLDRD_SCAN_ABLATE", 0)) {
             case 1: return launch_scan_stream_abl<24, 1, false>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
             case 2: return launch_scan_stream_abl<24, 2, false>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
             default: break;
         }
     }
+#endif
     if (nq > 128) {                                    // 129..256 queries: the 8-wave x 32-query instance (fp16 shadow, d = 768 only)
+#ifdef CLDRD_DEV_BUILD
         if (KS == 24 && f16) {
-            const char* ab = getenv("CLDRD_SCAN_ABLATE");
-            switch (ab ? atoi(ab) : 0) {
+            switch (cldrd_dev_int("CLDRD_SCAN_ABLATE", 0)) {
                 case 3: return launch_scan_stream_abl<24, 3, true, 8, 2>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
                 case 4: return launch_scan_stream_abl<24, 4, true, 8, 2>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
                 default: break;
             }
         }
+#endif
         if (KS == 24 && f16) return launch_scan_stream_abl<24, 0, true, 8, 2>(Q, P, nq, rows, thr, counts, cand_rows, cand_scores, cap, st);
         return -1;
     }

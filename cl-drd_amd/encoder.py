@@ -548,7 +548,7 @@ class HipEncoder(nn.Module):
         return torch.empty(ops.pad_rows(rows), cols, dtype=dtype, device=dev)
 
     def encode(self, input_ids: torch.Tensor, attention_mask: torch.Tensor | None, *, train: bool | None = None,
-               save: bool = False, seed: int | None = None, fp16: bool | None = None, lengths=None):
+               save: bool = False, seed: int | None = None, fp16: bool | None = None, lengths=None, device_seed: bool = False):
         """CLS embeddings fp32 [M, d] (== HF ``model(**enc)[0][:, 0, :]``).  With ``save`` also returns the tape.
 
         ``fp16`` (default: ``self.hp_forward``, which NwayDualEncoder sets on the QUERY tower): high-precision forward - the same
@@ -564,15 +564,29 @@ class HipEncoder(nn.Module):
         the batch and computes on the padding: ~40 % of the rows of an MS MARCO batch); attention keeps the padded layout; the CLS output
         is the same up to the order of fp32 summation.  Without them nothing is packed (finding the row count would cost a host sync)."""
         fp16 = self.hp_forward if fp16 is None else fp16
-        base = getattr(self, "seed_base_ptr", None)
+        base = getattr(self, "seed_base_ptr", None) if (device_seed and seed is None) else None
         if base:
-            # graph mode (NwayTrainer): the per-step part of the seed lives in device memory at `seed_base_ptr` (the trainer advances
-            # step_seed and writes next_seed() there before each step); the launches carry offsets only
+            # graph mode, NwayTrainer only (`device_seed`): the per-step part of the seed lives in device memory at `seed_base_ptr` (the
+            # trainer advances step_seed and writes next_seed() there before each step); the launches carry offsets only.  Any other
+            # caller (encode_autograd, an explicit seed) gets a by-value seed as before - the device word is only advanced by the trainer.
             with ops.seed_base(base):
-                return self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=0, fp16=fp16, lengths=lengths)
+                out = self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=0, fp16=fp16, lengths=lengths)
+            if save:
+                out[1].device_seed = True           # the backward adds the same device word
+            return out
         if seed is None:
             seed = self.next_seed()
         return self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=fp16, lengths=lengths)
+
+    def would_pack(self, lengths, M, L, has_mask=True, fp16=False) -> bool:
+        """Whether encode() packs a batch with these host-side token counts (CLDRD_PACK=0 turns packing off; a batch with less than
+        8 % padding is not worth the row moves around attention).  The trainer asks BEFORE choosing between the replayed graph and the
+        eager step: only a batch that really is packed changes its row count from step to step."""
+        if (lengths is None or not has_mask or fp16 or not self.cls_only_last or self.cfg.n_layers < 1 or L <= 1
+                or _env_flag("CLDRD_PACK", "1") == "0"):
+            return False
+        n_tok = int(sum(int(v) for v in (lengths.reshape(-1).tolist() if hasattr(lengths, "reshape") else lengths)))
+        return 0 < n_tok <= int(0.92 * M * L)
 
     def next_seed(self) -> int:
         """Advance the step counter; the dropout seed of the step (what encode() draws when no seed is given)."""
@@ -607,15 +621,12 @@ class HipEncoder(nn.Module):
         p_a = cfg.attention_dropout if train else 0.0
         dt16 = torch.float16 if fp16 else torch.bfloat16         # 16-bit activation format of this pass
         pk = None
-        if (lengths is not None and mask is not None and not fp16 and self.cls_only_last and cfg.n_layers >= 1 and L > 1
-                and _env_flag("CLDRD_PACK", "1") != "0"):
-            n_tok = int(sum(int(v) for v in (lengths.reshape(-1).tolist() if hasattr(lengths, "reshape") else lengths)))
-            if len(lengths) != M:
-                raise ValueError("lengths: one entry per sequence")
-            if 0 < n_tok <= int(0.92 * T):                       # enough padding to pay for the row moves around attention
-                pk = _Pack.build(lengths, L, dev)
-                T = pk.Tp
-                ids_padded, ids = ids, torch.index_select(ids.view(-1), 0, pk.tok_idx.long())
+        if lengths is not None and len(lengths) != M:
+            raise ValueError("lengths: one entry per sequence")
+        if self.would_pack(lengths, M, L, has_mask=mask is not None, fp16=fp16):
+            pk = _Pack.build(lengths, L, dev)
+            T = pk.Tp
+            ids_padded, ids = ids, torch.index_select(ids.view(-1), 0, pk.tok_idx.long())
         tape = None
         if save:
             tape = _Tape()
@@ -890,7 +901,7 @@ class HipEncoder(nn.Module):
         ``before_last_wgrad()`` (optional) is called once, right before the LAST group of deferred weight gradients is launched:
         from there on this stream runs one long launch that is on nobody's critical path - the place where the trainer puts
         the other tower's latency-bound backward."""
-        base = getattr(self, "seed_base_ptr", None)
+        base = getattr(self, "seed_base_ptr", None) if getattr(tape, "device_seed", False) else None
         if base and not getattr(self, "_in_seed_ctx", False):
             self._in_seed_ctx = True
             try:

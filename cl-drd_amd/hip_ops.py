@@ -9,6 +9,7 @@ from __future__ import annotations
 import torch
 
 import os
+import threading
 
 from . import _lib
 from ._lib import call
@@ -55,6 +56,9 @@ def _chk(t, dtype, name, dim=None):
     return t
 
 
+_TLS = threading.local()      # the library keeps these pointers per thread: so does the mirror that lets the contexts nest
+
+
 class seed_base:
     """``with seed_base(ptr):`` every launch inside passes its ``seed`` argument as an OFFSET: the kernels add the 64-bit word at the device
     address ``ptr`` at run time (include/cldrd_hip.h: cldrd_set_seed_base).  ``ptr`` None / 0: a no-op context."""
@@ -64,11 +68,14 @@ class seed_base:
 
     def __enter__(self):
         if self.ptr:
+            self.prev = getattr(_TLS, "seed_base", None)        # contexts nest (two towers): restore, do not clear
             _lib.load().cldrd_set_seed_base(self.ptr)
+            _TLS.seed_base = self.ptr
 
     def __exit__(self, *exc):
         if self.ptr:
-            _lib.load().cldrd_set_seed_base(None)
+            _lib.load().cldrd_set_seed_base(self.prev)
+            _TLS.seed_base = self.prev
 
 
 class optim_hyper:
@@ -79,11 +86,14 @@ class optim_hyper:
 
     def __enter__(self):
         if self.ptr:
+            self.prev = getattr(_TLS, "optim_hyper", None)
             _lib.load().cldrd_set_optim_hyper(self.ptr)
+            _TLS.optim_hyper = self.ptr
 
     def __exit__(self, *exc):
         if self.ptr:
-            _lib.load().cldrd_set_optim_hyper(None)
+            _lib.load().cldrd_set_optim_hyper(self.prev)
+            _TLS.optim_hyper = self.prev
 
 
 def write_step_state(seeds, seed0, seed1, hyper, lr, beta1, beta2, adam_step):
@@ -161,7 +171,7 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
     # small-M problems (CLS-only last layer, query tower) are split along K when that fills the chip: fp32 partials in a scratch tensor
     ws, ws_bytes = None, 0
     if M < 1024:
-        key = (M, N, K, os.environ.get("CLDRD_GEMM_SPLITK"))      # the library reads the switch per call: so does the cache key
+        key = (M, N, K, _TUNING.get("gemm_splitk", 0))      # the split choice is part of the cache key
         ws_bytes = _SPLITK_WS.get(key)
         if ws_bytes is None:
             ws_bytes = _SPLITK_WS[key] = int(_lib.load().cldrd_gemm_nt_splitk_workspace(M, N, K))
@@ -174,6 +184,14 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
 
 
 _SPLITK_WS = {}
+_TUNING = {}
+
+
+def set_tuning(key: str, value: int) -> None:
+    """cldrd_set_tuning: "gemm_splitk" | "attn_fwd2" | "attn_bwd2" (include/cldrd_hip.h).  Process-wide; tests use it to reach the
+    alternative kernels - the library itself reads no environment variable."""
+    call("cldrd_set_tuning", key.encode(), int(value))
+    _TUNING[key] = int(value)
 
 
 def wgrad_workspace_elems(M, N1, N2) -> int:

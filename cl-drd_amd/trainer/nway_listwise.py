@@ -92,9 +92,8 @@ class NwayTrainer:
         self.flat_p, self.flat_g = model.fuse_flat()
         # deferred weight gradients: one group launch per tower at the end of the backward on one GPU; with RCCL every
         # ceil(layers / 2) layers, so the first half of the buckets is all-reduced while the rest of the backward still runs
-        flush_env = _env_flag("CLDRD_WGRAD_FLUSH", "")              # experiments: layers per weight-gradient group under torch.distributed
         for t in model.towers():
-            t.wgrad_flush_layers = (int(flush_env) if flush_env != "" else max(1, -(-t.cfg.n_layers // 2))) if self.distributed else 0
+            t.wgrad_flush_layers = max(1, -(-t.cfg.n_layers // 2)) if self.distributed else 0
         dev = self.flat_p.device
         self._require_gpu(dev)
         n = self.flat_p.numel()
@@ -125,8 +124,8 @@ class NwayTrainer:
         self.comm_stream = torch.cuda.Stream(device=dev) if self.distributed else None
         if self.comm_stream is not None:
             self.flat_g.record_stream(self.comm_stream)        # the bucket slices are used on it (the buffer lives as long as the trainer)
-        # priority of the query tower's stream relative to torch's current stream (0): CLDRD_Q_PRIO=-1 high (A/B runs)
-        self.q_stream = torch.cuda.Stream(device=dev, priority=int(_env_flag("CLDRD_Q_PRIO", "0"))) if dev.type == "cuda" else None
+        # the query tower's stream, at the priority of torch's current stream (a high-priority stream changed nothing: profiles/r03_microbench.txt)
+        self.q_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = []
         if self.distributed:
             # DDP constructor semantics (reference :250-255): rank 0's parameters win
@@ -160,8 +159,6 @@ class NwayTrainer:
             ev.record(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ev)
-                if _env_flag("CLDRD_DDP_NOCOMM", "0") == "1":       # experiments only: what the hooks cost without the collective
-                    return
                 work = dist.all_reduce(self.flat_g[a:b], op=dist.ReduceOp.SUM, async_op=True)
             self._pending.append(work)
         return hook
@@ -231,9 +228,9 @@ class NwayTrainer:
                 if not getattr(tower, "_t_fresh", False):
                     tower.refresh_transposed()
         with torch.cuda.stream(side):
-            q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True, fp16=model.query_fp16)
+            q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True, fp16=model.query_fp16, device_seed=True)
         p_cls, p_tape = pe.encode(nw["input_ids"].reshape(bz * nway, L), nw["attention_mask"].reshape(bz * nway, L),
-                                  train=True, save=True, fp16=False, lengths=_lengths(nw))      # "lengths" given: a packed batch
+                                  train=True, save=True, fp16=False, lengths=_lengths(nw), device_seed=True)      # "lengths" given: a packed batch
         if side is not main:
             main.wait_stream(side)
             q_cls.record_stream(main)
@@ -265,20 +262,15 @@ class NwayTrainer:
                     dq.record_stream(side)
                 with torch.cuda.stream(side):
                     qe.backward_from_cls(q_tape, dq, after_layer=self._bucket_hook(0), accumulate=not write_once)
-            # Where the query tower's ~150 small backward launches run: next to the passage tower's data-gradient chain (default), or
-            # (CLDRD_Q_BWD=late) next to its LAST weight-gradient group - one ~3-ms launch off the critical path, where a stolen CU
-            # should cost least.  Measured the other way round (profiles/r03_microbench.txt: late = +1.2 % step time, twice on one
-            # box): the weight-gradient group loses more to the intruders (its workgroups share operand panels through L2 only while
-            # they stay in step) than the GEMM chain does.
-            late = side is not main and _env_flag("CLDRD_Q_BWD", "early") == "late"
-            if not late:
-                query_backward()
+            # The query tower's ~150 small backward launches run next to the passage tower's data-gradient chain.  (Next to its LAST
+            # weight-gradient group instead - one ~3-ms launch off the critical path - measured +1.2 % step time, profiles/r03_microbench.txt:
+            # that group loses more to the intruders than the GEMM chain does; the switch for it was removed in round 4.)
+            query_backward()
             self._norm_split = None
             p_hook = self._bucket_hook(1)
-            if p_hook is None and side is not main and not late and write_once and _env_flag("CLDRD_NORM_SPLIT", "1") != "0":
+            if p_hook is None and side is not main and write_once and _env_flag("CLDRD_NORM_SPLIT", "1") != "0":
                 p_hook = self._early_norm_hook(main, side)
-            pe.backward_from_cls(p_tape, dp, after_layer=p_hook, accumulate=not write_once,
-                                 before_last_wgrad=query_backward if late else None)
+            pe.backward_from_cls(p_tape, dp, after_layer=p_hook, accumulate=not write_once)
             main.wait_stream(side)
             if self.distributed:
                 self._wait_pending()
@@ -360,7 +352,17 @@ class NwayTrainer:
         from step to step - the two towers' dropout seeds, lr, Adam's bias-corrected step size - lives in device memory and is
         written by one small launch in front of each replay (``ops.write_step_state``); results are bit-identical to the eager path."""
         self._joint_shadow()
-        if self._graph_wanted() and _lengths(batch["nway_passages"]) is None:      # a packed batch changes its row count every step: eager
+        nw = batch["nway_passages"]
+        lens = _lengths(nw)
+        if lens is not None:
+            bz_, nway_, L_ = nw["input_ids"].shape
+            if not self.model.passage_encoder.would_pack(lens, bz_ * nway_, L_, has_mask=nw.get("attention_mask") is not None):
+                # "lengths" came with the batch (batch_to_device attaches them to every right-padded batch) but the encoder will not pack it
+                # (fill above 92 %, CLDRD_PACK=0): it is an ordinary padded batch and takes the graph path like one
+                batch = dict(batch.items())
+                batch["nway_passages"] = {k: v for k, v in nw.items() if k != "lengths"}
+                lens = None
+        if self._graph_wanted() and lens is None:      # a packed batch changes its row count every step: eager
             out = self._train_step_graph(batch)
             if out is not None:
                 return out
@@ -405,7 +407,7 @@ class NwayTrainer:
         entry = graphs.get(key)
         if entry is None:
             entry = graphs[key] = {"seen": 0, "graph": None}
-        warm = int(_env_flag("CLDRD_GRAPH_WARMUP", "3"))
+        warm = 3
         if entry["graph"] is None and entry["seen"] < warm:
             entry["seen"] += 1              # eager: allocator warm-up, one-time kernel attributes
             return None
@@ -424,7 +426,9 @@ class NwayTrainer:
                 self._graph_broken = True
                 for t in towers:
                     t.seed_base_ptr = None
+                    t._t_fresh = False       # refresh_transposed() inside the failed capture set the flag without executing a kernel
                 self._state = None
+                self._norm_split = None
                 torch.cuda.synchronize()
                 return None
         # this step's inputs and state, in stream order in front of the replay

@@ -28,6 +28,10 @@ extern "C" {
 const char* cldrd_last_error(void);
 int cldrd_version(void);
 int cldrd_device_ok(void);            /* 1 if device 0 is a gfx950 */
+/* The library reads NO environment variable.  The few kernel choices tests need to reach go through this call (process-wide):
+ * key "gemm_splitk" (0 heuristic, 1 never split K, n > 1 n splits of the small-M Linear GEMM), "attn_fwd2" / "attn_bwd2"
+ * (1: persistent attention kernels where they apply, 0: one item per workgroup).  Every choice computes the same function. */
+int cldrd_set_tuning(const char* key, int value);
 
 /* ---- encoder Linear layers -------------------------------------------------------------------------------
  * Replaces torch.nn.Linear inside the HF encoder (reference models/nway_dual_encoder.py:52,56,64 ->

@@ -35,6 +35,38 @@ def test_binding_table_matches_header():
     assert sorted(_lib.SIGNATURES) == declared_symbols()
 
 
+def test_product_library_reads_no_environment_variable():
+    """An inherited environment variable must not be able to change what a run computes (round-3 review): the shipped library imports no
+    getenv, contains no CLDRD_* switch name - in particular none of the timing-only ablation modes (CLDRD_GEMM_ABLATE, CLDRD_SCAN_ABLATE:
+    wrong results by design; they exist in tools/build_dev.py's development build only) - and its sources call getenv nowhere outside
+    the CLDRD_DEV_BUILD block."""
+    import subprocess
+    from cldrd_amd import _lib
+    path = os.path.join(ROOT, "cl-drd_amd", "libcldrd_hip.so")
+    if not os.path.exists(path):
+        import __graft_entry__
+        __graft_entry__.build()
+    blob = open(path, "rb").read()
+    for needle in (b"CLDRD_GEMM_ABLATE", b"CLDRD_SCAN_ABLATE", b"CLDRD_"):
+        assert needle not in blob, f"{needle.decode()} found in the product library"
+    und = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True).stdout
+    assert "getenv" not in und, "the product library imports getenv"
+    csrc = os.path.join(ROOT, "cl-drd_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".h")):
+            text = open(os.path.join(csrc, f)).read()
+            n = text.count("getenv(")
+            assert n == 0 or (f == "capi.hip" and n == 1 and "#ifdef CLDRD_DEV_BUILD" in text), f"{f}: getenv outside the development block"
+
+
+def test_set_tuning_rejects_unknown_keys():
+    from cldrd_amd import hip_ops as ops
+    from cldrd_amd._lib import CldrdError
+    ops.set_tuning("gemm_splitk", 0)
+    with pytest.raises(CldrdError):
+        ops.set_tuning("no_such_knob", 1)
+
+
 def test_version_and_error_string_without_gpu():
     from cldrd_amd import _lib
     lib = _lib.load()

@@ -112,7 +112,7 @@ def test_gemm_nt_epilogues(M, N, K):
 @pytest.mark.parametrize("flavour", ["bias", "bias_gelu_dpre", "gelugrad_d", "res16", "bias_drop_res32_f32", "ln_res32_f32", "f16_bias_gelu", "f16_res32_f32"])
 def test_gemm_nt_small_m_split_k(flavour, M, N, K):
     """Small-M problems are split along K (fp32 partials + a finishing launch with the same epilogue): against the one-pass kernel
-    (CLDRD_GEMM_SPLITK=1) on the same inputs - 16-bit outputs agree to one rounding of the last place (the partial sums are added in a
+    (ops.set_tuning("gemm_splitk", 1)) on the same inputs - 16-bit outputs agree to one rounding of the last place (the partial sums are added in a
     different order), fp32 outputs to 1e-5 of the row scale - and with an odd split count forced."""
     import oracle.dropout_ref as DRo
     f16 = flavour.startswith("f16")
@@ -145,11 +145,8 @@ def test_gemm_nt_small_m_split_k(flavour, M, N, K):
         kw["residual_ln"] = (s32.mean(1).contiguous(), (1.0 / torch.sqrt(s32.var(1, unbiased=False) + 1e-12)).contiguous(),
                              1 + 0.1 * torch.randn(N, device=DEV, generator=g), 0.1 * torch.randn(N, device=DEV, generator=g))
     outs, pres = [], []
-    for env in ("1", None, "5"):
-        if env is None:
-            os.environ.pop("CLDRD_GEMM_SPLITK", None)
-        else:
-            os.environ["CLDRD_GEMM_SPLITK"] = env
+    for forced in (1, 0, 5):
+        ops.set_tuning("gemm_splitk", forced)
         out = torch.full((M, N), float("nan"), dtype=out_dtype, device=DEV)
         if "preact" in kw:
             kw["preact"] = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -157,7 +154,7 @@ def test_gemm_nt_small_m_split_k(flavour, M, N, K):
             ops.gemm_nt(A, B, out, **kw)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("CLDRD_GEMM_SPLITK", None)
+            ops.set_tuning("gemm_splitk", 0)
         outs.append(out.float())
         pres.append(kw["preact"].float() if "preact" in kw else None)
     ref = outs[0]
@@ -190,48 +187,15 @@ def test_gemm_nt_dropout_is_deterministic_and_unbiased():
     assert not torch.equal(out1, out2)
 
 
-@pytest.mark.parametrize("M,N,K,kw", [(2048, 768, 3072, "res32"), (4100, 2304, 768, "bias"), (1536, 3072, 768, "gelu"), (3000, 768, 768, "plain"),
-                                      (1024, 768, 128, "plain")])
-def test_ring_gemm_schedule_switches_are_bit_identical(M, N, K, kw, monkeypatch):
-    """CLDRD_GEMM_ASYM (third A slot, A requested two K tiles ahead), CLDRD_GEMM_EARLY1 (K tile 1 requested with K tile 0) and
-    CLDRD_GEMM_STAGGER (waves 4..7 issue their LDS-DMA one k-step later) change WHEN operands are requested, never what is computed:
-    every combination must give the bits of the default (read per call, so they are flipped in-process).  K = 128: two K tiles only."""
-    A, B = bf(rnd(140, (M, K))).to(DEV), bf(rnd(141, (N, K), 0.05)).to(DEV)
-    args = {}
-    out_dt = torch.bfloat16
-    if kw == "bias":
-        args["bias"] = rnd(142, (N,)).to(DEV)
-    elif kw == "res32":
-        args["bias"], args["residual"], out_dt = rnd(142, (N,)).to(DEV), rnd(143, (M, N)).to(DEV), torch.float32
-    elif kw == "gelu":
-        args["bias"], args["act"] = rnd(142, (N,)).to(DEV), 1
-    outs = {}
-    for asym in ("1", "0"):
-        for early in ("1", "0"):
-            for stagger in ("1", "0"):
-                monkeypatch.setenv("CLDRD_GEMM_ASYM", asym)
-                monkeypatch.setenv("CLDRD_GEMM_EARLY1", early)
-                monkeypatch.setenv("CLDRD_GEMM_STAGGER", stagger)
-                out = torch.full((M, N), float("nan"), dtype=out_dt, device=DEV)
-                ops.gemm_nt(A, B, out, M, **args)
-                outs[(asym, early, stagger)] = out
-    base = outs[("1", "1", "1")]
-    assert torch.isfinite(base.float()).all().item()
-    for k, o in outs.items():
-        assert torch.equal(o, base), f"schedule switches {k} change the result"
-
-
-# The persistent large-M kernel (gemm_nt_pers.hip): every compiled epilogue flavour, BN = 192 and 256, more tiles than CUs (a
-# workgroup walks 2-3 tiles: next-tile DMA issued before the epilogue, stores left in flight under a counted vmcnt), a partial
-# last M tile (predicated epilogue + drain), against torch fp32 on the same bf16 inputs; the one-tile-per-workgroup ring kernel
-# (CLDRD_GEMM_PERSIST=0) must give the same bits for 16-bit outputs.
+# The large-M ring kernel: every compiled epilogue flavour, BN = 192 and 256, more tiles than CUs, a partial last M tile (predicated
+# epilogue), against torch fp32 on the same bf16 inputs.  (Until round 3 this also drove the persistent tile-walk kernel, removed in round 4.)
 _PERS_FLAVOURS = ["plain", "bias", "bias_gelu_pre", "bias_gelu_dpre", "bias_gelu", "bias_res16", "bias_drop_res16", "gelugrad",
                   "gelugrad_d", "res16", "f32", "bias_res32_f32", "bias_drop_res32_f32"]
 
 
 @pytest.mark.parametrize("M,N,K", [(16640, 768, 256), (20000, 1024, 192), (9000, 2304, 128)])
 @pytest.mark.parametrize("flavour", _PERS_FLAVOURS)
-def test_gemm_nt_persistent_flavours(flavour, M, N, K):
+def test_gemm_nt_ring_flavours_partial_tiles(flavour, M, N, K):
     import oracle.dropout_ref as DRo
     g = torch.Generator(device=DEV).manual_seed(M + N + K)
     A = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
@@ -280,12 +244,8 @@ def test_gemm_nt_persistent_flavours(flavour, M, N, K):
         kw["residual"] = res32
         ref = ref + res32
     out = torch.full((M + 8, N), float("nan"), dtype=out_dtype, device=DEV)
-    os.environ["CLDRD_GEMM_PERSIST"] = "1"
-    try:
-        ops.gemm_nt(A, B, out, M, **kw)
-        torch.cuda.synchronize()
-    finally:
-        os.environ.pop("CLDRD_GEMM_PERSIST", None)
+    ops.gemm_nt(A, B, out, M, **kw)
+    torch.cuda.synchronize()
     assert torch.isnan(out[M:].float()).all(), "rows past M were written"
     if out_dtype == torch.float32:
         close(out[:M], ref, 2e-5, 2e-4 * math.sqrt(K), flavour)
@@ -293,15 +253,15 @@ def test_gemm_nt_persistent_flavours(flavour, M, N, K):
         close(out[:M], ref, 1 / 128, 2e-2, flavour)
     if pre is not None:
         close(pre, pre_ref, 1 / 128, 2e-2, "preact")
-    # same numbers from the one-tile-per-workgroup kernel (same MFMA order; the epilogue arithmetic is the same fp32 sequence)
+    # and the same bits from a second launch
     out2 = torch.full((M + 8, N), float("nan"), dtype=out_dtype, device=DEV)
     ops.gemm_nt(A, B, out2, M, **kw)
     torch.cuda.synchronize()
-    assert torch.equal(out[:M], out2[:M]), f"{flavour}: persistent and ring kernels differ"
+    assert torch.equal(out[:M], out2[:M]), f"{flavour}: two launches differ"
 
 
-def test_gemm_nt_persistent_repeated_launches_are_stable():
-    """Race screen for the counted-vmcnt hand-off between tiles: 30 launches of a 3-tiles-per-workgroup problem must agree bit for bit."""
+def test_gemm_nt_ring_repeated_launches_are_stable():
+    """Race screen for the counted-vmcnt LDS-DMA ring: 30 launches of a 600-tile problem must agree bit for bit."""
     M, N, K = 256 * 200, 768, 768
     g = torch.Generator(device=DEV).manual_seed(3)
     A = torch.randn(M, K, device=DEV, generator=g).bfloat16()
@@ -309,17 +269,13 @@ def test_gemm_nt_persistent_repeated_launches_are_stable():
     bias = torch.randn(N, device=DEV, generator=g)
     res = torch.randn(M, N, device=DEV, generator=g)
     first = torch.empty(M, N, device=DEV)
-    os.environ["CLDRD_GEMM_PERSIST"] = "1"
-    try:
-        ops.gemm_nt(A, B, first, bias=bias, residual=res)
-        ref = A.float() @ B.float().T + bias + res
-        close(first, ref, 2e-5, 2e-4 * math.sqrt(K), "pers 200 row panels")
-        for _ in range(30):
-            out = torch.empty(M, N, device=DEV)
-            ops.gemm_nt(A, B, out, bias=bias, residual=res)
-            assert torch.equal(out, first)
-    finally:
-        os.environ.pop("CLDRD_GEMM_PERSIST", None)
+    ops.gemm_nt(A, B, first, bias=bias, residual=res)
+    ref = A.float() @ B.float().T + bias + res
+    close(first, ref, 2e-5, 2e-4 * math.sqrt(K), "200 row panels")
+    for _ in range(30):
+        out = torch.empty(M, N, device=DEV)
+        ops.gemm_nt(A, B, out, bias=bias, residual=res)
+        assert torch.equal(out, first)
 
 
 # ------------------------------------------------------------------------------------------------ weight gradient
@@ -427,11 +383,12 @@ def test_attention_fwd_bwd(nseq, L, H, masked):
 
 
 @pytest.mark.parametrize("nseq,L,H,fwd2", [(64, 128, 12, "1"), (64, 128, 12, "0"), (3, 40, 2, "1"), (2, 200, 2, "1"), (1, 256, 3, "1")])
-def test_attention_fwd_writes_an_fp16_copy_of_its_context(nseq, L, H, fwd2, monkeypatch):
+def test_attention_fwd_writes_an_fp16_copy_of_its_context(nseq, L, H, fwd2, request):
     """`ctx16`: the context of a bf16 pass a second time in fp16 (the out-projection's operand), from the persistent kernel, the
-    one-item-per-workgroup kernel (CLDRD_ATTN_FWD2=0), the streaming kernel (L > 128) and the CLS-only kernel; with `ctx = None` only the
+    one-item-per-workgroup kernel (ops.set_tuning("attn_fwd2", 0)), the streaming kernel (L > 128) and the CLS-only kernel; with `ctx = None` only the
     fp16 tensor is written.  Both are roundings of the same fp32 value: the bf16 one is unchanged bit for bit, the fp16 one 8x closer."""
-    monkeypatch.setenv("CLDRD_ATTN_FWD2", fwd2)
+    ops.set_tuning("attn_fwd2", int(fwd2))
+    request.addfinalizer(lambda: ops.set_tuning("attn_fwd2", 1))
     d, T = H * 64, nseq * L
     qkv = bf(rnd(150, (T, 3 * d), 1.0)).to(DEV)
     lens = np.clip(syn.msmarco_lengths(151, nseq, L), 2, L)
@@ -486,16 +443,13 @@ def test_attention_bwd_persistent_two_role_kernel(nseq, L, H, p):
     ops.attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=p, seed=99, drop_bits=bits)
     outs = []
     for env, b in (("0", None), (None, None), (None, None), (None, bits)):
-        if env is None:
-            os.environ.pop("CLDRD_ATTN_BWD2", None)
-        else:
-            os.environ["CLDRD_ATTN_BWD2"] = env
+        ops.set_tuning("attn_bwd2", 0 if env == "0" else 1)
         dqkv = torch.full((T, 3 * d), float("nan"), dtype=torch.bfloat16, device=DEV)
         try:
             ops.attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=p, seed=99, drop_bits=b)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("CLDRD_ATTN_BWD2", None)
+            ops.set_tuning("attn_bwd2", 1)
         outs.append(dqkv)
     valid = mask.bool().reshape(-1)
     assert not torch.isnan(outs[1][valid].float()).any()
@@ -516,10 +470,7 @@ def test_attention_fwd_persistent_loader_kernel(nseq, L, H, p):
     mask = (torch.arange(L, device=DEV)[None, :] < lens[:, None]).to(torch.int64).contiguous()
     outs = []
     for env in ("0", None, "bits"):
-        if env == "0":
-            os.environ["CLDRD_ATTN_FWD2"] = env
-        else:
-            os.environ.pop("CLDRD_ATTN_FWD2", None)
+        ops.set_tuning("attn_fwd2", 0 if env == "0" else 1)
         ctx = torch.full((T, d), float("nan"), dtype=torch.bfloat16, device=DEV)
         lse = torch.full((nseq, H, L), float("nan"), dtype=torch.float32, device=DEV)
         try:
@@ -527,7 +478,7 @@ def test_attention_fwd_persistent_loader_kernel(nseq, L, H, p):
             ops.attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=p, seed=1234, drop_bits=bits)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("CLDRD_ATTN_FWD2", None)
+            ops.set_tuning("attn_fwd2", 1)
         outs.append((ctx, lse))
     assert not torch.isnan(outs[1][0].float()).any() and not torch.isnan(outs[1][1]).any()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), "persistent forward differs from the one-item kernel"

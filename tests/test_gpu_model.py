@@ -674,7 +674,7 @@ def test_full_last_layer_equals_the_cls_only_last_layer(arch, packed, monkeypatc
 
 
 @pytest.mark.parametrize("switch,kind", [("CLDRD_Q_SIDE=0", "exec"), ("CLDRD_T_DEFER=0", "exec"), ("CLDRD_NORM_SPLIT=0", "exec"),
-                                         ("CLDRD_GRAD_ZERO=full", "exec"), ("CLDRD_Q_BWD=late", "exec"), ("CLDRD_ADAM_H16=0", "exec"),
+                                         ("CLDRD_GRAD_ZERO=full", "exec"), ("CLDRD_ADAM_H16=0", "exec"),
                                          ("CLDRD_LN_ON_THE_FLY=0", "numerics"),        # also turns the fp16-operand FFN GEMMs off
                                          ("CLDRD_FFN_FP16=0", "numerics"), ("CLDRD_QKV_FP16=1", "numerics"), ("CLDRD_QUERY_FP16=0", "numerics"),
                                          ("CLDRD_OUT_FP16=0", "numerics")])

@@ -4,6 +4,8 @@ K loop removed (CLDRD_GEMM_ABLATE, one process per mode: the mode is latched at 
 import os, subprocess, sys
 if len(sys.argv) > 1:
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _devlib  # noqa: F401  (the ablation modes exist in the development build only)
     import torch
     from cldrd_amd import hip_ops as ops
     M, N, K = (int(os.environ.get(k, d)) for k, d in (("M", 32768), ("N", 768), ("K", 3072)))

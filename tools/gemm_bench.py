@@ -2,6 +2,8 @@
 """Micro-benchmark of the NT GEMM variants on the encoder shapes (interleaved rounds in one process)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401  (development build: the knobs below do not exist in the product library)
 import torch
 from cldrd_amd import hip_ops as ops
 
@@ -13,7 +15,7 @@ def main():
               ("ffn1", T, 3072, 768, {"bias": 1, "pre": 1, "act": 3}), ("ffn1_old", T, 3072, 768, {"bias": 1, "pre": 1, "act": 1}), ("ffn2", T, 768, 3072, {"bias": 1, "res32": 1, "drop": 1}),
               ("dgrad_ffn2", T, 3072, 768, {"gp": 1, "act": 2}), ("dgrad_ffn2_old", T, 3072, 768, {"gp": 1}), ("dgrad_ffn1", T, 768, 3072, {"res": 1}),
               ("dgrad_out", T, 768, 768, {}), ("dgrad_qkv", T, 768, 2304, {"res": 1})]
-    variants = os.environ.get("VARIANTS", "pers,ring").split(",")      # pers | ring | ring128 | ring192 | ring256
+    variants = os.environ.get("VARIANTS", "ring,ring2s").split(",")      # ring | ring2s | ring128 | ring192 | ring256
     torch.manual_seed(0)
     tot = {v: 0.0 for v in variants}
     for name, M, N, K, ep in shapes:
@@ -36,7 +38,6 @@ def main():
         res = {}
         for rnd in range(3):
             for v in variants:
-                os.environ["CLDRD_GEMM_PERSIST"] = "1" if v == "pers" else ("2" if v == "pers1" else "0")
                 os.environ["CLDRD_GEMM_ASYM"] = "0" if v == "ring2s" else "1"          # ring2s: two A slots (the round-2 K-loop schedule)
                 if v.startswith("ring") and len(v) > 4 and v != "ring2s": os.environ["CLDRD_GEMM_TILE"] = v[4:]
                 else: os.environ.pop("CLDRD_GEMM_TILE", None)
@@ -55,7 +56,6 @@ def main():
             line += f" {v}: {t*1e3:7.1f} us {fl/t/1e9:7.1f} TF/s |"
         print(line, flush=True)
     print("layer total (8 GEMMs): " + " | ".join(f"{v}: {t*1e3:7.1f} us" for v, t in tot.items()), flush=True)
-    os.environ.pop("CLDRD_GEMM_PERSIST", None)
     os.environ.pop("CLDRD_GEMM_TILE", None)
     # weight gradients: dW[N1,N2] = dY[T,N1]^T X[T,N2] (+ bias gradient), split-K slabs + reduction included
     for name, N1, N2 in [("w_qkv", 2304, 768), ("w_out", 768, 768), ("w_ffn1", 3072, 768), ("w_ffn2", 768, 3072)]:

@@ -2,6 +2,8 @@
 """Diagnostics for the ring GEMM: time vs K (slope = marginal cost per K tile), vs M (CU occupancy), zero vs random data."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401  (development build: the knobs below do not exist in the product library)
 import torch
 from cldrd_amd import hip_ops as ops
 dev = "cuda"

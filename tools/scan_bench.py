@@ -4,6 +4,8 @@ on-chip hit list per workgroup)}, the bf16 ablations (CLDRD_SCAN_ABLATE=1 DMA on
 The memset of the counters is inside the timed loop.  Corpus = bench.py's (unit Gaussian direction x norm ~ U(9, 12))."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _devlib  # noqa: F401  (development build: the knobs below do not exist in the product library)
 import torch
 from cldrd_amd import hip_ops as ops
 dev = "cuda"; rows, d, nq, cap = 1105228, 768, 128, 8192
@@ -17,7 +19,7 @@ cr = torch.empty(nq, cap, dtype=torch.int32, device=dev); cs = torch.empty(nq, c
 
 
 def run(tag, Q, P, thr_val, env=None, reps=30):
-    for k in ("CLDRD_SCAN_ABLATE", "CLDRD_SCAN"):
+    for k in ("CLDRD_SCAN_ABLATE", "CLDRD_SCAN_GEMM"):
         os.environ.pop(k, None)
     os.environ.update(env or {})
     nq = Q.shape[0]
@@ -54,5 +56,5 @@ for thr_v in (11.9, 11.1):
     run(f"fp16 256 q thr {thr_v} no flush (4)", Q256h, Ph, thr_v, {"CLDRD_SCAN_ABLATE": "4"})
 run("bf16 DMA only (ablate 1)", Qb, Pb, 11.5, {"CLDRD_SCAN_ABLATE": "1"})
 run("bf16 no hit handling (ablate 2)", Qb, Pb, 11.5, {"CLDRD_SCAN_ABLATE": "2"})
-run("bf16 tiled GEMM scan", Qb, Pb, 11.5, {"CLDRD_SCAN": "gemm"}, reps=10)
-run("fp16 tiled GEMM scan", Qh, Ph, 11.5, {"CLDRD_SCAN": "gemm"}, reps=10)
+run("bf16 tiled GEMM scan", Qb, Pb, 11.5, {"CLDRD_SCAN_GEMM": "1"}, reps=10)
+run("fp16 tiled GEMM scan", Qh, Ph, 11.5, {"CLDRD_SCAN_GEMM": "1"}, reps=10)
