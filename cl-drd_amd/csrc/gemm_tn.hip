@@ -75,20 +75,31 @@ __device__ __forceinline__ int chunk_pos(int c, int m) {
 __device__ __forceinline__ void tn_dma16(uint32_t lds_addr, uint32_t voff, const void* sbase) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
 }
+// Round 4: the two transposing reads of a fragment are the BUILTIN again, and every LDS-DMA of the kernel is inline asm instead (the
+// partial-tile path included).  Rounds 1-3 had it the other way round - reads in asm because hipcc, seeing a global_load_lds builtin
+// anywhere in the loop, put s_waitcnt vmcnt(0) in front of every LDS read - and paid for it: two 64-bit asm outputs are two unrelated
+// register pairs, so hipcc copied every fragment into a 4-register tuple before its MFMA (56 v_mov per 48 MFMAs in the K loop;
+// PMC: 1.66 VALU instructions per MFMA in a kernel that has no arithmetic) and the hand-counted lgkmcnt waits had to live with the
+// 4-bit counter.  With no VMEM instruction visible to it the compiler inserts exact lgkmcnt waits for its own reads and allocates lo / hi
+// as one tuple (no copies); the vmcnt waits of the DMA ring stay ours.
 struct Frag { bf16x4 lo, hi; };
 template <int OFF, int HI>
 __device__ __forceinline__ void tr_issue(Frag& f, uint32_t addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr), "n"(OFF), "n"(OFF + HI) : "memory");
+    typedef __attribute__((address_space(3))) bf16x4* lds4;
+    f.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(uintptr_t)(addr + OFF));
+    f.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(uintptr_t)(addr + OFF + HI));
 }
-template <int N>
-__device__ __forceinline__ void tn_wait_frag(Frag& f) { asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N)); }
-__device__ __forceinline__ bf16x8 frag8(const Frag& f) { return (bf16x8){f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]}; }
+__device__ __forceinline__ bf16x8 frag8(const Frag& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+// one LDS-DMA piece with a per-lane 64-bit source address (partial last K tile: rows >= M come from the zero page)
+__device__ __forceinline__ void tn_dma16_addr(uint32_t lds_addr, const void* src) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory");
+}
 
-template <int T1, int T2, int NW>
+// ABL != 0 (development build only, tools/tn_ablate.py; WRONG results): 1 no LDS-DMA inside the K loop, 2 no fragment reads inside the
+// K loop, 3 no barrier and no vmcnt wait inside the K loop.
+template <int T1, int T2, int NW, int ABL = 0>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr bool BIAS = true;                         // bias columns are a per-problem run-time choice (dbias != null)
     constexpr int NBF = T2 == 192 ? 3 : 4;              // B fragments (16 n2 columns each) per wave
     constexpr int WGN = T2 / (16 * NBF), WGM = NW / WGN;        // wave grid; a wave owns (16 FA) x (16 NBF) of the tile
     constexpr int FA = T1 / WGM / 16;                   // A fragments (16 n1 columns each) per wave
@@ -133,22 +144,23 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
         ob[i] = (uint32_t)r * (uint32_t)(ldb * 2) + (uint32_t)(c2 * 2) + (uint32_t)(chunk_pos<T2 * 2>(pos, r) * 16);
     }
     auto stage = [&](int slot, int kt) {
-        char* base = smem + slot * SLOT;
+        if (ABL == 1 && kt >= NSLOT) return;
         const char* pa = (const char*)A + (size_t)(kbeg + kt) * BK * lda * 2;
         const char* pb = (const char*)B + (size_t)(kbeg + kt) * BK * ldb * 2;
         if (mtail != 0 && kbeg + kt == ktotal - 1) {
             // last, partial K tile: token rows >= M come from the zero page (once per workgroup at most; rows recomputed here
             // instead of being kept in registers)
             const char* zp = (const char*)g_zero_page + lane * 16;
+            const uint32_t lb = (uint32_t)(uintptr_t)LDS_PTR(smem) + slot * SLOT;
 #pragma unroll
             for (int i = 0; i < APW; ++i) {
                 const int r = RA * (APW * wid + i) + lane / LPR_A;
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(r < mtail ? pa + oa[i] : zp), LDS_PTR(base + (APW * wid + i) * 1024), 16, 0, 0);
+                tn_dma16_addr(lb + (APW * wid + i) * 1024, r < mtail ? pa + oa[i] : zp);
             }
 #pragma unroll
             for (int i = 0; i < BPW; ++i) {
                 const int r = ((BPW * wid + i) * 1024 + lane * 16) / (T2 * 2);
-                __builtin_amdgcn_global_load_lds(GLOBAL_PTR(r < mtail ? pb + ob[i] : zp), LDS_PTR(base + A_BYTES + (BPW * wid + i) * 1024), 16, 0, 0);
+                tn_dma16_addr(lb + A_BYTES + (BPW * wid + i) * 1024, r < mtail ? pb + ob[i] : zp);
             }
             return;
         }
@@ -177,160 +189,135 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
     }
 
     f32x4 acc[FA][NBF];
-    f32x4 accb[BIAS ? FA : 1];
+    f32x4 accb[FA];
 #pragma unroll
     for (int i = 0; i < FA; ++i) {
-        if (BIAS) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < NBF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const short one = (short)0x3F80;     // bf16 1.0
     const bf16x8 ones = (bf16x8){one, one, one, one, one, one, one, one};
 
-    Frag af[FA], b0[NBF], b1[NBF];
-    auto mfma_row = [&](int t1, Frag (&bc)[NBF]) {
-        const bf16x8 a = frag8(af[t1]);
-#pragma unroll
-        for (int t2 = 0; t2 < NBF; ++t2)
-            // swapped operands: D'[n2][n1] so the lane's 4 accumulators run along n2 (contiguous in dW rows)
-            acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(bc[t2]), a, acc[t1][t2], 0, 0, 0);
-        if (BIAS && do_bias) accb[BIAS ? t1 : 0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a, accb[BIAS ? t1 : 0], 0, 0, 0);
-    };
-    // LDS returns in issue order.  Issue order per k-step: A0, B'0..B'3, A1, .., A(FA-1) (2 reads each; B' = next k-step's B).
-    // Row 0 needs A0 and B, the 2 (FA-1) reads of A1.. are younger.  Row t1 >= 1 needs A[t1] of the previous k-step:
-    // 2 FA + 2 NBF - 2 younger reads (the lgkmcnt field stops at 15: for FA = 8 a few older refills are waited for too).
-    constexpr int W0 = 2 * (FA - 1), WR = 2 * FA + 2 * NBF - 2 < 15 ? 2 * FA + 2 * NBF - 2 : 15;
-    auto wait_row0 = [&](Frag (&bc)[NBF]) {
-        if constexpr (NBF == 4)
-            asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo),
-                         "+v"(bc[1].hi), "+v"(bc[2].lo), "+v"(bc[2].hi), "+v"(bc[3].lo), "+v"(bc[3].hi) : "n"(W0));
-        else
-            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo),
-                         "+v"(bc[1].hi), "+v"(bc[2].lo), "+v"(bc[2].hi) : "n"(W0));
-    };
     // waves w and w + NW/2 share a SIMD: the second half issues its LDS-DMA one k-step later, so the two do not stall the
     // MFMA pipe at the same time (measured on the NT kernel: +2..9 %)
     const bool late_wave = NW == 8 && wid >= 4 && stagger;
-    // one 32-token k-step over (af, bc); the next fragments come from slot offset noff, k-step NKS of that slot
-    auto kstep = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
-        constexpr int NKS = decltype(nks_tag)::value;
-        constexpr int OA = NKS * 32 * T1 * 2, OB = NKS * 32 * T2 * 2;
-        wait_row0(bc);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(0, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (sync) {
-            // K tile kt+1 must have landed; with three slots K tile kt+2 (issued one tile ago) may stay in flight
-            if (NSLOT == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (!late_wave && kt + NSLOT < nk) stage(slot, kt + NSLOT);  // slot of K tile kt: every wave holds its fragments in registers
-            __builtin_amdgcn_sched_barrier(0);
-        } else if (late_wave && slot >= 0 && kt + NSLOT < nk) {
-            stage(slot, kt + NSLOT);                       // postponed from the previous K tile's barrier (see gemm_nt_ring.hip)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        tr_issue<OA, 4 * T1 * 2>(af[0], ra[0] + noff);
-#pragma unroll
-        for (int t = 0; t < NBF; ++t) tr_issue<OB, 4 * T2 * 2>(bn[t], rb[t] + noff);
-#pragma unroll
-        for (int t1 = 1; t1 < FA; ++t1) {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(af[t1].lo), "+v"(af[t1].hi) : "n"(WR));
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(t1, bc);
-            __builtin_amdgcn_sched_barrier(0);
-            tr_issue<OA, 4 * T1 * 2>(af[t1], ra[t1] + noff);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
     using KS0 = std::integral_constant<int, 0>;
     using KS1 = std::integral_constant<int, 1>;
 
-    // FA = 8 (the 256-row tiles): A fragments are refilled FOUR rows after their last use instead of at once.
-    // lgkmcnt is a 4-bit counter.  With the schedule above a k-step keeps 2 FA + 2 NBF = 22 reads in flight and row t1 waits with
-    // lgkmcnt(15) where 20 were meant: it also waits for reads issued only ~2 rows (100 cycles) earlier, i.e. for LDS latency - halving
-    // the reads (a wrong-result experiment) gave +5..16 %.  Here fragment f of k-step s+1 is requested after row f + 4 (rows 0..3
-    // request fragments 4..7 of the SAME k-step, rows 4..7 fragments 0..3 and B of the next one): every request is 4 rows old when
-    // it is waited for and at most 6 (rows 0..4) or 6 + 2 NBF (rows 5..7) younger ones exist - exact counts, all <= 14.
-    // Consequences: a k-step starts with A0..A3 and B in registers only; the slot of K tile kt is free (barrier + DMA of K tile kt+2)
-    // after row 3 of its second k-step, not after row 0; the very last k-step still issues its (unused) requests so that the counts
-    // hold, and they are drained before the epilogue touches the registers.
-    constexpr int WLO = 6, WHI = 6 + 2 * NBF;
-    static_assert(FA != 8 || NSLOT == 2, "the 256-row tiles use two LDS slots");
-    auto wait_row0_lag = [&](Frag (&bc)[NBF]) {
-        if constexpr (NBF == 4)
-            asm volatile("s_waitcnt lgkmcnt(%10)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo),
-                         "+v"(bc[1].hi), "+v"(bc[2].lo), "+v"(bc[2].hi), "+v"(bc[3].lo), "+v"(bc[3].hi) : "n"(WLO));
-        else
-            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(bc[0].lo), "+v"(bc[0].hi), "+v"(bc[1].lo),
-                         "+v"(bc[1].hi), "+v"(bc[2].lo), "+v"(bc[2].hi) : "n"(WLO));
-    };
-    // one 32-token k-step; current fragments at slot offset coff / k-step CKS, the next k-step's at noff / NKS
-    auto kstep8 = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t coff, auto cks_tag, uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
-        constexpr int CKS = decltype(cks_tag)::value, NKS = decltype(nks_tag)::value;
-        constexpr int COA = CKS * 32 * T1 * 2, NOA = NKS * 32 * T1 * 2, NOB = NKS * 32 * T2 * 2;
-        wait_row0_lag(bc);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(0, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!sync && late_wave && slot >= 0 && kt + NSLOT < nk) {
-            stage(slot, kt + NSLOT);                       // postponed from the previous K tile's barrier (see gemm_nt_ring.hip)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        tr_issue<COA, 4 * T1 * 2>(af[4], ra[4] + coff);
+    // The whole K sweep, instantiated twice: with and without the bias-gradient MFMA (B = all-ones) per A fragment.  Which one a wave
+    // runs is decided ONCE (wave-uniform), not per fragment row: until round 3 every row of the K loop carried a v_cndmask / v_cmp /
+    // s_cbranch and three v_mov rebuilding the all-ones operand.
+    auto sweep = [&](auto bias_tag) {
+        constexpr bool WB = decltype(bias_tag)::value;
+        Frag af[FA], b0[NBF], b1[NBF];
+        auto tr_issue_ = [&](auto off_tag, auto hi_tag, Frag& f, uint32_t addr) {
+            if constexpr (ABL == 2) { asm volatile("" : "+v"(f.lo), "+v"(f.hi)); }
+            else tr_issue<decltype(off_tag)::value, decltype(hi_tag)::value>(f, addr);
+        };
+        auto mfma_row = [&](int t1, Frag (&bc)[NBF]) {
+            const bf16x8 a = frag8(af[t1]);
 #pragma unroll
-        for (int t1 = 1; t1 < 4; ++t1) {
-            __builtin_amdgcn_sched_barrier(0);
-            tn_wait_frag<WLO>(af[t1]);
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_row(t1, bc);
-            __builtin_amdgcn_sched_barrier(0);
-            tr_issue<COA, 4 * T1 * 2>(af[t1 + 4], ra[t1 + 4] + coff);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        tn_wait_frag<WLO>(af[4]);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(4, bc);
-        __builtin_amdgcn_sched_barrier(0);
-        if (sync) {
-            // every read of this K tile's slot has been issued (and is waited for here); K tile kt+1 must have landed
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            for (int t2 = 0; t2 < NBF; ++t2)
+                // swapped operands: D'[n2][n1] so the lane's 4 accumulators run along n2 (contiguous in dW rows)
+                acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(bc[t2]), a, acc[t1][t2], 0, 0, 0);
+            if constexpr (WB) accb[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a, accb[t1], 0, 0, 0);
+        };
+        // K tile kt+1 must have landed (with three slots K tile kt+2, issued one tile ago, may stay in flight) and every read of this K
+        // tile's slot must be back before the slot is handed to the DMA: lgkmcnt(0) covers the compiler's reads, which are all issued
+        // above this point (sched_barrier).
+        auto sync_and_recycle = [&](int slot, int kt) {
+            if (ABL == 3) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            else if (NSLOT == 3 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(G) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            if (ABL != 3) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (!late_wave && kt + NSLOT < nk) stage(slot, kt + NSLOT);
+            if (!late_wave && kt + NSLOT < nk) stage(slot, kt + NSLOT);  // slot of K tile kt: every wave holds its fragments in registers
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        // one 32-token k-step over (af, bc), FA < 8 (the 128 x 128 tile); the next fragments come from slot offset noff, k-step NKS of that slot.
+        // Reads are issued right behind the MFMA row that last used their destination; the compiler waits (exact lgkmcnt) where a fragment is used.
+        auto kstep = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
+            constexpr int NKS = decltype(nks_tag)::value;
+            constexpr int OA = NKS * 32 * T1 * 2, OB = NKS * 32 * T2 * 2;
+            mfma_row(0, bc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sync) {
+                sync_and_recycle(slot, kt);
+            } else if (late_wave && slot >= 0 && kt + NSLOT < nk) {
+                stage(slot, kt + NSLOT);                       // postponed from the previous K tile's barrier (see gemm_nt_ring.hip)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tr_issue_(std::integral_constant<int, OA>{}, std::integral_constant<int, 4 * T1 * 2>{}, af[0], ra[0] + noff);
 #pragma unroll
-        for (int t = 0; t < NBF; ++t) tr_issue<NOB, 4 * T2 * 2>(bn[t], rb[t] + noff);
-        tr_issue<NOA, 4 * T1 * 2>(af[0], ra[0] + noff);
+            for (int t = 0; t < NBF; ++t) tr_issue_(std::integral_constant<int, OB>{}, std::integral_constant<int, 4 * T2 * 2>{}, bn[t], rb[t] + noff);
 #pragma unroll
-        for (int t1 = 5; t1 < 8; ++t1) {
+            for (int t1 = 1; t1 < FA; ++t1) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_row(t1, bc);
+                __builtin_amdgcn_sched_barrier(0);
+                tr_issue_(std::integral_constant<int, OA>{}, std::integral_constant<int, 4 * T1 * 2>{}, af[t1], ra[t1] + noff);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            tn_wait_frag<WHI>(af[t1]);
+        };
+        // FA = 8 (the 256-row tiles): A fragments are refilled FOUR rows after their last use instead of at once, so that every request is
+        // four MFMA rows old when its fragment is used: fragment f of k-step s+1 is requested after row f + 4 (rows 0..3 request fragments
+        // 4..7 of the SAME k-step, rows 4..7 fragments 0..3 and B of the next one).  A k-step starts with A0..A3 and B in registers only;
+        // the slot of K tile kt is free (barrier + DMA of K tile kt+2) after row 4 of its second k-step; the very last k-step still issues
+        // its (unused) requests, which the compiler retires before the registers are reused.
+        // one 32-token k-step; current fragments at slot offset coff / k-step CKS, the next k-step's at noff / NKS
+        auto kstep8 = [&](Frag (&bc)[NBF], Frag (&bn)[NBF], uint32_t coff, auto cks_tag, uint32_t noff, auto nks_tag, bool sync, int slot, int kt) {
+            constexpr int CKS = decltype(cks_tag)::value, NKS = decltype(nks_tag)::value;
+            constexpr int COA = CKS * 32 * T1 * 2, NOA = NKS * 32 * T1 * 2, NOB = NKS * 32 * T2 * 2;
+            mfma_row(0, bc);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_row(t1, bc);
+            if (!sync && late_wave && slot >= 0 && kt + NSLOT < nk) {
+                stage(slot, kt + NSLOT);                       // postponed from the previous K tile's barrier (see gemm_nt_ring.hip)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            tr_issue_(std::integral_constant<int, COA>{}, std::integral_constant<int, 4 * T1 * 2>{}, af[4], ra[4] + coff);
+#pragma unroll
+            for (int t1 = 1; t1 < 4; ++t1) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_row(t1, bc);
+                __builtin_amdgcn_sched_barrier(0);
+                tr_issue_(std::integral_constant<int, COA>{}, std::integral_constant<int, 4 * T1 * 2>{}, af[t1 + 4], ra[t1 + 4] + coff);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            tr_issue<NOA, 4 * T1 * 2>(af[t1 - 4], ra[t1 - 4] + noff);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
+            mfma_row(4, bc);
+            __builtin_amdgcn_sched_barrier(0);
+            if (sync) sync_and_recycle(slot, kt);
+#pragma unroll
+            for (int t = 0; t < NBF; ++t) tr_issue_(std::integral_constant<int, NOB>{}, std::integral_constant<int, 4 * T2 * 2>{}, bn[t], rb[t] + noff);
+            tr_issue_(std::integral_constant<int, NOA>{}, std::integral_constant<int, 4 * T1 * 2>{}, af[0], ra[0] + noff);
+#pragma unroll
+            for (int t1 = 5; t1 < 8; ++t1) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_row(t1, bc);
+                __builtin_amdgcn_sched_barrier(0);
+                tr_issue_(std::integral_constant<int, NOA>{}, std::integral_constant<int, 4 * T1 * 2>{}, af[t1 - 4], ra[t1 - 4] + noff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
 
-    if constexpr (FA == 8) {
-        if (nk > 0) {
+        if constexpr (FA == 8) {
             stage(0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (NSLOT == 3 && nk > 1) {
+                stage(1, 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (nk > 1) stage(1, 1);
+            if (NSLOT == 3) { if (nk > 2) stage(2, 2); } else { if (nk > 1) stage(1, 1); }
 #pragma unroll
             for (int t = 0; t < NBF; ++t) tr_issue<0, 4 * T2 * 2>(b0[t], rb[t]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) tr_issue<0, 4 * T1 * 2>(af[t], ra[t]);
             int cs = 0, ps = -1;                               // slots of K tiles kt and kt-1
             for (int kt = 0; kt + 1 < nk; ++kt) {
-                const int ns = cs ^ 1;
+                const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
                 kstep8(b0, b1, (uint32_t)(cs * SLOT), KS0{}, (uint32_t)(cs * SLOT), KS1{}, false, ps, kt - 1);
                 kstep8(b1, b0, (uint32_t)(cs * SLOT), KS1{}, (uint32_t)(ns * SLOT), KS0{}, true, cs, kt);
                 ps = cs;
@@ -338,50 +325,38 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
             }
             kstep8(b0, b1, (uint32_t)(cs * SLOT), KS0{}, (uint32_t)(cs * SLOT), KS1{}, false, ps, nk - 2);
             kstep8(b1, b0, (uint32_t)(cs * SLOT), KS1{}, (uint32_t)(cs * SLOT), KS0{}, false, -1, nk);      // its next-k-step requests read stale LDS: unused
-            // drain them: an outstanding read lands in its destination register whatever the register holds by then
-            if constexpr (NBF == 4)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(af[1].lo), "+v"(af[1].hi), "+v"(af[2].lo), "+v"(af[2].hi),
-                             "+v"(af[3].lo), "+v"(af[3].hi), "+v"(b0[0].lo), "+v"(b0[0].hi), "+v"(b0[1].lo), "+v"(b0[1].hi), "+v"(b0[2].lo),
-                             "+v"(b0[2].hi), "+v"(b0[3].lo), "+v"(b0[3].hi));
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0].lo), "+v"(af[0].hi), "+v"(af[1].lo), "+v"(af[1].hi), "+v"(af[2].lo), "+v"(af[2].hi),
-                             "+v"(af[3].lo), "+v"(af[3].hi), "+v"(b0[0].lo), "+v"(b0[0].hi), "+v"(b0[1].lo), "+v"(b0[1].hi), "+v"(b0[2].lo),
-                             "+v"(b0[2].hi));
-        }
-    } else
-    if (nk > 0) {
-        stage(0, 0);
-        if (NSLOT == 3 && nk > 1) {
-            stage(1, 1);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (NSLOT == 3) { if (nk > 2) stage(2, 2); } else { if (nk > 1) stage(1, 1); }
-        tr_issue<0, 4 * T1 * 2>(af[0], ra[0]);
+            stage(0, 0);
+            if (NSLOT == 3 && nk > 1) {
+                stage(1, 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (NSLOT == 3) { if (nk > 2) stage(2, 2); } else { if (nk > 1) stage(1, 1); }
+            tr_issue<0, 4 * T1 * 2>(af[0], ra[0]);
 #pragma unroll
-        for (int t = 0; t < NBF; ++t) tr_issue<0, 4 * T2 * 2>(b0[t], rb[t]);
+            for (int t = 0; t < NBF; ++t) tr_issue<0, 4 * T2 * 2>(b0[t], rb[t]);
 #pragma unroll
-        for (int t = 1; t < FA; ++t) tr_issue<0, 4 * T1 * 2>(af[t], ra[t]);
-        int cs = 0, ps = -1;                               // slots of K tiles kt and kt-1
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
-            kstep(b0, b1, (uint32_t)(cs * SLOT), KS1{}, false, ps, kt - 1);
-            kstep(b1, b0, (uint32_t)(ns * SLOT), KS0{}, true, cs, kt);
-            ps = cs;
-            cs = ns;
-        }
-        kstep(b0, b1, (uint32_t)(cs * SLOT), KS1{}, false, ps, nk - 2);
-        wait_row0(b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(0, b1);
+            for (int t = 1; t < FA; ++t) tr_issue<0, 4 * T1 * 2>(af[t], ra[t]);
+            int cs = 0, ps = -1;                               // slots of K tiles kt and kt-1
+            for (int kt = 0; kt + 1 < nk; ++kt) {
+                const int ns = cs == NSLOT - 1 ? 0 : cs + 1;
+                kstep(b0, b1, (uint32_t)(cs * SLOT), KS1{}, false, ps, kt - 1);
+                kstep(b1, b0, (uint32_t)(ns * SLOT), KS0{}, true, cs, kt);
+                ps = cs;
+                cs = ns;
+            }
+            kstep(b0, b1, (uint32_t)(cs * SLOT), KS1{}, false, ps, nk - 2);
 #pragma unroll
-        for (int t1 = 1; t1 < FA; ++t1) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[t1].lo), "+v"(af[t1].hi));
-            mfma_row(t1, b1);
+            for (int t1 = 0; t1 < FA; ++t1) mfma_row(t1, b1);
         }
+    };
+    if (nk > 0) {
+        if (do_bias) sweep(std::true_type{});
+        else sweep(std::false_type{});
     }
 
     // ---- output.  One split: the tile is complete, write (or add to) dW / dbias directly.  Several: this split's slab.
@@ -523,16 +498,16 @@ extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
 
 static inline int wgrad_stagger() { return 1; }
 
-template <int T1, int T2, int NW>
+template <int T1, int T2, int NW, int ABL = 0>
 static int launch_tn_group(const TnGroupArgs& g, int items, hipStream_t st) {
     constexpr int slot = BK * (T1 + T2) * 2;
     constexpr int lds = (3 * slot <= 160 * 1024 ? 3 : 2) * slot;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T1, T2, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T1, T2, NW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_tn_kernel<T1, T2, NW>), dim3(items), dim3(64 * NW), lds, st, g);
+    hipLaunchKernelGGL((gemm_tn_kernel<T1, T2, NW, ABL>), dim3(items), dim3(64 * NW), lds, st, g);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -597,6 +572,16 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
             if (splits > 1) slab_off += (size_t)splits * ((size_t)N1[j] * N2[j] + (size_t)N1[j]);
         }
         int rc;
+#ifdef CLDRD_DEV_BUILD                                 // timing-only ablations (WRONG results): development build only
+        const int abl = cldrd_dev_int("CLDRD_TN_ABLATE", 0);
+        if (abl && t.t1 == 256 && t.t2 == 192) {
+            rc = abl == 1 ? launch_tn_group<256, 192, 8, 1>(g, items, st) : abl == 2 ? launch_tn_group<256, 192, 8, 2>(g, items, st)
+                                                                                      : launch_tn_group<256, 192, 8, 3>(g, items, st);
+        } else if (abl && t.t1 == 256) {
+            rc = abl == 1 ? launch_tn_group<256, 128, 8, 1>(g, items, st) : abl == 2 ? launch_tn_group<256, 128, 8, 2>(g, items, st)
+                                                                                      : launch_tn_group<256, 128, 8, 3>(g, items, st);
+        } else
+#endif
         if (t.t1 == 256 && t.t2 == 192) rc = launch_tn_group<256, 192, 8>(g, items, st);
         else if (t.t1 == 256) rc = launch_tn_group<256, 128, 8>(g, items, st);
         else rc = launch_tn_group<128, 128, 4>(g, items, st);

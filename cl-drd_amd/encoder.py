@@ -213,7 +213,7 @@ def _attach(root: nn.Module, dotted: str, param: nn.Parameter):
 
 class _Tape:
     """Activations saved by one training forward of one tower."""
-    __slots__ = ("M", "L", "T", "ids", "mask", "seed", "mean0", "rstd0", "layers", "p_embed", "pack")
+    __slots__ = ("M", "L", "T", "ids", "mask", "seed", "mean0", "rstd0", "layers", "p_embed", "pack", "device_seed")
 
 
 class _Pack:
@@ -631,7 +631,7 @@ class HipEncoder(nn.Module):
         if save:
             tape = _Tape()
             tape.M, tape.L, tape.T, tape.ids, tape.mask, tape.seed, tape.layers = M, L, T, ids, mask, seed, []
-            tape.p_embed, tape.pack = p_h, pk
+            tape.p_embed, tape.pack, tape.device_seed = p_h, pk, False
         f32 = dict(dtype=torch.float32, device=dev)
         S32 = self.stream32
         sdt = torch.float32 if S32 else torch.bfloat16         # storage type of the pre-LN sums

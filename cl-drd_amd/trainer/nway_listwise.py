@@ -422,7 +422,10 @@ class NwayTrainer:
                 entry.update(self._capture(batch))
             except Exception as exc:       # a capture problem must never take training down: fall back to the eager step for good
                 import warnings
-                warnings.warn(f"HIP-graph capture of the training step failed ({type(exc).__name__}: {exc}); staying eager")
+                first = exc
+                while first.__context__ is not None:          # what went wrong INSIDE the capture (the capture's own exit error hides it)
+                    first = first.__context__
+                warnings.warn(f"HIP-graph capture of the training step failed ({type(first).__name__}: {first}); staying eager")
                 self._graph_broken = True
                 for t in towers:
                     t.seed_base_ptr = None
@@ -467,8 +470,17 @@ class NwayTrainer:
         # the captured launches take seeds / lr from device memory: nothing of THIS step's values is baked in (the counters are not
         # advanced here; the capture itself executes nothing)
         with torch.cuda.graph(g):
-            loss_out, logits = self.forward_backward(static)
-            self._optimizer_launches(0.0, 1)
+            try:
+                loss_out, logits = self.forward_backward(static)
+                self._optimizer_launches(0.0, 1)
+            except BaseException:
+                # join every stream forked inside the capture before it ends: otherwise ending it fails too ("unjoined work"), the stream
+                # stays in capture mode and the eager fallback cannot run either
+                cur = torch.cuda.current_stream()
+                for s_ in (self.q_stream, self.comm_stream):
+                    if s_ is not None:
+                        cur.wait_stream(s_)
+                raise
         return {"graph": g, "inputs": self._flat_inputs(static), "loss_out": loss_out, "logits": logits, "static": static}
 
     # ---------------------------------------------------------------------------------------------------------
