@@ -554,8 +554,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
                     const uint32_t a = lq_off + 4u * (uint32_t)(wid * WCAP + pos);
                     asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:%4\n\tds_write_b32 %0, %3 offset:%5"
                                  ::"v"(a), "v"(qn), "v"(row0 + j), "v"(acc[j]), "n"(4 * LCAP), "n"(8 * LCAP) : "memory");
+                } else if (hit) {
+                    // This wave's on-chip list is full (the flush decision lags two tiles; a burst of hits - rows that score high for EVERY
+                    // query of the tile, the normal case on real dual-encoder embeddings - can outrun it): the hit goes straight to the
+                    // query's global list, as in the tiled kernels.  Slow (a returning global atomic: hipcc drains the LDS-DMA queue for
+                    // it), rare, and nothing is ever dropped: until round 4 such hits were counted in counts[nq] and the whole pass was
+                    // scanned again by the tiled kernels (every pass of the CLS-like shard: 27 rescans for 28 passes).
+                    const int gp = atomicAdd(counts + qn, 1);
+                    if (gp < cap) { cand_rows[(size_t)qn * cap + gp] = row0 + j; cand_scores[(size_t)qn * cap + gp] = acc[j]; }
                 }
-                wcnt += __builtin_popcountll(m);
+                wcnt = min(wcnt + (int)__builtin_popcountll(m), WCAP);
             }
         };
         fetch(ab[0], 0);

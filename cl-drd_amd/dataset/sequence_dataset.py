@@ -153,8 +153,7 @@ class SequenceTokenCache:
             try:
                 return cls.load(stem, want)
             except ValueError:
-                if rank != 0:
-                    raise
+                pass            # stale (another collection / tokenizer / length): rank 0 rebuilds it below, the others wait for that
         if rank == 0:
             return cls.build(path, tokenizer, max_length, stem)
         t0 = time.time()

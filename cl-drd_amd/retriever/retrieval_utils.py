@@ -165,13 +165,29 @@ class FlatIPIndex:
                 raise ValueError("FlatIPIndex: the embedding width must be a multiple of 4")
             flag = torch.zeros(1, dtype=torch.int32, device=device)
             self._p16 = torch.empty(n, d, dtype=torch.float16, device=device)
-            ops.cast_f16(self._p32.view(-1), self._p16.view(-1), flag)
+            # Round 4: the 16-bit scan shadow holds the rows CENTRED on the shard's mean row mu.  <q, p - mu> = <q, p> - <q, mu> moves every score
+            # of a query by the same constant, so the ranking - all the scan decides - is unchanged, while the rounding bound of the scan,
+            # eps ~ 2^-10 |q| max|p - mu|, shrinks with the rows' common component.  Dual-encoder CLS embeddings are dominated by one (reference
+            # model: q . p = 17 +- 2 over a corpus): on the CLS-like shard of the tests eps goes from 0.042 to 0.007 and the 2 eps band under the
+            # k-th score from ~1 250 rows to ~200, i.e. the re-score gathers about half the rows and the scan emits half the hits; on an isotropic
+            # corpus mu ~ 0 and nothing changes.  Exact scores still come from the untouched fp32 rows (re-score), so D / I are what they were.
             self._s_stride = max(1, n // SAMPLE_ROWS)
             self._s_rows = min(n, (n + self._s_stride - 1) // self._s_stride)
             # the GEMM wants a column count that is a multiple of 8: zero rows pad the sample (never read by the select)
             self._sample = torch.zeros((self._s_rows + 7) // 8 * 8, d, dtype=torch.bfloat16, device=device)
-            ops.gather_cast_rows(self._p32, self._sample, self._s_rows, self._s_stride)
-            self._max_norm = math.sqrt(ops.row_sqnorm_max(self._p32))
+            raw_max = math.sqrt(ops.row_sqnorm_max(self._p32))
+            mu = self._p32.mean(dim=0, dtype=torch.float64).to(torch.float32) if math.isfinite(raw_max) else torch.zeros(d, device=device)
+            self._mu = mu
+            cmax = torch.zeros((), dtype=torch.float32, device=device)
+            CH = 1 << 16
+            for lo in range(0, n, CH):
+                c = self._p32[lo:lo + CH] - mu
+                cmax = torch.maximum(cmax, (c.double() * c.double()).sum(1).max().float())
+                ops.cast_f16(c.view(-1), self._p16[lo:lo + CH].view(-1), flag)
+            self._sample[:self._s_rows] = (self._p32[::self._s_stride][:self._s_rows] - mu).to(torch.bfloat16)
+            # max |p - mu| for the bound, plus 2^-12 max|p|: the fp32 subtraction p - mu itself rounds (2^-24 |p| per element), which moves a
+            # centred score by up to |q| sqrt(d) 2^-24 max|p| < 2^-10 |q| (2^-12 max|p|) - folded into the norm the eps formula multiplies by 2^-10
+            self._max_norm = math.sqrt(float(cmax.item())) * (1.0 + 1e-6) + raw_max * 2.0 ** -12
             qt = os.environ.get("CLDRD_QUERY_TILE", "")
             self.query_tile = int(qt) if qt in ("128", "256") else (256 if d == 768 else 128)      # 256: only the d = 768 streaming scan
             if self.query_tile == 256 and d != 768:

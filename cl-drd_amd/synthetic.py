@@ -184,3 +184,27 @@ def init_param(seed: int, name: str, shape, std: float = 0.02, perturb: bool = T
     if is_bias:
         return torch.zeros(shape, dtype=torch.float32)
     return init_tensor(seed, name, shape, std=std)
+
+
+def cls_like_corpus(rows: int, d: int, seed: int, device, chunk: int = 1 << 20):
+    """CLS-like (anisotropic) embeddings on `device`, torch's generator (timing / regime workloads, not golden data): a dominant common
+    direction u scaled by 3.6 U(0.8, 1.2) per row plus 0.045 N(0, I), tuned so that one query's scores over the corpus have std / mean
+    ~ 0.12 - what the reference model's own CLS vectors show (tests/golden/full_distilbert_cfg2.npz: q_cls . p_cls = 17 +- 2 per row).
+    Every row scores close to every other: the regime an isotropic corpus (k-th score far out in a thin tail) does not exercise.
+    Returns (P fp32 [rows, d], u [d])."""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    u = torch.randn(d, device=device, generator=gen)
+    u /= u.norm()
+    P = torch.empty(rows, d, device=device)
+    for lo in range(0, rows, chunk):
+        m = min(chunk, rows - lo)
+        a = 3.6 * (0.8 + 0.4 * torch.rand(m, 1, device=device, generator=gen))
+        P[lo:lo + m] = a * u + 0.045 * torch.randn(m, d, device=device, generator=gen)
+    return P, u
+
+
+def cls_like_queries(nq: int, u: torch.Tensor, seed: int):
+    """Queries for `cls_like_corpus`: 4.6 U(0.9, 1.1) u + 0.06 N(0, I)."""
+    gen = torch.Generator(device=u.device).manual_seed(seed)
+    return 4.6 * (0.9 + 0.2 * torch.rand(nq, 1, device=u.device, generator=gen)) * u + 0.06 * torch.randn(nq, u.shape[0], device=u.device, generator=gen)
+

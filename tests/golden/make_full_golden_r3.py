@@ -8,9 +8,9 @@ For every config the existing ``full_*.npz`` keeps all of its entries and gains
   * ``logits_autocast_fp16``: the reference's forward under ``torch.autocast("cpu", dtype=torch.float16)`` - the mixed-precision
     mode the reference actually trains in (fp16 autocast, nway_listwise_1.py:334); the bf16-autocast logits stored earlier are the
     drift of the same code at this package's operand width;
-  * (cfg1, cfg2) ``gslice/<kind>/<tower>.<parameter>``: fp32 gradients of the reference for a handful of parameters - every 1-D
-    parameter of layers 0, 2, 5 and of the embedding LayerNorm in full, the first 16 rows of the four weight matrices of layers 0 and
-    5 and of the position embeddings - so that the GPU test can check gradient DIRECTIONS (cosine), not only norms;
+  * (every config since round 4) ``gslice/<kind>/<tower>.<parameter>``: fp32 gradients of the reference for a handful of parameters -
+    every 1-D parameter of the first / middle / last layer (DistilBERT 0, 2, 5; BERT-base 0, 5, 11) and of the embedding LayerNorm in
+    full, the first 16 rows of the weight matrices of the first and last layer and of the position embeddings - so that the GPU test can check gradient DIRECTIONS (cosine), not only norms;
     ``gslice_autocast/...``: the same slices from the reference's bf16-autocast forward + backward (the yardstick).
 
 Weights and inputs come from the portable generator (cl-drd_amd/synthetic.py), so only outputs are stored.
@@ -36,14 +36,16 @@ CONFIGS["cfg1"] = ("distilbert", 4, 8, 30, 128, "teacher", ["mse"])        # mak
 SLICE_ROWS = 16
 
 
-def wanted(name: str) -> bool:
+def wanted(name: str, n_layers: int = 6) -> bool:
+    """First / middle / last layer: DistilBERT 0, 2, 5 (``transformer.layer.i.``), BERT-base 0, 5, 11 (``encoder.layer.i.``)."""
     if name.startswith("embeddings.LayerNorm") or name == "embeddings.position_embeddings.weight":
         return True
-    for i in (0, 2, 5):
-        if name.startswith(f"transformer.layer.{i}."):
-            if name.endswith(".bias") or "layer_norm" in name:
+    first, mid, last = 0, (2 if n_layers <= 6 else n_layers // 2 - 1), n_layers - 1
+    for i in (first, mid, last):
+        if name.startswith(f"transformer.layer.{i}.") or name.startswith(f"encoder.layer.{i}."):
+            if name.endswith(".bias") or "layer_norm" in name or "LayerNorm" in name:
                 return True
-            if i in (0, 5) and name.endswith(".weight"):
+            if i in (first, last) and name.endswith(".weight"):
                 return True
     return False
 
@@ -73,7 +75,8 @@ def make(name, NwayDualEncoder, ref_losses):
     d16, dbf = (l16 - logits).abs().max().item(), np.abs(old["logits_autocast_bf16"] - old["logits"]).max()
     print(f"  {name}: fp16-autocast drift max {d16:.5f} rms {(l16 - logits).pow(2).mean().sqrt().item():.5f} | bf16-autocast drift max {dbf:.5f} "
           f"| max|logit| {logits.abs().max().item():.3f} ({time.time() - t0:.0f}s)", flush=True)
-    if name in ("cfg1", "cfg2"):
+    nl = cfgd["n_layers"]
+    if True:        # round 4: every config (cfg3 and cfg4 had per-tensor norms only)
         for kind in kinds:
             leaf = logits.clone().requires_grad_(True)
             loss = MF.loss_fn(ref_losses, kind)(leaf, batch["labels"])
@@ -87,7 +90,7 @@ def make(name, NwayDualEncoder, ref_losses):
             names = []
             for tower, enc in (("query_encoder", model.query_encoder), ("passage_encoder", model.passage_encoder)):
                 for k, p in enc.named_parameters():
-                    if p.grad is None or not wanted(k):
+                    if p.grad is None or not wanted(k, nl):
                         continue
                     g = p.grad if p.grad.dim() == 1 else p.grad[:SLICE_ROWS]
                     old[f"gslice/{kind}/{tower}.{k}"] = g.numpy().astype(np.float32).copy()
@@ -104,7 +107,7 @@ def make(name, NwayDualEncoder, ref_losses):
             MF.grads_per_sample(model, batch, leaf.grad, autocast=True)
             for tower, enc in (("query_encoder", model.query_encoder), ("passage_encoder", model.passage_encoder)):
                 for k, p in enc.named_parameters():
-                    if p.grad is None or not wanted(k):
+                    if p.grad is None or not wanted(k, nl):
                         continue
                     g = p.grad if p.grad.dim() == 1 else p.grad[:SLICE_ROWS]
                     old[f"gslice_autocast/{kind}/{tower}.{k}"] = g.float().numpy().astype(np.float32).copy()

@@ -53,9 +53,11 @@ def _retrieve_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_sharded_retrieve_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_retrieve_gloo(tmp_path, world):
+    """world 8 = the cfg5 layout: rank 0's merge of 8 row-range shards equals the global search."""
     out = str(tmp_path / "ok")
-    mp.spawn(_retrieve_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_retrieve_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert open(out).read() == "ok"
 
 
@@ -65,7 +67,7 @@ def _allreduce_worker(rank, world, port, out):
     buckets = [(0, 0, 0, 640), (0, 1, 640, 1600), (0, -1, 1600, n)]
     g = torch.arange(n, dtype=torch.float32) * (rank + 1)
     TL.allreduce_buckets(g, buckets, world)
-    expect = torch.arange(n, dtype=torch.float32) * 3.0          # (1 + 2) * x: sum over ranks (the mean is folded into dlogits)
+    expect = torch.arange(n, dtype=torch.float32) * float(world * (world + 1) // 2)     # (1 + 2 + ..) * x: SUM over ranks (the mean is folded into dlogits)
     assert torch.equal(g, expect)
     # rank-sharded data: the reference's line_idx % nranks == rank rule (dataset/nway_dataset.py:305)
     mine = [i for i in range(10) if TL.owns_example(i, rank, world)]
@@ -76,9 +78,10 @@ def _allreduce_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_gradient_bucket_allreduce_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gradient_bucket_allreduce_gloo(tmp_path, world):
     out = str(tmp_path / "ok")
-    mp.spawn(_allreduce_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_allreduce_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert open(out).read() == "ok"
 
 
@@ -117,9 +120,10 @@ def _steps_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_equal_steps_per_epoch_gloo_world2(tmp_path):
+@pytest.mark.parametrize("world", [2, 8])
+def test_equal_steps_per_epoch_gloo(tmp_path, world):
     out = str(tmp_path / "ok")
-    mp.spawn(_steps_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_steps_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert open(out).read() == "ok"
 
 

@@ -83,6 +83,17 @@ def test_ddp_bucket_hooks_world2_on_one_gpu(tmp_path, share):
     assert open(out).read().startswith("ok")
 
 
+@pytest.mark.parametrize("world", [4, 8])
+def test_ddp_bucket_hooks_world4_and_world8_on_one_gpu(tmp_path, world):
+    """The same at the world sizes of the scaling table (round-3 review): 4 and 8 rank processes share the one GPU; bucket plan, constructor
+    broadcast, 1 / world in dlogits, MIN step count and the reduced gradient against the single-process gradient of the concatenated
+    batch (8 ranks x 2 queries).  Still gloo: what crosses xGMI is not tested here."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok")
+    mp.spawn(_worker, args=(world, _free_port(), out, False), nprocs=world, join=True)
+    assert open(out).read().startswith("ok")
+
+
 def _rccl_worker(rank, port, out):
     """ONE rank over the real backend: `init_process_group("nccl")` is RCCL on ROCm.  With CLDRD_FORCE_DDP=1 the trainer takes its
     data-parallel path although world_size is 1, so everything that path does with ProcessGroupNCCL runs on the GPU for real: the

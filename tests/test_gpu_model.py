@@ -375,6 +375,15 @@ def test_full_size_configs_match_reference_goldens(name):
             bar2, bar1 = (0.999, 0.994) if gs32 else (0.997, 0.985)
             for c, c_amp, n, dim in rows:
                 assert c >= (bar2 if dim == 2 else bar1), f"{name}/{loss_kind}: gradient of {n}: cosine {c:.5f} (reference autocast {c_amp:.5f})"
+                # Round 4 (tools/grad_cos_report.py, profiles/r04_grad_cosines.txt): EVERY sum-type tensor - not only the q / k / v and FFN1
+                # biases - sits at 0.9955 - 0.9993: the biases in front of a LayerNorm and the LayerNorm betas read the fp32 stream, but the stream
+                # itself is fed by bf16 branch outputs (one rounding per data-gradient GEMM output), and a column sum over 32 768 tokens that
+                # nearly cancels keeps sqrt(T) of those roundings.  Taking the last sum from fp32 values (attention backward / GELU-gradient
+                # epilogue) would remove one of ~6 roundings per layer.  What the survey's 0.999 needs for sum-type tensors is 11-bit operands
+                # in the whole backward, i.e. the reference's own mode (fp16 autocast + loss scaling: 0.9999): DESIGN.md section 8.  Until
+                # then the bar that means something is the reference's OWN 16-bit-operand backward on the same tensor: never worse than it.
+                if gs32 and dim == 1:
+                    assert c >= c_amp - 5e-4, f"{name}/{loss_kind}: gradient of {n}: cosine {c:.5f} below the reference's bf16-autocast backward {c_amp:.5f}"
         del tr
 
 
@@ -516,6 +525,43 @@ def T_optimizer_groups(model):
     for g_, wd in zip(optimizer_param_groups(model), (0.01, 0.0)):
         out.append({"params": [params[e[0]] for e in g_ if e[1] is not None], "weight_decay": wd})
     return out
+
+
+def test_failed_graph_capture_falls_back_to_a_working_eager_step(monkeypatch):
+    """A capture that raises half-way (here: the optimizer launches, after both streams have been forked inside the capture) must leave a
+    trainer that keeps training eagerly: the capture is ended with its streams joined (otherwise the stream stays in capture mode and the
+    next launch fails), the device seed pointers are dropped, the transposed weight shadows - "refreshed" inside the capture without a
+    kernel having run - are refreshed for real, and the steps that follow equal those of a trainer that never tried a graph."""
+    cfg = small_cfg()
+    batch = syn.nway_batch(4680, 3, 4, 8, 16, vocab=cfg.vocab_size, ragged=True, label_kind="teacher")
+    batch = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in batch.items()}
+
+    def run(break_capture):
+        monkeypatch.setenv("CLDRD_GRAPH", "1" if break_capture else "0")
+        model = selftest.build_tiny_model(cfg).cuda().train()
+        tr = NwayTrainer(model, loss="kl_div", learning_rate=1e-3, warmup_steps=0, total_steps=20)
+        if break_capture:
+            real = tr._optimizer_launches
+
+            def boom(lr, step):
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("injected failure inside the capture")
+                return real(lr, step)
+            tr._optimizer_launches = boom
+        outs = []
+        for _ in range(6):
+            outs.append(tr.train_step(batch).clone())
+        torch.cuda.synchronize()
+        return tr, torch.stack(outs), tr.flat_p.clone()
+
+    with pytest.warns(UserWarning, match="injected failure inside the capture"):
+        tr_b, loss_b, p_b = run(True)
+    assert getattr(tr_b, "_graph_broken", False) and tr_b._state is None
+    assert not torch.cuda.is_current_stream_capturing()
+    tr_e, loss_e, p_e = run(False)
+    # dropout is off in small_cfg: the two runs are the same arithmetic (embedding-table atomics aside)
+    assert torch.allclose(loss_b, loss_e, rtol=1e-4, atol=1e-6), (loss_b, loss_e)
+    assert (p_b - p_e).abs().max().item() <= 1e-5 * p_e.abs().max().item()
 
 
 def test_graph_replay_of_the_training_step_equals_the_eager_step(monkeypatch):

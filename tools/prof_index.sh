@@ -1,6 +1,6 @@
 # rocprofv3 --kernel-trace --stats of the index (encode) leg of bench.py: forward of 512 passages x 128 tokens, 12 batches.
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_idx -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-retrieve --no-kernel-events --steps 1 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/prof_idx.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_idx -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-retrieve --no-kernel-events --no-ddp1 --no-ragged --no-pmc --steps 1 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/prof_idx.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob
