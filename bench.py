@@ -21,8 +21,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("CLDRD_FORCE_DDP", "0") == "1":
-    # before HIP initialises, ranks of a multi-process job only: see cl-drd_amd/__init__.py (two towers on two streams next to RCCL's)
+if (int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("CLDRD_FORCE_DDP", "0") == "1") and \
+        (os.environ.get("CLDRD_GRAPH", "1") == "0" or os.environ.get("CLDRD_DDP_GRAPH", "1") == "0"):
+    # before HIP initialises, EAGER ranks of a multi-process job only: see cl-drd_amd/__init__.py (two towers on two streams next to RCCL's;
+    # ranks that replay the step as a HIP graph - the default - are faster with the default four queues)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
@@ -578,7 +580,8 @@ def ddp1_child(args):
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"samples_per_s": round(args.batch * args.steps / dt, 2), "ms_per_step": round(1e3 * dt / args.steps, 3), "steps": args.steps,
-                      "backend": dist.get_backend(), "world_size": 1, "ddp_path": bool(trainer.distributed), "buckets": len(trainer.buckets), "step_launch": "eager",
+                      "backend": dist.get_backend(), "world_size": 1, "ddp_path": bool(trainer.distributed), "buckets": len(trainer.buckets),
+                      "step_launch": "hip graph replay (RCCL collectives captured)" if any(e["graph"] is not None for e in getattr(trainer, "_graphs", {}).values()) else "eager",
                       "final_loss": float(loss_out[0].item())}), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -12,13 +12,15 @@ the import shim).
 import os as _os
 
 # HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The trainer runs two towers on two streams; once an
-# RCCL communicator exists in the process (its own streams) the two collide on one hardware queue and the query tower no longer runs NEXT
-# to the passage tower: 13.4 instead of 12.1 ms per cfg2 step, measured with ProcessGroupNCCL initialised on one rank
-# (profiles/r03_microbench.txt).  Eight queues restore it.  Only for ranks of a multi-process job, though: the replayed HIP graph of the
-# single-process step is SLOWER with eight queues (14.7 against 11.9 ms: its branches spread over more queues and pay for the cross-queue
-# dependencies), and data-parallel ranks never replay a graph.  Read by the HIP runtime when it initialises, so this works only before the
-# first GPU call of the process - importing the package first is enough; an explicit setting wins.
-if int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1 or _os.environ.get("CLDRD_FORCE_DDP", "0") == "1":
+# RCCL communicator exists in the process (its own streams) the two collide on one hardware queue and an EAGER step loses the overlap of the
+# towers: 13.2 instead of 12.6 ms per cfg2 step with ProcessGroupNCCL initialised on one rank; eight queues restore it.  A REPLAYED HIP graph
+# is the other way round: 12.3 ms with the default four queues, 15.1 ms with eight (its branches spread over more queues and pay for the
+# cross-queue dependencies) - and since round 4 data-parallel ranks replay the step as a graph too, RCCL collectives captured inside
+# (profiles/r04_microbench.txt: tools/ddp_graph_ab.sh).  So eight queues only for ranks that will NOT replay a graph (CLDRD_GRAPH=0 or
+# CLDRD_DDP_GRAPH=0).  Read by the HIP runtime when it initialises: this works only before the first GPU call of the process - importing
+# the package first is enough; an explicit setting wins.
+if (int(_os.environ.get("WORLD_SIZE", "1") or 1) > 1 or _os.environ.get("CLDRD_FORCE_DDP", "0") == "1") and \
+        (_os.environ.get("CLDRD_GRAPH", "1") == "0" or _os.environ.get("CLDRD_DDP_GRAPH", "1") == "0"):
     _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 __version__ = "0.1.0"

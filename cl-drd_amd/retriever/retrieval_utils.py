@@ -171,7 +171,10 @@ class FlatIPIndex:
             # model: q . p = 17 +- 2 over a corpus): on the CLS-like shard of the tests eps goes from 0.042 to 0.007 and the 2 eps band under the
             # k-th score from ~1 250 rows to ~200, i.e. the re-score gathers about half the rows and the scan emits half the hits; on an isotropic
             # corpus mu ~ 0 and nothing changes.  Exact scores still come from the untouched fp32 rows (re-score), so D / I are what they were.
-            self._s_stride = max(1, n // SAMPLE_ROWS)
+            # sample size: SAMPLE_ROWS, or 1 / 64 of the rows on a larger index (the whole 8.84 M-row collection on one GPU: with 16 384 rows
+            # the expected number of sample rows inside the top 1000 is 1.9, the estimate is the 9th largest sample score and the candidate
+            # lists come out at ~6 300 +- 2 000 of their 8 192 slots: overflowing queries, one or two extra passes; with 138 k rows ~2 300)
+            self._s_stride = max(1, n // min(max(SAMPLE_ROWS, n // 64), 1 << 18))
             self._s_rows = min(n, (n + self._s_stride - 1) // self._s_stride)
             # the GEMM wants a column count that is a multiple of 8: zero rows pad the sample (never read by the select)
             self._sample = torch.zeros((self._s_rows + 7) // 8 * 8, d, dtype=torch.bfloat16, device=device)

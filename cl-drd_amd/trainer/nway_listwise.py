@@ -393,7 +393,13 @@ class NwayTrainer:
     _state = None
 
     def _graph_wanted(self):
-        return (not self.distributed and not self.model.share_weights and not getattr(self, "_graph_broken", False)
+        if self.distributed:
+            # data-parallel ranks: the bucket all-reduces are issued from hooks INSIDE the step.  Over ProcessGroupNCCL (= RCCL) they can be
+            # captured with it (the collective's launch is recorded on its stream, Work.wait() becomes an event edge of the graph); gloo
+            # (tests) copies through the host and cannot.  CLDRD_DDP_GRAPH=0: eager ranks.
+            if _env_flag("CLDRD_DDP_GRAPH", "1") == "0" or dist.get_backend() != "nccl":
+                return False
+        return (not self.model.share_weights and not getattr(self, "_graph_broken", False)
                 and _env_flag("CLDRD_GRAPH", "1") != "0" and self.flat_p.is_cuda)
 
     @staticmethod
