@@ -32,8 +32,10 @@ SIGNATURES = {
     "cldrd_attention_bits_words": (C.c_longlong, [ci, ci, ci, cf]),
     "cldrd_attention_fwd_bits": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp, vp]),
     "cldrd_attention_bwd_bits": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp, vp]),
+    "cldrd_attention_bwd_x": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp, ci, vp]),
     "cldrd_attention_cls_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp]),
     "cldrd_attention_cls_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
+    "cldrd_attention_cls_bwd_x": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
     "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_ln_partial_blocks": (ci, [ci]),
     "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, ci, vp, vp, vp]),
@@ -76,6 +78,8 @@ SIGNATURES = {
     "cldrd_add_rows_idx": (ci, [vp, vp, ci, ci, vp, ci, vp]),
     "cldrd_set_seed_base": (None, [vp]),
     "cldrd_set_optim_hyper": (None, [vp]),
+    "cldrd_set_loss_scale": (None, [vp, ci]),
+    "cldrd_loss_scale_adapt": (ci, [vp, csz, vp, csz, vp, vp]),
     "cldrd_write_step_state": (ci, [vp, cull, cull, vp, cf, cf, cf, ci, vp]),
     "cldrd_write_run_file": (C.c_longlong, [C.c_char_p, vp, vp, vp, C.c_longlong, ci, ci]),
     "cldrd_py_float_repr": (ci, [C.c_double, C.c_char_p]),

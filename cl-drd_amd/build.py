@@ -10,7 +10,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcldrd_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value"]
+# -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 adds / multiplies of the epilogues into v_pk_*_f32, which gfx950's 32-lane SIMDs
+# issue at half rate (no gain) and which cost extra beside MFMAs (cdna_hip_programming.md section 5.7): +0.2..0.5 % step, same-box A/B
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-fno-slp-vectorize"]
 
 
 def sources():

@@ -60,6 +60,19 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+template <bool F16> __device__ __forceinline__ uint32_t pack2x(float lo, float hi) {
+    if constexpr (F16) {
+        typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+        const cldrd_f32v2 f = {lo, hi};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, h2_t));      // one v_cvt_pk_f16_f32
+    } else return pack2bf(lo, hi);
+}
+// sum of the two products of a dword pair of 16-bit values (delta = rowsum(dO . O))
+template <bool F16> __device__ __forceinline__ float dot2x(uint32_t a, uint32_t b) {
+    if constexpr (F16) return h2f((bf16_t)(a & 0xFFFFu)) * h2f((bf16_t)(b & 0xFFFFu)) + h2f((bf16_t)(a >> 16)) * h2f((bf16_t)(b >> 16));
+    else return __uint_as_float(a << 16) * __uint_as_float(b << 16) + __uint_as_float(a & 0xFFFF0000u) * __uint_as_float(b & 0xFFFF0000u);
+}
+
 // dropout by keep BITS: value * (bit `pos` of w ? 1 : 0) as one v_bfe_i32 (0 / all ones) and one v_and
 __device__ __forceinline__ float keep_bit(float v, uint32_t w, int pos) {
     return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)w, pos, 1));
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
 // output is accumulated TRANSPOSED (lane = query column, registers = head dimension): no cross-lane traffic but one
 // shuffle per block, and 16 + 32 accumulator registers whatever L is (the first version kept all of S in registers:
 // 16 NKB of them, which spilled from L = 192 up and ran 2x slower at L = 256).
-template <int NKB, bool DROP>
+template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
             f32x16 S = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], S, 0, 0, 0);
+                S = mfma32<F16>(row_frag(sK, kb * 32 + r, s, h), qf[s], S);
             // S[t] = <K[key], Q[q]> with key = 32 kb + rowmap(t, h); keys rowmap(4u .. 4u+3, h) = 8u + 4h + 0..3 are consecutive
             float v[16];
             float mloc = NEG_BIG * 4.f;
@@ -453,10 +466,10 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
                 for (int t = 0; t < 16; ++t) O[dt][t] *= alpha;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pb = pack8(v + 8 * s2);
+                const bf16x8 pb = pack8x<F16>(v + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    O[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, O[dt], 0, 0, 0);
+                    O[dt] = mfma32<F16>(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, O[dt]);
             }
         }
         const float l = lsum + __shfl_xor(lsum, 32, 64);
@@ -471,8 +484,8 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
                     const float v0 = O[dt][4 * u] * inv, v1 = O[dt][4 * u + 1] * inv, v2 = O[dt][4 * u + 2] * inv, v3 = O[dt][4 * u + 3] * inv;
                     if (ctx) {
                         uint2 o;
-                        o.x = pack2bf(v0, v1);
-                        o.y = pack2bf(v2, v3);
+                        o.x = pack2x<F16>(v0, v1);
+                        o.y = pack2x<F16>(v2, v3);
                         *(uint2*)(ctx + orow + dt * 32 + 8 * u + 4 * h) = o;
                     }
                     if (ctx16) {       // fp16 copy (out-projection operand)
@@ -486,7 +499,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
     }
 }
 
-template <int NKB, bool DROP>
+template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
@@ -523,9 +536,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, oo[4] = {o.x, o.y, o.z, o.w};
             float dsum = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                dsum += __uint_as_float(vv[j] << 16) * __uint_as_float(oo[j] << 16) +
-                        __uint_as_float(vv[j] & 0xFFFF0000u) * __uint_as_float(oo[j] & 0xFFFF0000u);
+            for (int j = 0; j < 4; ++j) dsum += dot2x<F16>(vv[j], oo[j]);
             dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64);
             if (ch == 0) sDelta[row] = dsum;
         }
@@ -555,8 +566,8 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
             f32x16 S = (f32x16){0.f}, dP = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, qb * 32 + r, s, h), kf[s], S, 0, 0, 0);
-                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sdO, qb * 32 + r, s, h), vf[s], dP, 0, 0, 0);
+                S = mfma32<F16>(row_frag(sQ, qb * 32 + r, s, h), kf[s], S);
+                dP = mfma32<F16>(row_frag(sdO, qb * 32 + r, s, h), vf[s], dP);
             }
             // S[t], dP[t]: query q = 32 qb + rowmap(t, h), key = 32 kb + r
             float pd[16], ds[16];
@@ -585,11 +596,11 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pb = pack8(pd + 8 * s2), sb = pack8(ds + 8 * s2);
+                const bf16x8 pb = pack8x<F16>(pd + 8 * s2), sb = pack8x<F16>(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sdO, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, dV[dt], 0, 0, 0);
-                    dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sb, dK[dt], 0, 0, 0);
+                    dV[dt] = mfma32<F16>(tr_frag(sdO, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, dV[dt]);
+                    dK[dt] = mfma32<F16>(tr_frag(sQ, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sb, dK[dt]);
                 }
             }
         }
@@ -603,10 +614,10 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
                 for (int u = 0; u < 4; ++u) {
                     const int d0 = dt * 32 + 8 * u + 4 * h;
                     uint2 a, b;
-                    a.x = pack2bf(dK[dt][4 * u] * scale, dK[dt][4 * u + 1] * scale);
-                    a.y = pack2bf(dK[dt][4 * u + 2] * scale, dK[dt][4 * u + 3] * scale);
-                    b.x = pack2bf(dV[dt][4 * u], dV[dt][4 * u + 1]);
-                    b.y = pack2bf(dV[dt][4 * u + 2], dV[dt][4 * u + 3]);
+                    a.x = pack2x<F16>(dK[dt][4 * u] * scale, dK[dt][4 * u + 1] * scale);
+                    a.y = pack2x<F16>(dK[dt][4 * u + 2] * scale, dK[dt][4 * u + 3] * scale);
+                    b.x = pack2x<F16>(dV[dt][4 * u], dV[dt][4 * u + 1]);
+                    b.y = pack2x<F16>(dV[dt][4 * u + 2], dV[dt][4 * u + 3]);
                     *(uint2*)(ok + d0) = a;
                     *(uint2*)(ov + d0) = b;
                 }
@@ -627,8 +638,8 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
             f32x16 ST = (f32x16){0.f}, dPT = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                ST = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], ST, 0, 0, 0);
-                dPT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, kb * 32 + r, s, h), dof[s], dPT, 0, 0, 0);
+                ST = mfma32<F16>(row_frag(sK, kb * 32 + r, s, h), qf[s], ST);
+                dPT = mfma32<F16>(row_frag(sV, kb * 32 + r, s, h), dof[s], dPT);
             }
             float ds[16];
 #pragma unroll
@@ -653,12 +664,12 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 sa = pack8(ds + 8 * s2);
+                const bf16x8 sa = pack8x<F16>(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
                     // operands swapped: D[d][q], so a lane (= query) ends up with 4 consecutive head dimensions per register quad and dQ
                     // leaves in 8-byte stores (the other order gave 32 two-byte stores per lane)
-                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sa, dQ[dt], 0, 0, 0);
+                    dQ[dt] = mfma32<F16>(tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sa, dQ[dt]);
             }
         }
         if (q < L) {      // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
@@ -668,8 +679,8 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     uint2 a;
-                    a.x = pack2bf(dQ[dt][4 * u] * scale, dQ[dt][4 * u + 1] * scale);
-                    a.y = pack2bf(dQ[dt][4 * u + 2] * scale, dQ[dt][4 * u + 3] * scale);
+                    a.x = pack2x<F16>(dQ[dt][4 * u] * scale, dQ[dt][4 * u + 1] * scale);
+                    a.y = pack2x<F16>(dQ[dt][4 * u + 2] * scale, dQ[dt][4 * u + 3] * scale);
                     *(uint2*)(oq + dt * 32 + 8 * u + 4 * h) = a;
                 }
         }
@@ -687,7 +698,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 //     write them to the other LDS buffer (with delta, mask bias, LSE, dropout row keys): issue-early / write-late, the HBM latency
 //     sits under the sweep;  one __syncthreads per item.
 // The sweeps are the code of attn_bwd_kernel with the block loops rolled (the prefetch registers need the room).
-template <int NKB, bool DROP, bool BITS>
+template <int NKB, bool DROP, bool BITS, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                          const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
@@ -755,9 +766,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             const uint32_t vv[4] = {pdo[j].x, pdo[j].y, pdo[j].z, pdo[j].w}, oo[4] = {po[j].x, po[j].y, po[j].z, po[j].w};
             float dsum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                dsum += __uint_as_float(vv[e] << 16) * __uint_as_float(oo[e] << 16) +
-                        __uint_as_float(vv[e] & 0xFFFF0000u) * __uint_as_float(oo[e] & 0xFFFF0000u);
+            for (int e = 0; e < 4; ++e) dsum += dot2x<F16>(vv[e], oo[e]);
             dsum += __shfl_xor(dsum, 1, 64); dsum += __shfl_xor(dsum, 2, 64); dsum += __shfl_xor(dsum, 4, 64);
             if (ch == 0) fl[2 * Lp + row] = dsum;
         }
@@ -809,8 +818,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             if constexpr (BITS) wbits = sBits[kb * Lp + q] >> (4 * h);
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                ST = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb * 32 + r, s, h), qf[s], ST, 0, 0, 0);
-                dPT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, kb * 32 + r, s, h), dof[s], dPT, 0, 0, 0);
+                ST = mfma32<F16>(row_frag(sK, kb * 32 + r, s, h), qf[s], ST);
+                dPT = mfma32<F16>(row_frag(sV, kb * 32 + r, s, h), dof[s], dPT);
             }
             float ds[16];
 #pragma unroll
@@ -840,12 +849,12 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 sa = pack8(ds + 8 * s2);
+                const bf16x8 sa = pack8x<F16>(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
                     // operands swapped: D[d][q], so a lane (= query) ends up with 4 consecutive head dimensions per register quad and dQ
                     // leaves in 8-byte stores (the other order gave 32 two-byte stores per lane)
-                    dQ[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sa, dQ[dt], 0, 0, 0);
+                    dQ[dt] = mfma32<F16>(tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sa, dQ[dt]);
             }
         }
         if (q < L) {      // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
@@ -855,8 +864,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     uint2 a;
-                    a.x = pack2bf(dQ[dt][4 * u] * scale, dQ[dt][4 * u + 1] * scale);
-                    a.y = pack2bf(dQ[dt][4 * u + 2] * scale, dQ[dt][4 * u + 3] * scale);
+                    a.x = pack2x<F16>(dQ[dt][4 * u] * scale, dQ[dt][4 * u + 1] * scale);
+                    a.y = pack2x<F16>(dQ[dt][4 * u + 2] * scale, dQ[dt][4 * u + 3] * scale);
                     *(uint2*)(oq + dt * 32 + 8 * u + 4 * h) = a;
                 }
         }
@@ -874,8 +883,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             f32x16 S = (f32x16){0.f}, dP = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, qb * 32 + r, s, h), kf[s], S, 0, 0, 0);
-                dP = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sdO, qb * 32 + r, s, h), vf[s], dP, 0, 0, 0);
+                S = mfma32<F16>(row_frag(sQ, qb * 32 + r, s, h), kf[s], S);
+                dP = mfma32<F16>(row_frag(sdO, qb * 32 + r, s, h), vf[s], dP);
             }
             // S[t], dP[t]: query q = 32 qb + rowmap(t, h), key = 32 kb + r
             float pd[16], ds[16];
@@ -909,11 +918,11 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 pb = pack8(pd + 8 * s2), sb = pack8(ds + 8 * s2);
+                const bf16x8 pb = pack8x<F16>(pd + 8 * s2), sb = pack8x<F16>(ds + 8 * s2);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
-                    dV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sdO, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, dV[dt], 0, 0, 0);
-                    dK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQ, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sb, dK[dt], 0, 0, 0);
+                    dV[dt] = mfma32<F16>(tr_frag(sdO, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, dV[dt]);
+                    dK[dt] = mfma32<F16>(tr_frag(sQ, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sb, dK[dt]);
                 }
             }
         }
@@ -927,10 +936,10 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                 for (int u = 0; u < 4; ++u) {
                     const int d0 = dt * 32 + 8 * u + 4 * h;
                     uint2 a, b;
-                    a.x = pack2bf(dK[dt][4 * u] * scale, dK[dt][4 * u + 1] * scale);
-                    a.y = pack2bf(dK[dt][4 * u + 2] * scale, dK[dt][4 * u + 3] * scale);
-                    b.x = pack2bf(dV[dt][4 * u], dV[dt][4 * u + 1]);
-                    b.y = pack2bf(dV[dt][4 * u + 2], dV[dt][4 * u + 3]);
+                    a.x = pack2x<F16>(dK[dt][4 * u] * scale, dK[dt][4 * u + 1] * scale);
+                    a.y = pack2x<F16>(dK[dt][4 * u + 2] * scale, dK[dt][4 * u + 3] * scale);
+                    b.x = pack2x<F16>(dV[dt][4 * u], dV[dt][4 * u + 1]);
+                    b.y = pack2x<F16>(dV[dt][4 * u + 2], dV[dt][4 * u + 3]);
                     *(uint2*)(ok + d0) = a;
                     *(uint2*)(ov + d0) = b;
                 }
@@ -961,7 +970,7 @@ int launch_fwd_h(const void* qkv, const long long* mask, void* ctx, float* lse, 
                                               : launch_fwd_f16<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, st);
 }
 
-template <int NKB, bool DROP>
+template <int NKB, bool DROP, bool F16 = false>
 int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
                  unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st) {
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
@@ -970,29 +979,29 @@ int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, 
         const int nitems = nseq * H, cus = attn_num_cus();
         if (attn_fwd2_enabled(nseq, L, H)) {
             const size_t lds2 = 2 * (lds + (DROP ? 32 * NKB * NKB * sizeof(uint32_t) : 0));
-            (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            hipLaunchKernelGGL((attn_fwd2_kernel<NKB, DROP>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
+            (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            hipLaunchKernelGGL((attn_fwd2_kernel<NKB, DROP, F16>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems,
                                bits_out, (bf16_t*)ctx16);
             CLDRD_LAUNCH_CHECK();
             return 0;
         }
-        (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+        (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                            (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16);
     } else {
-        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(512), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+        (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(512), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                            (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16);
     }
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
-template <int NKB>
+template <int NKB, bool F16 = false>
 int launch_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
                unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st) {
-    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, bits_out, ctx16, st)
-                                              : launch_fwd_d<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, nullptr, ctx16, st);
+    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, bits_out, ctx16, st)
+                                              : launch_fwd_d<NKB, false, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, nullptr, ctx16, st);
 }
 int attn_num_cus() {
     static int n = 0;
@@ -1008,7 +1017,7 @@ bool attn_fwd2_enabled(int nseq, int L, int H) {
     return L <= 128 && nseq * H >= 2 * attn_num_cus() && g_cldrd_tune_attn_fwd2 != 0;
 }
 
-template <int NKB, bool DROP>
+template <int NKB, bool DROP, bool F16 = false>
 int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
                  int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st) {
     if constexpr (NKB <= 4) {
@@ -1018,13 +1027,13 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
             const size_t lds1 = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
             if (DROP && drop_bits) {
                 const size_t lds2 = 2 * (lds1 + 32 * NKB * NKB * sizeof(uint32_t));
-                (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-                hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, DROP>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, DROP, F16>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                    (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
                                    DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, drop_bits);
             } else {
-                (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
-                hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, false>), dim3(cus), dim3(512), 2 * lds1, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
+                hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, false, F16>), dim3(cus), dim3(512), 2 * lds1, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                    (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
                                    DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, (const uint32_t*)nullptr);
             }
@@ -1033,19 +1042,19 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
         }
     }
     const size_t lds = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                        (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
                        DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed));
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
-template <int NKB>
+template <int NKB, bool F16 = false>
 int launch_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
                int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st) {
     return p > 0.f && dropout_thresh16(p) > 0
-               ? launch_bwd_d<NKB, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, p, seed, drop_bits, st)
-               : launch_bwd_d<NKB, false>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, 0.f, seed, nullptr, st);
+               ? launch_bwd_d<NKB, true, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, p, seed, drop_bits, st)
+               : launch_bwd_d<NKB, false, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, 0.f, seed, nullptr, st);
 }
 
 }  // namespace
@@ -1076,9 +1085,22 @@ extern "C" int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, 
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_fwd: need 0 < L <= 256");
     CLDRD_CHECK(ctx != nullptr || ctx_f16_copy != nullptr, "attention_fwd: no output");
     CLDRD_CHECK(!(io_f16 && (ctx_f16_copy != nullptr || ctx == nullptr)), "attention_fwd: the fp16 pass writes ctx only");
+    CLDRD_CHECK(io_f16 == 0 || io_f16 == 1 || io_f16 == 5, "attention_fwd: io_f16 is 0 (bf16), 1 (fp16, L <= 128, no keep bits) or 5 (fp16, every kernel of the bf16 path)");
     const float scale = 0.125f;   // 1 / sqrt(64)
     const int nkb = (L + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    if (io_f16 == 5) {            // fp16 activations through the whole kernel family (round 4: the all-fp16 training mode)
+        switch (nkb) {
+            case 1: return launch_fwd<1, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
+            case 2: return launch_fwd<2, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
+            case 3: return launch_fwd<3, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
+            case 4: return launch_fwd<4, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
+            case 5: return launch_fwd<5, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
+            case 6: return launch_fwd<6, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
+            case 7: return launch_fwd<7, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
+            default: return launch_fwd<8, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
+        }
+    }
     if (io_f16) {                 // fp16 activations: the all-scores-in-registers kernel only (L <= 128)
         CLDRD_CHECK(L <= 128, "attention_fwd: the fp16 forward handles L <= 128");
         switch (nkb) {
@@ -1107,15 +1129,36 @@ extern "C" int cldrd_attention_bwd(const void* qkv, const long long* mask, const
                                    void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream) {
     return cldrd_attention_bwd_bits(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p, seed, nullptr, stream);
 }
+extern "C" int cldrd_attention_bwd_x(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
+                                     void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
+                                     int io_f16, void* stream);
 // drop_bits (optional): what cldrd_attention_fwd_bits left for the same (nseq, L, H, dropout_p, seed); null: the mask is re-hashed.
 extern "C" int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                                         void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
                                         void* stream) {
+    return cldrd_attention_bwd_x(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p, seed, drop_bits, 0, stream);
+}
+// io_f16 != 0: q / k / v, ctx, dctx and dqkv are fp16 (the all-fp16 training mode: gradients carry the loss scale)
+extern "C" int cldrd_attention_bwd_x(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
+                                     void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
+                                     int io_f16, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_bwd: need 0 < L <= 256");
     CLDRD_CHECK(lse != nullptr, "attention_bwd: lse is required");
     const float scale = 0.125f;
     const int nkb = (L + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
+    if (io_f16) {
+        switch (nkb) {
+            case 1: return launch_bwd<1, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+            case 2: return launch_bwd<2, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+            case 3: return launch_bwd<3, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+            case 4: return launch_bwd<4, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+            case 5: return launch_bwd<5, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+            case 6: return launch_bwd<6, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+            case 7: return launch_bwd<7, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+            default: return launch_bwd<8, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+        }
+    }
     switch (nkb) {
         case 1: return launch_bwd<1>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
         case 2: return launch_bwd<2>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
@@ -1220,6 +1263,7 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
     if (ctx16) ctx16[(size_t)seq * dm + hd * 64 + lane] = f2x<true>(o);       // fp16 copy of a bf16 pass (out-projection operand)
 }
 
+template <bool F16>
 __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
                                                            const float* __restrict__ probs, const bf16_t* __restrict__ dctx,
                                                            bf16_t* __restrict__ dqc, bf16_t* __restrict__ dkv, int L, int H,
@@ -1228,8 +1272,8 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
     __shared__ float sds[256], spd[256], sdo[64];
     const int seq = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x;
     const int dm = H * 64;
-    sdo[lane] = bf2f(dctx[(size_t)seq * dm + hd * 64 + lane]);
-    const float qd = bf2f(qc[(size_t)seq * dm + hd * 64 + lane]);
+    sdo[lane] = x2f<F16>(dctx[(size_t)seq * dm + hd * 64 + lane]);
+    const float qd = x2f<F16>(qc[(size_t)seq * dm + hd * 64 + lane]);
     __syncthreads();
     const bf16_t* kb = kv + (size_t)seq * L * 2 * dm + hd * 64;
     const bf16_t* vb = kb + dm;
@@ -1248,7 +1292,7 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
                 const uint32_t w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    a += __uint_as_float(w[j] << 16) * sdo[c * 8 + 2 * j] + __uint_as_float(w[j] & 0xFFFF0000u) * sdo[c * 8 + 2 * j + 1];
+                    a += x2f<F16>((bf16_t)(w[j] & 0xFFFFu)) * sdo[c * 8 + 2 * j] + x2f<F16>((bf16_t)(w[j] >> 16)) * sdo[c * 8 + 2 * j + 1];
             }
             float pdv = p[i];
             if (drop_thresh) {
@@ -1288,10 +1332,10 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
             uint32_t ok[4], ov[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                dq8[2 * j] += ds * __uint_as_float(w[j] << 16);
-                dq8[2 * j + 1] += ds * __uint_as_float(w[j] & 0xFFFF0000u);
-                ok[j] = (uint32_t)f2bf(ds * q8[2 * j]) | ((uint32_t)f2bf(ds * q8[2 * j + 1]) << 16);
-                ov[j] = (uint32_t)f2bf(pd * do8[2 * j]) | ((uint32_t)f2bf(pd * do8[2 * j + 1]) << 16);
+                dq8[2 * j] += ds * x2f<F16>((bf16_t)(w[j] & 0xFFFFu));
+                dq8[2 * j + 1] += ds * x2f<F16>((bf16_t)(w[j] >> 16));
+                ok[j] = (uint32_t)f2x<F16>(ds * q8[2 * j]) | ((uint32_t)f2x<F16>(ds * q8[2 * j + 1]) << 16);
+                ov[j] = (uint32_t)f2x<F16>(pd * do8[2 * j]) | ((uint32_t)f2x<F16>(pd * do8[2 * j + 1]) << 16);
             }
             *(uint4*)(dkb + (size_t)key * 2 * dm + c8 * 8) = make_uint4(ok[0], ok[1], ok[2], ok[3]);
             *(uint4*)(dkb + (size_t)key * 2 * dm + dm + c8 * 8) = make_uint4(ov[0], ov[1], ov[2], ov[3]);
@@ -1304,7 +1348,7 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
     float dq = 0.f;
 #pragma unroll
     for (int gg = 0; gg < 8; ++gg) dq += sdq[gg][lane];
-    dqc[(size_t)seq * dm + hd * 64 + lane] = f2bf(dq);
+    dqc[(size_t)seq * dm + hd * 64 + lane] = f2x<F16>(dq);
 }
 
 // dst[m * stride_rows] += src[m]  (bf16 rows of d elements)
@@ -1338,14 +1382,22 @@ extern "C" int cldrd_attention_cls_fwd(const void* qc, const void* kv, const lon
 }
 
 // dqc: bf16 [nseq, H*64]; dkv: bf16 [nseq*L, 2*H*64] (every row written)
-extern "C" int cldrd_attention_cls_bwd(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
-                                       int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream) {
+extern "C" int cldrd_attention_cls_bwd_x(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
+                                         int nseq, int L, int H, float dropout_p, unsigned long long seed, int io_f16, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_cls_bwd: need 0 < L <= 256");
-    hipLaunchKernelGGL(attn_cls_bwd_kernel, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv, probs,
-                       (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f,
-                       dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u, 1.0f / (1.0f - dropout_p), seed_arg(seed));
+    const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
+    if (io_f16)
+        hipLaunchKernelGGL(attn_cls_bwd_kernel<true>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv, probs,
+                           (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
+    else
+        hipLaunchKernelGGL(attn_cls_bwd_kernel<false>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv, probs,
+                           (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
     CLDRD_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int cldrd_attention_cls_bwd(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
+                                       int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream) {
+    return cldrd_attention_cls_bwd_x(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p, seed, 0, stream);
 }
 
 extern "C" int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, int f32, void* stream) {

@@ -46,6 +46,17 @@ extern "C" void cldrd_set_seed_base(const unsigned long long* base) { g_cldrd_se
 // cldrd_adamw_step* launched by this thread from now on take {lr, step size = lr sqrt(1 - beta2^t) / (1 - beta1^t)} from this device
 // float[2] instead of their by-value arguments; null: off.
 extern "C" void cldrd_set_optim_hyper(const float* hyper) { g_cldrd_optim_hyper = hyper; }
+// Loss scaling of the all-fp16 training mode (reference: torch.cuda.amp.GradScaler around nway_listwise_1.py:334-359).  scale = device
+// float[4] {S, 1 / S, finite steps since S last changed, skipped steps} (cldrd_clip_coef / cldrd_grad_clip_coef update it, optim.hip): launches made by this thread from now on that PRODUCE activation gradients from the loss multiply by S
+// (cldrd_loss_fwd_bwd*: dlogits) and launches that produce PARAMETER gradients multiply by 1 / S (cldrd_wgrad_group, cldrd_ln_reduce_group,
+// cldrd_layernorm_bwd's own reduction, cldrd_embed_ln_bwd) - so every 16-bit gradient tensor in between carries the scale and flat_g never
+// does.  Read on the device at run time (a replayed graph sees the current value).  null: off.
+thread_local const float* g_cldrd_loss_scale = nullptr;
+thread_local int g_cldrd_loss_scale_interval = 2000;
+extern "C" void cldrd_set_loss_scale(const float* scale, int growth_interval) {
+    g_cldrd_loss_scale = scale;
+    g_cldrd_loss_scale_interval = growth_interval > 0 ? growth_interval : 2000;
+}
 
 namespace {
 __global__ void step_state_kernel(unsigned long long* seeds, unsigned long long s0, unsigned long long s1, float* hyper, float lr, float step_size) {

@@ -36,6 +36,7 @@ struct GemmNtArgs {
     int stagger = 1;              // ring kernel: waves 4..7 issue their LDS-DMA one k-step after waves 0..3 (0: A/B runs)
     int asym = 1;                 // ring kernel, two whole slots: a third A slot, A requested two K tiles ahead (0: the round-2 schedule)
     int early1 = 1;               // ring kernel, two LDS slots: K tile 1 is requested together with K tile 0 at tile start (0: after tile 0 landed)
+    int tape_f16 = 0;             // with in_f16 (the all-fp16 training mode): `preact` is written and `gelu_pre` is read as fp16, not bf16
 };
 
 // compile-time epilogue flavours (each GEMM kernel is instantiated per flavour so the 16x-unrolled epilogue carries
@@ -93,9 +94,19 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
     o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
     return o;
 }
+// two floats -> one dword of fp16 (RNE): ONE v_cvt_pk_f16_f32 on gfx950 (two scalar converts + an or otherwise: 3 VALU per pair)
+typedef _Float16 cldrd_f16v2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack2half(float lo, float hi) {
-    const _Float16 a = (_Float16)lo, b = (_Float16)hi;
-    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+    const cldrd_f32v2 f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, cldrd_f16v2));
+}
+__device__ __forceinline__ void unpack8h(const uint4& u, float (&f)[8]) {
+    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[2 * j] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[j] & 0xFFFFu));
+        f[2 * j + 1] = (float)__builtin_bit_cast(_Float16, (uint16_t)(w[j] >> 16));
+    }
 }
 __device__ __forceinline__ uint4 pack8h(const float (&v)[8]) {
     uint4 o;
@@ -109,8 +120,10 @@ __device__ __forceinline__ uint4 pack8h(const float (&v)[8]) {
 template <int EPI>
 __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFlags<EPI>& fl, float (&v)[8], int m, int n,
                                                const float (&bias8)[8], const uint4& res, const uint4& res_hi, const uint4& gp) {
+    if (p.alpha != 1.0f) {          // scalar test: every encoder GEMM has alpha = 1 (one VALU per element saved in VALU-bound epilogues)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+        for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
+    }
     if (fl.bias) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bias8[j];
@@ -128,16 +141,16 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
             dv[j] = fmaf(v[j] * 0.39894228040143268f, e, c);
             v[j] *= c;
         }
-        st16_stream(p.preact + crow, pack8(dv));
+        { if (p.tape_f16) st16_stream(p.preact + crow, pack8h(dv)); else st16_stream(p.preact + crow, pack8(dv)); }
     } else {
         if (fl.preact) {
             if (fl.dgelu) {
                 float dv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dv[j] = gelu_grad_f(v[j]);
-                st16_stream(p.preact + crow, pack8(dv));
+                { if (p.tape_f16) st16_stream(p.preact + crow, pack8h(dv)); else st16_stream(p.preact + crow, pack8(dv)); }
             } else {
-                st16_stream(p.preact + crow, pack8(v));
+                { if (p.tape_f16) st16_stream(p.preact + crow, pack8h(v)); else st16_stream(p.preact + crow, pack8(v)); }
             }
         }
         if (fl.gelu) {
@@ -147,7 +160,7 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
     }
     if (fl.gelugrad) {
         float g[8];
-        unpack8(gp, g);
+        if (p.tape_f16) unpack8h(gp, g); else unpack8(gp, g);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= fl.dgelu ? g[j] : gelu_grad_f(g[j]);
     }

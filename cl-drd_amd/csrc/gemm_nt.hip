@@ -246,7 +246,8 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
                                      const float* ln_beta, void* c_copy_bf16, float* workspace, size_t workspace_bytes, void* stream) {
-    CLDRD_CHECK(io_f16 >= 0 && io_f16 <= 3 && io_f16 != 2, "gemm_nt: io_f16 is 0 (bf16), 1 (fp16 operands and 16-bit C) or 3 (fp16 operands, bf16 C)");
+    CLDRD_CHECK(io_f16 == 0 || io_f16 == 1 || io_f16 == 3 || io_f16 == 5,
+                "gemm_nt: io_f16 is 0 (bf16), 1 (fp16 operands and 16-bit C), 3 (fp16 operands, bf16 C) or 5 (1 + fp16 preact / gelu_pre: the all-fp16 training mode)");
     CLDRD_CHECK(c_copy_bf16 == nullptr || (io_f16 == 1 && !out_f32 && (uintptr_t)c_copy_bf16 % 16 == 0),
                 "gemm_nt: the bf16 copy of C goes with fp16 operands and an fp16 C");
     {
@@ -276,8 +277,9 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
     a.thr = nullptr; a.counts = nullptr; a.cand_rows = nullptr; a.cand_scores = nullptr; a.cap = 0;
     a.in_f16 = io_f16 ? 1 : 0;
     a.c_bf16 = (io_f16 & 2) ? 1 : 0;
+    a.tape_f16 = (io_f16 & 4) ? 1 : 0;
     a.c_copy = (bf16_t*)c_copy_bf16;
-    if (workspace != nullptr && K % BK == 0 && N % 8 == 0 && !(io_f16 && gelu_pre)) {
+    if (workspace != nullptr && K % BK == 0 && N % 8 == 0 && !(io_f16 && gelu_pre && !(io_f16 & 4))) {
         const int ks = splitk_choice(M, N, K);
         if (ks > 1 && workspace_bytes >= (size_t)ks * M * N * sizeof(float) && (uintptr_t)workspace % 16 == 0) {
             a.ksplit = ks;
@@ -304,7 +306,7 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
     if (io_f16) {
         // fp16 operands / 16-bit output (the high-precision forward of the query tower): small-M kernel, forward flavours only
         CLDRD_CHECK(K % BK == 0, "gemm_nt: K must be a multiple of 64");
-        CLDRD_CHECK(gelu_pre == nullptr, "gemm_nt: the fp16 format has no gelu_pre epilogue (forward flavours only)");
+        CLDRD_CHECK(gelu_pre == nullptr || (io_f16 & 4), "gemm_nt: gelu_pre with fp16 operands needs the fp16 tape format (io_f16 = 5)");
         {
             const int rc = cldrd_gemm_nt_ring_dispatch(a, 0, (hipStream_t)stream);      // large-M FFN forward flavours (gemm_nt_ring16.hip)
             if (rc >= 0) return rc;
@@ -322,6 +324,11 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
                 return launch_nt<EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN>(a, (hipStream_t)stream);
             case EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN:
                 return launch_nt<EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN>(a, (hipStream_t)stream);
+            // round 4, the all-fp16 training mode: backward flavours of the small-M kernel (CLS-only last layer, query tower)
+            case EPI_F16IN: return launch_nt<EPI_F16IN>(a, (hipStream_t)stream);
+            case EPI_F16IN | EPI_GELUGRAD | EPI_DGELU: return launch_nt<EPI_F16IN | EPI_GELUGRAD | EPI_DGELU>(a, (hipStream_t)stream);
+            case EPI_F16IN | EPI_F32: return launch_nt<EPI_F16IN | EPI_F32>(a, (hipStream_t)stream);
+            case EPI_F16IN | EPI_RESIDUAL | EPI_RES32 | EPI_F32: return launch_nt<EPI_F16IN | EPI_RESIDUAL | EPI_RES32 | EPI_F32>(a, (hipStream_t)stream);
             default: return cldrd_set_error("gemm_nt: this epilogue combination is not built for the fp16 format");
         }
     }

@@ -28,6 +28,10 @@ int launch_ring16(const GemmNtArgs& a, hipStream_t st) {
             return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN>(a, st);
         case EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN:
             return launch_ring_epi<BN, EPI_F16IN | EPI_BIAS | EPI_DROPOUT | EPI_RESIDUAL | EPI_RES32 | EPI_F32 | EPI_RESLN>(a, st);
+        // round 4, the all-fp16 training mode: the backward's data-gradient GEMMs on fp16 operands (gradients carry the loss scale)
+        case EPI_F16IN: return launch_ring_epi<BN, EPI_F16IN>(a, st);
+        case EPI_F16IN | EPI_GELUGRAD | EPI_DGELU: return launch_ring_epi<BN, EPI_F16IN | EPI_GELUGRAD | EPI_DGELU>(a, st);
+        case EPI_F16IN | EPI_F32: return launch_ring_epi<BN, EPI_F16IN | EPI_F32>(a, st);
         default: return -1;                               // not built: the caller falls back to the 128 x 128 kernel (or refuses)
     }
 }

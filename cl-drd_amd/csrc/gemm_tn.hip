@@ -46,6 +46,8 @@ struct TnProblem {
 struct TnGroupArgs {
     int n, splits, accumulate, stagger;
     float* slabs;
+    const float* inv_scale;            // device scalar or null: every output (dW, dbias) is multiplied by it - the operands of the all-fp16
+                                       // training mode carry the loss scale, parameter gradients do not (capi.hip: cldrd_set_loss_scale)
     TnProblem p[MAXP];
 };
 
@@ -97,7 +99,14 @@ __device__ __forceinline__ void tn_dma16_addr(uint32_t lds_addr, const void* src
 
 // ABL != 0 (development build only, tools/tn_ablate.py; WRONG results): 1 no LDS-DMA inside the K loop, 2 no fragment reads inside the
 // K loop, 3 no barrier and no vmcnt wait inside the K loop.
-template <int T1, int T2, int NW, int ABL = 0>
+typedef _Float16 tn_f16x8 __attribute__((ext_vector_type(8)));
+template <bool F16>
+__device__ __forceinline__ f32x4 tn_mfma(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(tn_f16x8, a), __builtin_bit_cast(tn_f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+// F16: the operands are fp16 (round 4: the all-fp16 training mode), same MFMA rate, same tiles
+template <int T1, int T2, int NW, int ABL = 0, bool F16 = false>
 __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NBF = T2 == 192 ? 3 : 4;              // B fragments (16 n2 columns each) per wave
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
 #pragma unroll
         for (int j = 0; j < NBF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const short one = (short)0x3F80;     // bf16 1.0
+    const short one = F16 ? (short)0x3C00 : (short)0x3F80;     // 1.0 in the operand format
     const bf16x8 ones = (bf16x8){one, one, one, one, one, one, one, one};
 
     // waves w and w + NW/2 share a SIMD: the second half issues its LDS-DMA one k-step later, so the two do not stall the
@@ -220,8 +229,8 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
 #pragma unroll
             for (int t2 = 0; t2 < NBF; ++t2)
                 // swapped operands: D'[n2][n1] so the lane's 4 accumulators run along n2 (contiguous in dW rows)
-                acc[t1][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag8(bc[t2]), a, acc[t1][t2], 0, 0, 0);
-            if constexpr (WB) accb[t1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a, accb[t1], 0, 0, 0);
+                acc[t1][t2] = tn_mfma<F16>(frag8(bc[t2]), a, acc[t1][t2]);
+            if constexpr (WB) accb[t1] = tn_mfma<F16>(ones, a, accb[t1]);
         };
         // K tile kt+1 must have landed (with three slots K tile kt+2, issued one tile ago, may stay in flight) and every read of this K
         // tile's slot must be back before the slot is handed to the DMA: lgkmcnt(0) covers the compiler's reads, which are all issued
@@ -364,19 +373,20 @@ __global__ __launch_bounds__(64 * NW, 2) void gemm_tn_kernel(TnGroupArgs ga) {
     float* outW = direct ? P.dW : ga.slabs + P.slab_off + (size_t)split * ((size_t)N1 * N2 + (size_t)N1);
     float* outB = direct ? P.dbias : outW + (size_t)N1 * N2;
     const bool add = direct && ga.accumulate != 0;
+    const float osc = (direct && ga.inv_scale) ? *ga.inv_scale : 1.0f;      // slabs stay raw: the reduction applies the factor
 #pragma unroll
     for (int t1 = 0; t1 < FA; ++t1) {
         const int n1 = c1 + wm * (16 * FA) + t1 * 16 + (lane & 15);
 #pragma unroll
         for (int t2 = 0; t2 < NBF; ++t2) {
             const int n2 = c2 + wn * (16 * NBF) + t2 * 16 + 4 * (lane >> 4);
-            float4 v = make_float4(acc[t1][t2][0], acc[t1][t2][1], acc[t1][t2][2], acc[t1][t2][3]);
+            float4 v = make_float4(acc[t1][t2][0] * osc, acc[t1][t2][1] * osc, acc[t1][t2][2] * osc, acc[t1][t2][3] * osc);
             float4* dst = (float4*)(outW + (size_t)n1 * N2 + n2);
             if (add) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
             *dst = v;
         }
         if (do_bias && lane < 16) {       // every n2 row of D' holds the same column sums
-            float b = accb[t1][0];
+            float b = accb[t1][0] * osc;
             if (add) b += outB[n1];
             outB[n1] = b;
         }
@@ -409,12 +419,14 @@ __global__ void reduce_slabs_group_kernel(TnGroupArgs ga) {
     const size_t stride4 = ((size_t)P.N1 * P.N2 + (size_t)P.N1) / 4;
     const float4* slabs = (const float4*)(ga.slabs + P.slab_off);
     const size_t step = (size_t)gridDim.x * blockDim.x;
+    const float osc = ga.inv_scale ? *ga.inv_scale : 1.0f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all4; i += step) {
         float4 s = slabs[i];
         for (int k = 1; k < ga.splits; ++k) {
             const float4 t = slabs[i + k * stride4];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
+        s.x *= osc; s.y *= osc; s.z *= osc; s.w *= osc;
         float4* dst = i < n_main4 ? (float4*)P.dW + i : (float4*)P.dbias + (i - n_main4);
         if (ga.accumulate) {
             const float4 o = *dst;
@@ -498,16 +510,16 @@ extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
 
 static inline int wgrad_stagger() { return 1; }
 
-template <int T1, int T2, int NW, int ABL = 0>
+template <int T1, int T2, int NW, int ABL = 0, bool F16 = false>
 static int launch_tn_group(const TnGroupArgs& g, int items, hipStream_t st) {
     constexpr int slot = BK * (T1 + T2) * 2;
     constexpr int lds = (3 * slot <= 160 * 1024 ? 3 : 2) * slot;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T1, T2, NW, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel<T1, T2, NW, ABL, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_tn_kernel<T1, T2, NW, ABL>), dim3(items), dim3(64 * NW), lds, st, g);
+    hipLaunchKernelGGL((gemm_tn_kernel<T1, T2, NW, ABL, F16>), dim3(items), dim3(64 * NW), lds, st, g);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -554,7 +566,8 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
     for (int lo = 0; lo < n; lo += MAXP) {
         const int m = n - lo < MAXP ? n - lo : MAXP;
         TnGroupArgs g;
-        g.n = m; g.splits = splits; g.accumulate = accumulate; g.stagger = wgrad_stagger(); g.slabs = workspace;
+        g.n = m; g.splits = splits; g.accumulate = accumulate & 1; g.stagger = wgrad_stagger(); g.slabs = workspace;
+        g.inv_scale = g_cldrd_loss_scale ? g_cldrd_loss_scale + 1 : nullptr;
         int items = 0;
         for (int i = 0; i < m; ++i) {
             TnProblem& P = g.p[i];
@@ -582,7 +595,11 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
                                                                                       : launch_tn_group<256, 128, 8, 3>(g, items, st);
         } else
 #endif
-        if (t.t1 == 256 && t.t2 == 192) rc = launch_tn_group<256, 192, 8>(g, items, st);
+        if (accumulate & 2) {             // bit 1 of `accumulate`: fp16 operands
+            if (t.t1 == 256 && t.t2 == 192) rc = launch_tn_group<256, 192, 8, 0, true>(g, items, st);
+            else if (t.t1 == 256) rc = launch_tn_group<256, 128, 8, 0, true>(g, items, st);
+            else rc = launch_tn_group<128, 128, 4, 0, true>(g, items, st);
+        } else if (t.t1 == 256 && t.t2 == 192) rc = launch_tn_group<256, 192, 8>(g, items, st);
         else if (t.t1 == 256) rc = launch_tn_group<256, 128, 8>(g, items, st);
         else rc = launch_tn_group<128, 128, 4>(g, items, st);
         if (rc) return rc;

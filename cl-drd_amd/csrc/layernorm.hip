@@ -30,6 +30,21 @@ __device__ __forceinline__ void load_row_bf16(const bf16_t* row, int d, int lane
         }
     }
 }
+// fp16 rows (round 4, the all-fp16 training mode: activation gradients are fp16 and carry the loss scale)
+__device__ __forceinline__ float ln_h2f(uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16); }
+__device__ __forceinline__ void load_row_f16(const bf16_t* row, int d, int lane, RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            const uint2 u = *(const uint2*)(row + c);
+            r.v[it][0] = ln_h2f(u.x & 0xFFFFu); r.v[it][1] = ln_h2f(u.x >> 16);
+            r.v[it][2] = ln_h2f(u.y & 0xFFFFu); r.v[it][3] = ln_h2f(u.y >> 16);
+        } else {
+            r.v[it][0] = r.v[it][1] = r.v[it][2] = r.v[it][3] = 0.f;
+        }
+    }
+}
 __device__ __forceinline__ void load_row_f32(const float* row, int d, int lane, RowF& r) {
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it) {
@@ -66,6 +81,12 @@ __device__ __forceinline__ void load_row_bf16_i(const bf16_t* row, int d, int la
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const int c = icol(it, j, lane); r.v[it][j] = c < d ? bf2f(row[c]) : 0.f; }
 }
+__device__ __forceinline__ void load_row_f16_i(const bf16_t* row, int d, int lane, RowF& r) {
+#pragma unroll
+    for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int c = icol(it, j, lane); r.v[it][j] = c < d ? ln_h2f(row[c]) : 0.f; }
+}
 __device__ __forceinline__ void load_row_f32_i(const float* row, int d, int lane, RowF& r) {
 #pragma unroll
     for (int it = 0; it < MAX_IT; ++it)
@@ -101,10 +122,11 @@ __device__ __forceinline__ void store_row_f16(bf16_t* row, int d, int lane, cons
     for (int it = 0; it < MAX_IT; ++it) {
         const int c = it * 256 + lane * 4;
         if (c < d) {
-            const _Float16 h0 = (_Float16)r.v[it][0], h1 = (_Float16)r.v[it][1], h2 = (_Float16)r.v[it][2], h3 = (_Float16)r.v[it][3];
+            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+            const cldrd_f32v2 f0 = {r.v[it][0], r.v[it][1]}, f1 = {r.v[it][2], r.v[it][3]};
             uint2 u;
-            u.x = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
-            u.y = (uint32_t)__builtin_bit_cast(uint16_t, h2) | ((uint32_t)__builtin_bit_cast(uint16_t, h3) << 16);
+            u.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(f0, h2_t));
+            u.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(f1, h2_t));
             *(uint2*)(row + c) = u;
         }
     }
@@ -291,7 +313,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
                                                       const float* __restrict__ gamma, void* __restrict__ dx_v,
                                                       bf16_t* __restrict__ dx2, float* __restrict__ partial, int T, int d_rt,
                                                       uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
-                                                      const bf16_t* __restrict__ dy_branch) {
+                                                      const bf16_t* __restrict__ dy_branch, int h16, const float* __restrict__ inv_scale) {
+    // h16: dy_branch and dx2 are fp16 (the all-fp16 training mode); inv_scale: the per-block parameter-gradient sums leave multiplied by it
     const uint64_t seed = seed_a.get();
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     extern __shared__ __attribute__((aligned(16))) float lsm[];
@@ -308,7 +331,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
             load_row_f32_stream((const float*)dy_v + (size_t)row * d, d, lane, g);
             if (dy_branch) {       // dy = fp32 stream + the bf16 output of the branch's data-gradient GEMM, added here instead of in its epilogue
                 RowF br;
-                load_row_bf16(dy_branch + (size_t)row * d, d, lane, br);
+                if (h16) load_row_f16(dy_branch + (size_t)row * d, d, lane, br);
+                else load_row_bf16(dy_branch + (size_t)row * d, d, lane, br);
 #pragma unroll
                 for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
@@ -357,7 +381,14 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
         }
         if (G32) store_row_f32((float*)dx_v + (size_t)row * d, d, lane, g);
         else store_row_bf16((bf16_t*)dx_v + (size_t)row * d, d, lane, g);
-        if (dx2) store_row_bf16(dx2 + (size_t)row * d, d, lane, o2);
+        if (dx2) { if (h16) store_row_f16(dx2 + (size_t)row * d, d, lane, o2); else store_row_bf16(dx2 + (size_t)row * d, d, lane, o2); }
+    }
+    if (inv_scale) {
+        const float is = *inv_scale;
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dg.v[it][j] *= is; db.v[it][j] *= is; dbias.v[it][j] *= is; }
     }
     block_partials(lsm, dg, db, dbias, d, lane, partial);
 }
@@ -373,8 +404,10 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const void* __restric
                                                             float* __restrict__ dword, float* __restrict__ dpos,
                                                             float* __restrict__ partial, int T, int L, int d_rt, int vocab,
                                                             uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int pos_uniform,
-                                                            const int* __restrict__ pos_idx, const bf16_t* __restrict__ dy_branch) {
+                                                            const int* __restrict__ pos_idx, const bf16_t* __restrict__ dy_branch, int h16,
+                                                            const float* __restrict__ inv_scale) {
     const uint64_t seed = seed_a.get();
+    const float is = inv_scale ? *inv_scale : 1.0f;       // the table and LayerNorm-parameter gradients leave without the loss scale
     const int d = DC ? DC : d_rt;      // compile-time row width: the `c < d` tests and the unused 4th column pass fold away
     extern __shared__ __attribute__((aligned(16))) float lsm[];
     const int lane = threadIdx.x & 63;
@@ -395,7 +428,8 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const void* __restric
             load_row_f32_i((const float*)dy_v + (size_t)row * d, d, lane, g);
             if (dy_branch) {       // + the bf16 output of layer 0's last data-gradient GEMM (see ln_bwd_kernel)
                 RowF br;
-                load_row_bf16_i(dy_branch + (size_t)row * d, d, lane, br);
+                if (h16) load_row_f16_i(dy_branch + (size_t)row * d, d, lane, br);
+                else load_row_bf16_i(dy_branch + (size_t)row * d, d, lane, br);
 #pragma unroll
                 for (int it = 0; it < MAX_IT; ++it)
 #pragma unroll
@@ -451,7 +485,7 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const void* __restric
             for (int j = 0; j < 4; ++j) {
                 const int c = icol(it, j, lane);
                 if (c < d) {
-                    const float v = rstd * (g.v[it][j] - s1 - xr.v[it][j] * s2);
+                    const float v = rstd * (g.v[it][j] - s1 - xr.v[it][j] * s2) * is;
                     dt.v[it][j] += v;
                     atomicAdd(dword + (size_t)id * d + c, v);          // 64 lanes x 4 B contiguous per instruction
                     if (pos_uniform) dp.v[it][j] += v;
@@ -468,6 +502,12 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const void* __restric
                 const int c = icol(it, j, lane);
                 if (c < d) atomicAdd(dpos + (size_t)l * d + c, dp.v[it][j]);
             }
+    }
+    if (inv_scale) {      // dt (and the table atomics above) already carry 1 / S
+#pragma unroll
+        for (int it = 0; it < MAX_IT; ++it)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dg.v[it][j] *= is; db.v[it][j] *= is; }
     }
     block_partials<true>(lsm, dg, db, dt, d, lane, partial);
 }
@@ -619,6 +659,9 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
                                    int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, const void* dy_branch, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_bwd: need 0 < d <= 1024, d % 4 == 0");
     CLDRD_CHECK(dy_branch == nullptr || (x_f32 & 2), "layernorm_bwd: dy_branch goes with the fp32 gradient stream (x_f32 bit 1)");
+    // x_f32 bit 2 (round 4): dx_dropped and dy_branch are fp16, not bf16 (the all-fp16 training mode)
+    const int h16 = (x_f32 & 4) ? 1 : 0;
+    const float* inv_scale = g_cldrd_loss_scale ? g_cldrd_loss_scale + 1 : nullptr;
     // x_f32: bit 0 = x holds fp32 pre-LN sums; bit 1 = dy and dx are fp32 rows (fp32 gradient stream; dx_dropped stays bf16 and is required:
     // it is the MFMA operand of the next data-gradient GEMM)
     const bool g_f32 = (x_f32 & 2) != 0;
@@ -633,11 +676,11 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
         hipStream_t st = (hipStream_t)stream;
         bf16_t* d2 = (bf16_t*)dx_dropped;
         if (g_f32)          // fp32 gradient stream: only with the fp32 pre-LN sums of the fp32 residual stream
-            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true, true>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)dy_branch);
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true, true>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)dy_branch, h16, inv_scale);
         else if (x_f32 & 1)
-            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)nullptr);
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)nullptr, 0, inv_scale);
         else
-            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, false>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)nullptr);
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, false>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)nullptr, 0, inv_scale);
     });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dbias, accumulate, (hipStream_t)stream);
@@ -669,7 +712,7 @@ extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const fl
                                   float dropout_p, unsigned long long seed, int accumulate, const int* pos_idx, int dy_f32, const void* dy_branch,
                                   void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_bwd: bad shape");
-    CLDRD_CHECK(dy_branch == nullptr || dy_f32, "embed_ln_bwd: dy_branch goes with an fp32 dy");
+    CLDRD_CHECK(dy_branch == nullptr || dy_f32, "embed_ln_bwd: dy_branch goes with an fp32 dy");      // dy_f32 bit 2: dy_branch is fp16
     int nb = ln_bwd_blocks(T);                      // the caller sized `partial` for this many blocks; fewer is fine
     int g4 = 4, r = L;                              // gcd(4, L)
     while (r) { const int t = g4 % r; g4 = r; r = t; }
@@ -682,11 +725,13 @@ extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const fl
         if (dy_f32)
             hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value, true>), dim3(nb), dim3(256), lds,
                                (hipStream_t)stream, dy, (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial,
-                               T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx, (const bf16_t*)dy_branch);
+                               T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx, (const bf16_t*)dy_branch,
+                               (dy_f32 & 4) ? 1 : 0, g_cldrd_loss_scale ? g_cldrd_loss_scale + 1 : nullptr);
         else
             hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value>), dim3(nb), dim3(256), lds,
                                (hipStream_t)stream, dy, (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial,
-                               T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx, (const bf16_t*)nullptr);
+                               T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx, (const bf16_t*)nullptr, 0,
+                               g_cldrd_loss_scale ? g_cldrd_loss_scale + 1 : nullptr);
     });
     CLDRD_LAUNCH_CHECK();
     return launch_reduce(partial, nb, d, dgamma, dbeta, dtype0, accumulate, (hipStream_t)stream);

@@ -26,7 +26,13 @@ __global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __rest
 }
 
 // out[0] = total L2 norm, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)), out[2] = 1 if the norm is not finite
-__global__ void clip_coef_kernel(const float* __restrict__ partial, int nblk, float max_norm, float* __restrict__ out) {
+// scale_state (optional, device float[8] = {S, 1 / S, good steps since the headroom last changed, skipped steps, headroom exponent h <= 0, ...}):
+// the loss scale of the all-fp16 training mode (cldrd_loss_scale_adapt below sets S every step from the gradient that enters the towers).
+// HERE - after the backward, the last reader of S in a step, and before AdamW - only the safety net runs, the analogue of
+// torch.cuda.amp.GradScaler's skip rule (the reference's scaler, nway_listwise_1.py:355-359): a non-finite gradient norm skips the step
+// (AdamW reads out[2]) and gives the next steps 4x more headroom (h -= 2); `interval` finite steps in a row give one factor 2 back.
+__global__ void clip_coef_kernel(const float* __restrict__ partial, int nblk, float max_norm, float* __restrict__ out, float* __restrict__ scale_state,
+                                 int interval) {
     __shared__ double red[256];
     double s = 0.0;
     for (int i = threadIdx.x; i < nblk; i += blockDim.x) s += (double)partial[i];
@@ -41,8 +47,53 @@ __global__ void clip_coef_kernel(const float* __restrict__ partial, int nblk, fl
         out[0] = norm;
         const float c = max_norm / (norm + 1e-6f);
         out[1] = (max_norm > 0.f) ? (c < 1.f ? c : 1.f) : 1.f;
-        out[2] = (norm == norm && norm < 3.0e38f) ? 0.f : 1.f;
+        const bool bad = !(norm == norm && norm < 3.0e38f);
+        out[2] = bad ? 1.f : 0.f;
+        if (scale_state) {
+            float good = scale_state[2], h = scale_state[4];
+            if (bad) { h = fmaxf(h - 2.f, -24.f); good = 0.f; scale_state[3] += 1.f; }
+            else if (++good >= (float)interval) { h = fminf(h + 1.f, 0.f); good = 0.f; }
+            scale_state[2] = good; scale_state[4] = h;
+        }
     }
+}
+
+// ---- loss scale of the all-fp16 training mode ------------------------------------------------------------------------------------
+// The activation gradients of that mode are fp16 (csrc/*: every 16-bit tensor of the backward), so they must sit inside fp16's range:
+// S = 2^(12 + h - ceil(log2 max|dCLS|)) puts the largest element of the gradient that ENTERS the towers (dL/dCLS of both, fp32, from
+// cldrd_score_bwd) at 2^11..2^12 - a factor 16+ below fp16's maximum for what the layers add, 2^26 above its smallest normal number.
+// A power of two: scaling and unscaling are exact.  Where the reference's GradScaler finds its scale by overflowing and backing off over
+// many steps, this one is recomputed from the data every step; h <= 0 is the safety net's extra headroom (clip_coef_kernel).
+constexpr int SCALE_BLOCKS = 64;
+__global__ __launch_bounds__(256) void scale_amax_kernel(const float* __restrict__ a, size_t na, const float* __restrict__ b, size_t nb,
+                                                        float* __restrict__ scratch) {
+    __shared__ float red[4];
+    float m = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < na; i += stride) m = fmaxf(m, fabsf(a[i]));          // fmaxf drops NaNs: a NaN gradient is caught by the norm later
+    for (size_t i = i0; i < nb; i += stride) m = fmaxf(m, fabsf(b[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) scratch[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void scale_apply_kernel(float* __restrict__ a, size_t na, float* __restrict__ b, size_t nb,
+                                                         float* __restrict__ state, const float* __restrict__ scratch) {
+    float m = 0.f;
+    for (int i = threadIdx.x & 63; i < SCALE_BLOCKS; i += 64) m = fmaxf(m, scratch[i]);      // every wave: the same maximum
+    m = wave_max(m);
+    float S = 1.0f;
+    if (m > 0.f && m < 3.0e38f) {
+        int e;
+        (void)frexpf(m, &e);                               // m = f 2^e, 0.5 <= f < 1: ceil(log2 m) <= e
+        int k = 12 - e + (int)state[4];
+        k = k < -24 ? -24 : (k > 24 ? 24 : k);
+        S = ldexpf(1.0f, k);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { state[0] = S; state[1] = 1.0f / S; }
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < na; i += stride) a[i] *= S;
+    for (size_t i = i0; i < nb; i += stride) b[i] *= S;
 }
 
 struct AdamArgs {
@@ -183,13 +234,25 @@ static inline int stream_blocks(size_t n4) {
 
 extern "C" int cldrd_sqnorm_blocks(void) { return 2048; }
 
+// state: device float[8 + 64] = {S, 1 / S, good steps, skipped steps, headroom exponent h, -, -, -, scratch[64]} (the block
+// cldrd_set_loss_scale points at).  Sets S from max(|a|, |b|) (both fp32, either may be null / empty) and multiplies a and b by it in place.
+extern "C" int cldrd_loss_scale_adapt(float* a, size_t na, float* b, size_t nb, float* state, void* stream) {
+    CLDRD_CHECK(state != nullptr && (na == 0 || a != nullptr) && (nb == 0 || b != nullptr), "loss_scale_adapt: bad arguments");
+    hipLaunchKernelGGL(scale_amax_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, (hipStream_t)stream, (const float*)a, na, (const float*)b, nb, state + 8);
+    CLDRD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scale_apply_kernel, dim3(SCALE_BLOCKS), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, state, (const float*)(state + 8));
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
 // out: device float[3] = {norm, clip coefficient, non-finite flag}; partial: device float[cldrd_sqnorm_blocks()].
 extern "C" int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, float* partial, float* out, void* stream) {
     CLDRD_CHECK(n > 0 && n % 4 == 0 && ((uintptr_t)g % 16 == 0), "grad_clip_coef: n must be a multiple of 4, g 16-byte aligned");
     const int nb = stream_blocks(n / 4);
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, n / 4, partial);
     CLDRD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, nb, max_norm, out);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)partial, nb, max_norm, out, (float*)g_cldrd_loss_scale,
+                       g_cldrd_loss_scale_interval);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
@@ -208,7 +271,8 @@ extern "C" int cldrd_sqnorm_partial(const float* g, size_t n, float* partial, in
 
 extern "C" int cldrd_clip_coef(const float* partial, int nblk_total, float max_norm, float* out, void* stream) {
     CLDRD_CHECK(nblk_total >= 1 && partial != nullptr && out != nullptr, "clip_coef: no partial sums");
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk_total, max_norm, out);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk_total, max_norm, out, (float*)g_cldrd_loss_scale,
+                       g_cldrd_loss_scale_interval);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

@@ -279,6 +279,13 @@ class HipEncoder(nn.Module):
         # worst per-tensor cosine against the fp32 reference goes 0.9978 -> 0.9997 (weights) and 0.986 -> 0.992+ (sum-type) with an fp32
         # stream (CPU emulation of the rounding points); the reference's own fp16 autocast reaches 0.9999.
         self.grad_stream32 = self.stream32 and os.environ.get("CLDRD_GRAD_STREAM", "fp32") != "bf16"
+        # Round 4, "amp16" (default; CLDRD_AMP=bf16 restores the bf16-base backward of rounds 1-3): a TRAINING pass (a forward that keeps a tape, and its backward) runs every MFMA on fp16 operands,
+        # like the reference's own mode - fp16 autocast + GradScaler, nway_listwise_1.py:334-359.  The forward is the high-precision pass with
+        # a tape: activations, q / k / v, the context, h and gelu'(x) are fp16 and exist ONCE (the bf16-base mode keeps bf16 copies of the
+        # LayerNorm output, h and the context for the backward next to the fp16 ones: 1.5 GB written per cfg2 step); the backward's 16-bit
+        # tensors are fp16 and carry the loss scale (hip_ops.loss_scale: born in score_bwd, removed where parameter gradients are
+        # written), the gradient stream and every parameter gradient stay fp32.  Needs the fp32 residual and gradient streams.
+        self._amp_fp16 = os.environ.get("CLDRD_AMP", "fp16") != "bf16"
 
     # ------------------------------------------------------------------ parameters
     def named_flat(self):
@@ -426,8 +433,13 @@ class HipEncoder(nn.Module):
             self._t_desc64 = (torch.tensor(p64, dtype=torch.int32, device=dev), t64)
 
     @property
+    def amp16(self):
+        """the all-fp16 training mode (see __init__): needs the fp32 residual stream and the fp32 gradient stream"""
+        return self._amp_fp16 and self.stream32 and self.grad_stream32
+
+    @property
     def needs_h16(self):
-        return self.hp_forward or self.ffn_fp16
+        return self.hp_forward or self.ffn_fp16 or self.amp16
 
     def h16_buffer(self):
         """The fp16 weight shadow of a tower whose forward reads fp16 weights (the high-precision pass of the query tower; the FFN GEMMs
@@ -450,16 +462,7 @@ class HipEncoder(nn.Module):
         if self.needs_h16 and (cast16 is None or cast16):
             ops.cast_f16(self.flat_p, self.h16_buffer())
         if need_transposed and self.cfg.n_layers:
-            if self.flat_t is None:
-                self.flat_t = torch.empty(self.layout.t_total, dtype=torch.bfloat16, device=self.flat_p.device)
-            if self._t_desc is None:
-                self._build_t_desc()
-            desc, prefix, nd, tiles = self._t_desc
-            if self._t_desc64 is not None:          # flat_h is current here (cast above, or written by the optimizer step)
-                ops.transpose_bf16_batched(self.flat_h, self.flat_t, desc, self._t_desc64[0], nd, self._t_desc64[1])
-            else:
-                ops.transpose_cast_batched(self.flat_p, self.flat_t, desc, prefix, nd, tiles)
-            self._t_fresh = True
+            self._transpose_shadows()
         else:
             self._t_fresh = False
         self._shadow_version = self.flat_p._version
@@ -471,13 +474,21 @@ class HipEncoder(nn.Module):
         if not self.cfg.n_layers:
             self._t_fresh = True
             return
-        if self.flat_t is None:
-            self.flat_t = torch.empty(self.layout.t_total, dtype=torch.bfloat16, device=self.flat_p.device)
+        self._transpose_shadows()
+
+    def _transpose_shadows(self):
+        """flat_t: K-contiguous copies of the four matrices of every layer for the data-gradient GEMMs, in the backward's operand format -
+        bf16 from the bf16 shadow, or (amp16) fp16 from the fp16 shadow.  Both shadows are current when this runs."""
+        t16 = torch.float16 if self.amp16 else torch.bfloat16
+        if self.flat_t is None or self.flat_t.dtype != t16:
+            self.flat_t = torch.empty(self.layout.t_total, dtype=t16, device=self.flat_p.device)
         if self._t_desc is None:
             self._build_t_desc()
         desc, prefix, nd, tiles = self._t_desc
         if self._t_desc64 is not None:
-            ops.transpose_bf16_batched(self.flat_h, self.flat_t, desc, self._t_desc64[0], nd, self._t_desc64[1])
+            ops.transpose_bf16_batched(self.h16_buffer() if self.amp16 else self.flat_h, self.flat_t, desc, self._t_desc64[0], nd, self._t_desc64[1])
+        elif self.amp16:
+            raise RuntimeError("CLDRD_AMP=fp16 needs layer matrices whose sides are multiples of 64 (the 16-bit transpose kernel)")
         else:
             ops.transpose_cast_batched(self.flat_p, self.flat_t, desc, prefix, nd, tiles)
         self._t_fresh = True
@@ -582,7 +593,7 @@ class HipEncoder(nn.Module):
         """Whether encode() packs a batch with these host-side token counts (CLDRD_PACK=0 turns packing off; a batch with less than
         8 % padding is not worth the row moves around attention).  The trainer asks BEFORE choosing between the replayed graph and the
         eager step: only a batch that really is packed changes its row count from step to step."""
-        if (lengths is None or not has_mask or fp16 or not self.cls_only_last or self.cfg.n_layers < 1 or L <= 1
+        if (lengths is None or not has_mask or (fp16 and not self.amp16) or not self.cls_only_last or self.cfg.n_layers < 1 or L <= 1
                 or _env_flag("CLDRD_PACK", "1") == "0"):
             return False
         n_tok = int(sum(int(v) for v in (lengths.reshape(-1).tolist() if hasattr(lengths, "reshape") else lengths)))
@@ -594,6 +605,9 @@ class HipEncoder(nn.Module):
         return (self.step_seed * 0x9E3779B1) & 0x7FFFFFFFFFFF
 
     def _encode_pair(self, input_ids, attention_mask, *, train, save, seed, fp16, lengths=None):
+        if self.amp16 and save:
+            # the all-fp16 training pass: one forward (the query tower's bf16 tape pass next to its fp16 pass is gone), fp16 tape
+            return self._encode(input_ids, attention_mask, train=train, save=True, seed=seed, fp16=True, lengths=lengths)
         if fp16 and self.stream32 and self.hp_forward and input_ids.dim() == 2 and input_ids.shape[1] <= 128:
             tape = None
             if save:
@@ -675,7 +689,7 @@ class HipEncoder(nn.Module):
             else:
                 ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
             lse = torch.empty(M, H, L, **f32) if save else None
-            dbits = ops.attention_drop_bits(M, L, H, p_a, dev) if (save and dt16 == torch.bfloat16) else None      # dropout keep bits for the backward
+            dbits = ops.attention_drop_bits(M, L, H, p_a, dev) if (save and (dt16 == torch.bfloat16 or self.amp16)) else None      # dropout keep bits for the backward
             ctx_pad = None
             # OUT16: the out-projection on fp16 operands too - the attention kernel leaves its context in fp16 next to (training) or
             # instead of (evaluation) the bf16 tensor the backward's MFMAs read.  With the FFN pair already on fp16 operands this is the
@@ -684,7 +698,7 @@ class HipEncoder(nn.Module):
             ctx16 = self._buf(T, d, dev, torch.float16) if OUT16 else None
             if pk is None:
                 ctx = self._buf(T, d, dev, dt16) if (save or not OUT16) else None
-                ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16)
+                ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16, full_family=fp16 and self.amp16)
             else:
                 # packed batch: attention works on the padded [M * L, .] layout (one item = one sequence x head, keys >= len masked): move
                 # the rows there (zeros in the padding: a masked key contributes exp(-inf) * v = 0 only for finite v) and the context back
@@ -692,7 +706,7 @@ class HipEncoder(nn.Module):
                 ops.unpack_rows16(qkv_p, qkv, pk.cu, M, L)
                 ctx_pad = self._buf(TP, d, dev, dt16) if (save or not OUT16) else None
                 ctx16_pad = self._buf(TP, d, dev, torch.float16) if OUT16 else None
-                ops.attention_fwd(qkv, mask, ctx_pad, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16_pad)
+                ops.attention_fwd(qkv, mask, ctx_pad, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16_pad, full_family=fp16 and self.amp16)
                 ctx = None
                 if ctx_pad is not None:
                     ctx = self._buf(T, d, dev, dt16)
@@ -839,13 +853,15 @@ class HipEncoder(nn.Module):
         s_l, p_h, p_a, p_out = a["seed"], a["p_h"], a["p_a"], a["p_out"]
         GS = self.grad_stream32 and a["s2"].dtype == torch.float32      # fp32 gradient stream (needs the fp32 pre-LN sums on the tape)
         sdt = torch.float32 if GS else torch.bfloat16
+        bdt = a["h"].dtype                                              # the backward's 16-bit format = the tape's (fp16 in amp16)
+        buf = lambda r, c, dv, dt=None: self._buf(r, c, dv, bdt if dt is None else dt)
         if GS:
             gc = dcls.contiguous()                                      # dL/dCLS is the stream's first tensor: no rounding at all
         else:
-            gc = self._buf(M, d, dev)
+            gc = buf(M, d, dev)
             ops.scatter_cls_grad(dcls.contiguous(), gc, M, 1, M)
-        ds2 = self._buf(M, d, dev, sdt)
-        ds2m = self._buf(M, d, dev) if (p_h > 0 or GS) else None       # bf16 MFMA operand of the next data-gradient GEMM
+        ds2 = buf(M, d, dev, sdt)
+        ds2m = buf(M, d, dev) if (p_h > 0 or GS) else None       # bf16 MFMA operand of the next data-gradient GEMM
         lnq = getattr(self, "_lnq", None)
         f32 = dict(dtype=torch.float32, device=dev)
         own = (lambda: torch.empty(ops.ln_partial_elems(M, d), **f32)) if lnq is not None else (lambda: partial)
@@ -853,33 +869,33 @@ class HipEncoder(nn.Module):
                           accumulate=self._acc, defer=lnq)
         dF = ds2m if ds2m is not None else ds2
         self._wq.add(dF, a["h"], G["W2"], M)
-        dpre = self._buf(M, f, dev)
+        dpre = buf(M, f, dev)
         ops.gemm_nt(dF, self.ht(i, "f2"), dpre, M, gelu_pre=a["pre"], act=2)
         self._wq.add(dpre, a["x1"], G["W1"], M, dbias=G["bf1"])
-        dx1 = self._buf(M, d, dev, sdt)
+        dx1 = buf(M, d, dev, sdt)
         ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, M, residual=ds2)
-        ds1 = self._buf(M, d, dev, sdt)
-        ds1m = self._buf(M, d, dev) if (p_out > 0 or GS) else None
+        ds1 = buf(M, d, dev, sdt)
+        ds1m = buf(M, d, dev) if (p_out > 0 or GS) else None
         ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), M, p_out, s_l + 2,
                           accumulate=self._acc, defer=lnq)
         dA = ds1m if ds1m is not None else ds1
         self._wq.add(dA, a["ctx"], G["Wo"], M)
-        dctx = self._buf(M, d, dev)
+        dctx = buf(M, d, dev)
         ops.gemm_nt(dA, self.ht(i, "o"), dctx, M)
-        dqc = self._buf(M, d, dev)
+        dqc = buf(M, d, dev)
         pk = tape.pack
-        dkv = self._buf(M * L, 2 * d, dev)
+        dkv = buf(M * L, 2 * d, dev)
         ops.attention_cls_bwd(a["qc"], a["kv"], a["probs"], dctx, dqc, dkv, M, L, H, p_a, s_l + 1)
         if pk is not None:                                          # padded -> packed rows (T = the packed row count)
-            dkv_pad, dkv = dkv, self._buf(T, 2 * d, dev)
+            dkv_pad, dkv = dkv, buf(T, 2 * d, dev)
             ops.gather_rows(dkv_pad, pk.tok_idx, dkv, T)
             del dkv_pad
         self._wq.add(dqc, a["xc"], G["Wqkv"][:d], M, dbias=G["bqkv"][:d])
         self._wq.add(dkv, a["x_in"], G["Wqkv"][d:], T, dbias=G["bqkv"][d:])
         wt = self.ht(i, "qkv")                                      # [d, 3d] = Wqkv^T
-        g = self._buf(T, d, dev, sdt)
+        g = buf(T, d, dev, sdt)
         ops.gemm_nt(dkv, wt[:, d:], g, T)                           # through K and V: every token
-        gq = self._buf(M, d, dev, sdt)
+        gq = buf(M, d, dev, sdt)
         ops.gemm_nt(dqc, wt[:, :d], gq, M, residual=ds1)            # through Q and the residual: CLS rows only
         if pk is None:
             ops.add_rows_strided(g, gq, M, L)
@@ -910,6 +926,18 @@ class HipEncoder(nn.Module):
                                                   before_last_wgrad=before_last_wgrad)
             finally:
                 self._in_seed_ctx = False
+        if (self.amp16 and getattr(ops._TLS, "loss_scale", None) is None and tape.layers and tape.layers[-1] is not None
+                and tape.layers[-1]["h"].dtype == torch.float16):
+            # an fp16 tape outside the trainer (the autograd bridge of the reference-style loop: dL/dCLS arrives unscaled): this tower scales
+            # it by its own data-derived power of two (ops.loss_scale_adapt); parameter gradients come out unscaled
+            st = self.__dict__.get("_own_scale")
+            if st is None or st.device != self.flat_p.device:
+                st = self.__dict__["_own_scale"] = ops.new_loss_scale_state(self.flat_p.device)
+            dcls = dcls.contiguous().clone()
+            ops.loss_scale_adapt(dcls, None, st)
+            with ops.loss_scale(st.data_ptr()):
+                return self.backward_from_cls(tape, dcls, after_layer=after_layer, accumulate=accumulate, check_grads=check_grads,
+                                              before_last_wgrad=before_last_wgrad)
         self._acc = bool(accumulate)
         cfg = self.cfg
         self.ensure_grads(check_all=check_grads)
@@ -959,16 +987,18 @@ class HipEncoder(nn.Module):
                 continue
             GS = self.grad_stream32 and a["s2"].dtype == torch.float32  # fp32 gradient stream (see __init__)
             sdt = torch.float32 if GS else torch.bfloat16
+            bdt = a["h"].dtype                                          # 16-bit format of this backward = the tape's (fp16 in amp16)
+            buf = lambda r, c, dv, dt=None: self._buf(r, c, dv, bdt if dt is None else dt)
             if g is None:
-                g = self._buf(T, d, dev, sdt)
+                g = buf(T, d, dev, sdt)
                 if tape.pack is None:
                     ops.scatter_cls_grad(dcls.contiguous(), g, M, L, T)
                 else:
                     ops.scatter_cls_grad_idx(dcls.contiguous(), g, tape.pack.cls_idx, T)
             s_l, p_h, p_a, p_out = a["seed"], a["p_h"], a["p_a"], a["p_out"]
             # --- output LayerNorm + FFN ---
-            ds2 = self._buf(T, d, dev, sdt)
-            ds2m = self._buf(T, d, dev) if (p_h > 0 or GS) else None    # bf16: the MFMA operand of the FFN2 data / weight gradients
+            ds2 = buf(T, d, dev, sdt)
+            ds2m = buf(T, d, dev) if (p_h > 0 or GS) else None    # bf16: the MFMA operand of the FFN2 data / weight gradients
             lnq = self._lnq
             own = (lambda: torch.empty(ops.ln_partial_elems(T, d), **f32)) if lnq is not None else (lambda: partial)
             # fp32 stream: the gradient of a LayerNorm output is `g` (fp32: the residual path) + `gb` (bf16: the plain output of the
@@ -977,44 +1007,44 @@ class HipEncoder(nn.Module):
                               p_h, s_l + 3, accumulate=self._acc, defer=lnq, dy_branch=gb)
             dF = ds2m if ds2m is not None else ds2
             self._wq.add(dF, a["h"], G["W2"], T)
-            dpre = self._buf(T, f, dev)
+            dpre = buf(T, f, dev)
             ops.gemm_nt(dF, self.ht(i, "f2"), dpre, T, gelu_pre=a["pre"], act=2)
             self._wq.add(dpre, a["x1"], G["W1"], T, dbias=G["bf1"])
-            dx1 = self._buf(T, d, dev)
+            dx1 = buf(T, d, dev)
             if GS:
                 ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T)             # the FFN branch alone; the residual path is ds2
             else:
                 ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T, residual=ds2)
             # --- attention-output LayerNorm + attention ---
-            ds1 = self._buf(T, d, dev, sdt)
-            ds1m = self._buf(T, d, dev) if (p_out > 0 or GS) else None
+            ds1 = buf(T, d, dev, sdt)
+            ds1m = buf(T, d, dev) if (p_out > 0 or GS) else None
             ops.layernorm_bwd(ds2 if GS else dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), T,
                               p_out, s_l + 2, accumulate=self._acc, defer=lnq, dy_branch=dx1 if GS else None)
             dA = ds1m if ds1m is not None else ds1
             self._wq.add(dA, a["ctx"], G["Wo"], T)
-            dctx = self._buf(T, d, dev)
+            dctx = buf(T, d, dev)
             ops.gemm_nt(dA, self.ht(i, "o"), dctx, T)
             pk = tape.pack
             if pk is None:
-                dqkv = self._buf(T, 3 * d, dev)
+                dqkv = buf(T, 3 * d, dev)
                 ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1, drop_bits=a.get("dbits"))
             else:
                 # packed batch: the context gradient goes to the padded layout attention works on (zero rows in the padding), the
                 # q / k / v gradients come back packed
-                dctx_pad = self._buf(M * L, d, dev)
+                dctx_pad = buf(M * L, d, dev)
                 ops.unpack_rows16(dctx, dctx_pad, pk.cu, M, L)
-                dqkv_pad = self._buf(M * L, 3 * d, dev)
+                dqkv_pad = buf(M * L, 3 * d, dev)
                 ops.attention_bwd(a["qkv"], tape.mask, a["ctx_pad"], dctx_pad, a["lse"], dqkv_pad, M, L, H, p_a, s_l + 1, drop_bits=a.get("dbits"))
-                dqkv = self._buf(T, 3 * d, dev)
+                dqkv = buf(T, 3 * d, dev)
                 ops.gather_rows(dqkv_pad, pk.tok_idx, dqkv, T)
                 del dctx_pad, dqkv_pad
             self._wq.add(dqkv, a["x_in"], G["Wqkv"], T, dbias=G["bqkv"])
             if GS:
-                gb = self._buf(T, d, dev)
+                gb = buf(T, d, dev)
                 ops.gemm_nt(dqkv, self.ht(i, "qkv"), gb, T)             # the attention branch alone
                 g = ds1                                                 # the residual path
             else:
-                g = self._buf(T, d, dev)
+                g = buf(T, d, dev)
                 ops.gemm_nt(dqkv, self.ht(i, "qkv"), g, T, residual=ds1)
             tape.layers[i] = None        # this layer's activations: the deferred weight-gradient jobs keep what they still need
             layer_done(i)

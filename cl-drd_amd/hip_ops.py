@@ -78,6 +78,47 @@ class seed_base:
             _TLS.seed_base = self.prev
 
 
+class loss_scale:
+    """``with loss_scale(ptr, interval):`` launches inside apply the loss scale at device address ``ptr`` (the float[72] block of
+    ``new_loss_scale_state``; include/cldrd_hip.h: cldrd_set_loss_scale).  ``ptr`` None / 0: a no-op context."""
+
+    def __init__(self, ptr, interval=2000):
+        self.ptr, self.interval = (int(ptr) if ptr else None), int(interval)
+
+    def __enter__(self):
+        if self.ptr:
+            self.prev = getattr(_TLS, "loss_scale", None)
+            _lib.load().cldrd_set_loss_scale(self.ptr, self.interval)
+            _TLS.loss_scale = (self.ptr, self.interval)
+
+    def __exit__(self, *exc):
+        if self.ptr:
+            prev = self.prev or (None, 0)
+            _lib.load().cldrd_set_loss_scale(prev[0], prev[1])
+            _TLS.loss_scale = self.prev
+
+
+def new_loss_scale_state(device):
+    """device float[72]: {S = 1, 1 / S = 1, good steps 0, skipped 0, headroom exponent 0, ..., scratch} (include/cldrd_hip.h)"""
+    st = torch.zeros(72, dtype=F32, device=device)
+    st[0] = 1.0
+    st[1] = 1.0
+    return st
+
+
+def loss_scale_adapt(a, b, state):
+    """S from max(|a|, |b|) (fp32 tensors: dL/dCLS of the two towers), written to ``state``; a and b are multiplied by S in place."""
+    _chk(state, F32, "state", 1)
+    if state.numel() < 72:
+        raise ValueError("loss_scale_adapt: state is a float[72] from new_loss_scale_state()")
+    for t, n in ((a, "a"), (b, "b")):
+        if t is not None:
+            _chk(t, F32, n)
+            if not t.is_contiguous():
+                raise ValueError("loss_scale_adapt: contiguous tensors")
+    call("cldrd_loss_scale_adapt", _p(a), a.numel() if a is not None else 0, _p(b), b.numel() if b is not None else 0, _p(state), _stream())
+
+
 class optim_hyper:
     """``with optim_hyper(ptr):`` adamw_step launches inside read {lr, step size} from the device float[2] at ``ptr``."""
 
@@ -145,9 +186,16 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
         _chk(out, dt16, "out", 2)
     if bias is not None:
         _chk(bias, F32, "bias", 1)
+    tape16 = False
     for t, n in ((preact, "preact"), (gelu_pre, "gelu_pre")):
         if t is not None:
-            _chk(t, BF16, n, 2)
+            if t.dtype == F16:        # the all-fp16 training mode: gelu'(x) lives on the tape in fp16 too
+                if io_f16 != 1:
+                    raise TypeError(f"gemm_nt: an fp16 {n} goes with fp16 operands and an fp16 / fp32 out")
+                tape16 = True
+            _chk(t, F16 if tape16 else BF16, n, 2)
+    if tape16:
+        io_f16 = 5
     res_f32 = 0
     if residual is not None:
         res_f32 = 1 if residual.dtype == F32 else 0        # fp32: the residual stream kept in full precision
@@ -200,7 +248,8 @@ def wgrad_workspace_elems(M, N1, N2) -> int:
 
 def wgrad(dY, X, dW, M, workspace, accumulate=False, dbias=None):
     """dW[N1,N2] (+)= dY[:M]^T @ X[:M] (and dbias[N1] (+)= column sums of dY[:M]); dY, X bf16 with >= M rows; dW, dbias fp32."""
-    _chk(dY, BF16, "dY", 2), _chk(X, BF16, "X", 2), _chk(dW, F32, "dW", 2), _chk(workspace, F32, "workspace")
+    f16 = dY.dtype == F16
+    _chk(dY, F16 if f16 else BF16, "dY", 2), _chk(X, F16 if f16 else BF16, "X", 2), _chk(dW, F32, "dW", 2), _chk(workspace, F32, "workspace")
     N1, N2 = dW.shape
     if dY.shape[1] != N1 or X.shape[1] != N2 or not dW.is_contiguous():
         raise ValueError("wgrad: shape mismatch")
@@ -209,7 +258,7 @@ def wgrad(dY, X, dW, M, workspace, accumulate=False, dbias=None):
     if dbias is not None:
         _chk(dbias, F32, "dbias", 1)
     call("cldrd_wgrad_bf16", _p(dY), _p(X), _p(dW), _p(dbias), M, N1, N2, dY.stride(0), X.stride(0), _p(workspace),
-         workspace.numel() * 4, 1 if accumulate else 0, _stream())
+         workspace.numel() * 4, (1 if accumulate else 0) | (2 if f16 else 0), _stream())
     return dW
 
 
@@ -223,7 +272,10 @@ class WgradQueue:
         self.jobs = []
 
     def add(self, dY, X, dW, M, dbias=None):
-        _chk(dY, BF16, "dY", 2), _chk(X, BF16, "X", 2), _chk(dW, F32, "dW", 2)
+        f16 = dY.dtype == F16        # fp16 operands (the all-fp16 training mode); one format per queue
+        _chk(dY, F16 if f16 else BF16, "dY", 2), _chk(X, F16 if f16 else BF16, "X", 2), _chk(dW, F32, "dW", 2)
+        if self.jobs and (self.jobs[0][0].dtype == F16) != f16:
+            raise TypeError("WgradQueue: fp16 and bf16 problems cannot share a launch")
         N1, N2 = dW.shape
         if dY.shape[1] != N1 or X.shape[1] != N2 or not dW.is_contiguous() or dY.shape[0] < M or X.shape[0] < M:
             raise ValueError("wgrad: shape mismatch")
@@ -247,7 +299,8 @@ class WgradQueue:
         lda, ldb = IN(*[j[0].stride(0) for j in jobs]), IN(*[j[1].stride(0) for j in jobs])
         need = _lib.load().cldrd_wgrad_group_workspace(Ms, N1s, N2s, n)
         ws = torch.empty(need, dtype=F32, device=jobs[0][2].device) if need else None
-        call("cldrd_wgrad_group", A, B, W, Bi, Ms, N1s, N2s, lda, ldb, n, _p(ws), need * 4, 1 if accumulate else 0, _stream())
+        call("cldrd_wgrad_group", A, B, W, Bi, Ms, N1s, N2s, lda, ldb, n, _p(ws), need * 4,
+             (1 if accumulate else 0) | (2 if jobs[0][0].dtype == F16 else 0), _stream())
         # `jobs` held the operands alive until here; they were allocated on the stream this launch is on, so releasing them now
         # is ordered behind it by the caching allocator
 
@@ -258,7 +311,7 @@ def attention_drop_bits(nseq, L, H, dropout_p, device):
     return torch.empty(n, dtype=torch.int32, device=device) if n > 0 else None
 
 
-def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, ctx16=None):
+def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, ctx16=None, full_family=False):
     """``ctx16`` (fp16, bf16 pass only): the same context in fp16, for an fp16-operand out-projection; ``ctx`` may then be None."""
     io_f16 = _fmt16(qkv, "qkv")
     _chk(qkv, F16 if io_f16 else BF16, "qkv", 2)
@@ -286,20 +339,23 @@ def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_b
         _chk(drop_bits, torch.int32, "drop_bits", 1)
         if drop_bits.numel() != _lib.load().cldrd_attention_bits_words(nseq, L, H, dropout_p):
             raise ValueError("attention_fwd: drop_bits must come from attention_drop_bits() for the same shape")
+    if io_f16 and (drop_bits is not None or L > 128 or full_family):
+        io_f16 = 5                    # fp16 through the whole kernel family of the bf16 path (persistent kernel, keep bits, L > 128)
     call("cldrd_attention_fwd_bits", _p(qkv), _p(mask), _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _p(drop_bits), _p(ctx16), _stream())
     return ctx
 
 
 def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None):
+    io_f16 = _fmt16(qkv, "qkv")       # fp16 everywhere (the all-fp16 training mode) or bf16 everywhere
     for t, n in ((qkv, "qkv"), (ctx, "ctx"), (dctx, "dctx"), (dqkv, "dqkv")):
-        _chk(t, BF16, n, 2)
+        _chk(t, F16 if io_f16 else BF16, n, 2)
         if not t.is_contiguous():
             raise ValueError(f"attention_bwd: {n} must be contiguous")
     _chk(lse, F32, "lse")
     if drop_bits is not None:
         _chk(drop_bits, torch.int32, "drop_bits", 1)
-    call("cldrd_attention_bwd_bits", _p(qkv), _p(mask), _p(ctx), _p(dctx), _p(lse), _p(dqkv), nseq, L, H, dropout_p, seed,
-         _p(drop_bits), _stream())
+    call("cldrd_attention_bwd_x", _p(qkv), _p(mask), _p(ctx), _p(dctx), _p(lse), _p(dqkv), nseq, L, H, dropout_p, seed,
+         _p(drop_bits), io_f16, _stream())
     return dqkv
 
 
@@ -321,11 +377,12 @@ def attention_cls_fwd(qc, kv, mask, ctx, probs, nseq, L, H, dropout_p=0.0, seed=
 
 
 def attention_cls_bwd(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p=0.0, seed=0):
+    io_f16 = _fmt16(qc, "qc")
     for t, n in ((qc, "qc"), (kv, "kv"), (dctx, "dctx"), (dqc, "dqc"), (dkv, "dkv")):
-        _chk(t, BF16, n, 2)
+        _chk(t, F16 if io_f16 else BF16, n, 2)
         if not t.is_contiguous():
             raise ValueError(f"attention_cls_bwd: {n} must be contiguous")
-    call("cldrd_attention_cls_bwd", _p(qc), _p(kv), _p(probs), _p(dctx), _p(dqc), _p(dkv), nseq, L, H, dropout_p, seed, _stream())
+    call("cldrd_attention_cls_bwd_x", _p(qc), _p(kv), _p(probs), _p(dctx), _p(dqc), _p(dkv), nseq, L, H, dropout_p, seed, io_f16, _stream())
 
 
 def add_rows_strided(dst, src, M, stride_rows):
@@ -359,11 +416,12 @@ def embed_ln_bwd(dy, ids, word, pos, type0, gamma, mean, rstd, dword, dpos, dtyp
         _chk(pos_idx, torch.int32, "pos_idx", 1)
     if dy.dtype not in (BF16, F32):
         raise TypeError("embed_ln_bwd: dy must be bf16, or fp32 (fp32 gradient stream)")
-    if dy_branch is not None and (dy.dtype != F32 or dy_branch.dtype != BF16 or dy_branch.shape[1] != dy.shape[1] or dy_branch.shape[0] < T):
-        raise ValueError("embed_ln_bwd: dy_branch (bf16 [>= T, d]) goes with an fp32 dy")
+    if dy_branch is not None and (dy.dtype != F32 or dy_branch.dtype not in (BF16, F16) or dy_branch.shape[1] != dy.shape[1] or dy_branch.shape[0] < T):
+        raise ValueError("embed_ln_bwd: dy_branch (bf16 or fp16 [>= T, d]) goes with an fp32 dy")
     call("cldrd_embed_ln_bwd", _p(dy), _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(mean), _p(rstd), _p(dword),
          _p(dpos), _p(dtype0), _p(dgamma), _p(dbeta), _p(partial), T, L, d, word.shape[0], dropout_p, seed,
-         1 if accumulate else 0, _p(pos_idx), 1 if dy.dtype == F32 else 0, _p(dy_branch), _stream())
+         1 if accumulate else 0, _p(pos_idx), (1 if dy.dtype == F32 else 0) | (4 if (dy_branch is not None and dy_branch.dtype == F16) else 0),
+         _p(dy_branch), _stream())
 
 
 # ---- variable-length packing (csrc/pack.hip) ---------------------------------------------------------------------------------------
@@ -457,17 +515,18 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_dropped, dgamma, dbeta, dbias
     if g_f32:
         if not x_f32 or dx_dropped is None:
             raise ValueError("layernorm_bwd: an fp32 dy needs fp32 x and the bf16 operand copy dx_dropped")
-        _chk(dx, F32, "dx", 2), _chk(dx_dropped, BF16, "dx_dropped", 2)
+        h16 = dx_dropped.dtype == F16        # the all-fp16 training mode: the operand copy and the branch term are fp16
+        _chk(dx, F32, "dx", 2), _chk(dx_dropped, F16 if h16 else BF16, "dx_dropped", 2)
         if dy_branch is not None:
-            _chk(dy_branch, BF16, "dy_branch", 2)
+            _chk(dy_branch, F16 if h16 else BF16, "dy_branch", 2)
             if dy_branch.shape[1] != dy.shape[1] or dy_branch.shape[0] < T:
                 raise ValueError("layernorm_bwd: dy_branch must be [>= T, d]")
-        x_f32 |= 2
+        x_f32 |= 2 | (4 if h16 else 0)
     else:
         if dy_branch is not None:
             raise ValueError("layernorm_bwd: dy_branch goes with an fp32 dy")
         _chk(dy, BF16, "dy", 2), _chk(dx, BF16, "dx", 2)
-    _chk(x, F32 if x_f32 else BF16, "x", 2)
+    _chk(x, F32 if (x_f32 & 1) else BF16, "x", 2)
     d = x.shape[1]
     if defer is not None:
         for t, nme in ((dgamma, "dgamma"), (dbeta, "dbeta"), (dbias, "dbias")):
@@ -611,7 +670,10 @@ def transpose_cast_batched(src, dst, desc, tile_prefix, ndesc, total_tiles):
 
 
 def transpose_bf16_batched(src, dst, desc, tile_prefix, ndesc, total_tiles):
-    _chk(src, BF16, "src", 1), _chk(dst, BF16, "dst", 1)
+    """16-bit -> 16-bit transposes: bf16 or fp16 (bytes are moved, nothing is converted)."""
+    if src.dtype not in (BF16, F16) or dst.dtype != src.dtype:
+        raise TypeError("transpose_bf16_batched: 16-bit tensors of one format")
+    _chk(src, src.dtype, "src", 1), _chk(dst, src.dtype, "dst", 1)
     call("cldrd_transpose_bf16_batched", _p(src), _p(dst), _p(desc), _p(tile_prefix), ndesc, total_tiles, _stream())
 
 

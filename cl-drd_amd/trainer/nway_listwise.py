@@ -127,6 +127,13 @@ class NwayTrainer:
         # the query tower's stream, at the priority of torch's current stream (a high-priority stream changed nothing: profiles/r03_microbench.txt)
         self.q_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = []
+        # CLDRD_AMP=fp16 towers (encoder.py: amp16): the loss scale lives in device memory (hip_ops.new_loss_scale_state).  It is set every
+        # step from dL/dCLS (ops.loss_scale_adapt: a power of two that puts the largest entering gradient at 2^11..2^12); what is kept of
+        # torch.cuda.amp.GradScaler (the reference: nway_listwise_1.py:355-359) is its safety net: a non-finite gradient norm skips the step
+        # and backs the scale off, `scale_growth_interval` (GradScaler's default 2000) finite steps give a factor 2 back.
+        self.amp16 = any(getattr(t, "amp16", False) for t in model.towers())
+        self.scale_growth_interval = 2000
+        self._scale_state = ops.new_loss_scale_state(dev) if self.amp16 else None
         if self.distributed:
             # DDP constructor semantics (reference :250-255): rank 0's parameters win
             dist.broadcast(self.flat_p, src=0)
@@ -248,7 +255,14 @@ class NwayTrainer:
         if self.world > 1:
             dlogits.mul_(1.0 / self.world)      # gradient mean over ranks == DDP's all-reduce / world_size
         dq, dp = torch.empty_like(q_cls), torch.empty_like(p_cls)
+        with ops.loss_scale(self._scale_state.data_ptr() if self.amp16 else None, self.scale_growth_interval):
+            return self._backward(batch, model, qe, pe, q_cls, p_cls, q_tape, p_tape, dlogits, dq, dp, bz, nway, mode, main, side, write_once, loss_out, logits)
+
+    def _backward(self, batch, model, qe, pe, q_cls, p_cls, q_tape, p_tape, dlogits, dq, dp, bz, nway, mode, main, side, write_once, loss_out, logits):
+        """score backward (where the loss scale of the amp16 mode enters) + both towers' backward + the bucket all-reduces"""
         ops.score_bwd(dlogits, q_cls, p_cls, dq, dp, bz, nway, mode)
+        if self.amp16:
+            ops.loss_scale_adapt(dq, dp, self._scale_state)          # dq, dp leave multiplied by S; every fp16 gradient downstream carries it
         if model.share_weights:
             # one tower, two tapes: gradients accumulate; all-reduce once everything is in
             pe.backward_from_cls(p_tape, dp)
@@ -287,6 +301,12 @@ class NwayTrainer:
     def _optimizer_launches(self, lr, adam_step):
         """The device work of one optimizer step.  Under a captured step (`_state` installed) lr and the bias-corrected step size are
         read from device memory at replay time and the by-value arguments given here are ignored by the kernel."""
+        with ops.loss_scale(self._scale_state.data_ptr() if self.amp16 else None, self.scale_growth_interval):     # clip_coef updates the scale
+            self._norm_launches()
+        towers = self.model.towers()
+        self._adamw_launches(lr, adam_step, towers)
+
+    def _norm_launches(self):
         split = getattr(self, "_norm_split", None)
         if split:
             # [0, split) was summed on the second stream during the backward (`_early_norm_hook`; the main stream has joined it since)
@@ -296,7 +316,8 @@ class NwayTrainer:
             self._norm_split = None
         else:
             ops.grad_clip_coef(self.flat_g, self.max_grad_norm, self.norm_partial, self.clip)
-        towers = self.model.towers()
+
+    def _adamw_launches(self, lr, adam_step, towers):
         # one AdamW launch over the joint buffer; it also writes the bf16 shadow of every tower
         shadow = self._joint_shadow()
         # ... and the fp16 shadow of the towers whose forward reads fp16 weights (the FFN GEMMs of every tower by default, the whole

@@ -111,6 +111,10 @@ int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, 
 int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                              void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
                              void* stream);
+/* the same with a format flag: io_f16 != 0 - q / k / v, ctx, dctx and dqkv are fp16 (the all-fp16 training mode) */
+int cldrd_attention_bwd_x(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
+                             void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits, int io_f16,
+                             void* stream);
 
 /* CLS-only attention of the LAST layer (the reference pools last_hidden_state[:, 0, :], models/nway_dual_encoder.py:52,56,64):
  * qc: bf16 [nseq, H*64] = queries of token 0; kv: bf16 [nseq*L, 2*H*64] = K | V of every token; ctx/dctx/dqc: bf16 [nseq, H*64];
@@ -120,6 +124,8 @@ int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mas
                             int H, float dropout_p, unsigned long long seed, int io_f16, void* ctx_f16_copy, void* stream);
 int cldrd_attention_cls_bwd(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
                             int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
+int cldrd_attention_cls_bwd_x(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
+                            int nseq, int L, int H, float dropout_p, unsigned long long seed, int io_f16, void* stream);
 int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, int f32, void* stream);   /* f32: fp32 rows (fp32 gradient stream) */
 
 /* ---- embeddings + LayerNorm (HF Embeddings.forward, sa_layer_norm / output_layer_norm) --------------------
@@ -278,6 +284,17 @@ int cldrd_add_rows_idx(void* dst, const void* src, int M, int d, const int* idx,
  * makes in front of each replay.  NULL uninstalls; nothing installed = the by-value arguments, as before (bit-identical results). */
 void cldrd_set_seed_base(const unsigned long long* base);
 void cldrd_set_optim_hyper(const float* hyper);
+/* The all-fp16 training mode (round 4; the reference trains under fp16 autocast + torch.cuda.amp.GradScaler, trainer/multistep-curriculum/
+ * nway_listwise_1.py:334-359): every 16-bit tensor of the backward is fp16 and carries a loss scale S, parameter gradients never do.
+ * `scale` = device float[72] {S, 1 / S, finite steps since the headroom changed, skipped steps, headroom exponent h <= 0, 3 unused, 64 scratch},
+ * or null (off).  While set, launches of THIS thread read it on the device at run time: cldrd_wgrad_group, cldrd_layernorm_bwd /
+ * cldrd_embed_ln_bwd (their parameter-gradient sums and the embedding-table scatter) multiply by 1 / S; cldrd_clip_coef /
+ * cldrd_grad_clip_coef run the safety net (non-finite gradient norm: AdamW skips the step and the next steps get 4x more headroom;
+ * growth_interval finite steps in a row give a factor 2 back).  cldrd_loss_scale_adapt sets S = 2^(12 + h - ceil(log2 max(|a|, |b|)))
+ * from the gradient that enters the towers (a, b = dL/dCLS of the two towers, fp32, from cldrd_score_bwd) and multiplies both by it in
+ * place: a power of two recomputed from the data every step, where GradScaler searches by overflowing and backing off. */
+void cldrd_set_loss_scale(const float* scale, int growth_interval);
+int cldrd_loss_scale_adapt(float* a, size_t na, float* b, size_t nb, float* state, void* stream);
 /* n <= 8 small device-to-device copies in one launch (host arrays of pointers / byte counts): the inputs of a captured step. */
 int cldrd_copy_segments(const void* const* src, void* const* dst, const size_t* bytes, int n, void* stream);
 int cldrd_write_step_state(unsigned long long* seeds, unsigned long long seed0, unsigned long long seed1, float* hyper, float lr,

@@ -41,7 +41,7 @@ def stubbed(monkeypatch):
 def _cpu_shadows(enc):
     enc.flat_h = torch.zeros(enc.layout.total, dtype=torch.bfloat16)
     enc.flat_h16 = torch.zeros(enc.layout.total, dtype=torch.float16)
-    enc.flat_t = torch.zeros(enc.layout.t_total, dtype=torch.bfloat16)
+    enc.flat_t = torch.zeros(enc.layout.t_total, dtype=torch.float16 if enc.amp16 else torch.bfloat16)
     enc._t_fresh = True
     enc._shadow_version = enc.flat_p._version
 
@@ -54,13 +54,16 @@ def cfg_of(arch, layers):
 @pytest.mark.parametrize("arch,layers", [("distilbert", 3), ("bert", 2), ("distilbert", 1)])
 @pytest.mark.parametrize("ffn16,qkv16,out16", [("1", "1", "1"), ("1", "0", "1"), ("1", "auto", "0"), ("0", "0", "1")])
 @pytest.mark.parametrize("packed", [False, True])
-@pytest.mark.parametrize("gs", ["fp32", "bf16"])
-def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, ffn16, qkv16, out16, packed, gs):
+@pytest.mark.parametrize("gs,amp", [("fp32", "fp16"), ("fp32", "bf16"), ("bf16", "fp16")])
+def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, ffn16, qkv16, out16, packed, gs, amp):
+    monkeypatch.setenv("CLDRD_AMP", amp)
     monkeypatch.setenv("CLDRD_FFN_FP16", ffn16)
     monkeypatch.setenv("CLDRD_QKV_FP16", qkv16)
     monkeypatch.setenv("CLDRD_OUT_FP16", out16)
     monkeypatch.setenv("CLDRD_GRAD_STREAM", gs)
     enc = HipEncoder(cfg_of(arch, layers), seed=1)
+    assert enc.amp16 == (amp == "fp16" and gs == "fp32")        # the all-fp16 training mode needs the fp32 gradient stream
+    t16 = torch.float16 if enc.amp16 else torch.bfloat16
     M, L = 6, 24
     lens = np.array([24, 3, 10, 17, 5, 8])
     ids = torch.randint(3, 500, (M, L))
@@ -71,12 +74,13 @@ def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, f
         cls = enc.encode(ids, mask, train=False, save=False, lengths=lengths)
         assert cls.shape == (M, 128) and cls.dtype == torch.float32
         cls, tape = enc.encode(ids, mask, train=True, save=True, lengths=lengths)
-        pk = packed and not hp                       # the dual-pass (fp16 + bf16 tape) forward of the query tower is never packed
+        # the dual-pass (fp16 + bf16 tape) forward of the query tower is never packed; the all-fp16 mode has one pass for both towers
+        pk = packed and (enc.amp16 or not hp)
         assert (tape.pack is not None) == pk and tape.T == (int(lens.sum()) if pk else M * L)
-        for a in tape.layers:                       # what the backward's MFMAs read is bf16
+        for a in tape.layers:                       # what the backward's MFMAs read: one 16-bit format per mode
             for k in ("x_in", "ctx", "x1", "h", "pre"):
-                assert a[k] is not None and a[k].dtype == torch.bfloat16, (k, a[k])
-            assert (a.get("qkv") if "qkv" in a else a["kv"]).dtype == torch.bfloat16
+                assert a[k] is not None and a[k].dtype == t16, (k, a[k].dtype)
+            assert (a.get("qkv") if "qkv" in a else a["kv"]).dtype == t16
         hooks = []
         enc.backward_from_cls(tape, torch.zeros(M, 128), after_layer=hooks.append, accumulate=False)
         assert sorted(hooks) == list(range(-1, layers))        # every bucket reported once (the embedding block before the last weight-gradient group)

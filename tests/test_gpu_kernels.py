@@ -1056,8 +1056,9 @@ def test_forward_kernels_in_the_fp16_format():
     out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
     ops.gemm_nt(A.to(DEV), B.to(DEV), out32, bias=bias.to(DEV), residual=res32.to(DEV))
     close(out32, ref + res32.double(), 1e-4, 2e-4 * math.sqrt(K), "fp16 gemm + bias + fp32 residual -> fp32")
-    with pytest.raises(Exception):      # no tape in this format: the backward runs on the bf16 pass
-        ops.gemm_nt(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), preact=torch.empty_like(out), act=1)
+    # a tape in this format (round 4, the all-fp16 training mode: tests/test_gpu_amp16.py) takes fp16 `preact`; a bf16 one is refused here
+    with pytest.raises(Exception):
+        ops.gemm_nt(A.to(DEV), B.to(DEV), out, bias=bias.to(DEV), gelu_pre=torch.empty(M, N, dtype=torch.bfloat16, device=DEV), act=2)
     # attention
     for nseq, L, H in ((3, 30, 2), (2, 128, 3)):
         d, T = H * 64, nseq * L
@@ -1077,8 +1078,12 @@ def test_forward_kernels_in_the_fp16_format():
         probs = torch.empty(nseq, H, L, dtype=torch.float32, device=DEV)
         ops.attention_cls_fwd(qc.to(DEV), kv.to(DEV), mask.to(DEV), ctxc, probs, nseq, L, H)
         close(ctxc, ref_ctx.view(nseq, L, d)[:, 0], 1 / 1024, 2e-3, f"fp16 CLS attention L={L}")
-    with pytest.raises(Exception):
-        ops.attention_fwd(torch.zeros(256, 192, dtype=torch.float16, device=DEV), None, torch.zeros(256, 64, dtype=torch.float16, device=DEV), None, 1, 256, 1)
+    # L > 128 in fp16 goes through the whole kernel family of the bf16 path since round 4 (io_f16 = 5)
+    qkv = rnd(50, (2 * 256, 192)).half()
+    ref_ctx, _ = attn_ref(qkv.double(), torch.ones(2, 256, dtype=torch.int64), 2, 256, 1)
+    ctx = torch.empty(512, 64, dtype=torch.float16, device=DEV)
+    ops.attention_fwd(qkv.to(DEV), None, ctx, None, 2, 256, 1)
+    close(ctx, ref_ctx, 1 / 512, 3e-3, "fp16 attention L=256")
     # LayerNorm: fp32 sum in, fp16 + fp32 out
     T, d = 77, 768
     x = rnd(47, (T, d), 2.0)

@@ -177,7 +177,7 @@ def test_trainer_step_matches_oracle_update():
     tr.forward_backward(batch)
     torch.cuda.synchronize()
     w2 = t.w("transformer.layer.0.ffn.lin2.weight")
-    assert t._t_fresh and torch.equal(t.ht(0, "f2").float(), w2.T.contiguous().to(torch.bfloat16).float())
+    assert t._t_fresh and torch.equal(t.ht(0, "f2").float(), w2.T.contiguous().to(t.flat_t.dtype).float())      # fp16 in the all-fp16 mode
 
 
 @pytest.mark.parametrize("arch", ["distilbert", "bert"])
@@ -403,10 +403,11 @@ def test_bf16_residual_stream_option_drift(monkeypatch):
 
 
 @pytest.mark.parametrize("arch", ["distilbert", "bert"])
-def test_bf16_gradient_stream_option_still_runs_and_differs_only_by_rounding(arch):
+def test_bf16_gradient_stream_option_still_runs_and_differs_only_by_rounding(arch, monkeypatch):
     """`grad_stream32` off (CLDRD_GRAD_STREAM=bf16, the round-2 backward: stream gradient stored in bf16, residual added in the data-gradient
     GEMM's epilogue) stays available as the fast mode: same forward, gradients equal to the fp32-stream ones up to bf16 rounding (the
     switch is alive: they are not bit-identical)."""
+    monkeypatch.setenv("CLDRD_AMP", "bf16")          # both arms on the bf16-base backward (the default all-fp16 mode needs the fp32 stream)
     cfg = small_cfg(arch=arch, layers=3)
     batch = syn.nway_batch(4680, 3, 4, 10, 32, vocab=cfg.vocab_size, ragged=True)
     grads, logits = {}, {}
@@ -721,9 +722,11 @@ def test_full_last_layer_equals_the_cls_only_last_layer(arch, packed, monkeypatc
 
 @pytest.mark.parametrize("switch,kind", [("CLDRD_Q_SIDE=0", "exec"), ("CLDRD_T_DEFER=0", "exec"), ("CLDRD_NORM_SPLIT=0", "exec"),
                                          ("CLDRD_GRAD_ZERO=full", "exec"), ("CLDRD_ADAM_H16=0", "exec"),
-                                         ("CLDRD_LN_ON_THE_FLY=0", "numerics"),        # also turns the fp16-operand FFN GEMMs off
-                                         ("CLDRD_FFN_FP16=0", "numerics"), ("CLDRD_QKV_FP16=1", "numerics"), ("CLDRD_QUERY_FP16=0", "numerics"),
-                                         ("CLDRD_OUT_FP16=0", "numerics")])
+                                         ("CLDRD_AMP=bf16", "numerics"),               # the bf16-base backward of rounds 1-3 instead of the all-fp16 mode
+                                         # the operand-format switches of the bf16-base mode (a training pass of the all-fp16 mode has no use for them)
+                                         ("CLDRD_LN_ON_THE_FLY=0", "numerics-bf16"),   # also turns the fp16-operand FFN GEMMs off
+                                         ("CLDRD_FFN_FP16=0", "numerics-bf16"), ("CLDRD_QKV_FP16=1", "numerics-bf16"), ("CLDRD_QUERY_FP16=0", "numerics-bf16"),
+                                         ("CLDRD_OUT_FP16=0", "numerics-bf16")])
 def test_switches_of_the_training_step(switch, kind, monkeypatch):
     """Every A/B switch of the step keeps working: two training steps (dropout off) under the switch against the default.
     Execution switches (where / when things run) give the same logits bit for bit and the same update up to the float atomics of the
@@ -731,6 +734,9 @@ def test_switches_of_the_training_step(switch, kind, monkeypatch):
     cfg = small_cfg("bert", 3)
     batch = syn.nway_batch(4680, 3, 4, 10, 32, vocab=cfg.vocab_size, ragged=True)
     monkeypatch.setenv("CLDRD_GRAPH", "0")
+    if kind == "numerics-bf16":
+        monkeypatch.setenv("CLDRD_AMP", "bf16")
+        kind = "numerics"
     res = {}
     for on in (False, True):
         if on:

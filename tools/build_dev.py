@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "cl-drd_amd", "csrc")
 OUT = os.path.join(ROOT, "cl-drd_amd", "libcldrd_hip_dev.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-DCLDRD_DEV_BUILD"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-value", "-fno-slp-vectorize", "-DCLDRD_DEV_BUILD"]
 
 
 def main(extra):
