@@ -6,7 +6,8 @@
 
 A "step" is one full training step of BASELINE.json configs[1] on one batch of synthetic MSMARCO-shaped input
 already resident in HBM: DistilBERT-6L dual encoder (two unshared towers, random init), N=32 passages per query,
-per-GPU batch B=8, seq_len 128 (queries 30), kl_div loss, bf16 MFMA compute with fp32 master weights, dropout 0.1
+per-GPU batch B=8, seq_len 128 (queries 30), kl_div loss, 16-bit MFMA compute (fp16 operands by default, the reference's own mixed-precision
+mode; CLDRD_AMP=bf16 for bf16 operands, timed as an extra leg) with fp32 accumulate and master weights, dropout 0.1
 active, forward + loss + backward + RCCL gradient all-reduce (N>1) + clip_grad_norm + AdamW.  Rank 0 prints ONE JSON
 line: whole-job samples/s, the roofline of the dominant kernel (the NT MFMA GEMM, timed live with HIP events on the
 launch stream), index-encode passages/s, and the CPU oracle timed on the host cores (N=1 only; a reported baseline,
@@ -70,7 +71,7 @@ def pmc_traffic(kernel_substr, timeout_s=150):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
             cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", out, "-o", "r", "--", sys.executable, here,
-                   "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-index", "--no-retrieve", "--no-kernel-events", "--no-pmc", "--no-ragged", "--no-ddp1"]
+                   "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-index", "--no-retrieve", "--no-kernel-events", "--no-pmc", "--no-ragged", "--no-ddp1", "--no-bf16-leg"]
             env = dict(os.environ, TMPDIR="/tmp")
             for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
                 env.pop(k, None)
@@ -114,6 +115,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--no-retrieve", action="store_true")
     ap.add_argument("--no-ragged", action="store_true", help="skip the MSMARCO-shaped (padded / packed) extra legs")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the extra timing of the step in the bf16-operand training mode (CLDRD_AMP=bf16)")
     ap.add_argument("--no-ddp1", action="store_true", help="skip the child run of the data-parallel code path over RCCL with one rank")
     ap.add_argument("--ddp1-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--retrieve-rows", type=int, default=1105228, help="index rows per GPU (8 841 823 / 8)")
@@ -180,6 +182,7 @@ def main():
         loss_out = trainer.train_step(batch)
     sync_all()
     dt = time.perf_counter() - t0
+    amp16 = bool(trainer.amp16)
     graph_replay = bool(getattr(trainer, "_graphs", None)) and any(e["graph"] is not None for e in trainer._graphs.values())
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -266,6 +269,41 @@ def main():
     except Exception as exc:
         ragged = None if args.no_ragged else {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
+    # ---- the same step with BF16 MFMA operands in the backward and the tape (CLDRD_AMP=bf16: the round 1-3 mode; BASELINE.json words cfg2 as
+    # "bf16").  The headline runs the framework's default, fp16 operands with a loss-scaled backward - what the reference itself trains in
+    # (trainer/multistep-curriculum/nway_listwise_1.py:129,328-352: use_fp16 default True, amp.autocast + GradScaler); both formats are 16-bit
+    # operands at the same MFMA rate, fp32 accumulate / residual stream / gradient stream / master weights.  One GPU only.
+    bf16_mode = None
+    if rank == 0 and world == 1 and not args.no_bf16_leg and not _being_profiled():     # (a profile of this command is of the default mode only)
+        try:
+            old_amp = os.environ.get("CLDRD_AMP")
+            os.environ["CLDRD_AMP"] = "bf16"
+            try:
+                torch.manual_seed(0)
+                model_b = NwayDualEncoder(cfg, share_weights=False).to(dev)
+                model_b.train()
+                trainer_b = NwayTrainer(model_b, loss=args.loss, T=1.0, learning_rate=7e-6, warmup_steps=4000, total_steps=100000)
+                assert not trainer_b.amp16
+                for _ in range(max(args.warmup, 5)):
+                    trainer_b.train_step(batch)
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                for _ in range(args.steps):
+                    lb_ = trainer_b.train_step(batch)
+                torch.cuda.synchronize()
+                db = time.perf_counter() - tb
+            finally:
+                if old_amp is None:
+                    os.environ.pop("CLDRD_AMP", None)
+                else:
+                    os.environ["CLDRD_AMP"] = old_amp
+            bf16_mode = {"samples_per_s": round(B * args.steps / db, 2), "ms_per_step": round(1e3 * db / args.steps, 3), "final_loss": float(lb_[0].item()),
+                         "mode": "CLDRD_AMP=bf16: bf16 tape + backward operands, fp16 forward FFN / query-tower pass (the round-3 configuration)"}
+            del trainer_b, model_b
+            torch.cuda.empty_cache()
+        except Exception as exc:
+            bf16_mode = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     roofline = None
     if gemm_events and rank == 0:
         # an event pair around NOTHING on the same stream: what the bracket itself adds to every sample (the second event's
@@ -282,7 +320,7 @@ def main():
         tot_ms = raw_ms - bracket_ms * len(gemm_events)
         tot_fl = sum(f for _, _, f in gemm_events)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-        roofline = {"kernel": "gemm_nt_ring_kernel (bf16 MFMA; forward + data-gradient Linear GEMMs of the passage tower)",
+        roofline = {"kernel": "gemm_nt_ring_kernel (16-bit MFMA, fp16 or bf16 operands at the same rate; forward + data-gradient Linear GEMMs of the passage tower)",
                     "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "traffic_source": "not measured (--no-pmc or N > 1)",
                     "launches_timed": len(gemm_events), "launches": timed_gemm.count, "avg_launch_us": round(1e3 * tot_ms / len(gemm_events), 2),
@@ -505,10 +543,12 @@ def main():
             "value": round(samples_per_s, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "step_launch": "hip graph replay" if graph_replay else "eager",
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "fp16" if amp16 else "bf16", "data": "synthetic",
             "config": {"workload": f"cfg2: DistilBERT-6L dual encoder (2 unshared towers), N={N}, {args.loss}, seq_len={L}, q_len={Lq}, "
-                                   f"per-GPU batch {B}, dropout {args.dropout:g}, fwd+loss+bwd+allreduce+clip+AdamW; bf16 MFMA operands "
-                                   f"(forward FFN GEMMs: fp16 operands, same rate), fp32 accumulate / residual stream / master weights",
+                                   f"per-GPU batch {B}, dropout {args.dropout:g}, fwd+loss+bwd+allreduce+clip+AdamW; "
+                                   + ("fp16 MFMA operands (16-bit, same MFMA rate as bf16; the reference's own use_fp16 autocast mode), loss-scaled backward, "
+                                      if amp16 else "bf16 MFMA operands (forward FFN GEMMs: fp16 operands, same rate), ")
+                                   + "fp32 accumulate / residual stream / gradient stream / master weights",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "model_tflop_per_sample": round(flops_per_sample / 1e12, 4),
             "step_mfma_frac": round(samples_per_s * flops_per_sample / (world * PEAK_BF16_TFLOPS * 1e12), 4),
@@ -516,6 +556,7 @@ def main():
             "executed_tflop_per_step": round(B * exec_per_sample / 1e12, 3),
             "step_mfma_frac_executed": round(samples_per_s * exec_per_sample / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "final_loss": final_loss,
+            "bf16_operand_mode": bf16_mode,
             "msmarco_shaped_train": ragged,
             "ddp_path_one_rank_rccl": ddp1,
             "index": index, "retrieve": retrieve, "roofline": roofline, "cpu_baseline": cpu,

@@ -294,10 +294,13 @@ def test_full_size_configs_match_reference_goldens(name):
             # GPU vs fp32 oracle, logits <= 5e-3 relative - every config, BERT-base at L = 256 included since the
             # out-projection reads fp16 operands too (measured 2.2e-3 - 3.0e-3: asserted at 4e-3), and within 1.5 x of the drift of the
             # reference's OWN fp16 autocast (measured 0.96 x - 1.36 x)
-            rel_bar = 4e-3
+            # all-fp16 training mode (round 4): 1.45e-3 - 2.25e-3 measured, asserted at 3e-3; 0.71 x - 1.05 x the max and 0.74 x - 0.92 x the rms
+            # of the reference's fp16-autocast drift, asserted at 1.25 x / 1.0 x
+            rel_bar = 3e-3 if tr.amp16 else 4e-3
             assert err <= rel_bar * np.abs(ref).max(), f"{name}: max|dlogit| {err:.4f} above {rel_bar:g} x max|logit| = {rel_bar * np.abs(ref).max():.4f}"
             if "logits_autocast_fp16" in g.files and os.environ.get("CLDRD_OUT_FP16", "1") != "0":
-                assert err <= 1.5 * a16.max() and rms <= 1.5 * np.sqrt(np.mean(a16 ** 2)), f"{name}: more than 1.5 x the reference's fp16-autocast drift"
+                kmax, krms = (1.25, 1.0) if tr.amp16 else (1.5, 1.5)
+                assert err <= kmax * a16.max() and rms <= krms * np.sqrt(np.mean(a16 ** 2)), f"{name}: more than {kmax} x / {krms} x the reference's fp16-autocast drift"
         if "loss" in g.files:                                # cfg1 golden (round 1 layout)
             ref_loss, names, vals = float(g["loss"]), [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]
             amp_loss, _ = ORACLE_LOSS[gk](g["logits_autocast_bf16"], batch["labels"].numpy())
@@ -373,6 +376,10 @@ def test_full_size_configs_match_reference_goldens(name):
             assert len(rows) >= 40
             gs32 = os.environ.get("CLDRD_GRAD_STREAM", "fp32") != "bf16" and os.environ.get("CLDRD_RESIDUAL", "fp32") != "bf16"
             bar2, bar1 = (0.999, 0.994) if gs32 else (0.997, 0.985)
+            if tr.amp16:
+                # the all-fp16 training mode (round 4, the default): 11-bit operands in the whole backward - the survey's 0.999 now holds for EVERY
+                # ranked tensor, sum-type ones included (profiles/r04_grad_cosines.txt: min 0.99992 over cfg1-4; the bf16-operand mode 0.9959)
+                bar2, bar1 = 0.9995, 0.9995
             for c, c_amp, n, dim in rows:
                 assert c >= (bar2 if dim == 2 else bar1), f"{name}/{loss_kind}: gradient of {n}: cosine {c:.5f} (reference autocast {c_amp:.5f})"
                 # Round 4 (tools/grad_cos_report.py, profiles/r04_grad_cosines.txt): EVERY sum-type tensor - not only the q / k / v and FFN1
