@@ -443,7 +443,8 @@ struct WgradTile { int t1, t2; };
 
 // One tile shape per launch: 256 x 192 (8 waves of 128 x 48: 7 LDS-DMA pieces per 48 MFMAs per wave, the ratio of the NT kernel's
 // BN = 192) when every problem allows it, else 256 x 128 (8 waves of 64 x 64), else 128 x 128 (4 waves).  The 256 x 256 tile of
-// round 1 (all 256 VGPRs, spills, two LDS slots: 430-480 TF/s against 690-810) is gone.  CLDRD_WGRAD_TILE=128|192 forces one.
+// round 1 (all 256 VGPRs, spills, two LDS slots: 430-480 TF/s against 690-810) came back in round 4 without the spills (below).
+// CLDRD_WGRAD_TILE=128|192|256 forces one (development build).
 static WgradTile wgrad_tile_group(const int* N1, const int* N2, int n) {
     const int force = CLDRD_DEV_INT("CLDRD_WGRAD_TILE", 0);
     bool ok192 = true, ok128w = true;
@@ -451,6 +452,13 @@ static WgradTile wgrad_tile_group(const int* N1, const int* N2, int n) {
         ok192 = ok192 && N1[i] % 256 == 0 && N2[i] % 192 == 0;
         ok128w = ok128w && N1[i] % 256 == 0 && N2[i] % 128 == 0;
     }
+    bool ok256 = true;
+    for (int i = 0; i < n; ++i) ok256 = ok256 && N1[i] % 256 == 0 && N2[i] % 256 == 0;
+    // Round 4: 256 x 256 (8 waves of 128 x 64; 256 VGPRs, no spills with the rewritten K sweep, two 64-KiB LDS slots) for GROUPS: 8 LDS-DMA
+    // pieces per 64 MFMAs per wave instead of 7 per 48, and the passage tower's three-layer group becomes 324 tiles instead of 432.  Alone per
+    // problem it is +3..7 % on the FFN shapes, -2 % on QKV, -14 % at 4096^3 (tools/tn_ablate.py); in the step 11.70 -> 11.44 and 11.67 ->
+    // 11.48 ms (profiles/r04_microbench.txt).  Single problems keep the measured per-shape choice below.
+    if (ok256 && force != 192 && force != 128 && (force == 256 || n > 1)) return {256, 256};
     if (ok192 && force != 128 && (force == 192 || !ok128w || n > 1)) return {256, 192};
     if (ok192 && force != 128) {
         // single problem: small outputs stay on 256 x 128 (measured at T = 32768: 768 x 768 -7 % on 256 x 192, the others +3..10 %)
@@ -595,7 +603,9 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
                                                                                       : launch_tn_group<256, 128, 8, 3>(g, items, st);
         } else
 #endif
-        if (accumulate & 2) {             // bit 1 of `accumulate`: fp16 operands
+        if (t.t2 == 256) {
+            rc = (accumulate & 2) ? launch_tn_group<256, 256, 8, 0, true>(g, items, st) : launch_tn_group<256, 256, 8>(g, items, st);
+        } else if (accumulate & 2) {             // bit 1 of `accumulate`: fp16 operands
             if (t.t1 == 256 && t.t2 == 192) rc = launch_tn_group<256, 192, 8, 0, true>(g, items, st);
             else if (t.t1 == 256) rc = launch_tn_group<256, 128, 8, 0, true>(g, items, st);
             else rc = launch_tn_group<128, 128, 4, 0, true>(g, items, st);

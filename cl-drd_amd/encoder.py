@@ -450,15 +450,20 @@ class HipEncoder(nn.Module):
             self.flat_h16 = torch.empty(self.layout.total, dtype=torch.float16, device=self.flat_p.device)
         return self.flat_h16
 
-    def refresh_shadows(self, need_transposed: bool = True, cast: bool = True, cast16: bool | None = None):
+    def refresh_shadows(self, need_transposed: bool = True, cast: bool = True, cast16: bool | None = None, h_stale: bool = False):
         """bf16 copies of the weights for the MFMA GEMMs (+ transposed copies for the data-gradient GEMMs).  ``cast`` / ``cast16`` False:
-        the optimizer step has already written the bf16 / fp16 shadow (``cast16`` None = cast the fp16 shadow whenever the tower has one)."""
+        the optimizer step has already written the bf16 / fp16 shadow (``cast16`` None = cast the fp16 shadow whenever the tower has one).
+        ``h_stale`` (with ``cast=False``): the optimizer step did NOT write the bf16 shadow - an all-fp16 training step reads none of it
+        (172 MB less written per step); the next pass that does (an evaluation forward) casts it first (`_shadows_ok`)."""
         if not self.flat_p.is_cuda:
             raise RuntimeError("HipEncoder runs on the GPU only: move the model with .cuda() first (no CPU path)")
         if self.flat_h is None:
             self.flat_h = torch.empty(self.layout.total, dtype=torch.bfloat16, device=self.flat_p.device)
         if cast:
             ops.cast_bf16(self.flat_p, self.flat_h)
+            self._h_stale = False
+        elif h_stale:
+            self._h_stale = True
         if self.needs_h16 and (cast16 is None or cast16):
             ops.cast_f16(self.flat_p, self.h16_buffer())
         if need_transposed and self.cfg.n_layers:
@@ -493,8 +498,9 @@ class HipEncoder(nn.Module):
             ops.transpose_cast_batched(self.flat_p, self.flat_t, desc, prefix, nd, tiles)
         self._t_fresh = True
 
-    def _shadows_ok(self, need_t):
+    def _shadows_ok(self, need_t, need_h=True):
         return (self.flat_h is not None and self._shadow_version == self.flat_p._version and (not self.needs_h16 or self.flat_h16 is not None) and
+                (not need_h or not getattr(self, "_h_stale", False)) and
                 (not need_t or (self.flat_t is not None and getattr(self, "_t_fresh", False))))
 
     def ht(self, layer, key):
@@ -625,7 +631,7 @@ class HipEncoder(nn.Module):
         if L > 256 or L > cfg.max_position_embeddings:
             raise ValueError("sequence length must be <= 256 (and <= max_position_embeddings)")
         dev = self.flat_p.device
-        if not self._shadows_ok(save):
+        if not self._shadows_ok(save, need_h=not (self.amp16 and save)):      # (the all-fp16 training pass reads the fp16 shadow only)
             self.refresh_shadows(need_transposed=save)
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         mask = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()

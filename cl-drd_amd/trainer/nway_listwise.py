@@ -320,19 +320,22 @@ class NwayTrainer:
     def _adamw_launches(self, lr, adam_step, towers):
         # one AdamW launch over the joint buffer; it also writes the bf16 shadow of every tower
         shadow = self._joint_shadow()
+        # all-fp16 training: no pass of a training step reads the bf16 shadow (forward, backward and the transposed copies come from the fp16
+        # one), so AdamW does not write it; the towers remember it is stale and an evaluation forward casts it first
+        skip_h = self.amp16 and all(t.amp16 for t in towers) and _env_flag("CLDRD_ADAM_SKIP_BF16", "1") != "0"
         # ... and the fp16 shadow of the towers whose forward reads fp16 weights (the FFN GEMMs of every tower by default, the whole
         # high-precision pass of the query tower): one contiguous range of the joint buffer
         s16, r16 = self._joint_shadow16()
         fused16 = s16 is not None and _env_flag("CLDRD_ADAM_H16", "1") != "0"
         with ops.optim_hyper(self._state["hyper"].data_ptr() if self._state else None):
-            ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, shadow, lr=lr, beta1=self.betas[0],
+            ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, None if (skip_h and fused16) else shadow, lr=lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=adam_step, clip=self.clip,
                            shadow16=s16[r16[0]:r16[1]] if fused16 else None, h16_range=r16 if fused16 else None)
         # the transposed copies wait for the next step's preamble on the second stream (forward_backward) when there is one
         defer_t = not self.model.share_weights and self.q_stream is not None and _env_flag("CLDRD_Q_SIDE", "1") != "0" \
             and _env_flag("CLDRD_T_DEFER", "1") != "0"
         for t in towers:
-            t.refresh_shadows(need_transposed=not defer_t, cast=False, cast16=not fused16)
+            t.refresh_shadows(need_transposed=not defer_t, cast=False, cast16=not fused16, h_stale=skip_h and fused16)
 
     def _joint_shadow(self):
         if getattr(self, "_shadow", None) is None:

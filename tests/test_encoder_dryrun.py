@@ -33,8 +33,8 @@ def stubbed(monkeypatch):
     monkeypatch.setattr(ops, "_chk", chk)
     monkeypatch.setattr(ops, "call", lambda name, *a: calls.append(name))
     monkeypatch.setattr(ops, "_stream", lambda: 0)
-    monkeypatch.setattr(HipEncoder, "refresh_shadows", lambda self, need_transposed=True, cast=True, cast16=None: _cpu_shadows(self))
-    monkeypatch.setattr(HipEncoder, "_shadows_ok", lambda self, need_t: self.flat_h is not None)
+    monkeypatch.setattr(HipEncoder, "refresh_shadows", lambda self, need_transposed=True, cast=True, cast16=None, h_stale=False: _cpu_shadows(self))
+    monkeypatch.setattr(HipEncoder, "_shadows_ok", lambda self, need_t, need_h=True: self.flat_h is not None)
     return calls
 
 

@@ -54,6 +54,27 @@ def test_wgrad_fp16_operands_and_inverse_scale(M, N1, N2):
     assert torch.equal(dW3, dW), "the scale must not outlive its context"
 
 
+def test_wgrad_group_fp16_on_256_tiles_with_inverse_scale():
+    """A layer's four weight gradients as one group in the fp16 format: every side a multiple of 256 -> 256 x 256 tiles (round 4), token splits with
+    slabs (the reduction applies 1 / S), a token tail, bias gradients on two of them."""
+    shapes = [(4100, 768, 768), (4100, 2304, 768), (4100, 3072, 768), (4100, 768, 3072)]
+    st = ops.new_loss_scale_state(DEV)
+    st[0], st[1] = 256.0, 1.0 / 256.0
+    q, refs = ops.WgradQueue(), []
+    for i, (M, N1, N2) in enumerate(shapes):
+        dY, X = rnd(30 + i, (M, N1)).half(), rnd(40 + i, (M, N2)).half()
+        dW = torch.full((N1, N2), float("nan"), device=DEV)
+        db = torch.full((N1,), float("nan"), device=DEV) if i % 2 == 0 else None
+        q.add(dY.to(DEV), X.to(DEV), dW, M, dbias=db)
+        refs.append((dW, db, dY.double().T @ X.double() / 256.0, dY.double().sum(0) / 256.0))
+    with ops.loss_scale(st.data_ptr()):
+        q.flush(accumulate=False)
+    for dW, db, rW, rb in refs:
+        close(dW, rW, 1e-3, 2e-4 * rW.abs().max().item(), "fp16 wgrad group")
+        if db is not None:
+            close(db, rb, 1e-3, 2e-4 * rb.abs().max().item(), "fp16 wgrad group bias")
+
+
 def _attn_ref(qkv, mask, nseq, L, H):
     d = H * 64
     x = qkv.double().view(nseq, L, 3, H, 64)
@@ -304,3 +325,35 @@ def test_amp16_and_bf16_base_modes_agree_to_rounding(arch, monkeypatch):
     assert (l16 - lb).abs().max().item() <= 2e-2 * lb.abs().max().item()
     c = torch.nn.functional.cosine_similarity(g16, gb, dim=0).item()
     assert c >= 0.9995 and abs((g16.norm() / gb.norm()).item() - 1.0) <= 5e-3, c
+
+
+def test_evaluation_after_fp16_steps_sees_current_bf16_weights(monkeypatch):
+    """AdamW does not write the bf16 weight shadow in the all-fp16 mode (no pass of a training step reads it); an evaluation forward, which
+    does, must cast it first: embeddings after two steps equal those from explicitly refreshed shadows, and differ from the pre-step ones."""
+    monkeypatch.setenv("CLDRD_GRAPH", "0")
+    cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=2, max_position_embeddings=64,
+                        dropout=0.0, attention_dropout=0.0)
+    model = selftest.build_tiny_model(cfg).cuda().train()
+    tr = NwayTrainer(model, loss="kl_div", learning_rate=1e-3, warmup_steps=0, total_steps=20)
+    assert tr.amp16
+    batch = syn.nway_batch(4680, 3, 4, 8, 16, vocab=cfg.vocab_size, ragged=True, label_kind="teacher")
+    enc = {k: v.view(-1, v.shape[-1]).cuda() for k, v in batch["nway_passages"].items()}
+    model.eval()
+    with torch.no_grad():
+        e0 = model.passage_embs(enc).clone()
+    model.train()
+    for _ in range(2):
+        tr.train_step(batch)
+    assert all(getattr(t, "_h_stale", False) for t in model.towers())
+    model.eval()
+    with torch.no_grad():
+        e1 = model.passage_embs(enc).clone()
+        assert not any(getattr(t, "_h_stale", False) for t in [model.passage_encoder])
+        for t in model.towers():
+            t.refresh_shadows(need_transposed=True)
+        e2 = model.passage_embs(enc).clone()
+    assert torch.equal(e1, e2) and not torch.equal(e0, e1)
+    model.train()
+    tr.train_step(batch)            # and training goes on from the refreshed state
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.flat_p).all()

@@ -302,7 +302,8 @@ def test_wgrad(M, N1, N2):
 
 @pytest.mark.parametrize("accumulate", [False, True])
 @pytest.mark.parametrize("shapes", [
-    [(4096, 768, 768), (4096, 2304, 768), (4096, 3072, 768), (4096, 768, 3072), (30, 768, 768)],       # encoder layer + a short problem, 256 x 192 tiles
+    [(4100, 768, 768), (4096, 2304, 768), (4096, 3072, 768), (4096, 768, 3072), (30, 768, 768)],       # encoder layer + a short problem: 256 x 256 tiles (round 4), token tails
+    [(3000, 768, 576), (3000, 1536, 768), (777, 512, 192)],                                            # N2 a multiple of 192 only: 256 x 192 tiles
     [(200, 128, 256), (200, 256, 128), (77, 128, 128)],                                                # tiny model: 128 x 128 tiles, token splits
     [(1000, 256, 192)] * 40,                                                                            # more than 32 problems: two launches
 ])

@@ -23,11 +23,18 @@ if len(sys.argv) > 1:
             for _ in range(10): ops.wgrad(dY, X, dW, T, ws)
             e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1) / 10)
-        out.append(f"{T}x{N1}x{N2}: {best*1e3:6.1f} us {2.0*T*N1*N2/best/1e9:5.0f} TF/s-eq")
+        err = ""
+        if sys.argv[1] == "0" and T == 4096:
+            ref = dY.float().T @ X.float()
+            err = f" (max rel err vs fp32 matmul {float((dW - ref).abs().max() / ref.abs().max()):.1e})"
+        out.append(f"{T}x{N1}x{N2}: {best*1e3:6.1f} us {2.0*T*N1*N2/best/1e9:5.0f} TF/s-eq{err}")
     print(f"mode {sys.argv[1]}: " + " | ".join(out))
 else:
     names = {0: "full kernel", 1: "no LDS-DMA in the K loop", 2: "no fragment reads in the K loop", 3: "no barrier, no vmcnt wait"}
-    for tile, mode in ((192, 0), (192, 1), (192, 2), (192, 3), (128, 0), (128, 1), (128, 2), (128, 3)):
+    combos = ((192, 0), (192, 1), (192, 2), (192, 3), (128, 0), (128, 1), (128, 2), (128, 3))
+    if os.environ.get("TN_TILES"):          # e.g. TN_TILES=192,256 : the full kernel only, these tiles
+        combos = tuple((int(t), 0) for t in os.environ["TN_TILES"].split(","))
+    for tile, mode in combos:
         env = dict(os.environ, CLDRD_TN_ABLATE=str(mode), CLDRD_WGRAD_TILE=str(tile))
         r = subprocess.run([sys.executable, __file__, str(mode)], env=env, capture_output=True, text=True)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-300:], "  <-", f"256 x {tile}:", names[mode], flush=True)
