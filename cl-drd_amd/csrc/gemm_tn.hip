@@ -487,6 +487,8 @@ static int wgrad_splits_group(const int* M, const int* N1, const int* N2, int n,
     const int overhead = 6;
     const int force = CLDRD_DEV_INT("CLDRD_WGRAD_SPLITS", 0);
     if (force > 0) return force < ktotal ? force : ktotal;
+    const int force_big = CLDRD_DEV_INT("CLDRD_WGRAD_SPLITS_BIG", 0);          // long sweeps only (the passage tower's group)
+    if (force_big > 0 && ktotal >= 256) return force_big;
     // Workgroups of one XCD share A / B panels through its 4-MiB L2 only while they sweep the same token range at about the same
     // time; nothing synchronises them, so over a long sweep they drift apart and every one of them streams its operands from HBM
     // (measured at cfg2: 512 K tiles per item, no split: 3.2 ms for the passage tower's group; 2 splits of 256: 2.9 ms + 0.1 ms of
