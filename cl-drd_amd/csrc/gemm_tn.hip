@@ -518,7 +518,7 @@ extern "C" int cldrd_wgrad_splits(int M, int N1, int N2) {
     return wgrad_splits_group(&M, &N1, &N2, 1, wgrad_tile_group(&N1, &N2, 1));
 }
 
-static inline int wgrad_stagger() { return 1; }
+static inline int wgrad_stagger() { return CLDRD_DEV_INT("CLDRD_WGRAD_STAGGER", 1); }
 
 template <int T1, int T2, int NW, int ABL = 0, bool F16 = false>
 static int launch_tn_group(const TnGroupArgs& g, int items, hipStream_t st) {

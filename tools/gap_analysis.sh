@@ -1,7 +1,7 @@
 # Where is the GPU idle inside a training step?  rocprofv3 --kernel-trace of the train leg, then per step (adamw to adamw):
 # wall, union of the intervals in which ANY kernel runs, and the idle gaps by the kernel that follows them.
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_gap -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-index --no-retrieve --no-kernel-events --no-pmc --no-ddp1 --steps 10 --warmup 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_gap.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_gap -o r -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-index --no-retrieve --no-kernel-events --no-pmc --no-ddp1 --no-ragged --no-bf16-leg --steps 10 --warmup 3 > $GRAFT_REPO_ROOT/gpurun_out/prof_gap.log 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - <<'PY'
 import csv, glob, collections
