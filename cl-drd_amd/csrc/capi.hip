@@ -16,6 +16,9 @@ extern "C" const char* cldrd_last_error(void) { return g_err; }
 #ifdef CLDRD_DEV_BUILD
 #include <stdlib.h>
 int cldrd_dev_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+extern "C" unsigned long long g_dev_stamps_host[1024 * 8];
+unsigned long long g_dev_stamps_host[1024 * 8];
+extern "C" const unsigned long long* cldrd_dev_stamps() { return g_dev_stamps_host; }      // after a stream synchronize (tools/epi_stamps.py)
 #endif
 int g_cldrd_tune_splitk = 0, g_cldrd_tune_attn_fwd2 = 1, g_cldrd_tune_attn_bwd2 = 1;
 // key: "gemm_splitk" | "attn_fwd2" | "attn_bwd2" (meanings: common.h).  Every choice computes the same function; tests use it to

@@ -119,7 +119,10 @@ __device__ __forceinline__ uint4 pack8h(const float (&v)[8]) {
 // * gelu_pre) -> dropout -> + residual -> store
 template <int EPI>
 __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFlags<EPI>& fl, float (&v)[8], int m, int n,
-                                               const float (&bias8)[8], const uint4& res, const uint4& res_hi, const uint4& gp) {
+                                               const float (&bias8)[8], const uint4& res, const uint4& res_hi, const uint4& gp,
+                                               unsigned long long seed_eff, bool ok = true) {
+    // `ok` guards the STORES only: loads and arithmetic of a lane outside the tile run on clamped addresses / dead values, so that the epilogue
+    // is straight-line code and the compiler can count its vmcnt waits (see gemm_nt_epilogue)
     if (p.alpha != 1.0f) {          // scalar test: every encoder GEMM has alpha = 1 (one VALU per element saved in VALU-bound epilogues)
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= p.alpha;
@@ -141,16 +144,16 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
             dv[j] = fmaf(v[j] * 0.39894228040143268f, e, c);
             v[j] *= c;
         }
-        { if (p.tape_f16) st16_stream(p.preact + crow, pack8h(dv)); else st16_stream(p.preact + crow, pack8(dv)); }
+        { const uint4 o = p.tape_f16 ? pack8h(dv) : pack8(dv); if (ok) st16_stream(p.preact + crow, o); }
     } else {
         if (fl.preact) {
             if (fl.dgelu) {
                 float dv[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) dv[j] = gelu_grad_f(v[j]);
-                { if (p.tape_f16) st16_stream(p.preact + crow, pack8h(dv)); else st16_stream(p.preact + crow, pack8(dv)); }
+                { const uint4 o = p.tape_f16 ? pack8h(dv) : pack8(dv); if (ok) st16_stream(p.preact + crow, o); }
             } else {
-                { if (p.tape_f16) st16_stream(p.preact + crow, pack8h(v)); else st16_stream(p.preact + crow, pack8(v)); }
+                { const uint4 o = p.tape_f16 ? pack8h(v) : pack8(v); if (ok) st16_stream(p.preact + crow, o); }
             }
         }
         if (fl.gelu) {
@@ -165,7 +168,7 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         for (int j = 0; j < 8; ++j) v[j] *= fl.dgelu ? g[j] : gelu_grad_f(g[j]);
     }
     if (fl.dropout) {
-        const uint32_t rk = drop_rowkey(p.seed_base ? p.seed + *p.seed_base : p.seed, (uint32_t)m);      // n is a multiple of 8: four column pairs
+        const uint32_t rk = drop_rowkey(seed_eff, (uint32_t)m);      // n is a multiple of 8: four column pairs
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
             const uint32_t h = drop_pair(rk, (uint32_t)(n + j));
@@ -186,15 +189,19 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
     }
     if (fl.f32) {
         float* C = (float*)p.C + crow;
-        *(float4*)C = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        if (ok) {
+            *(float4*)C = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(C + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
     } else {
         const bool h16 = (EPI == EPI_GENERIC ? p.in_f16 != 0 : (EPI & EPI_F16IN) != 0) && !p.c_bf16;
         if (h16) {
-            *(uint4*)((bf16_t*)p.C + crow) = pack8h(v);
-            if (p.c_copy) st16_stream(p.c_copy + crow, pack8(v));       // the tape copy: read ~10 ms later by the weight-gradient launch
+            const uint4 o = pack8h(v);
+            if (ok) *(uint4*)((bf16_t*)p.C + crow) = o;
+            if (p.c_copy) { const uint4 o2 = pack8(v); if (ok) st16_stream(p.c_copy + crow, o2); }       // the tape copy: read ~10 ms later by the weight-gradient launch
         } else {
-            *(uint4*)((bf16_t*)p.C + crow) = pack8(v);
+            const uint4 o = pack8(v);
+            if (ok) *(uint4*)((bf16_t*)p.C + crow) = o;
         }
     }
 }
@@ -212,54 +219,79 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
 // after the last fragment read of the K loop (the patch aliases the staging buffers).
 template <int MT, int NT, int EPI>
 __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane,
-                                                 float* patch) {
+                                                 float* patch, unsigned long long* dbg = nullptr) {
     constexpr int WCOLS = NT * 16, RS = WCOLS + 4, LPR = WCOLS / 8, RPP = 64 / LPR, NPASS = (32 + RPP - 1) / RPP;
     const EpiFlags<EPI> fl(p);
     const int frow = lane & 15, fq = lane >> 4;
     const int rr = lane / LPR, rc = (lane % LPR) * 8;
     const int n = col0 + rc;
     const bool lane_ok = rr < RPP && n < p.N;       // N % 8 == 0 (checked by the launcher): a started group is complete
+    // Round 4: the epilogue is STRAIGHT-LINE code.  Until then its loads sat in exec-masked `if (lane inside the tile)` regions; at the join
+    // behind such a region the compiler's wait-count pass must assume the path on which nothing was issued after the load, i.e. every later
+    // use waits with `s_waitcnt vmcnt(0)` - and on CDNA4 vmcnt counts STORES too, so each of the 16 passes of a wave began by waiting for the
+    // previous pass's stores to be acknowledged by L2 (~1 us under load; the per-column constants below were "pending" in every pass because a
+    // pass skipped by an empty exec mask does not wait for them).  tools/epi_ablate.py: 15-25 us per tile for the fused flavours against 3-4 us
+    // for the plain one.  Now every load is unconditional on a clamped address, the arithmetic runs on all lanes, only the stores are
+    // predicated (no branch around a single store), and the per-tile constants are consumed once, here, by an empty asm: one wait, in
+    // dominating code.
+    const int nc = n < p.N ? n : 0;
     float bias8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) bias8[j] = 0.f;
-    if (fl.bias && lane_ok) {
-        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+    if (fl.bias) {
+        const float4 b0 = *(const float4*)(p.bias + nc), b1 = *(const float4*)(p.bias + nc + 4);
         bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w;
         bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
     }
     float lng[8], lnb[8];
-    if (fl.resln && lane_ok) {
-        const float4 g0 = *(const float4*)(p.ln_gamma + n), g1 = *(const float4*)(p.ln_gamma + n + 4);
-        const float4 b0 = *(const float4*)(p.ln_beta + n), b1 = *(const float4*)(p.ln_beta + n + 4);
+    if (fl.resln) {
+        const float4 g0 = *(const float4*)(p.ln_gamma + nc), g1 = *(const float4*)(p.ln_gamma + nc + 4);
+        const float4 b0 = *(const float4*)(p.ln_beta + nc), b1 = *(const float4*)(p.ln_beta + nc + 4);
         lng[0] = g0.x; lng[1] = g0.y; lng[2] = g0.z; lng[3] = g0.w; lng[4] = g1.x; lng[5] = g1.y; lng[6] = g1.z; lng[7] = g1.w;
         lnb[0] = b0.x; lnb[1] = b0.y; lnb[2] = b0.z; lnb[3] = b0.w; lnb[4] = b1.x; lnb[5] = b1.y; lnb[6] = b1.z; lnb[7] = b1.w;
     }
+    // The effective dropout seed, read ONCE: until round 4 `*p.seed_base` (a global load: the step's seed lives in device memory for the graph
+    // replay) sat inside gemm_nt_apply8, behind the chunk loop's compiler barriers - reloaded in each of the 16 passes of a wave, every time
+    // followed by `s_waitcnt vmcnt(0)`, which also waits for the previous pass's STORES and the next chunk's prefetches: ~1.2 us x 16 per tile
+    // (tools/epi_ablate.py: the dropout + residual flavours spent 24 us per tile in the epilogue, 20 of them here).
+    unsigned long long seed_eff = 0;
+    if (fl.dropout) seed_eff = p.seed_base ? p.seed + *p.seed_base : p.seed;
+    if (fl.bias) asm volatile("" ::"v"(bias8[0]), "v"(bias8[1]), "v"(bias8[2]), "v"(bias8[3]), "v"(bias8[4]), "v"(bias8[5]), "v"(bias8[6]), "v"(bias8[7]));
+    if (fl.resln) {
+        asm volatile("" ::"v"(lng[0]), "v"(lng[1]), "v"(lng[2]), "v"(lng[3]), "v"(lng[4]), "v"(lng[5]), "v"(lng[6]), "v"(lng[7]));
+        asm volatile("" ::"v"(lnb[0]), "v"(lnb[1]), "v"(lnb[2]), "v"(lnb[3]), "v"(lnb[4]), "v"(lnb[5]), "v"(lnb[6]), "v"(lnb[7]));
+    }
+    if (fl.dropout) asm volatile("" ::"v"((uint32_t)seed_eff), "v"((uint32_t)(seed_eff >> 32)));
     uint4 res[NPASS], resh[NPASS], gp[NPASS];
     float lmu[NPASS], lrs[NPASS];
-    auto prefetch = [&](int mh) {
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int r = pass * RPP + rr;
-            const int m = row0 + mh * 32 + r;
-            res[pass] = make_uint4(0, 0, 0, 0);
-            resh[pass] = make_uint4(0, 0, 0, 0);
-            gp[pass] = make_uint4(0, 0, 0, 0);
-            if (lane_ok && r < 32 && m < p.M) {
-                if (fl.residual) {
-                    if (fl.res32) {
-                        const uint4* rp = (const uint4*)((const float*)p.residual + (size_t)m * p.ldr + n);
-                        res[pass] = ld16_stream(rp);              // the fp32 stream's last reader before the backward
-                        resh[pass] = ld16_stream(rp + 1);
-                        if (fl.resln) { lmu[pass] = p.ln_mean[m]; lrs[pass] = p.ln_rstd[m]; }
-                    } else {
-                        res[pass] = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + n);
-                    }
-                }
-                if (fl.gelugrad) gp[pass] = ld16_stream(p.gelu_pre + (size_t)m * p.ldc + n);
+    const int mlast = p.M - 1;
+    // operands of pass `pass` of chunk `mh` (residual, LayerNorm statistics, gelu' tape): requested right behind the same pass of chunk mh - 1,
+    // into the registers that pass has just consumed - a whole chunk of LDS trip, arithmetic and stores ahead of their use, without a second
+    // register set
+    auto prefetch_pass = [&](int mh, int pass) {
+        const int r = pass * RPP + rr;
+        const int mr = row0 + mh * 32 + (r < 32 ? r : 31);
+        const int m = mr < mlast ? mr : mlast;          // clamped: rows past the tile / the matrix read a valid row nobody stores
+        if (fl.residual) {
+            if (fl.res32) {
+                const uint4* rp = (const uint4*)((const float*)p.residual + (size_t)m * p.ldr + nc);
+                res[pass] = ld16_stream(rp);              // the fp32 stream's last reader before the backward
+                resh[pass] = ld16_stream(rp + 1);
+                if (fl.resln) { lmu[pass] = p.ln_mean[m]; lrs[pass] = p.ln_rstd[m]; }
+            } else {
+                res[pass] = *(const uint4*)((const bf16_t*)p.residual + (size_t)m * p.ldr + nc);
             }
         }
+        if (fl.gelugrad) gp[pass] = ld16_stream(p.gelu_pre + (size_t)m * p.ldc + nc);
     };
-    if (fl.residual || fl.gelugrad) prefetch(0);
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        res[pass] = make_uint4(0, 0, 0, 0);
+        resh[pass] = make_uint4(0, 0, 0, 0);
+        gp[pass] = make_uint4(0, 0, 0, 0);
+        lmu[pass] = 0.f; lrs[pass] = 0.f;
+        if (fl.residual || fl.gelugrad) prefetch_pass(0, pass);
+    }
     // The LDS executes one wave's instructions in order, so inside this wave-private patch a read issued after a write sees it and a write
     // issued after a read cannot overtake it: no s_waitcnt between them (until round 3 there were two lgkmcnt(0) per chunk, i.e. two LDS
     // round trips in front of every chunk's stores).  Chunk mh+1 is written right behind the reads of chunk mh, so its trip overlaps the
@@ -287,29 +319,28 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
         asm volatile("" ::: "memory");
         if (mh + 1 < MT / 2) write_patch(mh + 1);
         asm volatile("" ::: "memory");
-        uint4 cres[NPASS], cresh[NPASS], cgp[NPASS];
 #pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) { cres[pass] = res[pass]; cresh[pass] = resh[pass]; cgp[pass] = gp[pass]; }
-        if (fl.resln) {       // the residual is LayerNorm(pre-LN sum): same expression as ln_fwd_kernel's fp32 output
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
+        for (int pass = 0; pass < NPASS; ++pass) {
+            uint4 cres = res[pass], cresh = resh[pass];
+            const uint4 cgp = gp[pass];
+            if (fl.resln) {       // the residual is LayerNorm(pre-LN sum): same expression as ln_fwd_kernel's fp32 output
                 const float mu = lmu[pass], rs = lrs[pass];
-                uint32_t* lo = (uint32_t*)&cres[pass];
-                uint32_t* hi = (uint32_t*)&cresh[pass];
+                uint32_t* lo = (uint32_t*)&cres;
+                uint32_t* hi = (uint32_t*)&cresh;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     lo[j] = __float_as_uint((__uint_as_float(lo[j]) - mu) * rs * lng[j] + lnb[j]);
                     hi[j] = __float_as_uint((__uint_as_float(hi[j]) - mu) * rs * lng[4 + j] + lnb[4 + j]);
                 }
             }
-        }
-        if ((fl.residual || fl.gelugrad) && mh + 1 < MT / 2) prefetch(mh + 1);
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
+            if ((fl.residual || fl.gelugrad) && mh + 1 < MT / 2) prefetch_pass(mh + 1, pass);
             const int r = pass * RPP + rr;
             const int m = row0 + mh * 32 + r;
-            if (lane_ok && r < 32 && m < p.M) gemm_nt_apply8<EPI>(p, fl, v[pass], m, n, bias8, cres[pass], cresh[pass], cgp[pass]);
+            gemm_nt_apply8<EPI>(p, fl, v[pass], m, nc, bias8, cres, cresh, cgp, seed_eff, lane_ok && r < 32 && m < p.M);
         }
+#ifdef CLDRD_DEV_BUILD
+        if (dbg) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) dbg[mh] = t; }      // tools/epi_stamps.py
+#endif
     }
 }
 

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(GemmNtArgs p) {
         }
     }
     if (fl.gelugrad) gp = *(const uint4*)(p.gelu_pre + (size_t)m * p.ldc + n);
-    gemm_nt_apply8<EPI_GENERIC>(p, fl, v, m, n, bias8, res, resh, gp);
+    gemm_nt_apply8<EPI_GENERIC>(p, fl, v, m, n, bias8, res, resh, gp, fl.dropout ? (p.seed_base ? p.seed + *p.seed_base : p.seed) : 0ull);
 }
 
 // K splits of the small-M kernel for a shape (1: one pass).  The 128 x 128 kernel holds two workgroups per CU: aim at ~1.5 per CU with

@@ -40,6 +40,11 @@ constexpr int ring_lds_bytes() {
 // them per CU, so that one runs its K loop while the other is in its epilogue (21 % of this kernel's time at K = 768).  Each then stages
 // its own B tile (40 instead of 28 KiB of LDS-DMA per 128 rows and K tile) and that costs more than the overlap returns: -14 % (QKV) to
 // -20 % (FFN1) at K = 768, -4..-8 % at K = 2304 / 3072, -2.7 % on the training step.
+#ifdef CLDRD_DEV_BUILD
+// ABL == 10 (tools/epi_stamps.py): wave 0 of the first 1024 workgroups leaves cycle-counter stamps: [0] kernel entry, [1] first K tile landed,
+// [2] K loop done, [3] epilogue barrier passed, [4..7] after each 32-row chunk of its epilogue
+__device__ unsigned long long g_ring_stamps[1024 * 8];
+#endif
 template <int BN, int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -59,6 +64,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     constexpr int BRING = NA_MAX * A_BYTES;  // byte offset of the B ring
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef CLDRD_DEV_BUILD
+    unsigned long long* stamps = (ABL == 10 && blockIdx.x < 1024 && wid == 0) ? g_ring_stamps + blockIdx.x * 8 : nullptr;
+    auto stamp = [&](int k) { if (ABL == 10) { const unsigned long long t = __builtin_readcyclecounter(); if (stamps && lane == 0) stamps[k] = t; } };
+#else
+    auto stamp = [&](int) {};
+    unsigned long long* stamps = nullptr;
+#endif
+    stamp(0);
     const int ntn = (p.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     // Tile order inside an XCD's contiguous range.  Row-major (all N tiles of an M panel, then the next panel) streams the
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    stamp(1);
     if (NSLOT == 3) { if (nk_ > 2) { stageB(2, 2); stageA(2, 2); } } else { if (nk_ > 1 && !early1) { stageB(1, 1); stageA(1, 1); } }
 #pragma unroll
     for (int t = 0; t < NT; ++t) b0[t] = *(const bf16x8*)(smem + b_off[0] + t * 16 * 128);
@@ -245,9 +259,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     if constexpr ((EPI & EPI_FILTER) != 0 && EPI != EPI_GENERIC) {
         gemm_nt_filter_epilogue_cols<8, NT>(p, acc, m0 + wm * 128, n0 + wn * WN, lane);
     } else {
+        stamp(2);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();     // last K tile fully consumed by every wave: the slots become epilogue scratch
         asm volatile("" ::: "memory");
+        stamp(3);
+        if constexpr (ABL == 10) {
+            gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)), stamps ? stamps + 4 : nullptr);
+            return;
+        }
         if constexpr (ABL == 7) {
             float s = 0.f;
 #pragma unroll
@@ -261,10 +281,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
             gemm_nt_epilogue<8, NT, EPI>(p, acc, wm * 128, wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
             return;
         }
+        if constexpr (ABL == 9) {       // the tile's own columns, M panel folded onto the first four: a cache-resident footprint without same-line conflicts
+            gemm_nt_epilogue<8, NT, EPI>(p, acc, (mt_ & 3) * BM + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
+            return;
+        }
         gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
     }
 }
 
+#ifdef CLDRD_DEV_BUILD
+extern "C" unsigned long long g_dev_stamps_host[1024 * 8];      // capi.hip (dev build): the last stamped launch's stamps, read with cldrd_dev_stamps()
+#endif
 template <int BN, int ABL>
 int launch_ring_abl(const GemmNtArgs& a, hipStream_t st) {
     constexpr int lds = ring_lds_bytes<BN>();
@@ -296,6 +323,34 @@ int launch_ring_epi(const GemmNtArgs& a, hipStream_t st) {
     }
 #endif
     constexpr int lds = ring_lds_bytes<BN>();
+#ifdef CLDRD_DEV_BUILD
+    if constexpr (EPI != 0 && (EPI & EPI_FILTER) == 0 && EPI != EPI_GENERIC) {      // the epilogue ablations (7: none, 8: no HBM streams) for every fused flavour: tools/epi_ablate.py
+        const int abl = cldrd_dev_int("CLDRD_GEMM_ABLATE_EPI", 0);
+        if (abl == 10) {
+            static bool attr10 = false;
+            if (!attr10) { (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr10 = true; }
+            const int nb = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+            hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, EPI, 10>), dim3(nb), dim3(512), lds, st, a);
+            CLDRD_LAUNCH_CHECK();
+            return hipMemcpyFromSymbolAsync(g_dev_stamps_host, HIP_SYMBOL(g_ring_stamps), sizeof(unsigned long long) * 1024 * 8, 0, hipMemcpyDeviceToHost, st) == hipSuccess ? 0 : 1;
+        }
+        if (abl == 7 || abl == 8 || abl == 9) {
+            static bool attr7 = false;
+            if (!attr7) {
+                (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                attr7 = true;
+            }
+            const int nb = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+            if (abl == 7) hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, EPI, 7>), dim3(nb), dim3(512), lds, st, a);
+            else if (abl == 9) hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, EPI, 9>), dim3(nb), dim3(512), lds, st, a);
+            else hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, EPI, 8>), dim3(nb), dim3(512), lds, st, a);
+            CLDRD_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+#endif
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -499,7 +499,10 @@ class NwayTrainer:
         g = torch.cuda.CUDAGraph()
         # the captured launches take seeds / lr from device memory: nothing of THIS step's values is baked in (the counters are not
         # advanced here; the capture itself executes nothing)
-        with torch.cuda.graph(g):
+        # thread_local: only THIS thread's calls are checked against the capture.  The default ("global") makes any HIP call of any other thread
+        # an error while the capture runs - and a process with a ProcessGroupNCCL has such a thread: the watchdog polls the events of earlier
+        # collectives (seen as a 1-in-3 failure of the one-rank RCCL test when the whole suite ran before it).
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             try:
                 loss_out, logits = self.forward_backward(static)
                 self._optimizer_launches(0.0, 1)
