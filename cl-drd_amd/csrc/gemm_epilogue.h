@@ -36,6 +36,7 @@ struct GemmNtArgs {
     int stagger = 1;              // ring kernel: waves 4..7 issue their LDS-DMA one k-step after waves 0..3 (0: A/B runs)
     int asym = 1;                 // ring kernel, two whole slots: a third A slot, A requested two K tiles ahead (0: the round-2 schedule)
     int early1 = 1;               // ring kernel, two LDS slots: K tile 1 is requested together with K tile 0 at tile start (0: after tile 0 landed)
+    int phase_units = 0;          // ring kernel: half of the first round's workgroups start this many s_memtime units late (0: off)
     int tape_f16 = 0;             // with in_f16 (the all-fp16 training mode): `preact` is written and `gelu_pre` is read as fp16, not bf16
 };
 
@@ -342,6 +343,109 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
         if (dbg) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) dbg[mh] = t; }      // tools/epi_stamps.py
 #endif
     }
+}
+
+// The fp32-out flavours (bias [+ dropout] + fp32 residual [LayerNorm on the fly] -> fp32 sum; plain fp32 out): FOUR columns per lane.
+// With eight, a lane's 32 bytes of output went out as two 16-B stores at a 32-B lane stride: every store instruction wrote one half of each
+// 32-B sector, and so did the residual loads - tools/micro/store_rate.hip: 174 cycles per store instruction per CU and 3.4 TB/s chip-wide for
+// that pattern against 86-110 cycles and 5.7-7.3 TB/s for instructions that write whole row segments.  Here consecutive lanes own consecutive
+// 16-B pieces of a row: one load, one LDS read and one store per lane and pass, all of them contiguous row segments.
+template <int MT, int NT, int EPI>
+__device__ __forceinline__ void gemm_nt_epilogue_f32(const GemmNtArgs& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane, float* patch) {
+    constexpr int WCOLS = NT * 16, RS = WCOLS + 4, LPR = WCOLS / 4, RPP = 64 / LPR, NPASS = (32 + RPP - 1) / RPP;
+    const EpiFlags<EPI> fl(p);
+    const int frow = lane & 15, fq = lane >> 4;
+    const int rr = lane / LPR, rc = (lane % LPR) * 4;
+    const int n = col0 + rc;
+    const bool lane_ok = rr < RPP && n < p.N;
+    const int nc = n < p.N ? n : 0;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f), lng = bias4, lnb = bias4;
+    if (fl.bias) bias4 = *(const float4*)(p.bias + nc);
+    if (fl.resln) { lng = *(const float4*)(p.ln_gamma + nc); lnb = *(const float4*)(p.ln_beta + nc); }
+    unsigned long long seed_eff = 0;
+    if (fl.dropout) seed_eff = p.seed_base ? p.seed + *p.seed_base : p.seed;
+    if (fl.bias) asm volatile("" ::"v"(bias4.x), "v"(bias4.y), "v"(bias4.z), "v"(bias4.w));
+    if (fl.resln) asm volatile("" ::"v"(lng.x), "v"(lng.y), "v"(lng.z), "v"(lng.w), "v"(lnb.x), "v"(lnb.y), "v"(lnb.z), "v"(lnb.w));
+    if (fl.dropout) asm volatile("" ::"v"((uint32_t)seed_eff), "v"((uint32_t)(seed_eff >> 32)));
+    uint4 res[NPASS];
+    float lmu[NPASS], lrs[NPASS];
+    const int mlast = p.M - 1;
+    auto prefetch_pass = [&](int mh, int pass) {
+        const int r = pass * RPP + rr;
+        const int mr = row0 + mh * 32 + (r < 32 ? r : 31);
+        const int m = mr < mlast ? mr : mlast;
+        if (fl.residual) {
+            res[pass] = ld16_stream((const float*)p.residual + (size_t)m * p.ldr + nc);
+            if (fl.resln) { lmu[pass] = p.ln_mean[m]; lrs[pass] = p.ln_rstd[m]; }
+        }
+    };
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        res[pass] = make_uint4(0, 0, 0, 0);
+        lmu[pass] = 0.f; lrs[pass] = 0.f;
+        if (fl.residual) prefetch_pass(0, pass);
+    }
+    auto write_patch = [&](int mh) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                *(f32x4*)(patch + (t * 16 + frow) * RS + nt * 16 + fq * 4) = acc[2 * mh + t][nt];
+    };
+    write_patch(0);
+#pragma unroll
+    for (int mh = 0; mh < MT / 2; ++mh) {
+        asm volatile("" ::: "memory");
+        f32x4 v[NPASS];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int r = pass * RPP + rr;
+            v[pass] = *(const f32x4*)(patch + (r < 32 ? r : 0) * RS + rc);
+        }
+        asm volatile("" ::: "memory");
+        if (mh + 1 < MT / 2) write_patch(mh + 1);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int r = pass * RPP + rr;
+            const int m = row0 + mh * 32 + r;
+            float x[4] = {v[pass][0], v[pass][1], v[pass][2], v[pass][3]};
+            if (p.alpha != 1.0f) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] *= p.alpha;
+            }
+            if (fl.bias) { x[0] += bias4.x; x[1] += bias4.y; x[2] += bias4.z; x[3] += bias4.w; }
+            if (fl.dropout) {       // the same (row, column pair) hash as gemm_nt_apply8: nc is a multiple of 4 -> two column pairs
+                const uint32_t rk = drop_rowkey(seed_eff, (uint32_t)m);
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const uint32_t h = drop_pair(rk, (uint32_t)(nc + j));
+                    x[j] = drop_keep_lo(h, p.drop_thresh) ? x[j] * p.drop_scale : 0.f;
+                    x[j + 1] = drop_keep_hi(h, p.drop_thresh) ? x[j + 1] * p.drop_scale : 0.f;
+                }
+            }
+            if (fl.residual) {
+                const uint4 cr = res[pass];
+                float rv[4] = {__uint_as_float(cr.x), __uint_as_float(cr.y), __uint_as_float(cr.z), __uint_as_float(cr.w)};
+                if (fl.resln) {     // the residual is LayerNorm(pre-LN sum): same expression as ln_fwd_kernel's fp32 output
+                    const float mu = lmu[pass], rs = lrs[pass];
+                    rv[0] = (rv[0] - mu) * rs * lng.x + lnb.x; rv[1] = (rv[1] - mu) * rs * lng.y + lnb.y;
+                    rv[2] = (rv[2] - mu) * rs * lng.z + lnb.z; rv[3] = (rv[3] - mu) * rs * lng.w + lnb.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] += rv[j];
+            }
+            if (fl.residual && mh + 1 < MT / 2) prefetch_pass(mh + 1, pass);
+            if (lane_ok && r < 32 && m < p.M) *(float4*)((float*)p.C + (size_t)m * p.ldc + nc) = make_float4(x[0], x[1], x[2], x[3]);
+        }
+    }
+}
+
+// compile-time test: does this flavour take the four-columns-per-lane fp32 epilogue?
+template <int EPI>
+constexpr bool epi_is_f32_only() {
+    return EPI != EPI_GENERIC && (EPI & EPI_F32) != 0 && (EPI & (EPI_PREACT | EPI_GELU | EPI_GELUGRAD | EPI_FILTER | EPI_SPLITK)) == 0 &&
+           ((EPI & EPI_RESIDUAL) == 0 || (EPI & EPI_RES32) != 0);
 }
 
 // Top-k scan epilogue (no store of C): lane holds C[m = query][n = 4 consecutive index rows]; anything at or above the

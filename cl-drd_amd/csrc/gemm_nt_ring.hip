@@ -70,6 +70,11 @@ int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_
     // group pass would re-read the A panels - PMC: 436 MB instead of 293 MB for N = 768, K = 2304 / 3072)
     a.gn = gn_force >= 0 ? gn_force : (a.K <= 1024 ? (int)(2.0e6 / ((double)bn * a.K * 2.0) + 0.5) : 0);
     if (a.gn < 0) a.gn = 0;
+    {   // development build: phase shift of half the first round's workgroups (tools/epi_ablate.py), launches of >= MIN_ROUNDS rounds only
+        const int ph = CLDRD_DEV_INT("CLDRD_GEMM_PHASE", 0), minr = CLDRD_DEV_INT("CLDRD_GEMM_PHASE_MIN_ROUNDS", 3);
+        const long tiles = (long)((a.M + BM - 1) / BM) * (a.N / bn);
+        a.phase_units = (ph > 0 && tiles >= 256L * minr) ? ph : 0;
+    }
     // (A persistent tile walk with a register epilogue - gemm_nt_pers.hip of rounds 2-3 - measured equal to this kernel within 1 % on
     // the encoder shapes and in the training step, profiles/r02_microbench.txt, and was removed in round 4.)
     if (a.in_f16) return cldrd_gemm_nt_ring16_launch(a, bn, st);       // fp16 operands: the forward FFN flavours, or -1

@@ -72,6 +72,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
     unsigned long long* stamps = nullptr;
 #endif
     stamp(0);
+    if (p.phase_units > 0 && blockIdx.x < 256 && ((blockIdx.x >> 3) & 1)) {
+        // first round of tiles only (later rounds inherit their CU's phase): every second workgroup of an XCD starts `phase_units` of the
+        // s_memtime counter late (1 unit = 0.064 us), so that half of the chip is in its K loop while the other half is in its epilogue
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while ((long long)(__builtin_readcyclecounter() - t0) < (long long)p.phase_units) __builtin_amdgcn_s_sleep(8);
+    }
     const int ntn = (p.N + BN - 1) / BN;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     // Tile order inside an XCD's contiguous range.  Row-major (all N tiles of an M panel, then the next panel) streams the
@@ -281,11 +287,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
             gemm_nt_epilogue<8, NT, EPI>(p, acc, wm * 128, wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
             return;
         }
+        if constexpr (ABL == 11) {      // every CU stores to (and reads the epilogue operands of) a place of its own: tile index folded onto the first 256 -> no HBM streaming beyond the first round, no shared lines
+            const int tf = tile & 255;
+            gemm_nt_epilogue<8, NT, EPI>(p, acc, (tf & 127) * BM + wm * 128, (tf >> 7) * BN + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
+            return;
+        }
         if constexpr (ABL == 9) {       // the tile's own columns, M panel folded onto the first four: a cache-resident footprint without same-line conflicts
             gemm_nt_epilogue<8, NT, EPI>(p, acc, (mt_ & 3) * BM + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
             return;
         }
-        gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
+        if constexpr (epi_is_f32_only<EPI>()) gemm_nt_epilogue_f32<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
+        else gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)));
     }
 }
 
@@ -333,6 +345,14 @@ int launch_ring_epi(const GemmNtArgs& a, hipStream_t st) {
             hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, EPI, 10>), dim3(nb), dim3(512), lds, st, a);
             CLDRD_LAUNCH_CHECK();
             return hipMemcpyFromSymbolAsync(g_dev_stamps_host, HIP_SYMBOL(g_ring_stamps), sizeof(unsigned long long) * 1024 * 8, 0, hipMemcpyDeviceToHost, st) == hipSuccess ? 0 : 1;
+        }
+        if (abl == 11) {
+            static bool attr11 = false;
+            if (!attr11) { (void)hipFuncSetAttribute((const void*)gemm_nt_ring_kernel<BN, EPI, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); attr11 = true; }
+            const int nb = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+            hipLaunchKernelGGL((gemm_nt_ring_kernel<BN, EPI, 11>), dim3(nb), dim3(512), lds, st, a);
+            CLDRD_LAUNCH_CHECK();
+            return 0;
         }
         if (abl == 7 || abl == 8 || abl == 9) {
             static bool attr7 = false;

@@ -41,8 +41,8 @@ if len(sys.argv) > 1:
         res.append(f"{name}: {best * 1e3:6.1f} us")
     print(f"mode {sys.argv[1]}:\n   " + "\n   ".join(res))
 else:
-    names = {0: "full kernel", 7: "no epilogue", 8: "epilogue, every tile at the first tile's place (same-line conflicts)", 9: "epilogue, M panels folded onto the first four (cache-resident, no HBM streams)"}
-    for mode in (0, 7, 8, 9):
+    names = {0: "full kernel", 7: "no epilogue", 8: "epilogue, every tile at the first tile's place (same-line conflicts)", 9: "epilogue, M panels folded onto the first four (cache-resident, no HBM streams)", 11: "epilogue, every tile at the place of tile (index mod 256): 32 MB footprint, no line shared between CUs"}
+    for mode in (0, 7, 9, 11):
         env = dict(os.environ, CLDRD_GEMM_ABLATE_EPI=str(mode))
         r = subprocess.run([sys.executable, __file__, str(mode)], env=env, capture_output=True, text=True)
         print((r.stdout.strip() if r.stdout.strip() else r.stderr[-400:]), "  <-", names[mode], flush=True)

@@ -12,7 +12,7 @@ import torch
 from cldrd_amd import hip_ops as ops, _lib
 lib = _lib.load()
 lib.cldrd_dev_stamps.restype = ctypes.POINTER(ctypes.c_ulonglong)
-T, d, f = 32768, 768, 3072
+T, d, f = int(os.environ.get('T', 32768)), 768, 3072
 dev = "cuda"
 h16 = lambda *s: (torch.randn(*s, device=dev) * 0.5).half()
 x, hbig = h16(T, d), h16(T, f)
@@ -36,7 +36,7 @@ for name, fn in cases.items():
         fn()
     torch.cuda.synchronize()
     st = np.ctypeslib.as_array(lib.cldrd_dev_stamps(), shape=(1024, 8)).astype(np.int64).copy()
-    st = st[:256]                       # the first round of tiles (one workgroup per CU)
+    st = st[:min(256, (T // 256) * 4)]  # the first round of tiles (one workgroup per CU)
     us = lambda a: a / 100.0            # 100 MHz
     ph = [("prologue", st[:, 1] - st[:, 0]), ("K loop", st[:, 2] - st[:, 1]), ("barrier", st[:, 3] - st[:, 2])] + \
          [(f"chunk {k}", st[:, 4 + k] - st[:, 3 + k]) for k in range(4)]
