@@ -78,6 +78,18 @@ __device__ __forceinline__ float keep_bit(float v, uint32_t w, int pos) {
     return __uint_as_float(__float_as_uint(v) & (uint32_t)__builtin_amdgcn_sbfe((int)w, pos, 1));
 }
 
+// Output rows of the 32 x 32 MFMA layout: lanes r and r + 32 hold ADJACENT 8-byte pieces (4 head dimensions each) of the same row, so the
+// natural store is 8 bytes per lane - twice the store instructions, and a row-per-lane store is issue-bound per instruction
+// (tools/micro/store_rate.hip; cdna_hip_programming.md T21).  One v_permlane32_swap per dword trades the upper half-wave's piece of
+// column group u against the lower half-wave's piece of group u + 1: afterwards a lane of the lower half holds the 16 contiguous bytes of
+// group u, a lane of the upper half those of group u + 1 -> one 16-byte store at column 8 (u + h).  Executed by all lanes (outside `if (row < L)`).
+__device__ __forceinline__ uint4 widen_pair(const uint2& g0, const uint2& g1) {
+    typedef unsigned attn_u32x2 __attribute__((ext_vector_type(2)));
+    const attn_u32x2 rx = __builtin_amdgcn_permlane32_swap(g0.x, g1.x, false, false);
+    const attn_u32x2 ry = __builtin_amdgcn_permlane32_swap(g0.y, g1.y, false, false);
+    return make_uint4(rx[0], ry[0], rx[1], ry[1]);
+}
+
 // copy a [L, 64] bf16 head slice (row stride ld elements) into an LDS tile of Lp rows, zero-filling rows >= L
 __device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld, int L, int Lp) {
     for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
@@ -475,24 +487,29 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
         const float l = lsum + __shfl_xor(lsum, 32, 64);
         if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (m + __log2f(l)) * LN2;
         const float inv = (DROP ? drop_scale : 1.0f) / l;
-        if (q < L) {
+        {
             const size_t orow = ((size_t)seq * L + q) * dm + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float v0 = O[dt][4 * u] * inv, v1 = O[dt][4 * u + 1] * inv, v2 = O[dt][4 * u + 2] * inv, v3 = O[dt][4 * u + 3] * inv;
+                for (int u = 0; u < 4; u += 2) {
+                    uint2 o[2], o16[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int b = 4 * (u + k);
+                        const float v0 = O[dt][b] * inv, v1 = O[dt][b + 1] * inv, v2 = O[dt][b + 2] * inv, v3 = O[dt][b + 3] * inv;
+                        o[k].x = pack2x<F16>(v0, v1);
+                        o[k].y = pack2x<F16>(v2, v3);
+                        o16[k].x = (uint32_t)f2x<true>(v0) | ((uint32_t)f2x<true>(v1) << 16);
+                        o16[k].y = (uint32_t)f2x<true>(v2) | ((uint32_t)f2x<true>(v3) << 16);
+                    }
                     if (ctx) {
-                        uint2 o;
-                        o.x = pack2x<F16>(v0, v1);
-                        o.y = pack2x<F16>(v2, v3);
-                        *(uint2*)(ctx + orow + dt * 32 + 8 * u + 4 * h) = o;
+                        const uint4 w = widen_pair(o[0], o[1]);
+                        if (q < L) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                     if (ctx16) {       // fp16 copy (out-projection operand)
-                        uint2 o;
-                        o.x = (uint32_t)f2x<true>(v0) | ((uint32_t)f2x<true>(v1) << 16);
-                        o.y = (uint32_t)f2x<true>(v2) | ((uint32_t)f2x<true>(v3) << 16);
-                        *(uint2*)(ctx16 + orow + dt * 32 + 8 * u + 4 * h) = o;
+                        const uint4 w = widen_pair(o16[0], o16[1]);
+                        if (q < L) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                 }
         }
@@ -605,21 +622,28 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
             }
         }
         // dV[dt][t] = dV[key][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
-        if (key < L) {
+        {
             bf16_t* ok = dqkv + ((size_t)seq * L + key) * ld + dm + hd * 64;
             bf16_t* ov = ok + dm;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int d0 = dt * 32 + 8 * u + 4 * h;
-                    uint2 a, b;
-                    a.x = pack2x<F16>(dK[dt][4 * u] * scale, dK[dt][4 * u + 1] * scale);
-                    a.y = pack2x<F16>(dK[dt][4 * u + 2] * scale, dK[dt][4 * u + 3] * scale);
-                    b.x = pack2x<F16>(dV[dt][4 * u], dV[dt][4 * u + 1]);
-                    b.y = pack2x<F16>(dV[dt][4 * u + 2], dV[dt][4 * u + 3]);
-                    *(uint2*)(ok + d0) = a;
-                    *(uint2*)(ov + d0) = b;
+                for (int u = 0; u < 4; u += 2) {
+                    uint2 a[2], b[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int t = 4 * (u + k);
+                        a[k].x = pack2x<F16>(dK[dt][t] * scale, dK[dt][t + 1] * scale);
+                        a[k].y = pack2x<F16>(dK[dt][t + 2] * scale, dK[dt][t + 3] * scale);
+                        b[k].x = pack2x<F16>(dV[dt][t], dV[dt][t + 1]);
+                        b[k].y = pack2x<F16>(dV[dt][t + 2], dV[dt][t + 3]);
+                    }
+                    const uint4 wa = widen_pair(a[0], a[1]), wb = widen_pair(b[0], b[1]);      // 16 contiguous bytes per lane (see widen_pair)
+                    const int d0 = dt * 32 + 8 * (u + h);
+                    if (key < L) {
+                        *(uint4*)(ok + d0) = wa;
+                        *(uint4*)(ov + d0) = wb;
+                    }
                 }
         }
     }
@@ -672,16 +696,21 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
                     dQ[dt] = mfma32<F16>(tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sa, dQ[dt]);
             }
         }
-        if (q < L) {      // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
+        {                 // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
             bf16_t* oq = dqkv + ((size_t)seq * L + q) * ld + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    uint2 a;
-                    a.x = pack2x<F16>(dQ[dt][4 * u] * scale, dQ[dt][4 * u + 1] * scale);
-                    a.y = pack2x<F16>(dQ[dt][4 * u + 2] * scale, dQ[dt][4 * u + 3] * scale);
-                    *(uint2*)(oq + dt * 32 + 8 * u + 4 * h) = a;
+                for (int u = 0; u < 4; u += 2) {
+                    uint2 a[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int t = 4 * (u + k);
+                        a[k].x = pack2x<F16>(dQ[dt][t] * scale, dQ[dt][t + 1] * scale);
+                        a[k].y = pack2x<F16>(dQ[dt][t + 2] * scale, dQ[dt][t + 3] * scale);
+                    }
+                    const uint4 w = widen_pair(a[0], a[1]);
+                    if (q < L) *(uint4*)(oq + dt * 32 + 8 * (u + h)) = w;
                 }
         }
     }
@@ -857,16 +886,21 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                     dQ[dt] = mfma32<F16>(tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sa, dQ[dt]);
             }
         }
-        if (q < L) {      // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
+        {                 // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
             bf16_t* oq = dqkv + ((size_t)seq * L + q) * ld + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    uint2 a;
-                    a.x = pack2x<F16>(dQ[dt][4 * u] * scale, dQ[dt][4 * u + 1] * scale);
-                    a.y = pack2x<F16>(dQ[dt][4 * u + 2] * scale, dQ[dt][4 * u + 3] * scale);
-                    *(uint2*)(oq + dt * 32 + 8 * u + 4 * h) = a;
+                for (int u = 0; u < 4; u += 2) {
+                    uint2 a[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int t = 4 * (u + k);
+                        a[k].x = pack2x<F16>(dQ[dt][t] * scale, dQ[dt][t + 1] * scale);
+                        a[k].y = pack2x<F16>(dQ[dt][t + 2] * scale, dQ[dt][t + 3] * scale);
+                    }
+                    const uint4 w = widen_pair(a[0], a[1]);
+                    if (q < L) *(uint4*)(oq + dt * 32 + 8 * (u + h)) = w;
                 }
         }
                 }
@@ -927,21 +961,28 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             }
         }
         // dV[dt][t] = dV[key][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
-        if (key < L) {
+        {
             bf16_t* ok = dqkv + ((size_t)seq * L + key) * ld + dm + hd * 64;
             bf16_t* ov = ok + dm;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int d0 = dt * 32 + 8 * u + 4 * h;
-                    uint2 a, b;
-                    a.x = pack2x<F16>(dK[dt][4 * u] * scale, dK[dt][4 * u + 1] * scale);
-                    a.y = pack2x<F16>(dK[dt][4 * u + 2] * scale, dK[dt][4 * u + 3] * scale);
-                    b.x = pack2x<F16>(dV[dt][4 * u], dV[dt][4 * u + 1]);
-                    b.y = pack2x<F16>(dV[dt][4 * u + 2], dV[dt][4 * u + 3]);
-                    *(uint2*)(ok + d0) = a;
-                    *(uint2*)(ov + d0) = b;
+                for (int u = 0; u < 4; u += 2) {
+                    uint2 a[2], b[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int t = 4 * (u + k);
+                        a[k].x = pack2x<F16>(dK[dt][t] * scale, dK[dt][t + 1] * scale);
+                        a[k].y = pack2x<F16>(dK[dt][t + 2] * scale, dK[dt][t + 3] * scale);
+                        b[k].x = pack2x<F16>(dV[dt][t], dV[dt][t + 1]);
+                        b[k].y = pack2x<F16>(dV[dt][t + 2], dV[dt][t + 3]);
+                    }
+                    const uint4 wa = widen_pair(a[0], a[1]), wb = widen_pair(b[0], b[1]);      // 16 contiguous bytes per lane (see widen_pair)
+                    const int d0 = dt * 32 + 8 * (u + h);
+                    if (key < L) {
+                        *(uint4*)(ok + d0) = wa;
+                        *(uint4*)(ov + d0) = wb;
+                    }
                 }
         }
             }

@@ -351,7 +351,8 @@ __device__ __forceinline__ void gemm_nt_epilogue(const GemmNtArgs& p, f32x4 (&ac
 // that pattern against 86-110 cycles and 5.7-7.3 TB/s for instructions that write whole row segments.  Here consecutive lanes own consecutive
 // 16-B pieces of a row: one load, one LDS read and one store per lane and pass, all of them contiguous row segments.
 template <int MT, int NT, int EPI>
-__device__ __forceinline__ void gemm_nt_epilogue_f32(const GemmNtArgs& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane, float* patch) {
+__device__ __forceinline__ void gemm_nt_epilogue_f32(const GemmNtArgs& p, f32x4 (&acc)[MT][NT], int row0, int col0, int lane, float* patch,
+                                                     unsigned long long* dbg = nullptr) {
     constexpr int WCOLS = NT * 16, RS = WCOLS + 4, LPR = WCOLS / 4, RPP = 64 / LPR, NPASS = (32 + RPP - 1) / RPP;
     const EpiFlags<EPI> fl(p);
     const int frow = lane & 15, fq = lane >> 4;
@@ -438,6 +439,9 @@ __device__ __forceinline__ void gemm_nt_epilogue_f32(const GemmNtArgs& p, f32x4 
             if (fl.residual && mh + 1 < MT / 2) prefetch_pass(mh + 1, pass);
             if (lane_ok && r < 32 && m < p.M) *(float4*)((float*)p.C + (size_t)m * p.ldc + nc) = make_float4(x[0], x[1], x[2], x[3]);
         }
+#ifdef CLDRD_DEV_BUILD
+        if (dbg) { const unsigned long long t = __builtin_readcyclecounter(); if (lane == 0) dbg[mh] = t; }      // tools/epi_stamps.py
+#endif
     }
 }
 

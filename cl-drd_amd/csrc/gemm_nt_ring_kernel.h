@@ -271,7 +271,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
         asm volatile("" ::: "memory");
         stamp(3);
         if constexpr (ABL == 10) {
-            gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)), stamps ? stamps + 4 : nullptr);
+            if constexpr (epi_is_f32_only<EPI>()) gemm_nt_epilogue_f32<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)), stamps ? stamps + 4 : nullptr);
+            else gemm_nt_epilogue<8, NT, EPI>(p, acc, m0 + wm * 128, n0 + wn * WN, lane, (float*)smem + wid * (32 * (WN + 4)), stamps ? stamps + 4 : nullptr);
             return;
         }
         if constexpr (ABL == 7) {
