@@ -751,7 +751,11 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
     auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };
     int tb = tid & 255;
     uint4 pq[NCH], pk[NCH], pv[NCH], pdo[NCH], po[NCH];
-    float p_bias = 0.f, p_lse = 0.f;
+    // raw prefetched scalars of the next item: consumed in commit(), i.e. BEHIND the sweep.  (Until round 4 issue() compared the mask word
+    // and scaled the LSE at once: the compiler had to wait for those two loads right there with vmcnt(0) - the counter is in order - and
+    // with them for the twenty tile loads issued just before: the "issue early, write late" prefetch waited for itself.)
+    long long p_mask = 1;
+    float p_lse = 0.f;
     uint32_t pbits[NBW > 0 ? NBW : 1];
     auto issue = [&](int item) {
         const int seq = item / H, hd = item % H;
@@ -772,8 +776,9 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             }
         }
         if (tb < Lp) {
-            p_bias = (tb < L && (!mask || mask[(size_t)seq * L + tb] != 0)) ? 0.f : NEG_BIG;
-            p_lse = tb < L ? lse[((size_t)seq * H + hd) * L + tb] * LOG2E : 1.0e30f;
+            const int tc = tb < L ? tb : L - 1;           // clamped: the compare with L happens in commit()
+            p_mask = mask ? mask[(size_t)seq * L + tc] : 1;
+            p_lse = lse[((size_t)seq * H + hd) * L + tc];
         }
         if constexpr (BITS) {
 #pragma unroll
@@ -800,8 +805,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             if (ch == 0) fl[2 * Lp + row] = dsum;
         }
         if (tb < Lp) {
-            fl[tb] = p_bias;
-            fl[Lp + tb] = p_lse;
+            fl[tb] = (tb < L && p_mask != 0) ? 0.f : NEG_BIG;
+            fl[Lp + tb] = tb < L ? p_lse * LOG2E : 1.0e30f;
             ((uint32_t*)fl)[3 * Lp + tb] = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + tb));
         }
         if constexpr (BITS) {

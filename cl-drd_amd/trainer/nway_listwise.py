@@ -126,6 +126,8 @@ class NwayTrainer:
             self.flat_g.record_stream(self.comm_stream)        # the bucket slices are used on it (the buffer lives as long as the trainer)
         # the query tower's stream, at the priority of torch's current stream (a high-priority stream changed nothing: profiles/r03_microbench.txt)
         self.q_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        # third stream: scoring + loss + score backward between the towers' forward and backward (see forward_backward)
+        self.l_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = []
         # CLDRD_AMP=fp16 towers (encoder.py: amp16): the loss scale lives in device memory (hip_ops.new_loss_scale_state).  It is set every
         # step from dL/dCLS (ops.loss_scale_adapt: a power of two that puts the largest entering gradient at 2^11..2^12); what is kept of
@@ -170,7 +172,7 @@ class NwayTrainer:
             self._pending.append(work)
         return hook
 
-    def _early_norm_hook(self, main, side):
+    def _early_norm_hook(self, main, side, defer=False):
         """One GPU: the clip norm is taken in two pieces.  When the passage tower's embedding block is complete (hook -1, called BEFORE
         its last weight-gradient group is launched) every gradient of the query tower (whose backward is already queued on the second
         stream) and of that block is final: [0, split) of the joint buffer, two thirds of it.  Their sums of squares are taken on the
@@ -185,11 +187,27 @@ class NwayTrainer:
                 return
             ev = torch.cuda.Event()
             ev.record(main)
+            if defer:
+                # the query tower's backward is enqueued BEHIND the passage tower's (graph capture, see _backward): the partial norm has to
+                # follow it on the second stream - `_finish_early_norm` - and still only waits for THIS point of the main stream
+                self._norm_deferred = (ev, split, half)
+                return
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 ops.sqnorm_partial(self.flat_g[:split], self.norm_partial, half)
             self._norm_split = split
         return hook
+
+    def _finish_early_norm(self, side):
+        d = getattr(self, "_norm_deferred", None)
+        self._norm_deferred = None
+        if d is None:
+            return
+        ev, split, half = d
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            ops.sqnorm_partial(self.flat_g[:split], self.norm_partial, half)
+        self._norm_split = split
 
     def _wait_pending(self):
         """Order every outstanding bucket all-reduce before whatever the CURRENT stream runs next (the gradient norm / optimizer):
@@ -243,26 +261,44 @@ class NwayTrainer:
             q_cls.record_stream(main)
         mode = score_mode(model.in_batch_loss, model.all_in_batch_neg)
         Np = nway if mode == 0 else (bz * nway if mode == 1 else 2 * nway)
-        logits = torch.empty(bz, Np, dtype=torch.float32, device=q_cls.device)
-        ops.score_fwd(q_cls, p_cls, logits, bz, nway, mode)
-        labels = batch["labels"].to(device=logits.device, dtype=torch.float32)
-        if mode != 0:   # in-batch negatives get the -0.5 label (reference nway_listwise_1.py:341-344)
-            labels = torch.cat([labels, torch.full((bz, Np - nway), -0.5, dtype=torch.float32, device=logits.device)], dim=-1)
-        loss_out, dlogits = ops.loss_fwd_bwd(self.loss_kind, logits, labels.contiguous(), T=self.T)
-        if self.reg_lambda > 0.0 and mode == 0:     # reference nway_listwise_1.py:346-350: only without in-batch negatives
-            self.last_reg = torch.empty(1, dtype=torch.float32, device=logits.device)
-            ops.logit_norm_reg(logits, self.reg_lambda, loss_out, dlogits, self.last_reg)
-        if self.world > 1:
-            dlogits.mul_(1.0 / self.world)      # gradient mean over ranks == DDP's all-reduce / world_size
-        dq, dp = torch.empty_like(q_cls), torch.empty_like(p_cls)
+        # Scoring, loss and score backward on a stream of their OWN between the two joins.  In a replayed HIP graph a cross-stream edge is
+        # honoured when the source stream's run of consecutive nodes ENDS, not at the node the edge leaves from: with the loss kernels on the
+        # main stream the executor kept them and the query tower's backward (the branch captured first) in one run on one hardware queue, and
+        # the passage tower's backward - the critical path - started only when that run was over: 0.62 ms of 5-10-us kernels with the rest of
+        # the chip idle (kernel trace of the replayed step, profiles/r04_microbench.txt section 14).  A run that contains nothing but the loss
+        # ends where both towers' backward begin.
+        lst = self.l_stream if (side is not main and self.l_stream is not None and _env_flag("CLDRD_L_STREAM", "1") != "0") else main
+        if lst is not main:
+            lst.wait_stream(main)
+        with torch.cuda.stream(lst):
+            logits = torch.empty(bz, Np, dtype=torch.float32, device=q_cls.device)
+            ops.score_fwd(q_cls, p_cls, logits, bz, nway, mode)
+            labels = batch["labels"].to(device=logits.device, dtype=torch.float32)
+            if mode != 0:   # in-batch negatives get the -0.5 label (reference nway_listwise_1.py:341-344)
+                labels = torch.cat([labels, torch.full((bz, Np - nway), -0.5, dtype=torch.float32, device=logits.device)], dim=-1)
+            loss_out, dlogits = ops.loss_fwd_bwd(self.loss_kind, logits, labels.contiguous(), T=self.T)
+            if self.reg_lambda > 0.0 and mode == 0:     # reference nway_listwise_1.py:346-350: only without in-batch negatives
+                self.last_reg = torch.empty(1, dtype=torch.float32, device=logits.device)
+                ops.logit_norm_reg(logits, self.reg_lambda, loss_out, dlogits, self.last_reg)
+            if self.world > 1:
+                dlogits.mul_(1.0 / self.world)      # gradient mean over ranks == DDP's all-reduce / world_size
+            dq, dp = torch.empty_like(q_cls), torch.empty_like(p_cls)
+            ops.score_bwd(dlogits, q_cls, p_cls, dq, dp, bz, nway, mode)
+            if self.amp16:
+                ops.loss_scale_adapt(dq, dp, self._scale_state)          # dq, dp leave multiplied by S; every fp16 gradient downstream carries it
+        if lst is not main:
+            main.wait_stream(lst)
+            for t_ in (logits, loss_out, dq, dp, q_cls, p_cls):
+                t_.record_stream(main)
+            q_cls.record_stream(lst)
+            p_cls.record_stream(lst)
         with ops.loss_scale(self._scale_state.data_ptr() if self.amp16 else None, self.scale_growth_interval):
-            return self._backward(batch, model, qe, pe, q_cls, p_cls, q_tape, p_tape, dlogits, dq, dp, bz, nway, mode, main, side, write_once, loss_out, logits)
+            return self._backward(batch, model, qe, pe, q_cls, p_cls, q_tape, p_tape, dlogits, dq, dp, bz, nway, mode, main, side, write_once, loss_out, logits,
+                                  lst)
 
-    def _backward(self, batch, model, qe, pe, q_cls, p_cls, q_tape, p_tape, dlogits, dq, dp, bz, nway, mode, main, side, write_once, loss_out, logits):
-        """score backward (where the loss scale of the amp16 mode enters) + both towers' backward + the bucket all-reduces"""
-        ops.score_bwd(dlogits, q_cls, p_cls, dq, dp, bz, nway, mode)
-        if self.amp16:
-            ops.loss_scale_adapt(dq, dp, self._scale_state)          # dq, dp leave multiplied by S; every fp16 gradient downstream carries it
+    def _backward(self, batch, model, qe, pe, q_cls, p_cls, q_tape, p_tape, dlogits, dq, dp, bz, nway, mode, main, side, write_once, loss_out, logits,
+                  lst=None):
+        """both towers' backward from dq / dp (scaled by the loss scale in the amp16 mode) + the bucket all-reduces"""
         if model.share_weights:
             # one tower, two tapes: gradients accumulate; all-reduce once everything is in
             pe.backward_from_cls(p_tape, dp)
@@ -272,19 +308,32 @@ class NwayTrainer:
         else:
             def query_backward():
                 if side is not main:
-                    side.wait_stream(main)
+                    side.wait_stream(lst if (lst is not None and lst is not main) else main)
                     dq.record_stream(side)
                 with torch.cuda.stream(side):
                     qe.backward_from_cls(q_tape, dq, after_layer=self._bucket_hook(0), accumulate=not write_once)
             # The query tower's ~150 small backward launches run next to the passage tower's data-gradient chain.  (Next to its LAST
             # weight-gradient group instead - one ~3-ms launch off the critical path - measured +1.2 % step time, profiles/r03_microbench.txt:
             # that group loses more to the intruders than the GEMM chain does; the switch for it was removed in round 4.)
-            query_backward()
+            # Order of the two towers' backward.  Eager: the query tower first - its ~150 small launches then run next to the passage tower's
+            # data-gradient chain (enqueued behind ~150 passage launches they would start late and land on the last weight-gradient group:
+            # +1.2 %, round 3).  Under GRAPH CAPTURE the order decides something else: the branch captured first behind the fork continues on
+            # the hardware queue that ran the loss, the other one is released late - with the query tower first, the passage tower's backward
+            # (the critical path) sat idle for 0.62 ms behind the loss in every replayed step (kernel trace, profiles/r04_microbench.txt
+            # section 14).  So a captured step enqueues the passage tower first; the query tower's chain is released ~1.8 ms behind the loss
+            # and still ends 4 ms before the join.
+            q_late = side is not main and torch.cuda.is_current_stream_capturing() and _env_flag("CLDRD_Q_BWD_LATE", "1") != "0"
+            if not q_late:
+                query_backward()
             self._norm_split = None
+            self._norm_deferred = None
             p_hook = self._bucket_hook(1)
             if p_hook is None and side is not main and write_once and _env_flag("CLDRD_NORM_SPLIT", "1") != "0":
-                p_hook = self._early_norm_hook(main, side)
+                p_hook = self._early_norm_hook(main, side, defer=q_late)
             pe.backward_from_cls(p_tape, dp, after_layer=p_hook, accumulate=not write_once)
+            if q_late:
+                query_backward()
+                self._finish_early_norm(side)
             main.wait_stream(side)
             if self.distributed:
                 self._wait_pending()
@@ -462,6 +511,7 @@ class NwayTrainer:
                     t._t_fresh = False       # refresh_transposed() inside the failed capture set the flag without executing a kernel
                 self._state = None
                 self._norm_split = None
+                self._norm_deferred = None
                 torch.cuda.synchronize()
                 return None
         # this step's inputs and state, in stream order in front of the replay
@@ -510,7 +560,7 @@ class NwayTrainer:
                 # join every stream forked inside the capture before it ends: otherwise ending it fails too ("unjoined work"), the stream
                 # stays in capture mode and the eager fallback cannot run either
                 cur = torch.cuda.current_stream()
-                for s_ in (self.q_stream, self.comm_stream):
+                for s_ in (self.q_stream, self.l_stream, self.comm_stream):
                     if s_ is not None:
                         cur.wait_stream(s_)
                 raise
