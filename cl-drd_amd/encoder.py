@@ -603,6 +603,10 @@ class HipEncoder(nn.Module):
                 or _env_flag("CLDRD_PACK", "1") == "0"):
             return False
         n_tok = int(sum(int(v) for v in (lengths.reshape(-1).tolist() if hasattr(lengths, "reshape") else lengths)))
+        if n_tok < 1024 <= M * L:
+            # packing would move the Linear layers from the large-M GEMM kernel to the small-M one (split along K: another summation order), and
+            # "packed == padded bit for bit" would stop holding (tools/model_fuzz.py, seed 1 case 0); at such sizes packing buys nothing
+            return False
         return 0 < n_tok <= int(0.92 * M * L)
 
     def next_seed(self) -> int:
