@@ -25,6 +25,7 @@ out_f, pre = torch.empty(T, f, device=dev, dtype=torch.float16), torch.empty(T, 
 out32, out_d = torch.empty(T, d, device=dev), torch.empty(T, d, device=dev, dtype=torch.float16)
 cases = {
     "FFN1 fwd (bias, GELU, gelu' tape) N3072 K768": lambda: ops.gemm_nt(x, W1, out_f, T, bias=b_f, preact=pre, act=3),
+    "FFN1 eval (bias, GELU, no tape) N3072 K768": lambda: ops.gemm_nt(x, W1, out_f, T, bias=b_f, act=1),
     "FFN2 fwd (bias, drop, LN(res32), f32) N768 K3072": lambda: ops.gemm_nt(hbig, W2, out32, T, bias=b_d, residual=s32, dropout_p=0.1, seed=5, residual_ln=(mean, rstd, gam, bet)),
     "out-proj (bias, drop, LN(res32), f32) N768 K768": lambda: ops.gemm_nt(x, Wo, out32, T, bias=b_d, residual=s32, dropout_p=0.1, seed=5, residual_ln=(mean, rstd, gam, bet)),
     "dgrad FFN2 (x gelu' tape) N3072 K768": lambda: ops.gemm_nt(x, W1, out_f, T, gelu_pre=pre, act=2),
