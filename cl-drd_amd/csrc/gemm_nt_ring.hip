@@ -60,7 +60,7 @@ int cldrd_gemm_nt_ring_dispatch(const GemmNtArgs& a_in, int force_bn, hipStream_
             // prefer the tile count that fills whole rounds of 256 CUs; tie -> the larger tile
             const long t256 = tiles_m * (a.N / 256), t192 = tiles_m * (a.N / 192);
             const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256), e192 = (double)t192 / (double)(((t192 + 255) / 256) * 256);
-            bn = (e192 > e256 + 0.15) ? 192 : 256;     // measured: N=768 -> 192, N=2304/3072 -> 256 (profiles/r01_gemm_bench.txt)
+            bn = (e192 > e256 + 0.01 * CLDRD_DEV_INT("CLDRD_GEMM_BN_MARGIN", 15)) ? 192 : 256;     // measured: N=768 -> 192, N=2304/3072 -> 256 (profiles/r01_gemm_bench.txt)
         } else {
             bn = ok256 ? 256 : 192;
         }
