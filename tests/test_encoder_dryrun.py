@@ -126,3 +126,18 @@ class _FakeStream:
 
     def wait_event(self, e):
         pass
+
+
+def test_would_pack_rules():
+    """Packing is chosen from the host-side token counts: needs a mask and lengths, at least 8 % padding, and never moves the Linear layers across the
+    M = 1024 boundary between the large-M and the small-M GEMM kernels (their summation orders differ: packed == padded would stop being bit-exact)."""
+    enc = HipEncoder(cfg_of("distilbert", 2), seed=1)
+    M, L = 64, 32                                     # 2048 padded rows
+    full = [L] * M
+    assert not enc.would_pack(full, M, L)             # no padding at all
+    assert not enc.would_pack(None, M, L)
+    assert enc.would_pack([20] * M, M, L)             # 1280 tokens: both sides of the run on the large-M kernel
+    assert not enc.would_pack([20] * M, M, L, has_mask=False)
+    assert not enc.would_pack([10] * M, M, L)         # 640 tokens < 1024 <= 2048 padded rows: stays padded
+    assert enc.would_pack([10] * 16, 16, L)           # 160 of 512: both small-M
+    assert not enc.would_pack([31] * M, M, L)         # 3 % padding: not worth the row moves
