@@ -571,7 +571,7 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
         for (int i = 0; i < n; ++i) need += (size_t)splits * ((size_t)N1[i] * N2[i] + (size_t)N1[i]);
         CLDRD_CHECK(workspace != nullptr && ((uintptr_t)workspace % 16 == 0) && workspace_bytes >= need * sizeof(float), "wgrad: workspace too small");
     }
-    const int env_order = -1;       // tile order per problem (below)
+    const int env_order = CLDRD_DEV_INT("CLDRD_WGRAD_ORDER", -1);       // tile order per problem (below); development build: 0 / 1 force n2- / n1-fastest
     size_t slab_off = 0;
     for (int lo = 0; lo < n; lo += MAXP) {
         const int m = n - lo < MAXP ? n - lo : MAXP;
