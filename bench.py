@@ -22,10 +22,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-if (int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("CLDRD_FORCE_DDP", "0") == "1") and \
-        (os.environ.get("CLDRD_GRAPH", "1") == "0" or os.environ.get("CLDRD_DDP_GRAPH", "1") == "0"):
+_W = int(os.environ.get("WORLD_SIZE", "1") or 1)
+if (_W > 1 or os.environ.get("CLDRD_FORCE_DDP", "0") == "1") and \
+        (os.environ.get("CLDRD_GRAPH", "1") == "0" or os.environ.get("CLDRD_DDP_GRAPH", "1" if _W == 1 else "0") != "1"):
     # before HIP initialises, EAGER ranks of a multi-process job only: see cl-drd_amd/__init__.py (two towers on two streams next to RCCL's;
-    # ranks that replay the step as a HIP graph - the default - are faster with the default four queues)
+    # ranks that replay the step as a HIP graph - one-rank groups by default, multi-rank jobs with CLDRD_DDP_GRAPH=1 - are faster with four)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
@@ -173,7 +174,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- the timed region: W warm-up steps, then exactly K steps between barriers.  At N = 1 the trainer replays the step as a HIP graph
-    # after its first three eager steps (trainer/nway_listwise.py: train_step); under torch.distributed the step is eager.
+    # after its first three eager steps (trainer/nway_listwise.py: train_step); data-parallel ranks run it eagerly unless CLDRD_DDP_GRAPH=1.
     for _ in range(args.warmup):
         trainer.train_step(batch)
     sync_all()
@@ -428,6 +429,55 @@ def main():
                     write_run_file(os.path.join(td, "dev.run"), list(range(nq_r)), Ih, Dh)
                     run_file_s = time.perf_counter() - t4
             del Dh, Ih
+            # (3b) the 8-way sharded search END TO END (north_star: "per-shard brute-force top-k GEMM then a host-side merge"; the reference's
+            # dead faiss branch retriever/retrieval_utils.py:164-182): every rank searches its shard, the lists go to rank 0 with one
+            # dist.gather per tensor over RCCL and rank 0 merges them on the device (ShardedFlatIPIndex.gather_merge_device) - search,
+            # gather AND merge inside the wall clock.  At N = 1 there is nobody to gather from: the merge alone is timed on eight
+            # synthetic shard lists of the cfg5 shape (this shard's own lists, scores shifted per shard so that the lists interleave).
+            from cldrd_amd.retriever.retrieval_utils import ShardedFlatIPIndex
+            sharded = {}
+            if world > 1:
+                sh = ShardedFlatIPIndex(flat_index, rank, world)
+                for rep in range(2):                          # the first pass warms the communicator up
+                    sync_all()
+                    t6 = time.perf_counter()
+                    Dd_, Id_ = flat_index.search_ids_device(qn, kq)
+                    Dm_, Im_ = sh.gather_merge_device(Dd_.contiguous(), Id_.contiguous(), kq)
+                    torch.cuda.synchronize()
+                    d_sh = time.perf_counter() - t6
+                ts_ = torch.tensor([d_sh], dtype=torch.float64, device=dev)
+                dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+                d_sh = float(ts_.item())
+                if rank == 0:
+                    assert bool((Dm_[:, 1:] <= Dm_[:, :-1]).all()) and int(Im_.min()) >= 0 and int(Im_.max()) < world * rows
+                sharded = {"sharded_wall_s": round(d_sh, 4), "sharded_wall_ms_per_batch": round(1e3 * d_sh / nb, 3), "sharded_merge": sh.last_merge.get("path"),
+                           "sharded_queries_per_s": round(nq_r / d_sh, 1),
+                           # sum of the bytes all shards stream (SURVEY.md 8d unit x batches x shards) / (wall x n_gpu x HBM peak)
+                           "sharded_wall_hbm_frac": round((rows * D * 2 + 128 * D * 2) / (1e3 * d_sh / nb) / 1e6 / 8000.0, 4)}
+                del Dd_, Id_, Dm_, Im_
+            else:
+                Id64 = Iq.to(torch.int64)
+                allD = torch.stack([Dq + 0.37 * r_ / 8.0 for r_ in range(8)]).contiguous()
+                allI = torch.stack([torch.where(Id64 >= 0, Id64 + r_ * rows, Id64) for r_ in range(8)]).contiguous()
+                ops2m = ops.merge_topk_device
+                ops2m(allD[:, :64].contiguous(), allI[:, :64].contiguous(), kq)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                Dm_, Im_ = ops2m(allD, allI, kq)
+                e1.record()
+                torch.cuda.synchronize()
+                hD, hI = list(allD.cpu().numpy()), list(allI.cpu().numpy())
+                ops.merge_topk_host([d_[:8] for d_ in hD], [i_[:8] for i_ in hI], kq)
+                t7 = time.perf_counter()
+                Dh8, Ih8 = ops.merge_topk_host(hD, hI, kq)
+                d_h8 = time.perf_counter() - t7
+                import numpy as _np
+                assert _np.array_equal(Ih8, Im_.cpu().numpy()) and _np.array_equal(Dh8, Dm_.cpu().numpy()), "device and host merge disagree"
+                sharded = {"merge8_ms": round(e0.elapsed_time(e1), 3), "merge8_host_ms": round(1e3 * d_h8, 2),
+                           "merge8": f"eight synthetic shard lists of {nq_r} x {kq} (this shard's lists, scores shifted per shard) merged on the device "
+                                     "(cldrd_merge_topk_device, HIP events) and by the native host merge (cldrd_merge_topk, wall clock); results identical"}
+                del allD, allI, Dm_, Im_, hD, hI, Dh8, Ih8, Id64
             # (4) the dominant kernel alone: the fp16 streaming scan of one 128-query batch, HIP events on its stream
             from cldrd_amd import hip_ops as ops2
             qh16 = qn[:128].half().contiguous()
@@ -471,7 +521,7 @@ def main():
                         "path_hbm_frac": round(scan_bytes / batch_ms / 1e6 / 8000.0, 4),
                         "wall_ms_per_batch": round(1e3 * dr / nb, 3), "wall_hbm_frac": round(scan_bytes / (1e3 * dr / nb) / 1e6 / 8000.0, 4),
                         "host_api_queries_per_s": round(nq_r / dh, 1), "host_api_s": round(dh, 4),
-                        "run_file_s": None if run_file_s is None else round(run_file_s, 4), "run_file_lines": nq_r * kq}
+                        "run_file_s": None if run_file_s is None else round(run_file_s, 4), "run_file_lines": nq_r * kq, **sharded}
             del flat_index, P
             # (5) the same search on a CLS-LIKE (anisotropic) shard: the regime of real dual-encoder embeddings, where every row scores
             # close to every other, the 2 eps band under the k-th score holds ~3x the rows and the re-score is the larger part of a pass

@@ -80,9 +80,12 @@ SIGNATURES = {
     "cldrd_set_optim_hyper": (None, [vp]),
     "cldrd_set_loss_scale": (None, [vp, ci]),
     "cldrd_loss_scale_adapt": (ci, [vp, csz, vp, csz, vp, vp]),
-    "cldrd_write_step_state": (ci, [vp, cull, cull, vp, cf, cf, cf, ci, vp]),
+    "cldrd_write_step_state": (ci, [vp, cull, cull, vp, cf, cf, cf, ci, vp, vp]),
     "cldrd_write_run_file": (C.c_longlong, [C.c_char_p, vp, vp, vp, C.c_longlong, ci, ci]),
     "cldrd_py_float_repr": (ci, [C.c_double, C.c_char_p]),
+    "cldrd_merge_topk": (ci, [vp, vp, ci, C.c_longlong, ci, ci, vp, vp, ci]),
+    "cldrd_merge_topk_device_workspace": (csz, [ci, C.c_longlong, ci, ci]),
+    "cldrd_merge_topk_device": (ci, [vp, vp, ci, C.c_longlong, ci, ci, vp, vp, vp, csz, vp]),
 }
 
 

@@ -50,10 +50,12 @@ extern "C" void cldrd_set_seed_base(const unsigned long long* base) { g_cldrd_se
 // float[2] instead of their by-value arguments; null: off.
 extern "C" void cldrd_set_optim_hyper(const float* hyper) { g_cldrd_optim_hyper = hyper; }
 // Loss scaling of the all-fp16 training mode (reference: torch.cuda.amp.GradScaler around nway_listwise_1.py:334-359).  scale = device
-// float[4] {S, 1 / S, finite steps since S last changed, skipped steps} (cldrd_clip_coef / cldrd_grad_clip_coef update it, optim.hip): launches made by this thread from now on that PRODUCE activation gradients from the loss multiply by S
-// (cldrd_loss_fwd_bwd*: dlogits) and launches that produce PARAMETER gradients multiply by 1 / S (cldrd_wgrad_group, cldrd_ln_reduce_group,
-// cldrd_layernorm_bwd's own reduction, cldrd_embed_ln_bwd) - so every 16-bit gradient tensor in between carries the scale and flat_g never
-// does.  Read on the device at run time (a replayed graph sees the current value).  null: off.
+// float[72] (ALL 72 are written: a shorter buffer is overrun) = {[0] S, [1] 1 / S, [2] finite steps since the headroom last changed,
+// [3] skipped steps, [4] headroom exponent h <= 0, [5..7] unused, [8..71] scratch of cldrd_loss_scale_adapt}.  cldrd_loss_scale_adapt
+// sets S every step from dL/dCLS and multiplies dL/dCLS by it (so every 16-bit gradient tensor of the backward carries S);
+// cldrd_clip_coef / cldrd_grad_clip_coef run the safety net ([2..4]).  Launches made by this thread from now on that produce PARAMETER
+// gradients multiply by 1 / S where they write them: cldrd_wgrad_group (epilogue / slab reduction), cldrd_layernorm_bwd (inside its
+// per-block partial sums, so cldrd_ln_reduce_group adds unscaled numbers), cldrd_embed_ln_bwd (atomics) - flat_g never carries the scale.  Read on the device at run time (a replayed graph sees the current value).  null: off.
 thread_local const float* g_cldrd_loss_scale = nullptr;
 thread_local int g_cldrd_loss_scale_interval = 2000;
 extern "C" void cldrd_set_loss_scale(const float* scale, int growth_interval) {
@@ -62,10 +64,22 @@ extern "C" void cldrd_set_loss_scale(const float* scale, int growth_interval) {
 }
 
 namespace {
-__global__ void step_state_kernel(unsigned long long* seeds, unsigned long long s0, unsigned long long s1, float* hyper, float lr, float step_size) {
+__global__ void step_state_kernel(unsigned long long* seeds, unsigned long long s0, unsigned long long s1, float* hyper, float lr, float step_size,
+                                  float beta1, float beta2, int adam_step, const float* scale_state) {
     if (threadIdx.x == 0) {
         if (seeds) { seeds[0] = s0; seeds[1] = s1; }
-        if (hyper) { hyper[0] = lr; hyper[1] = step_size; }
+        if (hyper) {
+            if (scale_state) {
+                // GradScaler semantics (reference nway_listwise_1.py:357: scaler.step() does not call optimizer.step() on a non-finite
+                // gradient, so Adam's per-parameter `step` - the bias-correction exponent - only counts the steps that were applied):
+                // the skipped count lives on the device (clip_coef_kernel), so the exponent is formed here, not on the host
+                int t = adam_step - (int)scale_state[3];
+                if (t < 1) t = 1;
+                const double bc1 = 1.0 - pow((double)beta1, (double)t), bc2 = 1.0 - pow((double)beta2, (double)t);
+                step_size = (float)((double)lr * sqrt(bc2) / bc1);
+            }
+            hyper[0] = lr; hyper[1] = step_size;
+        }
     }
 }
 }  // namespace
@@ -110,11 +124,13 @@ extern "C" int cldrd_copy_segments(const void* const* src, void* const* dst, con
 
 // One tiny launch that writes this step's values (two seed words, lr, Adam step size for bias-correction step `adam_step`) to device
 // memory, in stream order in front of the replay that reads them.
+// scale_state (optional): the float[72] loss-scale block; the bias-correction exponent becomes adam_step - skipped steps (state[3]), read on the device.
 extern "C" int cldrd_write_step_state(unsigned long long* seeds, unsigned long long seed0, unsigned long long seed1, float* hyper, float lr,
-                                      float beta1, float beta2, int adam_step, void* stream) {
+                                      float beta1, float beta2, int adam_step, const float* scale_state, void* stream) {
     CLDRD_CHECK(adam_step >= 1, "write_step_state: the Adam step is 1-based");
     const double bc1 = 1.0 - pow((double)beta1, (double)adam_step), bc2 = 1.0 - pow((double)beta2, (double)adam_step);
-    hipLaunchKernelGGL(step_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seeds, seed0, seed1, hyper, lr, (float)((double)lr * sqrt(bc2) / bc1));
+    hipLaunchKernelGGL(step_state_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, seeds, seed0, seed1, hyper, lr, (float)((double)lr * sqrt(bc2) / bc1),
+                       beta1, beta2, adam_step, scale_state);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

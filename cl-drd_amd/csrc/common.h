@@ -115,7 +115,7 @@ struct SeedArg {
 };
 extern thread_local const unsigned long long* g_cldrd_seed_base;      // capi.hip; host side
 extern thread_local const float* g_cldrd_optim_hyper;                 // capi.hip: device float[2] = {lr, step size} or null
-extern thread_local const float* g_cldrd_loss_scale;                  // capi.hip: device float[4] = {S, 1 / S, good steps, skipped steps} or null
+extern thread_local const float* g_cldrd_loss_scale;                  // capi.hip: device float[72] = {S, 1 / S, good steps, skipped steps, headroom h, 3 unused, 64 scratch} or null
 extern thread_local int g_cldrd_loss_scale_interval;                  // finite steps in a row after which S doubles (cldrd_set_loss_scale)
 static inline SeedArg seed_arg(unsigned long long s) { return SeedArg{s, g_cldrd_seed_base}; }
 

@@ -61,9 +61,7 @@ __global__ __launch_bounds__(256) void score_fwd_kernel(const float* __restrict_
 
 // dq[b] = sum_j dl[b][j] * p[passage(b, j)]
 __global__ __launch_bounds__(256) void score_bwd_q_kernel(const float* __restrict__ dl, const float* __restrict__ p,
-                                                           float* __restrict__ dq, int B, int N, int Np, int d, int mode,
-                                                           const float* __restrict__ scale) {
-    // scale (device scalar or null): an optional factor on the result (unused: the amp16 loss scale is applied by cldrd_loss_scale_adapt)
+                                                           float* __restrict__ dq, int B, int N, int Np, int d, int mode) {
     // grid (B, column chunks of 256): with one block per query a thread walked its Np passages one dependent load after the other
     // (26 us at B = 8, N = 32 on the step's critical path between the loss and the first backward GEMM); the loads of eight passages are
     // now in flight together.  Same summation order (j ascending): same bits.
@@ -80,14 +78,12 @@ __global__ __launch_bounds__(256) void score_bwd_q_kernel(const float* __restric
         for (int u = 0; u < 8; ++u) s += w[u] * v[u];
     }
     for (; j < Np; ++j) s += dl[(size_t)b * Np + j] * p[(size_t)col_to_passage(mode, b, j, B, N) * d + c];
-    dq[(size_t)b * d + c] = scale ? s * *scale : s;
+    dq[(size_t)b * d + c] = s;
 }
 // dp[m] = sum over (b, j) with passage(b, j) == m of dl[b][j] * q[b]
 __global__ __launch_bounds__(256) void score_bwd_p_kernel(const float* __restrict__ dl, const float* __restrict__ q,
-                                                           float* __restrict__ dp, int B, int N, int Np, int d, int mode,
-                                                           const float* __restrict__ scale) {
+                                                           float* __restrict__ dp, int B, int N, int Np, int d, int mode) {
     const int m = blockIdx.x;
-    const float sc = scale ? *scale : 1.0f;
     const int bo = m / N, o = m % N;
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float s = dl[(size_t)bo * Np + o] * q[(size_t)bo * d + c];
@@ -98,7 +94,7 @@ __global__ __launch_bounds__(256) void score_bwd_p_kernel(const float* __restric
             const int b = (bo - 1 + B) % B;
             s += dl[(size_t)b * Np + N + o] * q[(size_t)b * d + c];
         }
-        dp[(size_t)m * d + c] = s * sc;
+        dp[(size_t)m * d + c] = s;
     }
 }
 
@@ -370,9 +366,9 @@ extern "C" int cldrd_score_bwd(const float* dlogits, const float* q, const float
                                int mode, void* stream) {
     CLDRD_CHECK(B > 0 && N > 0 && d > 0 && mode >= 0 && mode <= 2, "score_bwd: bad arguments");
     const int Np = mode == 0 ? N : (mode == 1 ? B * N : 2 * N);
-    hipLaunchKernelGGL(score_bwd_q_kernel, dim3(B, (d + 255) / 256), dim3(256), 0, (hipStream_t)stream, dlogits, p, dq, B, N, Np, d, mode, (const float*)nullptr);
+    hipLaunchKernelGGL(score_bwd_q_kernel, dim3(B, (d + 255) / 256), dim3(256), 0, (hipStream_t)stream, dlogits, p, dq, B, N, Np, d, mode);
     CLDRD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(score_bwd_p_kernel, dim3(B * N), dim3(256), 0, (hipStream_t)stream, dlogits, q, dp, B, N, Np, d, mode, (const float*)nullptr);
+    hipLaunchKernelGGL(score_bwd_p_kernel, dim3(B * N), dim3(256), 0, (hipStream_t)stream, dlogits, q, dp, B, N, Np, d, mode);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

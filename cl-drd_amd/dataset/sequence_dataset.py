@@ -149,22 +149,38 @@ class SequenceTokenCache:
         process group on that path - wait for its metadata file to appear."""
         stem = cls.stem_for(cache_dir, path, max_length)
         want = cls.source_meta(path, tokenizer, max_length)
+        stale_err = None
         if os.path.exists(stem + ".meta.json"):
             try:
                 return cls.load(stem, want)
-            except ValueError:
-                pass            # stale (another collection / tokenizer / length): rank 0 rebuilds it below, the others wait for that
+            except ValueError as exc:
+                stale_err = exc            # stale (another collection / tokenizer / length): rank 0 rebuilds it below, the others wait for that
         if rank == 0:
+            # the metadata file goes FIRST: waiters key on it, and while a rebuild replaces ids / lens / keys one by one nobody may load a
+            # mix of new arrays and old metadata
+            try:
+                os.remove(stem + ".meta.json")
+            except FileNotFoundError:
+                pass
             return cls.build(path, tokenizer, max_length, stem)
+        # Other ranks wait for rank 0 - but not blindly: a STALE metadata file that rank 0 has not removed within `stale_grace_s` means
+        # rank 0 does not see it as stale (another tokenizer / collection there), has not started, or died: fail with the reason instead of
+        # polling for two hours.  Progress of a build is visible as the growing temporary ids file.
+        stale_grace_s = min(wait_s, 120.0)
         t0 = time.time()
+        last_err = stale_err
         while time.time() - t0 < wait_s:
             if os.path.exists(stem + ".meta.json"):
                 try:
                     return cls.load(stem, want)
-                except ValueError:
-                    pass
+                except ValueError as exc:
+                    last_err = exc
+                    if time.time() - t0 > stale_grace_s:
+                        raise ValueError(f"{exc} (rank {rank}: rank 0 has not replaced this cache within {stale_grace_s:.0f} s - does it run with "
+                                         f"the same collection / tokenizer / max_length?)") from exc
             time.sleep(1.0)
-        raise TimeoutError(f"sequence token cache {stem}: rank 0 did not finish it within {wait_s:.0f} s")
+        raise TimeoutError(f"sequence token cache {stem}: rank 0 did not finish it within {wait_s:.0f} s"
+                           + (f" (last problem: {last_err})" if last_err else ""))
 
 
 class CachedSequenceDataset(torch.utils.data.Dataset):

@@ -137,10 +137,15 @@ class optim_hyper:
             _TLS.optim_hyper = self.prev
 
 
-def write_step_state(seeds, seed0, seed1, hyper, lr, beta1, beta2, adam_step):
-    """seeds: device int64[>= 2]; hyper: device float32[>= 2] (either may be None)."""
+def write_step_state(seeds, seed0, seed1, hyper, lr, beta1, beta2, adam_step, scale_state=None):
+    """seeds: device int64[>= 2]; hyper: device float32[>= 2] (either may be None).  ``scale_state`` (the float[72] loss-scale block,
+    optional): Adam's bias-correction exponent becomes ``adam_step`` minus the steps the safety net skipped, read on the device."""
+    if scale_state is not None:
+        _chk(scale_state, F32, "scale_state", 1)
+        if scale_state.numel() < 72:
+            raise ValueError("write_step_state: scale_state is the float[72] block of new_loss_scale_state()")
     call("cldrd_write_step_state", _p(seeds), int(seed0) & 0xFFFFFFFFFFFFFFFF, int(seed1) & 0xFFFFFFFFFFFFFFFF, _p(hyper), float(lr), float(beta1),
-         float(beta2), int(adam_step), _stream())
+         float(beta2), int(adam_step), _p(scale_state), _stream())
 
 
 def copy_segments(dsts, srcs):
@@ -768,3 +773,47 @@ def row_sqnorm_max(P32) -> float:
 def gather_cast_rows(src32, dst_bf16, n_out, stride):
     _chk(src32, F32, "src32", 2), _chk(dst_bf16, BF16, "dst_bf16", 2)
     call("cldrd_gather_cast_rows", _p(src32), _p(dst_bf16), n_out, stride, src32.shape[1], _stream())
+
+
+# ---------------------------------------------------------------------------------------------------- merge of shard lists
+
+def merge_topk_host(shard_D, shard_I, k, nthreads=0):
+    """Host k-way merge (include/cldrd_hip.h: cldrd_merge_topk) of per-shard lists: numpy float32 [nq, k_in] / int64 [nq, k_in] per shard
+    -> (D float32 [nq, k], I int64 [nq, k]).  Native host threads; no GPU work."""
+    import ctypes as C
+    import numpy as np
+    world = len(shard_D)
+    if world == 0 or len(shard_I) != world:
+        raise ValueError("merge_topk_host: one score list and one id list per shard")
+    Ds = [np.ascontiguousarray(d, dtype=np.float32) for d in shard_D]
+    Is = [np.ascontiguousarray(i, dtype=np.int64) for i in shard_I]
+    nq, k_in = Ds[0].shape
+    if any(d.shape != (nq, k_in) for d in Ds) or any(i.shape != (nq, k_in) for i in Is):
+        raise ValueError("merge_topk_host: every shard list must be [nq, k_in]")
+    k = int(k)
+    D = np.empty((nq, k), dtype=np.float32)
+    I = np.empty((nq, k), dtype=np.int64)
+    if nq == 0:
+        return D, I
+    VP = C.c_void_p * world
+    call("cldrd_merge_topk", VP(*[d.ctypes.data for d in Ds]), VP(*[i.ctypes.data for i in Is]), world, nq, k_in, k, D.ctypes.data,
+         I.ctypes.data, int(nthreads))
+    return D, I
+
+
+def merge_topk_device(scores, ids, k):
+    """Device merge (cldrd_merge_topk_device): scores fp32 [world, nq, k_in], ids int64 [world, nq, k_in] in HBM -> (D fp32 [nq, k],
+    I int64 [nq, k]) in HBM; world * k_in <= 8192, k <= world * k_in."""
+    _chk(scores, F32, "scores", 3), _chk(ids, torch.int64, "ids", 3)
+    if scores.shape != ids.shape or not scores.is_contiguous() or not ids.is_contiguous():
+        raise ValueError("merge_topk_device: contiguous [world, nq, k_in] scores and ids")
+    world, nq, k_in = scores.shape
+    k = int(k)
+    D = torch.empty(nq, k, dtype=F32, device=scores.device)
+    I = torch.empty(nq, k, dtype=torch.int64, device=scores.device)
+    if nq == 0:
+        return D, I
+    nbytes = int(_lib.load().cldrd_merge_topk_device_workspace(world, nq, k_in, k))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=scores.device)
+    call("cldrd_merge_topk_device", _p(scores), _p(ids), world, nq, k_in, k, _p(D), _p(I), _p(ws), nbytes, _stream())
+    return D, I

@@ -8,7 +8,12 @@ One process per GPU (``torch.distributed`` backend "nccl" == RCCL over xGMI).  P
     -> clip_grad_norm_(max_grad_norm) as one norm pass -> legacy-HF AdamW + bf16 shadows in one pass -> linear schedule
 
 Differences from the reference, on purpose (SURVEY.md sections 7, 8a14):
-  * bf16 compute with fp32 master weights instead of fp16 autocast + GradScaler (no loss scaling is needed);
+  * mixed precision is hand-placed instead of autocast: every MFMA operand of a training pass is fp16 (the reference's own
+    ``use_fp16`` mode; ``CLDRD_AMP=bf16`` runs the backward / tape on bf16 operands instead - there is NO all-bf16 mode: its forward FFN /
+    out-projection / query tower stay fp16), fp32 accumulate, residual stream, gradient stream and master weights;
+  * the loss scale is a power of two recomputed from dL/dCLS every step (``cldrd_loss_scale_adapt``), where ``GradScaler`` starts at
+    65 536 and searches by overflowing: no early skipped steps here; what is kept is the safety net (a non-finite gradient norm skips the
+    step, which - as in ``scaler.step`` - does not advance Adam's bias-correction step);
   * no per-step D2H sync: loss / train-MRR are read back only every ``logging_steps``;
   * the three stage scripts differ only in defaults, so there is one trainer with a ``--loss`` selector
     (default ``lambda_mrr`` as in the reference).
@@ -136,6 +141,10 @@ class NwayTrainer:
         self.amp16 = any(getattr(t, "amp16", False) for t in model.towers())
         self.scale_growth_interval = 2000
         self._scale_state = ops.new_loss_scale_state(dev) if self.amp16 else None
+        self._hyper = None          # device {lr, Adam step size} of the eager loss-scaled step (see _optimizer_launches)
+        self._last_skip_h = False
+        self._ddp_steps = 0         # train_step calls under torch.distributed (the captured-graph agreement happens at a fixed count)
+        self._ddp_graph_key = None
         if self.distributed:
             # DDP constructor semantics (reference :250-255): rank 0's parameters win
             dist.broadcast(self.flat_p, src=0)
@@ -354,7 +363,16 @@ class NwayTrainer:
         with ops.loss_scale(self._scale_state.data_ptr() if self.amp16 else None, self.scale_growth_interval):     # clip_coef updates the scale
             self._norm_launches()
         towers = self.model.towers()
-        self._adamw_launches(lr, adam_step, towers)
+        hyper = self._state["hyper"] if self._state else None
+        if hyper is None and self.amp16:
+            # eager step of the loss-scaled mode: {lr, step size} go through device memory too, because the bias-correction exponent
+            # is adam_step MINUS the steps the safety net skipped, and that count lives on the device (`_scale_state[3]`, updated by the
+            # clip_coef launch just above; a skipped step leaves p / m / v untouched, so its own step size does not matter)
+            if self._hyper is None:
+                self._hyper = torch.zeros(2, dtype=torch.float32, device=self.flat_p.device)
+            hyper = self._hyper
+            ops.write_step_state(None, 0, 0, hyper, lr, self.betas[0], self.betas[1], adam_step, scale_state=self._scale_state)
+        self._adamw_launches(lr, adam_step, towers, hyper)
 
     def _norm_launches(self):
         split = getattr(self, "_norm_split", None)
@@ -367,7 +385,7 @@ class NwayTrainer:
         else:
             ops.grad_clip_coef(self.flat_g, self.max_grad_norm, self.norm_partial, self.clip)
 
-    def _adamw_launches(self, lr, adam_step, towers):
+    def _adamw_launches(self, lr, adam_step, towers, hyper=None):
         # one AdamW launch over the joint buffer; it also writes the bf16 shadow of every tower
         shadow = self._joint_shadow()
         # all-fp16 training: no pass of a training step reads the bf16 shadow (forward, backward and the transposed copies come from the fp16
@@ -377,7 +395,8 @@ class NwayTrainer:
         # high-precision pass of the query tower): one contiguous range of the joint buffer
         s16, r16 = self._joint_shadow16()
         fused16 = s16 is not None and _env_flag("CLDRD_ADAM_H16", "1") != "0"
-        with ops.optim_hyper(self._state["hyper"].data_ptr() if self._state else None):
+        self._last_skip_h = bool(skip_h and fused16)
+        with ops.optim_hyper(hyper.data_ptr() if hyper is not None else None):
             ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, None if (skip_h and fused16) else shadow, lr=lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=adam_step, clip=self.clip,
                            shadow16=s16[r16[0]:r16[1]] if fused16 else None, h16_range=r16 if fused16 else None)
@@ -460,8 +479,12 @@ class NwayTrainer:
         lr = self.lr(self.global_step - 1)
         seeds = [t.next_seed() for t in self.model.towers()]
         ops.write_step_state(self._state["seeds"], seeds[0], seeds[1] if len(seeds) > 1 else 0, self._state["hyper"], lr, self.betas[0],
-                             self.betas[1], self.adam_step)
+                             self.betas[1], self.adam_step, scale_state=self._scale_state)
         return lr
+
+    def skipped_steps(self) -> int:
+        """Steps the loss-scale safety net skipped so far (a device -> host read: logging / checkpoint time only)."""
+        return int(self._scale_state[3].item()) if self._scale_state is not None else 0
 
     # ---- HIP-graph replay of the step --------------------------------------------------------------------------------------
     _state = None
@@ -470,8 +493,10 @@ class NwayTrainer:
         if self.distributed:
             # data-parallel ranks: the bucket all-reduces are issued from hooks INSIDE the step.  Over ProcessGroupNCCL (= RCCL) they can be
             # captured with it (the collective's launch is recorded on its stream, Work.wait() becomes an event edge of the graph); gloo
-            # (tests) copies through the host and cannot.  CLDRD_DDP_GRAPH=0: eager ranks.
-            if _env_flag("CLDRD_DDP_GRAPH", "1") == "0" or dist.get_backend() != "nccl":
+            # (tests) copies through the host and cannot.  With MORE THAN ONE rank this is opt-in (CLDRD_DDP_GRAPH=1): capture + replay of
+            # collectives has only ever run with one rank on this pool (one GPU per box), so real multi-rank jobs launch eagerly by default;
+            # a one-rank process group (CLDRD_FORCE_DDP: the bench's ddp leg, tests) captures by default.
+            if _env_flag("CLDRD_DDP_GRAPH", "1" if self.world == 1 else "0") != "1" or dist.get_backend() != "nccl":
                 return False
         return (not self.model.share_weights and not getattr(self, "_graph_broken", False)
                 and _env_flag("CLDRD_GRAPH", "1") != "0" and self.flat_p.is_cuda)
@@ -488,6 +513,25 @@ class NwayTrainer:
         if entry is None:
             entry = graphs[key] = {"seen": 0, "graph": None}
         warm = 3
+        ddp = self.distributed        # (a one-rank forced group, CLDRD_FORCE_DDP, takes the same path: the agreement is then a one-rank all-reduce)
+        if ddp:
+            # Ranks that replay captured collectives must all do so for the SAME steps, or the collectives of one rank's replay meet another
+            # rank's eager launches in another order / never (a hang no capture-time check can see).  So: (a) the decision is taken ONCE, at
+            # train_step call number `warm` + 1 on every rank (a count, not a per-shape condition: ranks with dynamic padding see different
+            # shapes); there each rank tries to capture its current batch shape if it has seen nothing else so far, and the ranks agree with
+            # one all_reduce(MIN) of the outcome: a single failure anywhere leaves every rank eager for good; (b) afterwards only that ONE
+            # shape replays - an eager step of another shape issues the same bucket all-reduces in the same order as a replay does, so
+            # mixing the two across ranks is safe, a second capture (another agreement collective at a rank-dependent step) would not be.
+            self._ddp_steps += 1
+            if self._ddp_steps <= warm:
+                entry["seen"] += 1
+                return None
+            if self._ddp_steps > warm + 1:
+                if entry["graph"] is None:
+                    return None
+            elif len(graphs) > 1 or entry["seen"] < warm:
+                self._agree_on_capture(False)
+                return None
         if entry["graph"] is None and entry["seen"] < warm:
             entry["seen"] += 1              # eager: allocator warm-up, one-time kernel attributes
             return None
@@ -498,14 +542,22 @@ class NwayTrainer:
         if entry["graph"] is None:
             if len(graphs) > 4:            # a few shapes at most (the last partial batch is dropped: drop_last): anything else stays eager
                 return None
+            ok = True
             try:
                 entry.update(self._capture(batch))
+                entry["h_stale"] = self._last_skip_h        # the captured AdamW does not write the bf16 shadow (see the replay below)
             except Exception as exc:       # a capture problem must never take training down: fall back to the eager step for good
                 import warnings
                 first = exc
                 while first.__context__ is not None:          # what went wrong INSIDE the capture (the capture's own exit error hides it)
                     first = first.__context__
                 warnings.warn(f"HIP-graph capture of the training step failed ({type(first).__name__}: {first}); staying eager")
+                ok = False
+            if ddp:
+                ok = self._agree_on_capture(ok)
+                if not ok:
+                    entry["graph"] = None
+            if not ok:
                 self._graph_broken = True
                 for t in towers:
                     t.seed_base_ptr = None
@@ -524,8 +576,26 @@ class NwayTrainer:
                 dst.copy_(src, non_blocking=True)
         self._advance_step_state()
         entry["graph"].replay()
+        if entry.get("h_stale"):
+            # The captured AdamW skipped the bf16 weight shadow (all-fp16 training reads none of it).  The Python call that records this
+            # (refresh_shadows(h_stale=True)) ran at capture time only; a replay changes the weights again, so every replay has to leave the
+            # towers marked - or an evaluation forward after further replays would encode with the bf16 matrices of the LAST evaluation.
+            for t in towers:
+                t._h_stale = True
         self.last_logits = entry["logits"]
         return entry["loss_out"]
+
+    def _agree_on_capture(self, ok: bool) -> bool:
+        """MIN over ranks of "my capture worked" (one small all-reduce + a host read, once per job)."""
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.flat_p.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        agreed = bool(int(flag.item()))
+        if not agreed and ok:
+            import warnings
+            warnings.warn("HIP-graph capture of the training step failed on another rank; every rank stays eager")
+        if not agreed:
+            self._graph_broken = True
+        return agreed
 
     @staticmethod
     def _flat_inputs(batch):
@@ -597,11 +667,12 @@ class NwayTrainer:
         index; two param groups), so a reference run can resume from a checkpoint written here and vice versa."""
         groups = self._optimizer_names()
         state, param_groups, idx = {}, [], 0
+        applied = max(0, self.adam_step - self.skipped_steps())      # scaler.step() semantics: skipped steps do not count (reference :357)
         for gi, entries in enumerate(groups):
             ids = []
             for _, ti, n in entries:
-                if ti is not None and self.adam_step > 0:
-                    state[idx] = {"step": self.adam_step, "exp_avg": self._slice(self.m, ti, n).detach().cpu().clone(),
+                if ti is not None and applied > 0:
+                    state[idx] = {"step": applied, "exp_avg": self._slice(self.m, ti, n).detach().cpu().clone(),
                                   "exp_avg_sq": self._slice(self.v, ti, n).detach().cpu().clone()}
                 ids.append(idx)
                 idx += 1
@@ -672,6 +743,8 @@ class NwayTrainer:
         if "scheduler" in ckpt and isinstance(ckpt["scheduler"], dict) and "last_epoch" in ckpt["scheduler"] and "global_step" not in ckpt:
             self.global_step = int(ckpt["scheduler"]["last_epoch"])
         self.adam_step = self.global_step if self._opt_step_loaded is None else self._opt_step_loaded
+        if self._scale_state is not None:
+            self._scale_state[3] = 0.0          # the loaded step already excludes the skipped ones
         for t in self.model.towers():
             t.refresh_shadows(need_transposed=True)
 
@@ -708,7 +781,7 @@ def get_args(argv=None):
     ap.add_argument("--reg_lambda", default=0.0, type=float)
     ap.add_argument("--query_max_len", default=30, type=int)
     ap.add_argument("--passage_max_len", default=256, type=int)
-    ap.add_argument("--use_fp16", default=True, type=bool, help="accepted for compatibility: compute is bf16 MFMA with fp32 master weights")
+    ap.add_argument("--use_fp16", default=True, type=bool, help="accepted for compatibility: MFMA operands are fp16 (loss-scaled backward) with fp32 master weights; CLDRD_AMP=bf16 for a bf16 backward")
     ap.add_argument("--train_batch_size", default=8, type=int)
     ap.add_argument("--share_weights", action="store_true", default=False)
     ap.add_argument("--label_mode", default="8", type=str)
@@ -941,6 +1014,8 @@ def train(args):
                     reg = float(trainer.last_reg.item())
                     reg_m.update(reg), ratio_m.update(reg / loss_val if loss_val else 0.0)
                     extra = dict(reg_loss=reg_m.avg, total_aux_ratio=ratio_m.avg)
+                if trainer.amp16:
+                    extra["skipped_steps"] = float(trainer.skipped_steps())     # the loss-scale safety net (GradScaler's skipped steps)
                 write_train_logs(epoch + 1, trainer.global_step, loss_m.avg, mrr_m.avg, rec_m.avg, trainer.lr(), filename=log_file,
                                  cutoff=topk, **extra)
                 for m in (loss_m, mrr_m, rec_m, reg_m, ratio_m):

@@ -298,7 +298,7 @@ int cldrd_loss_scale_adapt(float* a, size_t na, float* b, size_t nb, float* stat
 /* n <= 8 small device-to-device copies in one launch (host arrays of pointers / byte counts): the inputs of a captured step. */
 int cldrd_copy_segments(const void* const* src, void* const* dst, const size_t* bytes, int n, void* stream);
 int cldrd_write_step_state(unsigned long long* seeds, unsigned long long seed0, unsigned long long seed1, float* hyper, float lr,
-                           float beta1, float beta2, int adam_step, void* stream);
+                           float beta1, float beta2, int adam_step, const float* scale_state, void* stream);
 
 /* ---- run file (retriever/retrieve_top_passages.py:98-105), HOST side: no GPU work -----------------------------------------
  * Writes `qid\tdocid\trank\tscore\n` for nq queries x k hits (rank 1..k) to `path`; the score text is Python's repr of the fp32
@@ -307,6 +307,21 @@ int cldrd_write_step_state(unsigned long long* seeds, unsigned long long seed0, 
 long long cldrd_write_run_file(const char* path, const long long* qids, const long long* docids, const float* scores,
                                long long nq, int k, int nthreads);
 int cldrd_py_float_repr(double x, char* out32);
+
+/* ---- merge of per-shard top-k lists (the host-side merge of the 8-way sharded retrieve, BASELINE.json north_star; the reference meant
+ * faiss' IndexShards for it: retriever/retrieval_utils.py:164-182, retrieve_top_passages.py:85-88) -------------------------------------
+ * Shard r contributes, per query, scores fp32 [k_in] descending and global ids int64 [k_in] (-1 = missing, missing last).  Result: the
+ * k_out best of the world * k_in candidates by (score desc; ties: shard asc, then list position asc = global row position asc, the tie
+ * rule of the single-index search), padded with (-inf, -1).
+ * cldrd_merge_topk: HOST pointers (shard_scores[r] / shard_ids[r] = that shard's [nq, k_in] block), nthreads host threads (<= 0: one
+ *   per hardware thread, at most 64).  Unsorted lists are accepted (that query is partially sorted instead of merged).
+ * cldrd_merge_topk_device: DEVICE pointers, scores / ids = [world, nq, k_in] (what a gather over RCCL leaves on rank 0), world * k_in
+ *   <= 8192 and k_out <= world * k_in; one sort launch per call; `workspace` of cldrd_merge_topk_device_workspace() bytes. */
+int cldrd_merge_topk(const float* const* shard_scores, const long long* const* shard_ids, int world, long long nq, int k_in, int k_out,
+                     float* D, long long* I, int nthreads);
+size_t cldrd_merge_topk_device_workspace(int world, long long nq, int k_in, int k_out);
+int cldrd_merge_topk_device(const float* scores, const long long* ids, int world, long long nq, int k_in, int k_out, float* D,
+                            long long* I, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

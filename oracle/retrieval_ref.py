@@ -77,9 +77,20 @@ def run_file_lines(query_ids, nn_doc_ids, nn_scores):
 
 
 def merge_shard_results(shard_D, shard_I, k):
-    """Host k-way merge of per-shard top-k lists: score desc, tie -> lower global id position."""
+    """Host merge of per-shard top-k lists: score desc; ties -> shard asc, then position in the shard's list asc (for contiguous row-range
+    shards whose lists are ordered (score desc, row asc) that IS global row position asc, the tie rule of flat_ip_search above; with
+    ids = row positions - every test, and the CLIs - it is also "lower id first", the rule this function had until round 4); missing
+    entries (id -1) last; (-inf, -1) padding when fewer than k candidates exist."""
     D = np.concatenate(shard_D, axis=1).astype(np.float64)
     I = np.concatenate(shard_I, axis=1)
-    key_i = np.where(I < 0, np.iinfo(np.int64).max, I)
-    order = np.lexsort((key_i, -D), axis=1)[:, :k]
-    return np.take_along_axis(D, order, axis=1).astype(np.float32), np.take_along_axis(I, order, axis=1)
+    pos = np.broadcast_to(np.arange(D.shape[1], dtype=np.int64), D.shape)
+    missing = (I < 0)
+    order = np.lexsort((pos, -D, missing), axis=1)[:, :k]
+    Dm = np.take_along_axis(D, order, axis=1).astype(np.float32)
+    Im = np.take_along_axis(I, order, axis=1)
+    Dm[Im < 0] = -np.inf
+    if Dm.shape[1] < k:
+        pad = k - Dm.shape[1]
+        Dm = np.concatenate([Dm, np.full((Dm.shape[0], pad), -np.inf, dtype=np.float32)], axis=1)
+        Im = np.concatenate([Im, np.full((Im.shape[0], pad), -1, dtype=np.int64)], axis=1)
+    return Dm, Im

@@ -102,6 +102,68 @@ def test_merge_matches_oracle_merge():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def _shard_lists(seed, world, nq, k, rows_per_shard, tie_levels=0, short=()):
+    """Synthetic per-shard top-k lists in the search's output contract: scores descending, ties ordered by row, global ids = row positions,
+    shards listed in `short` hold fewer than k rows (-1 / -inf padding at the tail).  `tie_levels` > 0 quantises the scores so that equal
+    scores occur inside and ACROSS shards (the tie rule decides)."""
+    rng = np.random.default_rng(seed)
+    Ds, Is = [], []
+    for r in range(world):
+        have = k if r not in short else max(1, k // 3)
+        rows = np.stack([np.sort(rng.choice(rows_per_shard, size=have, replace=False)) for _ in range(nq)])
+        sc = rng.standard_normal((nq, have)).astype(np.float32) * 3.0 + 10.0
+        if tie_levels:
+            sc = np.round(sc * tie_levels) / np.float32(tie_levels)
+        order = np.lexsort((rows, -sc.astype(np.float64)), axis=1)
+        sc, rows = np.take_along_axis(sc, order, axis=1), np.take_along_axis(rows, order, axis=1)
+        D = np.full((nq, k), -np.inf, dtype=np.float32)
+        I = np.full((nq, k), -1, dtype=np.int64)
+        D[:, :have], I[:, :have] = sc, rows + r * rows_per_shard
+        Ds.append(D)
+        Is.append(I)
+    return Ds, Is
+
+
+@pytest.mark.parametrize("tie_levels,short", [(0, ()), (4, ()), (4, (2, 7)), (1, (0, 1, 2, 3, 4, 5, 6))])
+def test_native_merge_equals_oracle_merge_with_ties_and_padding(tie_levels, short):
+    Ds, Is = _shard_lists(5, 8, 64, 100, 5000, tie_levels, short)
+    for k in (100, 37):
+        a = RU.merge_shard_results(Ds, Is, k)
+        b = R.merge_shard_results(Ds, Is, k)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    # fewer candidates than k in total: (-inf, -1) padding
+    a = RU.merge_shard_results(Ds[:1], Is[:1], 150)
+    b = R.merge_shard_results(Ds[:1], Is[:1], 150)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0]) and (a[1][:, 100:] == -1).all()
+
+
+def test_native_merge_accepts_unsorted_lists():
+    """A list that is not sorted (not what a search returns) takes the partial-sort path: same order as the oracle's full sort."""
+    rng = np.random.default_rng(9)
+    Ds = [rng.standard_normal((16, 50)).astype(np.float32) for _ in range(3)]
+    Is = [rng.permutation(150)[:50][None, :].repeat(16, 0).astype(np.int64) + 1000 * r for r in range(3)]
+    Is[1][:, 7] = -1                      # a missing entry in the middle of a list
+    a = RU.merge_shard_results(Ds, Is, 60)
+    b = R.merge_shard_results(Ds, Is, 60)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+
+
+def test_native_merge_at_cfg5_size_is_fast():
+    """cfg5: 8 shards x 6 980 queries x top-1000.  Round 4's np.lexsort merge took 15.6 s; the native k-way merge
+    has to stay far below the search it follows (asked: <= 30 ms on the GPU box's host; this container has 8 cores: bound 0.5 s here)."""
+    import time
+    Ds, Is = _shard_lists(6, 8, 6980, 1000, 1105228, tie_levels=64)
+    RU.merge_shard_results([d[:8] for d in Ds], [i[:8] for i in Is], 1000)       # load the library outside the clock
+    t0 = time.perf_counter()
+    D, I = RU.merge_shard_results(Ds, Is, 1000)
+    dt = time.perf_counter() - t0
+    sel = np.arange(0, 6980, 97)
+    Dr, Ir = R.merge_shard_results([d[sel] for d in Ds], [i[sel] for i in Is], 1000)
+    assert np.array_equal(I[sel], Ir) and np.array_equal(D[sel], Dr)
+    assert (np.diff(D.astype(np.float64), axis=1) <= 0).all()
+    assert dt < 0.5, f"native merge of 8 x 6980 x 1000 took {dt:.3f} s"
+
+
 def test_run_file_writer_matches_reference_format(tmp_path):
     from cldrd_amd.retriever.retrieve_top_passages import write_run_file
     p = tmp_path / "dev" / "x.run"

@@ -357,3 +357,80 @@ def test_evaluation_after_fp16_steps_sees_current_bf16_weights(monkeypatch):
     tr.train_step(batch)            # and training goes on from the refreshed state
     torch.cuda.synchronize()
     assert torch.isfinite(tr.flat_p).all()
+
+
+def test_evaluation_between_replayed_steps_sees_current_weights():
+    """train (graph replay), evaluate, train (replay), evaluate.  The captured AdamW skips the bf16 weight shadow; the Python
+    bookkeeping that marks it stale ran at capture time only, so every replay has to mark the towers again - otherwise the SECOND evaluation
+    encodes with the bf16 matrices cast at the first one.  Graph replay ON (the default)."""
+    cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=2, max_position_embeddings=64,
+                        dropout=0.0, attention_dropout=0.0)
+    model = selftest.build_tiny_model(cfg).cuda().train()
+    tr = NwayTrainer(model, loss="kl_div", learning_rate=1e-3, warmup_steps=0, total_steps=50)
+    assert tr.amp16
+    batch = syn.nway_batch(4680, 3, 4, 8, 16, vocab=cfg.vocab_size, ragged=False, label_kind="teacher")
+    batch = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in batch.items()}
+    enc = {k: v.view(-1, v.shape[-1]) for k, v in batch["nway_passages"].items()}
+
+    def evaluate():
+        model.eval()
+        with torch.no_grad():
+            e = model.passage_embs(enc).clone()
+        model.train()
+        return e
+    for _ in range(6):                     # three eager steps, the capture, replays
+        tr.train_step(batch)
+    assert any(e["graph"] is not None for e in tr._graphs.values()), "the step was not captured"
+    e1 = evaluate()
+    for _ in range(3):
+        tr.train_step(batch)               # replays only
+    assert all(getattr(t, "_h_stale", False) for t in model.towers()), "a replay left the bf16 shadow marked fresh"
+    e2 = evaluate()
+    for t in model.towers():
+        t.refresh_shadows(need_transposed=True)
+    e3 = evaluate()
+    assert torch.equal(e2, e3), "the evaluation after replayed steps used stale bf16 weights"
+    assert not torch.equal(e1, e2)
+
+
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_skipped_steps_do_not_advance_adams_bias_correction(graph, monkeypatch):
+    """GradScaler semantics (reference nway_listwise_1.py:357): scaler.step() does not call optimizer.step() on a non-finite gradient, so the
+    per-parameter Adam `step` - the bias-correction exponent - counts applied steps only.  Two trainers from the same state: A runs steps
+    1..3, B runs a poisoned (skipped) step followed by the same three batches; B's parameters after its 4 calls must equal A's after 3 (the
+    lr schedule is flat here), and the checkpointed optimizer step is 3 in both."""
+    monkeypatch.setenv("CLDRD_GRAPH", graph)
+    cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=2, max_position_embeddings=64,
+                        dropout=0.0, attention_dropout=0.0)
+    batch = syn.nway_batch(4680, 3, 4, 8, 16, vocab=cfg.vocab_size, ragged=False, label_kind="teacher")
+    batch = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in batch.items()}
+
+    def make():
+        model = selftest.build_tiny_model(cfg).cuda().train()
+        # a constant lr (total_steps huge, no warm-up): the only thing that can differ between A and B is the bias-correction exponent
+        return NwayTrainer(model, loss="kl_div", learning_rate=1e-3, warmup_steps=0, total_steps=10 ** 9, weight_decay=0.0)
+    A, Bt = make(), make()
+    assert torch.equal(A.flat_p, Bt.flat_p)
+    for _ in range(3):
+        A.train_step(batch)
+    real = Bt._norm_launches
+
+    def poisoned():
+        Bt.flat_g[-1] = float("nan")
+        real()
+    Bt._norm_launches = poisoned
+    p0 = Bt.flat_p.clone()
+    Bt.train_step(batch)                    # skipped
+    torch.cuda.synchronize()
+    assert torch.equal(Bt.flat_p, p0) and Bt.skipped_steps() == 1
+    Bt._norm_launches = real
+    for _ in range(3):
+        Bt.train_step(batch)
+    torch.cuda.synchronize()
+    # the embedding-table gradients are float atomics (not bit-reproducible run to run): compare outside them to 1e-6 of the update size
+    a, b = A.flat_p, Bt.flat_p
+    upd = (a - p0).abs().max().item()
+    assert upd > 0 and (a - b).abs().max().item() <= 2e-3 * upd, ((a - b).abs().max().item(), upd)
+    sa, sb = A.optimizer_state_dict(), Bt.optimizer_state_dict()
+    assert {v["step"] for v in sa["state"].values()} == {3} and {v["step"] for v in sb["state"].values()} == {3}
+    # without the correction B's exponent would have been 2, 3, 4: its first applied update alone would differ by ~(1 - b1^2)/(1 - b1) ~ 1.9x

@@ -173,3 +173,78 @@ def test_ddp_path_over_rccl_with_one_rank(tmp_path):
     out = str(tmp_path / "ok")
     mp.spawn(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True)
     assert open(out).read().startswith("ok")
+
+
+def _rccl_replay_worker(rank, port, out):
+    """200 replays of the captured data-parallel step (bucket all-reduces over ProcessGroupNCCL inside the graph) against the EAGER
+    data-parallel step, each pair from identical state: loss, logits and every gradient outside the embedding tables (float atomics) bit for
+    bit.  One rank: what is proven is that capture + replay of the collectives and their event edges reproduce the eager ordering - a
+    replay that ran an all-reduce before its bucket was complete, or the norm before an all-reduce, would differ."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CLDRD_FORCE_DDP="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import cldrd_amd.synthetic as syn
+    import selftest
+    from cldrd_amd.encoder import EncoderConfig
+    from cldrd_amd.trainer import NwayTrainer
+
+    cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=3,
+                        max_position_embeddings=64, dropout=0.1, attention_dropout=0.1)
+    batches = [syn.nway_batch(4680 + i, 4, 5, 10, 40, vocab=cfg.vocab_size, ragged=False, label_kind="teacher") for i in range(4)]
+    batches = [{k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in b.items()} for b in batches]
+
+    def make():
+        m = selftest.build_tiny_model(cfg, seed=3).cuda()
+        m.train()
+        return NwayTrainer(m, loss="kl_div", learning_rate=1e-4, warmup_steps=0, total_steps=10 ** 6)
+    G, E = make(), make()
+    assert G.distributed and E.distributed
+
+    def step(tr, b, graph):
+        os.environ["CLDRD_DDP_GRAPH"] = "1" if graph else "0"
+        return tr.train_step(b)
+    for i in range(4):
+        step(G, batches[0], True)
+    assert any(e["graph"] is not None for e in G._graphs.values()) and not getattr(G, "_graph_broken", False)
+    keep = torch.ones(G.flat_g.numel(), dtype=torch.bool, device="cuda")
+    for tower, toff in zip(G.model.towers(), G.model._tower_offsets):
+        for name in tower.layout.order:
+            if name.startswith("embeddings.") and name.endswith("_embeddings.weight"):
+                off, shape = tower.layout.entries[name]
+                n = 1
+                for s_ in shape:
+                    n *= s_
+                keep[toff + off:toff + off + n] = False
+    worst = 0
+    for i in range(200):
+        # identical state: parameters, moments, step counters, dropout counters, loss-scale block
+        E.flat_p.copy_(G.flat_p), E.m.copy_(G.m), E.v.copy_(G.v)
+        E.global_step, E.adam_step = G.global_step, G.adam_step
+        if G._scale_state is not None:
+            E._scale_state.copy_(G._scale_state)
+        for tg, te in zip(G.model.towers(), E.model.towers()):
+            te.step_seed = tg.step_seed
+            te.refresh_shadows(need_transposed=True)
+        b = batches[i % len(batches)]
+        lg = step(G, b, True).clone()
+        le = step(E, b, False).clone()
+        torch.cuda.synchronize()
+        assert not any(e["graph"] is not None for e in getattr(E, "_graphs", {}).values())
+        assert torch.equal(lg, le), (i, lg, le)
+        assert torch.equal(G.last_logits, E.last_logits), i
+        same = torch.equal(G.flat_g[keep], E.flat_g[keep])
+        if not same:
+            worst = max(worst, int((G.flat_g[keep] != E.flat_g[keep]).sum().item()))
+        assert same, f"replay {i}: {worst} gradient elements outside the embedding tables differ from the eager data-parallel step"
+    open(out, "w").write("ok 200")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_captured_ddp_step_replays_bit_for_bit_200_times(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok")
+    mp.spawn(_rccl_replay_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert open(out).read().startswith("ok 200")

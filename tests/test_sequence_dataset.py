@@ -86,3 +86,37 @@ def test_repeated_ids_follow_the_reference_dict(tmp_path):
     b0, b1 = ds.collate_fn([ds[i] for i in range(3)]), CachedSequenceDataset(cache, batch_size=3)[0]
     assert torch.equal(b0["seq"]["input_ids"], b1["seq"]["input_ids"]) and b1["id"] == [5, 7, 9]
     assert int(b1["seq"]["attention_mask"][0].sum()) == 5          # id 5 carries its LAST text: [CLS] delta epsilon zeta [SEP]
+
+
+def test_waiting_rank_fails_fast_on_a_stale_cache_that_rank0_never_replaces(tmp_path, monkeypatch):
+    """a rank != 0 that finds a cache built with other metadata waits for rank 0's rebuild - but only for a grace period when
+    the stale metadata file never goes away (rank 0 not started / sees another tokenizer): ValueError with the reason, not a 2-hour poll.
+    And rank 0 removes the metadata file FIRST when it rebuilds, so that no waiter can load new arrays with old metadata."""
+    import json
+    import time as _time
+    tok = make_tokenizer()
+    cache = SequenceTokenCache.open_or_build(str(tmp_path), COLLECTION, tok, 12)
+    stem = SequenceTokenCache.stem_for(str(tmp_path), COLLECTION, 12)
+    del cache
+    meta = json.load(open(stem + ".meta.json"))
+    stale = dict(meta)
+    key = next(k for k in meta if k not in ("rows", "max_length"))
+    stale[key] = "something else"
+    json.dump(stale, open(stem + ".meta.json", "w"))
+    clock = {"t": 1000.0}
+    monkeypatch.setattr(_time, "time", lambda: clock["t"])
+    monkeypatch.setattr(_time, "sleep", lambda s: clock.__setitem__("t", clock["t"] + 30.0))
+    with pytest.raises(ValueError, match="rank 0 has not replaced"):
+        SequenceTokenCache.open_or_build(str(tmp_path), COLLECTION, tok, 12, rank=1, world=2, wait_s=7200.0)
+    assert clock["t"] - 1000.0 <= 200.0           # gave up after the grace period, not after wait_s
+    monkeypatch.undo()
+    # rank 0: the stale metadata disappears before anything else is replaced
+    seen = {}
+    real_build = SequenceTokenCache.build.__func__
+
+    def spy(cls, *a, **k):
+        seen["meta_present_at_build"] = os.path.exists(stem + ".meta.json")
+        return real_build(cls, *a, **k)
+    monkeypatch.setattr(SequenceTokenCache, "build", classmethod(spy))
+    again = SequenceTokenCache.open_or_build(str(tmp_path), COLLECTION, tok, 12, rank=0, world=2)
+    assert seen["meta_present_at_build"] is False and len(again) == meta["rows"]
