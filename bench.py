@@ -368,6 +368,38 @@ def main():
                         torch.cuda.synchronize()
                         index[f"ragged_{tag}_s"] = time.perf_counter() - t1
                 index["ragged_fill"] = float(ilen.sum()) / (512 * longest)
+            # the reference's own index length: retriever/index_text.py:37 defaults max_length = 256 ("L = 256 fixed (worst
+            # case) and MSMARCO-shaped").  512 passages x 256 tokens, all-ones mask; and MSMARCO-shaped lengths truncated at 256, padded to the
+            # longest of the batch (what the tokenizer's padding=True gives) and packed.
+            L2 = 256
+            ib2 = syn.seq_batch(299 + rank, 512, L2)["seq"]
+            ids2, mask2 = ib2["input_ids"].to(dev), ib2["attention_mask"].to(dev)
+            with torch.no_grad():
+                for _ in range(2):
+                    model.passage_embs({"input_ids": ids2, "attention_mask": mask2})
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                it2 = 6
+                for _ in range(it2):
+                    model.passage_embs({"input_ids": ids2, "attention_mask": mask2})
+                torch.cuda.synchronize()
+                index["l256_s"], index["l256_it"] = time.perf_counter() - t1, it2
+                if not args.no_ragged:
+                    rb2 = syn.seq_batch(399 + rank, 512, L2, ragged=True)["seq"]
+                    il2 = rb2["attention_mask"].sum(-1)
+                    lg2 = int(il2.max())
+                    rid2, rm2 = rb2["input_ids"][:, :lg2].contiguous().to(dev), rb2["attention_mask"][:, :lg2].contiguous().to(dev)
+                    for tag, extra in (("padded", {}), ("packed", {"lengths": il2})):
+                        enc = {"input_ids": rid2, "attention_mask": rm2, **extra}
+                        for _ in range(2):
+                            model.passage_embs(enc)
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(it2):
+                            model.passage_embs(enc)
+                        torch.cuda.synchronize()
+                        index[f"l256_ragged_{tag}_s"] = time.perf_counter() - t1
+                    index["l256_ragged_fill"], index["l256_longest"] = float(il2.sum()) / (512 * lg2), lg2
     except Exception as exc:      # a secondary leg must not take the headline line down with it
         index = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     if not args.no_index:         # the collective sits outside the try: every rank reaches it whatever happened above
@@ -381,8 +413,21 @@ def main():
                 extra = {"msmarco_shaped": {"token_fill_of_padded_batch": round(index["ragged_fill"], 3),
                                             "padded_passages_per_s": round(world * 512 * index["it"] / index["ragged_padded_s"], 1),
                                             "packed_passages_per_s": round(world * 512 * index["it"] / index["ragged_packed_s"], 1)}}
+            l256 = None
+            if "l256_s" in index:
+                t2 = torch.tensor([index["l256_s"]], dtype=torch.float64, device=dev)
+                if world > 1:
+                    dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                pps2 = world * 512 * index["l256_it"] / float(t2.item())
+                l256 = {"value": round(pps2, 1), "unit": "passages/s", "batch": 512, "seq_len": 256,
+                        "mfma_frac": round(pps2 * flops_seq_fwd(256) / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+                        "note": "the reference's index length (retriever/index_text.py:37 max_length = 256), every passage 256 tokens: the worst case"}
+                if "l256_ragged_packed_s" in index:
+                    l256["msmarco_shaped"] = {"token_fill_of_padded_batch": round(index["l256_ragged_fill"], 3), "longest": index["l256_longest"],
+                                              "padded_passages_per_s": round(world * 512 * index["l256_it"] / index["l256_ragged_padded_s"], 1),
+                                              "packed_passages_per_s": round(world * 512 * index["l256_it"] / index["l256_ragged_packed_s"], 1)}
             index = {"value": round(pps, 1), "unit": "passages/s", "batch": 512, "seq_len": L,
-                     "mfma_frac": round(pps * flops_seq_fwd(L) / (world * PEAK_BF16_TFLOPS * 1e12), 4), **extra}
+                     "mfma_frac": round(pps * flops_seq_fwd(L) / (world * PEAK_BF16_TFLOPS * 1e12), 4), **extra, "l256": l256}
         elif "error" not in index:
             index = {"error": "another rank failed in the index leg"}
 

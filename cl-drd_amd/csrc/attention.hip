@@ -516,6 +516,183 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
     }
 }
 
+// Streaming forward for 128 < L <= 256 and many (sequence, head) items (round 5: cfg5's index encode runs at max_length 256, reference
+// retriever/index_text.py:37; cfg4 trains BERT-base at L = 256): ONE persistent 8-wave workgroup per CU walks its items.  The one-item form
+// above does load -> barrier -> compute per workgroup, and at L = 256 an item's Q, K, V tiles (110 KB of LDS) leave room for one workgroup
+// per CU: nothing overlaps the 147 KB of HBM reads of an item with the arithmetic of another, and every CU loads at the same moment.  Here
+//   * Q never goes through LDS: a wave's four Q fragments are 64 bytes per lane straight from global memory (row_frag's layout);
+//   * K, V (+ the key bias) are double-buffered in LDS (2 x 74 KB): each thread requests its 16-byte pieces of the NEXT item into registers
+//     before it starts on the current item (issue early), and writes them to the other buffer when it is done (write late): an item's HBM
+//     latency sits under the previous item's arithmetic; one __syncthreads per item;
+//   * the body is attn_fwd_kernel's, instruction for instruction (same results bit for bit: tests flip cldrd_set_tuning("attn_fwd2", 0)).
+template <int NKB, bool DROP, bool F16 = false>
+__global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
+                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
+                                                         float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
+                                                         bf16_t* __restrict__ ctx16) {
+    const uint64_t seed = seed_a.get();
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Lp = 32 * NKB;
+    constexpr int TILE = Lp * RSB;
+    constexpr int BUF = 2 * TILE + Lp * (int)sizeof(float);
+    constexpr int NCH = (Lp * 8 + 511) / 512;           // 16-byte pieces per thread and tile
+    const int dm = H * 64, ld = 3 * dm;
+    auto opaque = [](int x) { asm volatile("" : "+v"(x)); return x; };      // see attn_bwd2_kernel: keeps 40 address halves from being hoisted
+    int tid = threadIdx.x;
+    u32x4 pk[NCH], pv[NCH];          // (first-class vector values: as `uint4` structs hipcc kept the two arrays in scratch memory)
+    bf16x8 qn[4];
+    long long pm = 0;
+    // Every load of issue() is UNCONDITIONAL on a clamped row (no exec-masked region, no branch): the compiler can then count its vmcnt waits -
+    // the pieces are consumed at commit(), behind this item's ctx stores, and must not wait for those (vmcnt counts stores too).  A row >= L
+    // therefore arrives as a copy of row L - 1 instead of zeros: a K row that the key bias masks (score + -1e30 is -1e30 whatever the score),
+    // a V row that meets p = 0, a Q row whose output nobody stores - all finite, results unchanged bit for bit.
+    const long long* mask_or_any = mask ? (const long long*)mask : (const long long*)qkv;      // null mask: the value loaded is ignored
+    auto issue = [&](int item) {
+        const int seq = item / H, hd = item % H;
+        const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tid + 512 * j, row = min(idx >> 3, L - 1), ch = idx & 7;
+            const bf16_t* rp = base + (size_t)row * ld + ch * 8;
+            pk[j] = *(const u32x4*)(rp + dm);
+            pv[j] = *(const u32x4*)(rp + 2 * dm);
+        }
+        pm = mask_or_any[(size_t)seq * L + min(tid, L - 1)];
+        // this wave's Q block of the item: row 32 qb + r, 16-byte pieces 2 s + h (row_frag's layout)
+        const int lane = tid & 63, r = lane & 31, h = lane >> 5, qb = min(tid >> 6, NKB - 1);
+        const int qrow = min(qb * 32 + r, L - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qn[s] = *(const bf16x8*)(base + (size_t)qrow * ld + (2 * s + h) * 8);
+    };
+    auto commit = [&](int b) {
+        char* base = smem + b * BUF;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int idx = tid + 512 * j, row = idx >> 3, ch = idx & 7;
+            if (NCH * 512 == Lp * 8 || idx < Lp * 8) {
+                const int off = row * RSB + ch * 16;
+                *(u32x4*)(base + off) = pk[j];
+                *(u32x4*)(base + TILE + off) = pv[j];
+            }
+        }
+        if (tid < Lp) ((float*)(base + 2 * TILE))[tid] = (tid < L && (!mask || pm != 0)) ? 0.f : NEG_BIG;
+    };
+    int item = blockIdx.x;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (item < nitems) {
+        issue(item);
+        commit(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+    }
+    __syncthreads();
+    int cur = 0;
+    const float scale2 = scale * LOG2E;      // scores in the log2 domain (v_exp_f32 is 2^x)
+    for (; item < nitems; item += gridDim.x) {
+        const int next = item + gridDim.x;
+        tid = opaque((int)threadIdx.x);
+        // in flight while this item is computed.  UNCONDITIONAL (the last item of a workgroup requests itself again: cache hits, and the
+        // commit below lands in the buffer nobody reads any more): with the prefetch registers live across a branch hipcc kept them in scratch
+        // memory - a scratch store and an s_waitcnt vmcnt(0) behind every load
+        issue(next < nitems ? next : item);
+        const char* sK = smem + cur * BUF;
+        const char* sV = sK + TILE;
+        const float* sBias = (const float*)(sV + TILE);
+        const int seq = item / H, hd = item % H;
+        const int lane = tid & 63, wid = tid >> 6;
+        const int r = lane & 31, h = lane >> 5;
+        if (wid < NKB) {
+            const int qb = wid;
+            const int q = qb * 32 + r;
+            // dropout mask element (row, col) = ((seq*H + hd)*L + q, key); keys rowmap(t, h), t even / odd, are a column pair
+            const uint32_t rk = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + q));
+            float m = NEG_BIG * 4.f, lsum = 0.f;                       // lsum: this half's share of the denominator
+            f32x16 O[2] = {(f32x16){0.f}, (f32x16){0.f}};              // O[dt][t] = ctx^T[d = 32 dt + rowmap(t, h)][q]
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                f32x16 S = (f32x16){0.f};
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    S = mfma32<F16>(row_frag(sK, kb * 32 + r, s, h), qf[s], S);
+                float v[16];
+                float mloc = NEG_BIG * 4.f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
+                    const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[4 * u + j] = fmaf(S[4 * u + j], scale2, bb[j]);
+                        mloc = fmaxf(mloc, v[4 * u + j]);
+                    }
+                }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float mn = fmaxf(m, mloc);
+                const float alpha = __builtin_amdgcn_exp2f(m - mn);
+                m = mn;
+                float psum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; t += 2) {
+                    float p0 = __builtin_amdgcn_exp2f(v[t] - mn), p1 = __builtin_amdgcn_exp2f(v[t + 1] - mn);
+                    psum += p0 + p1;
+                    if (DROP) {
+                        const uint32_t hh = drop_pair(rk, (uint32_t)(kb * 32 + rowmap(t, h)));
+                        p0 = drop_keep_lo(hh, drop_thresh) ? p0 : 0.f;
+                        p1 = drop_keep_hi(hh, drop_thresh) ? p1 : 0.f;
+                    }
+                    v[t] = p0; v[t + 1] = p1;
+                }
+                lsum = fmaf(lsum, alpha, psum);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int t = 0; t < 16; ++t) O[dt][t] *= alpha;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 pb = pack8x<F16>(v + 8 * s2);
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt)
+                        O[dt] = mfma32<F16>(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, O[dt]);
+                }
+            }
+            const float l = lsum + __shfl_xor(lsum, 32, 64);
+            if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (m + __log2f(l)) * LN2;
+            const float inv = (DROP ? drop_scale : 1.0f) / l;
+            const size_t orow = ((size_t)seq * L + q) * dm + hd * 64;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                    uint2 o[2], o16[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int b = 4 * (u + k);
+                        const float v0 = O[dt][b] * inv, v1 = O[dt][b + 1] * inv, v2 = O[dt][b + 2] * inv, v3 = O[dt][b + 3] * inv;
+                        o[k].x = pack2x<F16>(v0, v1);
+                        o[k].y = pack2x<F16>(v2, v3);
+                        o16[k].x = (uint32_t)f2x<true>(v0) | ((uint32_t)f2x<true>(v1) << 16);
+                        o16[k].y = (uint32_t)f2x<true>(v2) | ((uint32_t)f2x<true>(v3) << 16);
+                    }
+                    if (ctx) {
+                        const uint4 w = widen_pair(o[0], o[1]);
+                        if (q < L) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
+                    }
+                    if (ctx16) {       // fp16 copy (out-projection operand)
+                        const uint4 w = widen_pair(o16[0], o16[1]);
+                        if (q < L) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
+                    }
+                }
+        }
+        commit(cur ^ 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+        __syncthreads();          // the other buffer is complete, and nobody reads this one any more
+        cur ^= 1;
+    }
+}
+
 template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
@@ -1036,6 +1213,18 @@ int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, 
         hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                            (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16);
     } else {
+        // many items at 128 < L <= 256: the persistent streaming kernel (K / V double-buffered, Q from global memory); cldrd_set_tuning("attn_fwd2", 0)
+        // keeps the one-item-per-workgroup kernel (tests: the two are bit-identical)
+        const int nitems = nseq * H, cus = attn_num_cus();
+        if (nitems >= 2 * cus && g_cldrd_tune_attn_fwd2 != 0) {
+            const size_t lds3 = 2 * (2 * 32 * NKB * RSB + 32 * NKB * sizeof(float));
+            (void)hipFuncSetAttribute((const void*)attn_fwd3_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            hipLaunchKernelGGL((attn_fwd3_kernel<NKB, DROP, F16>), dim3(cus), dim3(512), lds3, st, (const bf16_t*)qkv, (const int64_t*)mask,
+                               (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems,
+                               (bf16_t*)ctx16);
+            CLDRD_LAUNCH_CHECK();
+            return 0;
+        }
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(512), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                            (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16);

@@ -427,10 +427,14 @@ def test_skipped_steps_do_not_advance_adams_bias_correction(graph, monkeypatch):
     for _ in range(3):
         Bt.train_step(batch)
     torch.cuda.synchronize()
-    # the embedding-table gradients are float atomics (not bit-reproducible run to run): compare outside them to 1e-6 of the update size
-    a, b = A.flat_p, Bt.flat_p
-    upd = (a - p0).abs().max().item()
-    assert upd > 0 and (a - b).abs().max().item() <= 2e-3 * upd, ((a - b).abs().max().item(), upd)
+    # Not bit for bit: the embedding-table gradients are float atomics, B's loss scale is 4x smaller after its skipped step (other fp16
+    # roundings), and Adam's first steps turn a last-bit difference of a near-zero gradient into +-lr on that element.  The UPDATE as a
+    # whole must agree: with the host's step count as the exponent (2, 3, 4 instead of 1, 2, 3) B's three updates would be 0.74, 0.86 and
+    # 0.91 of A's - 16 % short in norm.
+    ua, ub = (A.flat_p - p0).double(), (Bt.flat_p - p0).double()
+    rel = ((ua - ub).norm() / ua.norm()).item()
+    short = 1.0 - (ub.norm() / ua.norm()).item()
+    assert ua.norm().item() > 0 and rel <= 0.05 and abs(short) <= 0.02, (rel, short)
     sa, sb = A.optimizer_state_dict(), Bt.optimizer_state_dict()
     assert {v["step"] for v in sa["state"].values()} == {3} and {v["step"] for v in sb["state"].values()} == {3}
     # without the correction B's exponent would have been 2, 3, 4: its first applied update alone would differ by ~(1 - b1^2)/(1 - b1) ~ 1.9x

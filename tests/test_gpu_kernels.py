@@ -486,6 +486,49 @@ def test_attention_fwd_persistent_loader_kernel(nseq, L, H, p):
     assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
 
 
+@pytest.mark.parametrize("nseq,L,H,p,f16,masked", [(48, 256, 12, 0.0, False, True), (48, 256, 12, 0.1, True, True), (90, 200, 6, 0.1, False, True),
+                                                     (60, 130, 12, 0.0, True, False), (64, 161, 8, 0.0, False, True), (260, 256, 2, 0.1, True, True),
+                                                     (70, 250, 8, 0.0, False, False)])
+def test_attention_fwd_streaming_persistent_kernel(nseq, L, H, p, f16, masked):
+    """128 < L <= 256 with >= 2 items per CU (cfg5 index encode at max_length 256, cfg4 training): the persistent streaming forward (K / V
+    double-buffered in LDS, Q straight from global memory, next item prefetched through registers) must reproduce the one-item-per-workgroup
+    streaming kernel bit for bit - context, fp16 context copy and LSE; masked, unmasked, ragged, odd key-block counts, bf16 and fp16 families,
+    with and without dropout, several items per workgroup (a stale or half-written LDS buffer, or a Q fragment of the wrong item, shows here)."""
+    d, T = H * 64, nseq * L
+    g = torch.Generator(device=DEV).manual_seed(nseq * L + H + 7)
+    dt = torch.float16 if f16 else torch.bfloat16
+    qkv = torch.randn(T, 3 * d, device=DEV, generator=g).to(dt)
+    mask = None
+    if masked:
+        lens = torch.randint(2, L + 1, (nseq,), device=DEV, generator=g)
+        lens[0] = L
+        mask = (torch.arange(L, device=DEV)[None, :] < lens[:, None]).to(torch.int64).contiguous()
+    outs = []
+    for tune in (0, 1, 1):
+        ops.set_tuning("attn_fwd2", tune)
+        ctx = torch.full((T, d), float("nan"), dtype=dt, device=DEV)
+        c16 = None if f16 else torch.full((T, d), float("nan"), dtype=torch.float16, device=DEV)
+        lse = torch.full((nseq, H, L), float("nan"), dtype=torch.float32, device=DEV)
+        try:
+            ops.attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=p, seed=4321, ctx16=c16, full_family=f16)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_tuning("attn_fwd2", 1)
+        outs.append((ctx, lse, c16))
+    valid = mask.bool().reshape(-1) if masked else torch.ones(T, dtype=torch.bool, device=DEV)
+    assert not torch.isnan(outs[1][0][valid].float()).any()
+    lv = mask.bool()[:, None, :].expand(nseq, H, L) if masked else torch.ones(nseq, H, L, dtype=torch.bool, device=DEV)
+    assert torch.equal(outs[0][0][valid], outs[1][0][valid]), "persistent streaming forward differs from the one-item kernel (context)"
+    assert torch.equal(outs[0][1][lv], outs[1][1][lv]), "persistent streaming forward differs from the one-item kernel (LSE)"
+    if c16 is not None:
+        assert torch.equal(outs[0][2][valid], outs[1][2][valid])
+    assert torch.equal(outs[1][0][valid], outs[2][0][valid]) and torch.equal(outs[1][1][lv], outs[2][1][lv]), "two launches differ"
+    # and against the fp64 reference (the one-item kernel is pinned elsewhere; this is the new kernel's own check)
+    if p == 0.0:
+        ref, ref_lse = attn_ref(qkv.cpu().double(), mask.cpu() if masked else None, nseq, L, H)
+        close(outs[1][0][valid], ref.to(DEV)[valid], 1 / 64, 2e-2, "streaming persistent forward vs fp64")
+
+
 def test_attention_dropout_statistics():
     nseq, L, H = 2, 64, 2
     T, d = nseq * L, H * 64
