@@ -1587,13 +1587,14 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
 }
 
 // dst[m * stride_rows] += src[m]  (bf16 rows of d elements)
-template <bool F32>
+template <int FMT>      // 0: bf16 += bf16; 1: fp32 += fp32; 2: fp16 dst += fp32 src (fp32 add, one rounding: the fp16 gradient stream)
 __global__ __launch_bounds__(256) void add_rows_strided_kernel(void* __restrict__ dst_v, const void* __restrict__ src_v, int M, int d,
                                                                 int stride_rows) {
     const int m = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         const size_t o = (size_t)m * stride_rows * d + c;
-        if (F32) ((float*)dst_v)[o] += ((const float*)src_v)[(size_t)m * d + c];
+        if (FMT == 1) ((float*)dst_v)[o] += ((const float*)src_v)[(size_t)m * d + c];
+        else if (FMT == 2) ((_Float16*)dst_v)[o] = (_Float16)((float)((const _Float16*)dst_v)[o] + ((const float*)src_v)[(size_t)m * d + c]);
         else ((bf16_t*)dst_v)[o] = f2bf(bf2f(((const bf16_t*)dst_v)[o]) + bf2f(((const bf16_t*)src_v)[(size_t)m * d + c]));
     }
 }
@@ -1637,8 +1638,9 @@ extern "C" int cldrd_attention_cls_bwd(const void* qc, const void* kv, const flo
 
 extern "C" int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, int f32, void* stream) {
     CLDRD_CHECK(M > 0 && d > 0 && stride_rows > 0, "add_rows_strided: bad shape");
-    if (f32) hipLaunchKernelGGL(add_rows_strided_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, M, d, stride_rows);
-    else hipLaunchKernelGGL(add_rows_strided_kernel<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, M, d, stride_rows);
+    if (f32 == 1) hipLaunchKernelGGL(add_rows_strided_kernel<1>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, M, d, stride_rows);
+    else if (f32 == 2) hipLaunchKernelGGL(add_rows_strided_kernel<2>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, M, d, stride_rows);
+    else hipLaunchKernelGGL(add_rows_strided_kernel<0>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, M, d, stride_rows);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

@@ -307,7 +307,13 @@ __device__ __forceinline__ void block_partials(float* smem, RowF& a, RowF& b, Ro
 // dy_branch (optional, bf16): the output of the data-gradient GEMM of the branch that joins the stream here (FFN / attention), added on
 // load: dy = stream + branch.  That GEMM then has a plain bf16 epilogue (no fp32 residual in, no fp32 sum out: 200 MB less per GEMM at
 // T = 32768 than adding in its epilogue) and only the branch's own contribution is rounded, once, like any MFMA operand.
-template <int DC, bool DROP, bool X32, bool G32 = false>
+// GS: format of the gradient STREAM (dy in, dx out): 0 = bf16 (rounds 1-2), 1 = fp32 (round 3), 2 = fp16 (round 5, the all-fp16 training mode:
+// the stream carries the loss scale like every other 16-bit gradient tensor; dy_branch and dx2 are fp16 too).  With GS = 2 the stream tensor dx IS
+// the MFMA operand of the next data / weight gradient unless dropout makes the two differ: dx2 may be null, and a LayerNorm backward then moves
+// 250 MB at T = 32768 instead of the 400 MB of the fp32 stream (read 50 + 50 + 100, write 50).  Measured on the reference's fp32 gradients
+// (tools/r05_cos.sh, every ranked tensor of cfg1-4): min cosine 0.99990 / 0.99992 / 0.99994 / 0.99992 / 0.99995 with the stream rounded to
+// fp16 at exactly these points, against 0.99992 / 0.99994 / 0.99998 / 0.99995 / 0.99996 with the fp32 stream (profiles/r05_grad_cosines.txt).
+template <int DC, bool DROP, bool X32, int GS = 0>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy_v, const void* __restrict__ x,
                                                       const float* __restrict__ mean_i, const float* __restrict__ rstd_i,
                                                       const float* __restrict__ gamma, void* __restrict__ dx_v,
@@ -327,9 +333,10 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
     const int wpb = blockDim.x >> 6;      // waves per block: 8 -> 16 waves per CU keep enough loads in flight
     for (int row = blockIdx.x * wpb + (threadIdx.x >> 6); row < T; row += gridDim.x * wpb) {
         RowF g, xr;
-        if (G32) {
-            load_row_f32_stream((const float*)dy_v + (size_t)row * d, d, lane, g);
-            if (dy_branch) {       // dy = fp32 stream + the bf16 output of the branch's data-gradient GEMM, added here instead of in its epilogue
+        if (GS != 0) {
+            if (GS == 2) load_row_f16((const bf16_t*)dy_v + (size_t)row * d, d, lane, g);
+            else load_row_f32_stream((const float*)dy_v + (size_t)row * d, d, lane, g);
+            if (dy_branch) {       // dy = stream + the 16-bit output of the branch's data-gradient GEMM, added here instead of in its epilogue
                 RowF br;
                 if (h16) load_row_f16(dy_branch + (size_t)row * d, d, lane, br);
                 else load_row_bf16(dy_branch + (size_t)row * d, d, lane, br);
@@ -379,7 +386,8 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
                 dbias.v[it][j] += v;
             }
         }
-        if (G32) store_row_f32((float*)dx_v + (size_t)row * d, d, lane, g);
+        if (GS == 1) store_row_f32((float*)dx_v + (size_t)row * d, d, lane, g);
+        else if (GS == 2) store_row_f16((bf16_t*)dx_v + (size_t)row * d, d, lane, g);
         else store_row_bf16((bf16_t*)dx_v + (size_t)row * d, d, lane, g);
         if (dx2) { if (h16) store_row_f16(dx2 + (size_t)row * d, d, lane, o2); else store_row_bf16(dx2 + (size_t)row * d, d, lane, o2); }
     }
@@ -396,7 +404,7 @@ __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy
 // Embedding backward: dy -> (dropout) -> LN backward (statistics saved, input recomputed from the tables)
 // -> scatter-add into the word / position tables (fp32 atomics); LN-parameter and token-type gradients go
 // through per-block partials {dgamma, dbeta, dtype}.
-template <int DC, bool DROP, bool G32 = false>
+template <int DC, bool DROP, int GS = 0>      // GS: format of dy, as in ln_bwd_kernel (0 bf16, 1 fp32, 2 fp16)
 __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const void* __restrict__ dy_v, const int64_t* __restrict__ ids,
                                                             const float* __restrict__ word, const float* __restrict__ pos,
                                                             const float* __restrict__ type0, const float* __restrict__ gamma,
@@ -424,8 +432,9 @@ __global__ __launch_bounds__(256) void embed_ln_bwd_kernel(const void* __restric
         id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
         const int l = pos_idx ? pos_idx[row] : row % L;
         RowF g, xr, p;
-        if (G32) {
-            load_row_f32_i((const float*)dy_v + (size_t)row * d, d, lane, g);
+        if (GS != 0) {
+            if (GS == 2) load_row_f16_i((const bf16_t*)dy_v + (size_t)row * d, d, lane, g);
+            else load_row_f32_i((const float*)dy_v + (size_t)row * d, d, lane, g);
             if (dy_branch) {       // + the bf16 output of layer 0's last data-gradient GEMM (see ln_bwd_kernel)
                 RowF br;
                 if (h16) load_row_f16_i(dy_branch + (size_t)row * d, d, lane, br);
@@ -553,11 +562,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 }
 
 // g[T, d] = 0 except rows r*stride <- dcls[r] (gradient of the CLS pooling)
-template <bool F32>
+template <int FMT>      // 0 bf16, 1 fp32, 2 fp16
 __global__ void scatter_cls_kernel(const float* __restrict__ dcls, void* __restrict__ g, int R, int d, int stride) {
     const int r = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        if (F32) ((float*)g)[(size_t)r * stride * d + c] = dcls[(size_t)r * d + c];
+        if (FMT == 1) ((float*)g)[(size_t)r * stride * d + c] = dcls[(size_t)r * d + c];
+        else if (FMT == 2) ((_Float16*)g)[(size_t)r * stride * d + c] = (_Float16)dcls[(size_t)r * d + c];
         else ((bf16_t*)g)[(size_t)r * stride * d + c] = f2bf(dcls[(size_t)r * d + c]);
     }
 }
@@ -658,14 +668,19 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
                                    void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
                                    int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, const void* dy_branch, void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0, "layernorm_bwd: need 0 < d <= 1024, d % 4 == 0");
-    CLDRD_CHECK(dy_branch == nullptr || (x_f32 & 2), "layernorm_bwd: dy_branch goes with the fp32 gradient stream (x_f32 bit 1)");
+    CLDRD_CHECK(dy_branch == nullptr || (x_f32 & (2 | 8)), "layernorm_bwd: dy_branch goes with the fp32 / fp16 gradient stream (x_f32 bit 1 / 3)");
     // x_f32 bit 2 (round 4): dx_dropped and dy_branch are fp16, not bf16 (the all-fp16 training mode)
-    const int h16 = (x_f32 & 4) ? 1 : 0;
+    // x_f32 bit 3 (round 5): dy and dx are FP16 rows (the fp16 gradient stream; implies bit 2); dx_dropped may be null when no dropout
+    //   separates the stream from the MFMA operand - dx then serves as both
+    const bool g_f16 = (x_f32 & 8) != 0;
+    const int h16 = ((x_f32 & 4) || g_f16) ? 1 : 0;
     const float* inv_scale = g_cldrd_loss_scale ? g_cldrd_loss_scale + 1 : nullptr;
-    // x_f32: bit 0 = x holds fp32 pre-LN sums; bit 1 = dy and dx are fp32 rows (fp32 gradient stream; dx_dropped stays bf16 and is required:
+    // x_f32: bit 0 = x holds fp32 pre-LN sums; bit 1 = dy and dx are fp32 rows (fp32 gradient stream; dx_dropped stays 16-bit and is required:
     // it is the MFMA operand of the next data-gradient GEMM)
     const bool g_f32 = (x_f32 & 2) != 0;
-    CLDRD_CHECK(!g_f32 || ((x_f32 & 1) && dx_dropped != nullptr), "layernorm_bwd: the fp32 gradient stream needs fp32 x and the bf16 operand copy (dx_dropped)");
+    CLDRD_CHECK(!(g_f32 && g_f16), "layernorm_bwd: the gradient stream is fp32 or fp16, not both");
+    CLDRD_CHECK(!g_f32 || ((x_f32 & 1) && dx_dropped != nullptr), "layernorm_bwd: the fp32 gradient stream needs fp32 x and the 16-bit operand copy (dx_dropped)");
+    CLDRD_CHECK(!g_f16 || (x_f32 & 1), "layernorm_bwd: the fp16 gradient stream needs fp32 x (the pre-LN sums of the fp32 residual stream)");
     const int nb = ln_bwd_blocks(T);
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
@@ -675,8 +690,10 @@ extern "C" int cldrd_layernorm_bwd(const void* dy, const void* x, const float* m
         const float sc = 1.0f / (1.0f - dropout_p);
         hipStream_t st = (hipStream_t)stream;
         bf16_t* d2 = (bf16_t*)dx_dropped;
-        if (g_f32)          // fp32 gradient stream: only with the fp32 pre-LN sums of the fp32 residual stream
-            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true, true>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)dy_branch, h16, inv_scale);
+        if (g_f16)
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true, 2>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)dy_branch, 1, inv_scale);
+        else if (g_f32)     // fp32 gradient stream: only with the fp32 pre-LN sums of the fp32 residual stream
+            hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true, 1>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)dy_branch, h16, inv_scale);
         else if (x_f32 & 1)
             hipLaunchKernelGGL((ln_bwd_kernel<DCV, DRV, true>), dim3(nb), dim3(512), lds, st, dy, x, mean, rstd, gamma, dx, d2, partial, T, d, th, sc, seed_arg(seed), (const bf16_t*)nullptr, 0, inv_scale);
         else
@@ -712,7 +729,9 @@ extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const fl
                                   float dropout_p, unsigned long long seed, int accumulate, const int* pos_idx, int dy_f32, const void* dy_branch,
                                   void* stream) {
     CLDRD_CHECK(T > 0 && d > 0 && d <= 1024 && d % 4 == 0 && L > 0, "embed_ln_bwd: bad shape");
-    CLDRD_CHECK(dy_branch == nullptr || dy_f32, "embed_ln_bwd: dy_branch goes with an fp32 dy");      // dy_f32 bit 2: dy_branch is fp16
+    // dy_f32: bit 0 = dy is fp32; bit 2 = dy_branch is fp16; bit 3 (round 5) = dy is FP16 (the fp16 gradient stream; dy_branch fp16 then)
+    CLDRD_CHECK(dy_branch == nullptr || (dy_f32 & (1 | 8)), "embed_ln_bwd: dy_branch goes with an fp32 / fp16 dy");
+    CLDRD_CHECK((dy_f32 & 9) != 9, "embed_ln_bwd: dy is fp32 or fp16, not both");
     int nb = ln_bwd_blocks(T);                      // the caller sized `partial` for this many blocks; fewer is fine
     int g4 = 4, r = L;                              // gcd(4, L)
     while (r) { const int t = g4 % r; g4 = r; r = t; }
@@ -722,8 +741,13 @@ extern "C" int cldrd_embed_ln_bwd(const void* dy, const long long* ids, const fl
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     ln_dispatch(d, th != 0, [&](auto dc, auto dr) {
         const size_t lds = (256 / 128) * 3 * MAX_IT * 64 * sizeof(float4);
-        if (dy_f32)
-            hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value, true>), dim3(nb), dim3(256), lds,
+        if (dy_f32 & 8)
+            hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value, 2>), dim3(nb), dim3(256), lds,
+                               (hipStream_t)stream, dy, (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial,
+                               T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx, (const bf16_t*)dy_branch,
+                               1, g_cldrd_loss_scale ? g_cldrd_loss_scale + 1 : nullptr);
+        else if (dy_f32 & 1)
+            hipLaunchKernelGGL((embed_ln_bwd_kernel<decltype(dc)::value, decltype(dr)::value, 1>), dim3(nb), dim3(256), lds,
                                (hipStream_t)stream, dy, (const int64_t*)ids, word, pos, type0, gamma, mean, rstd, dword, dpos, partial,
                                T, L, d, vocab, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), pos_uniform, pos_idx, (const bf16_t*)dy_branch,
                                (dy_f32 & 4) ? 1 : 0, g_cldrd_loss_scale ? g_cldrd_loss_scale + 1 : nullptr);
@@ -752,9 +776,11 @@ extern "C" int cldrd_colsum_bf16(const void* x, float* out, float* partial, int 
 
 extern "C" int cldrd_scatter_cls_grad(const float* dcls, void* g, int R, int d, int stride, int T, int g_f32, void* stream) {
     CLDRD_CHECK(R > 0 && d > 0 && stride > 0 && (long long)R * stride <= (long long)T + stride - 1, "scatter_cls_grad: bad shape");
-    if (hipMemsetAsync(g, 0, (size_t)T * d * (g_f32 ? sizeof(float) : sizeof(bf16_t)), (hipStream_t)stream) != hipSuccess) return cldrd_set_error("scatter_cls_grad: memset failed");
-    if (g_f32) hipLaunchKernelGGL(scatter_cls_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, R, d, stride);
-    else hipLaunchKernelGGL(scatter_cls_kernel<false>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, R, d, stride);
+    // g_f32: 0 = bf16 rows, 1 = fp32, 2 = fp16
+    if (hipMemsetAsync(g, 0, (size_t)T * d * (g_f32 == 1 ? sizeof(float) : sizeof(bf16_t)), (hipStream_t)stream) != hipSuccess) return cldrd_set_error("scatter_cls_grad: memset failed");
+    if (g_f32 == 1) hipLaunchKernelGGL(scatter_cls_kernel<1>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, R, d, stride);
+    else if (g_f32 == 2) hipLaunchKernelGGL(scatter_cls_kernel<2>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, R, d, stride);
+    else hipLaunchKernelGGL(scatter_cls_kernel<0>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, R, d, stride);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

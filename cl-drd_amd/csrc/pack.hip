@@ -38,22 +38,24 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
 }
 
 // g[idx[r], :] = bf16(dcls[r, :])   (g zeroed by the launcher)
-template <bool F32>
+template <int FMT>      // 0 bf16, 1 fp32, 2 fp16
 __global__ void scatter_cls_idx_kernel(const float* __restrict__ dcls, void* __restrict__ g, const int* __restrict__ idx, int d) {
     const int r = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
-        if (F32) ((float*)g)[(size_t)idx[r] * d + c] = dcls[(size_t)r * d + c];
+        if (FMT == 1) ((float*)g)[(size_t)idx[r] * d + c] = dcls[(size_t)r * d + c];
+        else if (FMT == 2) ((_Float16*)g)[(size_t)idx[r] * d + c] = (_Float16)dcls[(size_t)r * d + c];
         else ((bf16_t*)g)[(size_t)idx[r] * d + c] = f2bf(dcls[(size_t)r * d + c]);
     }
 }
 
 // dst[idx[m], :] += src[m, :]   (bf16 rows, fp32 add, one rounding)
-template <bool F32>
+template <int FMT>      // 0: bf16 += bf16; 1: fp32 += fp32; 2: fp16 dst += fp32 src (fp32 add, one rounding: the fp16 gradient stream)
 __global__ void add_rows_idx_kernel(void* __restrict__ dst_v, const void* __restrict__ src_v, const int* __restrict__ idx, int d) {
     const int m = blockIdx.x;
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         const size_t o = (size_t)idx[m] * d + c;
-        if (F32) ((float*)dst_v)[o] += ((const float*)src_v)[(size_t)m * d + c];
+        if (FMT == 1) ((float*)dst_v)[o] += ((const float*)src_v)[(size_t)m * d + c];
+        else if (FMT == 2) ((_Float16*)dst_v)[o] = (_Float16)((float)((const _Float16*)dst_v)[o] + ((const float*)src_v)[(size_t)m * d + c]);
         else ((bf16_t*)dst_v)[o] = f2bf(bf2f(((const bf16_t*)dst_v)[o]) + bf2f(((const bf16_t*)src_v)[(size_t)m * d + c]));
     }
 }
@@ -79,17 +81,19 @@ extern "C" int cldrd_gather_rows(const void* src, const int* idx, void* dst, int
 
 extern "C" int cldrd_scatter_cls_grad_idx(const float* dcls, void* g, int R, int d, const int* idx, int T, int g_f32, void* stream) {
     CLDRD_CHECK(R > 0 && d > 0 && T >= R, "scatter_cls_grad_idx: bad shape");
-    if (hipMemsetAsync(g, 0, (size_t)T * d * (g_f32 ? sizeof(float) : sizeof(bf16_t)), (hipStream_t)stream) != hipSuccess) return cldrd_set_error("scatter_cls_grad_idx: memset failed");
-    if (g_f32) hipLaunchKernelGGL(scatter_cls_idx_kernel<true>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, idx, d);
-    else hipLaunchKernelGGL(scatter_cls_idx_kernel<false>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, idx, d);
+    if (hipMemsetAsync(g, 0, (size_t)T * d * (g_f32 == 1 ? sizeof(float) : sizeof(bf16_t)), (hipStream_t)stream) != hipSuccess) return cldrd_set_error("scatter_cls_grad_idx: memset failed");
+    if (g_f32 == 1) hipLaunchKernelGGL(scatter_cls_idx_kernel<1>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, idx, d);
+    else if (g_f32 == 2) hipLaunchKernelGGL(scatter_cls_idx_kernel<2>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, idx, d);
+    else hipLaunchKernelGGL(scatter_cls_idx_kernel<0>, dim3(R), dim3(256), 0, (hipStream_t)stream, dcls, g, idx, d);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int cldrd_add_rows_idx(void* dst, const void* src, int M, int d, const int* idx, int f32, void* stream) {
     CLDRD_CHECK(M > 0 && d > 0, "add_rows_idx: bad shape");
-    if (f32) hipLaunchKernelGGL(add_rows_idx_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, idx, d);
-    else hipLaunchKernelGGL(add_rows_idx_kernel<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, idx, d);
+    if (f32 == 1) hipLaunchKernelGGL(add_rows_idx_kernel<1>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, idx, d);
+    else if (f32 == 2) hipLaunchKernelGGL(add_rows_idx_kernel<2>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, idx, d);
+    else hipLaunchKernelGGL(add_rows_idx_kernel<0>, dim3(M), dim3(256), 0, (hipStream_t)stream, dst, src, idx, d);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

@@ -286,6 +286,14 @@ class HipEncoder(nn.Module):
         # tensors are fp16 and carry the loss scale (hip_ops.loss_scale: born in score_bwd, removed where parameter gradients are
         # written), the gradient stream and every parameter gradient stay fp32.  Needs the fp32 residual and gradient streams.
         self._amp_fp16 = os.environ.get("CLDRD_AMP", "fp16") != "bf16"
+        # Round 5: in the all-fp16 mode the gradient stream itself is fp16 between kernels (CLDRD_GRAD_STREAM=fp32 keeps the round-3/4 fp32
+        # stream).  It carries the loss scale like every 16-bit gradient tensor; each LayerNorm backward still forms dy = stream + branch and
+        # its whole arithmetic in fp32 and rounds dx once.  A LayerNorm backward then moves 250-300 MB at T = 32768 instead of 400 (twelve of
+        # them per cfg2 step: 1.22 ms at the HBM roof).  Gradient directions against the reference's fp32 gradients, every ranked tensor of
+        # cfg1-4: min cosine 0.99990-0.99995 with the stream rounded at exactly these points, against 0.99992-0.99998 with the fp32 stream
+        # (profiles/r05_grad_cosines.txt) - the level of the reference's own fp16 autocast (>= 0.9999).  The CLS-only last layer keeps its
+        # (256-row) stream in fp32.
+        self._grad_stream16 = os.environ.get("CLDRD_GRAD_STREAM", "fp16") == "fp16"
 
     # ------------------------------------------------------------------ parameters
     def named_flat(self):
@@ -436,6 +444,11 @@ class HipEncoder(nn.Module):
     def amp16(self):
         """the all-fp16 training mode (see __init__): needs the fp32 residual stream and the fp32 gradient stream"""
         return self._amp_fp16 and self.stream32 and self.grad_stream32
+
+    @property
+    def grad_stream16(self):
+        """the gradient stream is fp16 between kernels (round 5; only in the all-fp16 training mode, see __init__)"""
+        return self.amp16 and self._grad_stream16
 
     @property
     def needs_h16(self):
@@ -903,7 +916,9 @@ class HipEncoder(nn.Module):
         self._wq.add(dqc, a["xc"], G["Wqkv"][:d], M, dbias=G["bqkv"][:d])
         self._wq.add(dkv, a["x_in"], G["Wqkv"][d:], T, dbias=G["bqkv"][d:])
         wt = self.ht(i, "qkv")                                      # [d, 3d] = Wqkv^T
-        g = buf(T, d, dev, sdt)
+        # the [T, d] gradient this layer hands down: fp32 - or fp16 with the fp16 gradient stream (the layer's own M-row stream stays fp32:
+        # the CLS rows are added from the fp32 gq with one rounding)
+        g = buf(T, d, dev, torch.float16 if (GS and self.grad_stream16 and bdt == torch.float16) else sdt)
         ops.gemm_nt(dkv, wt[:, d:], g, T)                           # through K and V: every token
         gq = buf(M, d, dev, sdt)
         ops.gemm_nt(dqc, wt[:, :d], gq, M, residual=ds1)            # through Q and the residual: CLS rows only
@@ -995,9 +1010,10 @@ class HipEncoder(nn.Module):
                 tape.layers[i] = None
                 layer_done(i)
                 continue
-            GS = self.grad_stream32 and a["s2"].dtype == torch.float32  # fp32 gradient stream (see __init__)
-            sdt = torch.float32 if GS else torch.bfloat16
+            GS = self.grad_stream32 and a["s2"].dtype == torch.float32  # fp32 residual sums on the tape: the stream is added in the LayerNorm backward
             bdt = a["h"].dtype                                          # 16-bit format of this backward = the tape's (fp16 in amp16)
+            G16 = GS and self.grad_stream16 and bdt == torch.float16    # ... and is itself fp16 between kernels (round 5, see __init__)
+            sdt = torch.float16 if G16 else (torch.float32 if GS else torch.bfloat16)
             buf = lambda r, c, dv, dt=None: self._buf(r, c, dv, bdt if dt is None else dt)
             if g is None:
                 g = buf(T, d, dev, sdt)
@@ -1008,7 +1024,9 @@ class HipEncoder(nn.Module):
             s_l, p_h, p_a, p_out = a["seed"], a["p_h"], a["p_a"], a["p_out"]
             # --- output LayerNorm + FFN ---
             ds2 = buf(T, d, dev, sdt)
-            ds2m = buf(T, d, dev) if (p_h > 0 or GS) else None    # bf16: the MFMA operand of the FFN2 data / weight gradients
+            # the 16-bit MFMA operand of the FFN2 data / weight gradients: a tensor of its own when dropout separates it from the stream, or
+            # when the stream is fp32; with the fp16 stream and no dropout the stream tensor serves
+            ds2m = buf(T, d, dev) if (p_h > 0 or (GS and not G16)) else None
             lnq = self._lnq
             own = (lambda: torch.empty(ops.ln_partial_elems(T, d), **f32)) if lnq is not None else (lambda: partial)
             # fp32 stream: the gradient of a LayerNorm output is `g` (fp32: the residual path) + `gb` (bf16: the plain output of the
@@ -1027,7 +1045,7 @@ class HipEncoder(nn.Module):
                 ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T, residual=ds2)
             # --- attention-output LayerNorm + attention ---
             ds1 = buf(T, d, dev, sdt)
-            ds1m = buf(T, d, dev) if (p_out > 0 or GS) else None
+            ds1m = buf(T, d, dev) if (p_out > 0 or (GS and not G16)) else None
             ops.layernorm_bwd(ds2 if GS else dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), T,
                               p_out, s_l + 2, accumulate=self._acc, defer=lnq, dy_branch=dx1 if GS else None)
             dA = ds1m if ds1m is not None else ds1

@@ -392,9 +392,9 @@ def attention_cls_bwd(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p=0.0, 
 
 def add_rows_strided(dst, src, M, stride_rows):
     """dst[m * stride_rows] += src[m]: bf16 rows (fp32 add, one rounding), or fp32 rows (fp32 gradient stream)."""
-    dt = F32 if dst.dtype == F32 else BF16
-    _chk(dst, dt, "dst", 2), _chk(src, dt, "src", 2)
-    call("cldrd_add_rows_strided", _p(dst), _p(src), M, src.shape[1], stride_rows, 1 if dt == F32 else 0, _stream())
+    fmt = _stream_fmt(dst)           # fp16 dst (the fp16 gradient stream) takes an fp32 src
+    _chk(dst, dst.dtype, "dst", 2), _chk(src, F32 if fmt else BF16, "src", 2)
+    call("cldrd_add_rows_strided", _p(dst), _p(src), M, src.shape[1], stride_rows, fmt, _stream())
 
 
 def ln_partial_elems(T, d) -> int:
@@ -419,14 +419,15 @@ def embed_ln_bwd(dy, ids, word, pos, type0, gamma, mean, rstd, dword, dpos, dtyp
     d = word.shape[1]
     if pos_idx is not None:
         _chk(pos_idx, torch.int32, "pos_idx", 1)
-    if dy.dtype not in (BF16, F32):
-        raise TypeError("embed_ln_bwd: dy must be bf16, or fp32 (fp32 gradient stream)")
-    if dy_branch is not None and (dy.dtype != F32 or dy_branch.dtype not in (BF16, F16) or dy_branch.shape[1] != dy.shape[1] or dy_branch.shape[0] < T):
-        raise ValueError("embed_ln_bwd: dy_branch (bf16 or fp16 [>= T, d]) goes with an fp32 dy")
+    if dy.dtype not in (BF16, F32, F16):
+        raise TypeError("embed_ln_bwd: dy must be bf16, fp32 (fp32 gradient stream) or fp16 (fp16 gradient stream)")
+    if dy_branch is not None and (dy.dtype not in (F32, F16) or dy_branch.dtype not in (BF16, F16) or dy_branch.shape[1] != dy.shape[1] or dy_branch.shape[0] < T
+                                  or (dy.dtype == F16 and dy_branch.dtype != F16)):
+        raise ValueError("embed_ln_bwd: dy_branch (bf16 or fp16 [>= T, d]) goes with an fp32 dy, an fp16 one with an fp16 dy")
     call("cldrd_embed_ln_bwd", _p(dy), _p(ids), _p(word), _p(pos), _p(type0), _p(gamma), _p(mean), _p(rstd), _p(dword),
          _p(dpos), _p(dtype0), _p(dgamma), _p(dbeta), _p(partial), T, L, d, word.shape[0], dropout_p, seed,
-         1 if accumulate else 0, _p(pos_idx), (1 if dy.dtype == F32 else 0) | (4 if (dy_branch is not None and dy_branch.dtype == F16) else 0),
-         _p(dy_branch), _stream())
+         1 if accumulate else 0, _p(pos_idx), (1 if dy.dtype == F32 else 0) | (4 if (dy_branch is not None and dy_branch.dtype == F16) else 0)
+         | (8 if dy.dtype == F16 else 0), _p(dy_branch), _stream())
 
 
 # ---- variable-length packing (csrc/pack.hip) ---------------------------------------------------------------------------------------
@@ -453,15 +454,23 @@ def gather_rows(src, idx, dst, n=None):
     return dst
 
 
+def _stream_fmt(t):
+    """row format code of a gradient-stream tensor: 0 bf16, 1 fp32, 2 fp16"""
+    if t.dtype not in (BF16, F32, F16):
+        raise TypeError(f"gradient stream tensor: expected bf16, fp32 or fp16, got {t.dtype}")
+    return 1 if t.dtype == F32 else (2 if t.dtype == F16 else 0)
+
+
 def scatter_cls_grad_idx(dcls, g, idx, T):
-    _chk(dcls, F32, "dcls", 2), _chk(g, F32 if g.dtype == F32 else BF16, "g", 2), _chk(idx, torch.int32, "idx", 1)
-    call("cldrd_scatter_cls_grad_idx", _p(dcls), _p(g), dcls.shape[0], dcls.shape[1], _p(idx), T, 1 if g.dtype == F32 else 0, _stream())
+    _chk(dcls, F32, "dcls", 2), _chk(g, g.dtype, "g", 2), _chk(idx, torch.int32, "idx", 1)
+    call("cldrd_scatter_cls_grad_idx", _p(dcls), _p(g), dcls.shape[0], dcls.shape[1], _p(idx), T, _stream_fmt(g), _stream())
 
 
 def add_rows_idx(dst, src, idx, M):
-    dt = F32 if dst.dtype == F32 else BF16
-    _chk(dst, dt, "dst", 2), _chk(src, dt, "src", 2), _chk(idx, torch.int32, "idx", 1)
-    call("cldrd_add_rows_idx", _p(dst), _p(src), M, src.shape[1], _p(idx), 1 if dt == F32 else 0, _stream())
+    """dst[idx[m]] += src[m]: bf16 += bf16, fp32 += fp32, or fp16 dst += fp32 src (the fp16 gradient stream)"""
+    fmt = _stream_fmt(dst)
+    _chk(dst, dst.dtype, "dst", 2), _chk(src, F32 if fmt else BF16, "src", 2), _chk(idx, torch.int32, "idx", 1)
+    call("cldrd_add_rows_idx", _p(dst), _p(src), M, src.shape[1], _p(idx), fmt, _stream())
 
 
 def layernorm_fwd(x, gamma, beta, out, mean, rstd, T, eps, cls_out=None, cls_stride=0, out32=None, out_copy=None):
@@ -516,7 +525,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_dropped, dgamma, dbeta, dbias
     fp32 ``dy`` = the fp32 gradient stream: ``dx`` fp32, ``dx_dropped`` (bf16, required) the MFMA operand copy; ``dy_branch`` (bf16,
     optional) is added to dy on load (the branch's data-gradient GEMM output, instead of a residual add in that GEMM's epilogue)."""
     x_f32 = 1 if x.dtype == F32 else 0
-    g_f32 = dy.dtype == F32               # fp32 gradient stream: dy and dx fp32, dx_dropped (the bf16 MFMA operand) required
+    g_f32 = dy.dtype == F32               # fp32 gradient stream: dy and dx fp32, dx_dropped (the 16-bit MFMA operand) required
+    g_f16 = dy.dtype == F16               # fp16 gradient stream (round 5): dy, dx, dy_branch and dx_dropped fp16; dx_dropped optional
     if g_f32:
         if not x_f32 or dx_dropped is None:
             raise ValueError("layernorm_bwd: an fp32 dy needs fp32 x and the bf16 operand copy dx_dropped")
@@ -527,9 +537,20 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dx_dropped, dgamma, dbeta, dbias
             if dy_branch.shape[1] != dy.shape[1] or dy_branch.shape[0] < T:
                 raise ValueError("layernorm_bwd: dy_branch must be [>= T, d]")
         x_f32 |= 2 | (4 if h16 else 0)
+    elif g_f16:
+        if not x_f32:
+            raise ValueError("layernorm_bwd: an fp16 dy (the fp16 gradient stream) needs fp32 x")
+        _chk(dx, F16, "dx", 2)
+        if dx_dropped is not None:
+            _chk(dx_dropped, F16, "dx_dropped", 2)
+        if dy_branch is not None:
+            _chk(dy_branch, F16, "dy_branch", 2)
+            if dy_branch.shape[1] != dy.shape[1] or dy_branch.shape[0] < T:
+                raise ValueError("layernorm_bwd: dy_branch must be [>= T, d]")
+        x_f32 |= 4 | 8
     else:
         if dy_branch is not None:
-            raise ValueError("layernorm_bwd: dy_branch goes with an fp32 dy")
+            raise ValueError("layernorm_bwd: dy_branch goes with an fp32 / fp16 dy")
         _chk(dy, BF16, "dy", 2), _chk(dx, BF16, "dx", 2)
     _chk(x, F32 if (x_f32 & 1) else BF16, "x", 2)
     d = x.shape[1]
@@ -554,8 +575,8 @@ def colsum(x, out, partial, T, accumulate=True):
 
 def scatter_cls_grad(dcls, g, R, stride, T):
     """g[T, d] (bf16, or fp32 for the fp32 gradient stream) = 0 except rows r * stride <- dcls[r]."""
-    _chk(dcls, F32, "dcls", 2), _chk(g, F32 if g.dtype == F32 else BF16, "g", 2)
-    call("cldrd_scatter_cls_grad", _p(dcls), _p(g), R, dcls.shape[1], stride, T, 1 if g.dtype == F32 else 0, _stream())
+    _chk(dcls, F32, "dcls", 2), _chk(g, g.dtype, "g", 2)
+    call("cldrd_scatter_cls_grad", _p(dcls), _p(g), R, dcls.shape[1], stride, T, _stream_fmt(g), _stream())
 
 
 def score_fwd(q, p, logits, B, N, mode=0):

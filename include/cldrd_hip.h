@@ -154,7 +154,11 @@ int cldrd_layernorm_fwd(const void* x, const float* gamma, const float* beta, vo
  * x_f32: bit 0 = x holds fp32 pre-LN sums; bit 1 = fp32 GRADIENT STREAM: dy is read and dx written as fp32 rows, dx_dropped (bf16, then
  * required and written without dropout too) is the MFMA operand of the next data-gradient GEMM, and dy_branch (bf16, optional) is added to dy
  * on load - the output of the data-gradient GEMM of the branch that joins the residual path here.  cldrd_embed_ln_bwd: dy_f32 / dy_branch
- * likewise. */
+ * likewise.  bit 2 = dx_dropped / dy_branch are fp16, not bf16 (the all-fp16 training mode).  bit 3 = FP16 GRADIENT STREAM (round 5; implies
+ * bit 2, needs bit 0, excludes bit 1): dy is read and dx written as fp16 rows carrying the loss scale; dx_dropped may be NULL when no dropout
+ * separates the stream from the MFMA operand (dx then is that operand).  cldrd_embed_ln_bwd: dy_f32 bit 3 = dy is fp16.
+ * cldrd_scatter_cls_grad(_idx) g_f32 / cldrd_add_rows_strided, cldrd_add_rows_idx f32: 0 = bf16 rows, 1 = fp32, 2 = fp16 (the add forms
+ * then take an fp32 src: fp16 dst += fp32 src, one rounding). */
 int cldrd_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
                         void* dx, void* dx_dropped, float* dgamma, float* dbeta, float* dbias, float* partial, int T,
                         int d, float dropout_p, unsigned long long seed, int accumulate, int x_f32, const void* dy_branch, void* stream);

@@ -438,3 +438,100 @@ def test_skipped_steps_do_not_advance_adams_bias_correction(graph, monkeypatch):
     sa, sb = A.optimizer_state_dict(), Bt.optimizer_state_dict()
     assert {v["step"] for v in sa["state"].values()} == {3} and {v["step"] for v in sb["state"].values()} == {3}
     # without the correction B's exponent would have been 2, 3, 4: its first applied update alone would differ by ~(1 - b1^2)/(1 - b1) ~ 1.9x
+
+
+@pytest.mark.parametrize("T,d,p,branch", [(300, 768, 0.0, True), (1000, 768, 0.1, True), (130, 128, 0.1, False), (2050, 768, 0.0, False)])
+def test_layernorm_bwd_fp16_gradient_stream(T, d, p, branch):
+    """Round 5: the gradient stream itself is fp16 (dy in, dx out; CLDRD_GRAD_STREAM=fp16, the default of the all-fp16 mode).  Same arithmetic as the
+    fp32-stream kernel on the same (fp16-representable) inputs: dx equals the fp32-stream dx rounded once to fp16, the dropped operand copy and the
+    parameter-gradient sums are bit-identical; without dropout no second tensor is written at all."""
+    x = rnd(51, (T, d))
+    dy16 = rnd(52, (T, d)).half()
+    br = rnd(53, (T, d), 0.3).half() if branch else None
+    gamma = 1 + 0.1 * rnd(54, (d,))
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-12)
+    args = (x.to(DEV), mean.to(DEV), rstd.to(DEV), gamma.to(DEV))
+    brd = br.to(DEV) if branch else None
+
+    def run(dy, stream16, with_copy):
+        dx = torch.full((T, d), float("nan"), dtype=torch.float16 if stream16 else torch.float32, device=DEV)
+        d2 = torch.full((T, d), float("nan"), dtype=torch.float16, device=DEV) if with_copy else None
+        dg, db, dbi = torch.empty(d, device=DEV), torch.empty(d, device=DEV), torch.empty(d, device=DEV)
+        ops.layernorm_bwd(dy, *args, dx, d2, dg, db, dbi, torch.empty(ops.ln_partial_elems(T, d), device=DEV), T, dropout_p=p, seed=9,
+                          accumulate=False, dy_branch=brd)
+        return dx, d2, dg, db, dbi
+    ref = run(dy16.float().to(DEV), False, True)                 # the fp32-stream kernel on the same values
+    got = run(dy16.to(DEV), True, True)
+    assert torch.equal(got[0], ref[0].half()), "fp16 stream dx is not the fp32-stream dx rounded once"
+    assert torch.equal(got[1], ref[1]), "operand copy differs"
+    for i in (2, 3, 4):
+        assert torch.equal(got[i], ref[i]), "parameter-gradient sums differ"
+    if p == 0.0:
+        only = run(dy16.to(DEV), True, False)                   # no dropout: the stream tensor is the operand
+        assert only[1] is None and torch.equal(only[0], got[0]) and torch.equal(only[0], got[1])
+        assert torch.equal(only[4], got[4])
+    with pytest.raises((TypeError, ValueError)):
+        ops.layernorm_bwd(dy16.to(DEV), *args, torch.empty(T, d, device=DEV), None, None, None, None,
+                          torch.empty(ops.ln_partial_elems(T, d), device=DEV), T)          # fp16 dy with an fp32 dx
+
+
+def test_fp16_stream_row_helpers():
+    """scatter_cls_grad(_idx) into an fp16 stream tensor; fp16 dst += fp32 src for the CLS rows (one rounding)."""
+    R, d, L = 6, 128, 5
+    dcls = rnd(61, (R, d)).to(DEV)
+    g = torch.full((R * L, d), float("nan"), dtype=torch.float16, device=DEV)
+    ops.scatter_cls_grad(dcls, g, R, L, R * L)
+    want = torch.zeros(R * L, d, dtype=torch.float16, device=DEV)
+    want[::L] = dcls.half()
+    assert torch.equal(g, want)
+    idx = torch.tensor([0, 3, 4, 9, 17, 29], dtype=torch.int32, device=DEV)
+    g2 = torch.full((R * L, d), float("nan"), dtype=torch.float16, device=DEV)
+    ops.scatter_cls_grad_idx(dcls, g2, idx, R * L)
+    want2 = torch.zeros(R * L, d, dtype=torch.float16, device=DEV)
+    want2[idx.long()] = dcls.half()
+    assert torch.equal(g2, want2)
+    base = rnd(62, (R * L, d)).half().to(DEV)
+    src = rnd(63, (R, d)).to(DEV)
+    a = base.clone()
+    ops.add_rows_strided(a, src, R, L)
+    w = base.clone()
+    w[::L] = (base[::L].float() + src).half()
+    assert torch.equal(a, w)
+    b = base.clone()
+    ops.add_rows_idx(b, src, idx, R)
+    w2 = base.clone()
+    w2[idx.long()] = (base[idx.long()].float() + src).half()
+    assert torch.equal(b, w2)
+
+
+def test_fp16_and_fp32_gradient_streams_agree_end_to_end(monkeypatch):
+    """The whole backward of a small model with the fp16 stream (default) and with CLDRD_GRAD_STREAM=fp32 from the same state: every
+    parameter-gradient tensor agrees to fp16 rounding noise (cosine >= 0.99999 per tensor, norms to 1e-3)."""
+    cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=3, max_position_embeddings=64,
+                        dropout=0.1, attention_dropout=0.1)
+    batch = syn.nway_batch(4680, 4, 6, 10, 40, vocab=cfg.vocab_size, ragged=True, label_kind="teacher")
+    grads = {}
+    for mode in ("fp16", "fp32"):
+        monkeypatch.setenv("CLDRD_GRAD_STREAM", mode)
+        monkeypatch.setenv("CLDRD_GRAPH", "0")
+        model = selftest.build_tiny_model(cfg, seed=5).cuda().train()
+        tr = NwayTrainer(model, loss="kl_div", learning_rate=1e-4, warmup_steps=0, total_steps=10)
+        assert tr.amp16 and all(t.grad_stream16 == (mode == "fp16") for t in model.towers())
+        for t in model.towers():
+            t.step_seed = 11
+        tr.forward_backward(batch)
+        torch.cuda.synchronize()
+        grads[mode] = {n: p.grad.detach().double().clone() for n, p in model.named_parameters()}
+    worst = 1.0
+    for n, a in grads["fp16"].items():
+        b = grads["fp32"][n]
+        if b.norm().item() < 1e-9:
+            continue
+        c = float((a * b).sum() / (a.norm() * b.norm()))
+        worst = min(worst, c)
+        if "k_lin.bias" in n:           # mathematically zero gradient: noise in every implementation
+            continue
+        assert c >= 0.99999, (n, c)
+        assert abs(a.norm().item() / b.norm().item() - 1.0) <= 1e-3, n
+    print("worst cosine fp16-stream vs fp32-stream:", worst)
