@@ -79,6 +79,8 @@ SIGNATURES = {
     "cldrd_set_seed_base": (None, [vp]),
     "cldrd_set_optim_hyper": (None, [vp]),
     "cldrd_set_loss_scale": (None, [vp, ci]),
+    "cldrd_set_norm_sink": (None, [vp, ci]),
+    "cldrd_norm_sink_used": (ci, []),
     "cldrd_loss_scale_adapt": (ci, [vp, csz, vp, csz, vp, vp]),
     "cldrd_write_step_state": (ci, [vp, cull, cull, vp, cf, cf, cf, ci, vp, vp]),
     "cldrd_write_run_file": (C.c_longlong, [C.c_char_p, vp, vp, vp, C.c_longlong, ci, ci]),

@@ -63,6 +63,32 @@ extern "C" void cldrd_set_loss_scale(const float* scale, int growth_interval) {
     g_cldrd_loss_scale_interval = growth_interval > 0 ? growth_interval : 2000;
 }
 
+// Clip-norm partial sums from the kernels that WRITE the gradients (round 5).  While a sink is set, launches of this thread that produce final
+// parameter gradients - the slab reduction of cldrd_wgrad_group, cldrd_ln_reduce_group - also write one sum of squares per workgroup of what
+// they wrote to slots[cursor ...] and advance the (host-side, thread-local) cursor; cldrd_clip_coef then reduces those slots next to the ones of
+// cldrd_sqnorm_partial.  The trainer uses it for the passage tower's layer gradients, the only ones that are complete AFTER the last
+// weight-gradient group: the separate norm pass over them (265 MB re-read, ~90 us on the critical path of every step) is gone.  A launch that
+// cannot contribute (a weight-gradient group that writes its tiles directly, without slabs) marks the sink incomplete: cldrd_norm_sink_used()
+// then returns -1 and the caller takes the norm of that range the old way.
+thread_local float* g_cldrd_norm_sink = nullptr;
+thread_local int g_cldrd_norm_sink_cap = 0, g_cldrd_norm_sink_used = 0, g_cldrd_norm_sink_bad = 0;
+extern "C" void cldrd_set_norm_sink(float* slots, int capacity) {
+    g_cldrd_norm_sink = slots;
+    g_cldrd_norm_sink_cap = slots ? capacity : 0;
+    g_cldrd_norm_sink_used = 0;
+    g_cldrd_norm_sink_bad = 0;
+}
+extern "C" int cldrd_norm_sink_used(void) { return g_cldrd_norm_sink_bad ? -1 : g_cldrd_norm_sink_used; }
+// reserve n slots for a launch; null when no sink is set or it is full (the sink is then marked incomplete)
+float* cldrd_norm_sink_take(int n) {
+    if (!g_cldrd_norm_sink) return nullptr;
+    if (n <= 0 || g_cldrd_norm_sink_used + n > g_cldrd_norm_sink_cap) { g_cldrd_norm_sink_bad = 1; return nullptr; }
+    float* p = g_cldrd_norm_sink + g_cldrd_norm_sink_used;
+    g_cldrd_norm_sink_used += n;
+    return p;
+}
+void cldrd_norm_sink_miss(void) { if (g_cldrd_norm_sink) g_cldrd_norm_sink_bad = 1; }
+
 namespace {
 __global__ void step_state_kernel(unsigned long long* seeds, unsigned long long s0, unsigned long long s1, float* hyper, float lr, float step_size,
                                   float beta1, float beta2, int adam_step, const float* scale_state) {

@@ -117,6 +117,8 @@ extern thread_local const unsigned long long* g_cldrd_seed_base;      // capi.hi
 extern thread_local const float* g_cldrd_optim_hyper;                 // capi.hip: device float[2] = {lr, step size} or null
 extern thread_local const float* g_cldrd_loss_scale;                  // capi.hip: device float[72] = {S, 1 / S, good steps, skipped steps, headroom h, 3 unused, 64 scratch} or null
 extern thread_local int g_cldrd_loss_scale_interval;                  // finite steps in a row after which S doubles (cldrd_set_loss_scale)
+float* cldrd_norm_sink_take(int n);      // capi.hip: n slots of the clip-norm sink for one launch (null: no sink / full), see cldrd_set_norm_sink
+void cldrd_norm_sink_miss(void);         // a gradient-producing launch that cannot contribute marks the sink incomplete
 static inline SeedArg seed_arg(unsigned long long s) { return SeedArg{s, g_cldrd_seed_base}; }
 
 // XCD-aware bijective block remap (cdna_hip_programming.md section 5, T1): blocks b and b+8 share an XCD, so

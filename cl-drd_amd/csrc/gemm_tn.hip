@@ -48,6 +48,7 @@ struct TnGroupArgs {
     float* slabs;
     const float* inv_scale;            // device scalar or null: every output (dW, dbias) is multiplied by it - the operands of the all-fp16
                                        // training mode carry the loss scale, parameter gradients do not (capi.hip: cldrd_set_loss_scale)
+    float* sq_out;                     // slab reduction only: [gridDim.y][gridDim.x] sums of squares of what each workgroup wrote, or null
     TnProblem p[MAXP];
 };
 
@@ -413,13 +414,14 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, float* __re
 }
 
 // the same for every problem of a group in one launch: blockIdx.y = problem
-__global__ void reduce_slabs_group_kernel(TnGroupArgs ga) {
+__global__ __launch_bounds__(256) void reduce_slabs_group_kernel(TnGroupArgs ga) {
     const TnProblem& P = ga.p[blockIdx.y];
     const size_t n_main4 = (size_t)P.N1 * P.N2 / 4, n_all4 = n_main4 + (P.dbias ? (size_t)P.N1 / 4 : 0);
     const size_t stride4 = ((size_t)P.N1 * P.N2 + (size_t)P.N1) / 4;
     const float4* slabs = (const float4*)(ga.slabs + P.slab_off);
     const size_t step = (size_t)gridDim.x * blockDim.x;
     const float osc = ga.inv_scale ? *ga.inv_scale : 1.0f;
+    float sq = 0.f;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_all4; i += step) {
         float4 s = slabs[i];
         for (int k = 1; k < ga.splits; ++k) {
@@ -433,6 +435,14 @@ __global__ void reduce_slabs_group_kernel(TnGroupArgs ga) {
             s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
         }
         *dst = s;
+        sq += s.x * s.x + s.y * s.y + s.z * s.z + s.w * s.w;
+    }
+    if (ga.sq_out) {       // the clip norm's share of this workgroup (capi.hip: cldrd_set_norm_sink): fixed order, no atomics
+        __shared__ float red[4];
+        sq = wave_sum(sq);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) ga.sq_out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     }
 }
 
@@ -578,6 +588,7 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
         TnGroupArgs g;
         g.n = m; g.splits = splits; g.accumulate = accumulate & 1; g.stagger = wgrad_stagger(); g.slabs = workspace;
         g.inv_scale = g_cldrd_loss_scale ? g_cldrd_loss_scale + 1 : nullptr;
+        g.sq_out = nullptr;
         int items = 0;
         for (int i = 0; i < m; ++i) {
             TnProblem& P = g.p[i];
@@ -615,10 +626,12 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
         else if (t.t1 == 256) rc = launch_tn_group<256, 128, 8>(g, items, st);
         else rc = launch_tn_group<128, 128, 4>(g, items, st);
         if (rc) return rc;
+        if (splits == 1) cldrd_norm_sink_miss();      // tiles written directly by the GEMM: no slab reduction to take the sums of squares from
         if (splits > 1) {
             size_t biggest = 0;
             for (int i = 0; i < m; ++i) biggest = biggest > (size_t)g.p[i].N1 * g.p[i].N2 / 4 ? biggest : (size_t)g.p[i].N1 * g.p[i].N2 / 4;
             const int rb = (int)((biggest + 255) / 256 < 256 ? (biggest + 255) / 256 : 256);
+            g.sq_out = cldrd_norm_sink_take(rb * m);       // clip-norm partial sums of what this reduction writes, when a sink is set
             hipLaunchKernelGGL(reduce_slabs_group_kernel, dim3(rb, m), dim3(256), 0, st, g);       // one reduction launch for the group
             CLDRD_LAUNCH_CHECK();
         }

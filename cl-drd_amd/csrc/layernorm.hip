@@ -631,7 +631,7 @@ struct LnReduceGroup {
     float* out[LN_GROUP_MAX][3];
     int nblk[LN_GROUP_MAX];
 };
-__global__ __launch_bounds__(1024) void reduce_partials_group_kernel(LnReduceGroup g, int n, int seg, int accumulate) {
+__global__ __launch_bounds__(1024) void reduce_partials_group_kernel(LnReduceGroup g, int n, int seg, int accumulate, float* __restrict__ sq_out) {
     constexpr int RG = 16;
     __shared__ float red[RG][64];
     const float* __restrict__ partial = g.partial[blockIdx.y];
@@ -645,14 +645,23 @@ __global__ __launch_bounds__(1024) void reduce_partials_group_kernel(LnReduceGro
     }
     red[rg][threadIdx.x & 63] = s0 + s1;
     __syncthreads();
-    if (rg != 0 || c >= n) return;
-    float s = 0.f;
+    if (rg != 0) return;           // wave 0 from here on (whole: lanes past n carry zeros)
+    float v = 0.f;
+    if (c < n) {
+        float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < RG; i += 4) s += (red[i][threadIdx.x] + red[i + 1][threadIdx.x]) + (red[i + 2][threadIdx.x] + red[i + 3][threadIdx.x]);
-    float* out = g.out[blockIdx.y][c < seg ? 0 : (c < 2 * seg ? 1 : 2)];
-    if (!out) return;
-    const int i = c % seg;
-    out[i] = accumulate ? out[i] + s : s;
+        for (int i = 0; i < RG; i += 4) s += (red[i][threadIdx.x] + red[i + 1][threadIdx.x]) + (red[i + 2][threadIdx.x] + red[i + 3][threadIdx.x]);
+        float* out = g.out[blockIdx.y][c < seg ? 0 : (c < 2 * seg ? 1 : 2)];
+        if (out) {
+            const int i = c % seg;
+            v = accumulate ? out[i] + s : s;
+            out[i] = v;
+        }
+    }
+    if (sq_out) {                  // the clip norm's share of these 64 columns (capi.hip: cldrd_set_norm_sink)
+        const float q = wave_sum(v * v);
+        if (threadIdx.x == 0) sq_out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = q;
+    }
 }
 
 static int launch_reduce(const float* partial, int nblk, int d, float* o0, float* o1, float* o2, int accumulate, hipStream_t st) {
@@ -717,7 +726,8 @@ extern "C" int cldrd_ln_reduce_group(const float* const* partial, const int* T, 
             g.nblk[i] = ln_bwd_blocks(T[lo + i]);
             g.out[i][0] = dgamma[lo + i]; g.out[i][1] = dbeta[lo + i]; g.out[i][2] = dbias[lo + i];
         }
-        hipLaunchKernelGGL(reduce_partials_group_kernel, dim3((3 * d + 63) / 64, m), dim3(1024), 0, (hipStream_t)stream, g, 3 * d, d, accumulate);
+        float* sq = cldrd_norm_sink_take(((3 * d + 63) / 64) * m);      // clip-norm partial sums of what this launch writes, when a sink is set
+        hipLaunchKernelGGL(reduce_partials_group_kernel, dim3((3 * d + 63) / 64, m), dim3(1024), 0, (hipStream_t)stream, g, 3 * d, d, accumulate, sq);
         CLDRD_LAUNCH_CHECK();
     }
     return 0;

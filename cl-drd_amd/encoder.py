@@ -990,9 +990,14 @@ class HipEncoder(nn.Module):
             if force or (flush_every > 0 and len(waiting) >= flush_every):
                 if force and before_last_wgrad is not None:
                     before_last_wgrad()
-                if self._lnq is not None:
-                    self._lnq.flush(accumulate=self._acc)
-                self._wq.flush(accumulate=self._acc)
+                # `norm_sink` (the trainer's, one GPU): when this ONE flush produces every layer gradient of the tower - LayerNorm reductions
+                # deferred, no early flushes - the two launches also leave the clip norm's partial sums of what they write (hip_ops.norm_sink)
+                sink = getattr(self, "norm_sink", None) if (force and flush_every == 0 and self._lnq is not None and not self._acc) else None
+                with ops.norm_sink(sink) as ns:
+                    if self._lnq is not None:
+                        self._lnq.flush(accumulate=self._acc)
+                    self._wq.flush(accumulate=self._acc)
+                self.norm_sink_used = ns.used if sink is not None else -1
                 if after_layer is not None:
                     for j in waiting:
                         after_layer(j)

@@ -98,6 +98,27 @@ class loss_scale:
             _TLS.loss_scale = self.prev
 
 
+class norm_sink:
+    """``with norm_sink(slots) as sink:`` weight-gradient slab reductions and LayerNorm-parameter reductions launched inside also write
+    per-workgroup sums of squares of the gradients they write to ``slots`` (fp32, device); ``sink.used`` afterwards = slots written, or -1
+    when a launch inside could not contribute (include/cldrd_hip.h: cldrd_set_norm_sink).  ``slots`` None: a no-op context (used = -1)."""
+
+    def __init__(self, slots):
+        self.slots, self.used = slots, -1
+
+    def __enter__(self):
+        if self.slots is not None:
+            _chk(self.slots, F32, "slots", 1)
+            _lib.load().cldrd_set_norm_sink(self.slots.data_ptr(), self.slots.numel())
+        return self
+
+    def __exit__(self, *exc):
+        if self.slots is not None:
+            lib = _lib.load()
+            self.used = int(lib.cldrd_norm_sink_used())
+            lib.cldrd_set_norm_sink(None, 0)
+
+
 def new_loss_scale_state(device):
     """device float[72]: {S = 1, 1 / S = 1, good steps 0, skipped 0, headroom exponent 0, ..., scratch} (include/cldrd_hip.h)"""
     st = torch.zeros(72, dtype=F32, device=device)

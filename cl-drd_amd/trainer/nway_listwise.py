@@ -125,7 +125,9 @@ class NwayTrainer:
             self.buckets.append((ti, -1, toff + a, toff + b))
         self.decay_flags = flags.to(dev)
         self.clip = torch.zeros(3, dtype=torch.float32, device=dev)
-        self.norm_partial = torch.empty(ops.sqnorm_blocks(), dtype=torch.float32, device=dev)
+        # clip-norm partial sums: [0, half) the early piece (sqnorm_partial on the second stream), [half, 2 half) the late piece when it is taken by
+        # sqnorm_partial, or [half, half + used) when the kernels that write the passage tower's layer gradients leave them (norm sink, round 5)
+        self.norm_partial = torch.empty(ops.sqnorm_blocks() // 2 + 12288, dtype=torch.float32, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.distributed else None
         if self.comm_stream is not None:
             self.flat_g.record_stream(self.comm_stream)        # the bucket slices are used on it (the buffer lives as long as the trainer)
@@ -134,6 +136,7 @@ class NwayTrainer:
         # third stream: scoring + loss + score backward between the towers' forward and backward (see forward_backward)
         self.l_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = []
+        self._sink_on = False
         # CLDRD_AMP=fp16 towers (encoder.py: amp16): the loss scale lives in device memory (hip_ops.new_loss_scale_state).  It is set every
         # step from dL/dCLS (ops.loss_scale_adapt: a power of two that puts the largest entering gradient at 2^11..2^12); what is kept of
         # torch.cuda.amp.GradScaler (the reference: nway_listwise_1.py:355-359) is its safety net: a non-finite gradient norm skips the step
@@ -189,7 +192,7 @@ class NwayTrainer:
         tower's layers are left (`_optimizer_launches`).  Same fp64 reduction of fp32 partial sums as the one-piece norm."""
         toff = self.model._tower_offsets[-1]
         split = toff + self.model.towers()[-1].layout.embed_range[1]
-        half = self.norm_partial.numel() // 2
+        half = ops.sqnorm_blocks() // 2
 
         def hook(layer):
             if layer != -1 or split % 4 != 0 or split >= self.flat_g.numel():
@@ -337,8 +340,13 @@ class NwayTrainer:
             self._norm_split = None
             self._norm_deferred = None
             p_hook = self._bucket_hook(1)
+            self._sink_on = False
+            pe.norm_sink, pe.norm_sink_used = None, -1
             if p_hook is None and side is not main and write_once and _env_flag("CLDRD_NORM_SPLIT", "1") != "0":
                 p_hook = self._early_norm_hook(main, side, defer=q_late)
+                if _env_flag("CLDRD_NORM_SINK", "1") != "0":      # "0": the late piece by a separate pass (A/B runs, tests)
+                    self._sink_on = True
+                    pe.norm_sink = self.norm_partial[ops.sqnorm_blocks() // 2:]
             pe.backward_from_cls(p_tape, dp, after_layer=p_hook, accumulate=not write_once)
             if q_late:
                 # (released together with the passage tower's last weight-gradient group instead: +1.4 %, as in round 3's eager measurement)
@@ -377,10 +385,16 @@ class NwayTrainer:
     def _norm_launches(self):
         split = getattr(self, "_norm_split", None)
         if split:
-            # [0, split) was summed on the second stream during the backward (`_early_norm_hook`; the main stream has joined it since)
-            half = self.norm_partial.numel() // 2
-            ops.sqnorm_partial(self.flat_g[split:], self.norm_partial[half:], half)
-            ops.clip_coef(self.norm_partial, 2 * half, self.max_grad_norm, self.clip)
+            # [0, split) was summed on the second stream during the backward (`_early_norm_hook`; the main stream has joined it since).  The rest -
+            # the passage tower's layer gradients - is final only behind its last weight-gradient group; when that group's slab reduction
+            # and the LayerNorm-parameter reduction left their sums of squares (norm sink), nothing is re-read; else one more pass over them
+            half = ops.sqnorm_blocks() // 2
+            used = int(getattr(self.model.passage_encoder, "norm_sink_used", -1))
+            if used > 0 and self._sink_on:
+                ops.clip_coef(self.norm_partial, half + used, self.max_grad_norm, self.clip)
+            else:
+                ops.sqnorm_partial(self.flat_g[split:], self.norm_partial[half:2 * half], half)
+                ops.clip_coef(self.norm_partial, 2 * half, self.max_grad_norm, self.clip)
             self._norm_split = None
         else:
             ops.grad_clip_coef(self.flat_g, self.max_grad_norm, self.norm_partial, self.clip)

@@ -209,6 +209,13 @@ int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, float* partia
  * last weight-gradient launch): cldrd_sqnorm_partial writes exactly nblk partial sums of squares of g[0, n) to partial[0, nblk);
  * cldrd_clip_coef reduces nblk_total of them (fixed order, fp64) to out[3] as cldrd_grad_clip_coef does. */
 int cldrd_sqnorm_partial(const float* g, size_t n, float* partial, int nblk, void* stream);
+/* Clip-norm partial sums from the kernels that WRITE the gradients (round 5): while a sink is set (thread-local, like the loss scale),
+ * cldrd_wgrad_group - when it reduces token-split slabs - and cldrd_ln_reduce_group also write one sum of squares per workgroup of the
+ * values they wrote to slots[used ...]; cldrd_norm_sink_used() returns the number of slots written since cldrd_set_norm_sink, or -1 when
+ * a launch could not contribute (a weight-gradient group without slabs; sink full): the caller then takes that range's norm with
+ * cldrd_sqnorm_partial as before.  cldrd_clip_coef reduces the slots like any others.  slots = NULL: off. */
+void cldrd_set_norm_sink(float* slots, int capacity);
+int cldrd_norm_sink_used(void);
 int cldrd_clip_coef(const float* partial, int nblk_total, float max_norm, float* out, void* stream);
 int cldrd_adamw_step(float* p, const float* g, float* m, float* v, const unsigned char* decay_flags, void* shadow,
                      size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
