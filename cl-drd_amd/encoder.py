@@ -987,7 +987,11 @@ class HipEncoder(nn.Module):
                 after_layer(-1)
             else:
                 waiting.append(i)
-            if force or (flush_every > 0 and len(waiting) >= flush_every):
+            # (layer 0 never triggers an early flush: its group waits for the forced one behind embed_ln_bwd, so that the embedding block's
+            # hook - the tower's largest all-reduce bucket - is issued IN FRONT of a weight-gradient group it can travel under.  Until round 5
+            # a layer count that `wgrad_flush_layers` divides (6 / 3, 12 / 6: every shipped config) launched the last group at layer 0 and the
+            # embedding bucket went out with nothing left to overlap it: tools/bucket_plan.py)
+            if force or (flush_every > 0 and len(waiting) >= flush_every and i != 0):
                 if force and before_last_wgrad is not None:
                     before_last_wgrad()
                 # `norm_sink` (the trainer's, one GPU): when this ONE flush produces every layer gradient of the tower - LayerNorm reductions

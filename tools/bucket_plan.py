@@ -46,7 +46,7 @@ def plan(name, world):
         # embedding block's hook runs right behind embed_ln_bwd, in front of whatever weight-gradient group is still waiting
         for li in reversed(range(cfg.n_layers)):
             waiting.append(li)
-            if len(waiting) >= flush:
+            if len(waiting) >= flush and li != 0:      # layer 0 never triggers an early flush (encoder.py: layer_done)
                 emit(waiting)
                 waiting = []
         a, b = lay.embed_range
