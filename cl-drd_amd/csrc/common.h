@@ -67,19 +67,36 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // erf-GELU and its derivative (HF GELUActivation == F.gelu).  erf by Abramowitz-Stegun 7.1.26
-// (|error| <= 1.5e-7, far below the bf16 output rounding): one v_rcp + one v_exp + 6 FMAs instead of libm's erff
-// (~40 VALU ops), which made the GELU epilogues VALU-bound (100 M activations per FFN GEMM).  exp(-x^2/2) is shared
-// between erf(x / sqrt 2) and the Gaussian density of the derivative.
-__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    e = __expf(-z * z);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+// (|error| <= 1.5e-7, far below the 16-bit output rounding): one v_rcp + one v_exp + FMAs instead of libm's erff
+// (~40 VALU ops), which made the GELU epilogues VALU-bound (100 M activations per FFN GEMM).
+// Round 5: the same polynomial in the erfc form, which is what GELU needs - with z = |x| / sqrt 2, t = 1 / (1 + p z):
+//     q = Phi(-|x|) = erfc(z) / 2 = (t (a1/2 + t (a2/2 + ...))) exp(-z^2),     gelu(x) = x Phi(x) = max(x, 0) - |x| q
+// (x > 0: x (1 - q) = x - x q; x <= 0: x q = -|x| q).  No erf -> copysign -> 0.5 (1 + .) chain, the 1/2 sits in the coefficients and
+// exp(-z^2) is 2^(-(c |x|)^2) with c = sqrt(log2(e) / 2): 15 VALU per element (two of them transcendental) instead of 19 for the value
+// alone, same accuracy (the identical A-S polynomial; in the NEGATIVE tail even the relative error is A-S's, where the erf form cancelled).
+// The derivative Phi(x) + x phi(x) shares q and the exponential: Phi(x) = x > 0 ? 1 - q : q, phi(x) = exp(-x^2 / 2) / sqrt(2 pi).
+__device__ __forceinline__ void gelu_q(float x, float& q, float& e) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, ax, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f), 0.5f * 1.421413741f), 0.5f * -0.284496736f), 0.5f * 0.254829592f);
+    const float w = ax * 0.84932180028801904f;          // sqrt(log2(e) / 2): exp(-x^2 / 2) = 2^(-w^2)
+    e = __builtin_amdgcn_exp2f(-w * w);
+    q = poly * e;
 }
-__device__ __forceinline__ float gelu_f(float x) { float c, e; gelu_parts(x, c, e); return x * c; }
-__device__ __forceinline__ float gelu_grad_f(float x) { float c, e; gelu_parts(x, c, e); return fmaf(x * 0.39894228040143268f, e, c); }
+__device__ __forceinline__ float gelu_f(float x) {
+    float q, e;
+    gelu_q(x, q, e);
+    return fmaf(-fabsf(x), q, fmaxf(x, 0.f));
+}
+// value and derivative together (the training forward of FFN1: one rcp and one exp serve both)
+__device__ __forceinline__ void gelu_value_grad(float x, float& h, float& dh) {
+    float q, e;
+    gelu_q(x, q, e);
+    h = fmaf(-fabsf(x), q, fmaxf(x, 0.f));
+    const float cdf = x > 0.f ? 1.0f - q : q;
+    dh = fmaf(x * 0.39894228040143268f, e, cdf);
+}
+__device__ __forceinline__ float gelu_grad_f(float x) { float h, d; gelu_value_grad(x, h, d); return d; }
 
 // Counter-based dropout, regenerated (never stored) wherever a mask is needed: forward, backward, and the numpy mirror in
 // oracle/dropout_ref.py.  An element is addressed by (row, col) of the tensor the mask applies to:

@@ -139,12 +139,7 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         // erf and exp again - that epilogue was VALU-bound: 12 us of a 31-us tile round with the MFMA pipe idle)
         float dv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float c, e;
-            gelu_parts(v[j], c, e);
-            dv[j] = fmaf(v[j] * 0.39894228040143268f, e, c);
-            v[j] *= c;
-        }
+        for (int j = 0; j < 8; ++j) gelu_value_grad(v[j], v[j], dv[j]);
         { const uint4 o = p.tape_f16 ? pack8h(dv) : pack8(dv); if (ok) st16_stream(p.preact + crow, o); }
     } else {
         if (fl.preact) {
