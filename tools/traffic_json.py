@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/r04_train_step_hbm_traffic.json from the per-kernel PMC pass of tools/pmc_step.sh (counters.json): memory-side bytes per launch
+"""profiles/r05_train_step_hbm_traffic.json from the per-kernel PMC pass of tools/pmc_step.sh (counters.json): memory-side bytes per launch
 (reads = 2 x FETCH_SIZE KiB, gfx950 correction; writes = WRITE_SIZE) x launches per step, per kernel and in total.  Usage:
-python tools/traffic_json.py gpurun_out/pmc_step_amp16/counters.json 7 > profiles/r04_train_step_hbm_traffic.json   (7 = steps the pass ran)"""
+python tools/traffic_json.py gpurun_out/pmc_step_amp16/counters.json 7 > profiles/r05_train_step_hbm_traffic.json   (7 = steps the pass ran)"""
 import json, sys
 d = json.load(open(sys.argv[1]))
 steps = float(sys.argv[2]) if len(sys.argv) > 2 else 7.0
