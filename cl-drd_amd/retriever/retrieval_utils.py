@@ -73,7 +73,8 @@ def batch_to_device(batch, target_device: torch.device):
 def get_embeddings_from_scratch(model, dataloader, use_fp16, is_query, show_progress_bar=False):
     """Encode every batch of ``dataloader`` ({"seq": {input_ids, attention_mask}, "id": list[int]}) with the query or
     passage tower in eval mode -> (np.float32 [n, D], list[int]).  ``use_fp16`` is accepted for signature compatibility:
-    the towers always run bf16 MFMA compute with fp32 CLS output (the reference's output is fp32 too, :56)."""
+    the towers always run 16-bit MFMA compute (evaluation: fp16 operands in the FFN / out-projection GEMMs, bf16 QKV / attention) with fp32
+    accumulate, fp32 residual stream and fp32 CLS output (the reference's output is fp32 too, :56)."""
     embeddings, embeddings_ids = [], []
     model.eval()
     dev = next(model.parameters()).device
