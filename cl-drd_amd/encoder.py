@@ -803,17 +803,17 @@ class HipEncoder(nn.Module):
             ops.gemm_nt(x, W["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
         S32 = x32 is not None
         sdt = torch.float32 if S32 else torch.bfloat16
-        xc = self._buf(M, d, dev, dt16) if x is not None else None          # bf16 CLS rows: the weight gradient's operand (and, without Q16, the GEMM's)
-        xch = self._buf(M, d, dev, torch.float16) if Q16 else None
-        xc32 = self._buf(M, d, dev, torch.float32) if S32 else None
         if pk is None:
-            if xc is not None:
-                xc[:M].copy_(x[:T].view(M, L, d)[:, 0, :])         # gather the CLS rows (a copy, no arithmetic)
-            if Q16:
-                xch[:M].copy_(xh[:T].view(M, L, d)[:, 0, :])
-            if S32:
-                xc32[:M].copy_(x32[:T].view(M, L, d)[:, 0, :])
+            # the CLS rows are rows 0, L, 2L, ... of the layer input: STRIDED VIEWS (row pitch L * d), no copies - every consumer (the Q
+            # projection's A operand, its weight gradient's X operand, the out-projection's fp32 residual) takes a row pitch.  Until round 5
+            # two or three 6-us gather launches sat here, on the critical path between the towers' forward and the loss
+            xc = x[:T].view(M, L * d)[:, :d] if x is not None else None
+            xch = xh[:T].view(M, L * d)[:, :d] if Q16 else None
+            xc32 = x32[:T].view(M, L * d)[:, :d] if S32 else None
         else:
+            xc = self._buf(M, d, dev, dt16) if x is not None else None          # 16-bit CLS rows: the weight gradient's operand (and, without Q16, the GEMM's)
+            xch = self._buf(M, d, dev, torch.float16) if Q16 else None
+            xc32 = self._buf(M, d, dev, torch.float32) if S32 else None
             # packed batch: the CLS token of sequence m is row cu[m]; K / V go to the padded layout the CLS attention kernel reads
             if xc is not None:
                 ops.gather_rows(x, pk.cls_idx, xc, M)
