@@ -193,23 +193,39 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pa = pack8x<F16>(pv + 8 * s2);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    O[dt] = mfma32<F16>(pa, tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), O[dt]);
+                for (int dt = 0; dt < 2; ++dt)      // operands swapped: O^T[d][q], so that a lane (= query) holds consecutive head dimensions
+                    O[dt] = mfma32<F16>(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pa, O[dt]);
             }
         }
-        // O[dt][t] = ctx[q = 32 qb + rowmap(t, h)][d = 32 dt + r]     (the transposed form - lane = query, 8-byte stores - was tried:
-        // 8 % SLOWER here, 70 -> 79 us with dropout; it is what the streaming kernel below and the backward's dQ use)
+        // O[dt][t] = ctx^T[d = 32 dt + rowmap(t, h)][q = 32 qb + r]: registers 4u .. 4u+3 are 4 consecutive head dimensions of the lane's query row;
+        // one v_permlane32_swap pair makes them 16 contiguous bytes (widen_pair): 4 (+ 4 for the fp16 copy) 16-byte stores per lane instead of
+        // 32 (+ 32) two-byte ones.  (Round 2 tried the transposed form with 8-byte stores and found it 8 % slower; round 5, with the widened
+        // stores: profiles/r05_microbench.txt section 6.)
+        {
+            const size_t orow = ((size_t)seq * L + q) * dm + hd * 64;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int qq = qb * 32 + rowmap(t, h);
-                if (qq < L) {       // ctx: the kernel's own format (may be absent); ctx16: an fp16 copy of a bf16 pass (out-projection operand)
-                    const size_t o = ((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r;
-                    if (ctx) ctx[o] = f2x<F16>(O[dt][t]);
-                    if (ctx16) ctx16[o] = f2x<true>(O[dt][t]);
+                for (int u = 0; u < 4; u += 2) {
+                    uint2 o[2], o16[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int b = 4 * (u + k);
+                        o[k].x = pack2x<F16>(O[dt][b], O[dt][b + 1]);
+                        o[k].y = pack2x<F16>(O[dt][b + 2], O[dt][b + 3]);
+                        o16[k].x = (uint32_t)f2x<true>(O[dt][b]) | ((uint32_t)f2x<true>(O[dt][b + 1]) << 16);
+                        o16[k].y = (uint32_t)f2x<true>(O[dt][b + 2]) | ((uint32_t)f2x<true>(O[dt][b + 3]) << 16);
+                    }
+                    if (ctx) {       // ctx: the kernel's own format (may be absent); ctx16: an fp16 copy of a bf16 pass (out-projection operand)
+                        const uint4 w = widen_pair(o[0], o[1]);
+                        if (q < L) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
+                    }
+                    if (ctx16) {
+                        const uint4 w = widen_pair(o16[0], o16[1]);
+                        if (q < L) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
+                    }
                 }
-            }
+        }
     }
 }
 
@@ -371,23 +387,39 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pa = pack8x<F16>(pv + 8 * s2);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    O[dt] = mfma32<F16>(pa, tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), O[dt]);
+                for (int dt = 0; dt < 2; ++dt)      // operands swapped: O^T[d][q], so that a lane (= query) holds consecutive head dimensions
+                    O[dt] = mfma32<F16>(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pa, O[dt]);
             }
         }
-        // O[dt][t] = ctx[q = 32 qb + rowmap(t, h)][d = 32 dt + r]     (the transposed form - lane = query, 8-byte stores - was tried:
-        // 8 % SLOWER here, 70 -> 79 us with dropout; it is what the streaming kernel below and the backward's dQ use)
+        // O[dt][t] = ctx^T[d = 32 dt + rowmap(t, h)][q = 32 qb + r]: registers 4u .. 4u+3 are 4 consecutive head dimensions of the lane's query row;
+        // one v_permlane32_swap pair makes them 16 contiguous bytes (widen_pair): 4 (+ 4 for the fp16 copy) 16-byte stores per lane instead of
+        // 32 (+ 32) two-byte ones.  (Round 2 tried the transposed form with 8-byte stores and found it 8 % slower; round 5, with the widened
+        // stores: profiles/r05_microbench.txt section 6.)
+        {
+            const size_t orow = ((size_t)seq * L + q) * dm + hd * 64;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int qq = qb * 32 + rowmap(t, h);
-                if (qq < L) {       // ctx: the kernel's own format (may be absent); ctx16: an fp16 copy of a bf16 pass (out-projection operand)
-                    const size_t o = ((size_t)seq * L + qq) * dm + hd * 64 + dt * 32 + r;
-                    if (ctx) ctx[o] = f2x<F16>(O[dt][t]);
-                    if (ctx16) ctx16[o] = f2x<true>(O[dt][t]);
+                for (int u = 0; u < 4; u += 2) {
+                    uint2 o[2], o16[2];
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int b = 4 * (u + k);
+                        o[k].x = pack2x<F16>(O[dt][b], O[dt][b + 1]);
+                        o[k].y = pack2x<F16>(O[dt][b + 2], O[dt][b + 3]);
+                        o16[k].x = (uint32_t)f2x<true>(O[dt][b]) | ((uint32_t)f2x<true>(O[dt][b + 1]) << 16);
+                        o16[k].y = (uint32_t)f2x<true>(O[dt][b + 2]) | ((uint32_t)f2x<true>(O[dt][b + 3]) << 16);
+                    }
+                    if (ctx) {       // ctx: the kernel's own format (may be absent); ctx16: an fp16 copy of a bf16 pass (out-projection operand)
+                        const uint4 w = widen_pair(o[0], o[1]);
+                        if (q < L) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
+                    }
+                    if (ctx16) {
+                        const uint4 w = widen_pair(o16[0], o16[1]);
+                        if (q < L) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
+                    }
                 }
-            }
+        }
             }
         __syncthreads();          // the other buffer is complete, and nobody reads this one any more
         cur ^= 1;
