@@ -20,7 +20,7 @@ extern "C" unsigned long long g_dev_stamps_host[1024 * 8];
 unsigned long long g_dev_stamps_host[1024 * 8];
 extern "C" const unsigned long long* cldrd_dev_stamps() { return g_dev_stamps_host; }      // after a stream synchronize (tools/epi_stamps.py)
 #endif
-int g_cldrd_tune_splitk = 0, g_cldrd_tune_attn_fwd2 = 1, g_cldrd_tune_attn_bwd2 = 1;
+int g_cldrd_tune_splitk = 0, g_cldrd_tune_attn_fwd2 = 1, g_cldrd_tune_attn_bwd2 = 1, g_cldrd_tune_nt64 = 1;
 // key: "gemm_splitk" | "attn_fwd2" | "attn_bwd2" (meanings: common.h).  Every choice computes the same function; tests use it to
 // reach the alternative kernels.  Process-wide, not thread-safe against concurrent launches.
 extern "C" int cldrd_set_tuning(const char* key, int value) {
@@ -28,6 +28,7 @@ extern "C" int cldrd_set_tuning(const char* key, int value) {
     if (!strcmp(key, "gemm_splitk")) { CLDRD_CHECK(value >= 0, "set_tuning: gemm_splitk >= 0"); g_cldrd_tune_splitk = value; return 0; }
     if (!strcmp(key, "attn_fwd2")) { g_cldrd_tune_attn_fwd2 = value != 0; return 0; }
     if (!strcmp(key, "attn_bwd2")) { g_cldrd_tune_attn_bwd2 = value != 0; return 0; }
+    if (!strcmp(key, "gemm_nt64")) { g_cldrd_tune_nt64 = value != 0; return 0; }
     return cldrd_set_error("set_tuning: unknown key");
 }
 extern "C" int cldrd_version(void) { return 100; }

@@ -160,5 +160,6 @@ int cldrd_dev_int(const char* name, int dflt);
 extern int g_cldrd_tune_splitk;        // 0: heuristic, 1: never split K, n > 1: n splits (small-M NT GEMM)
 extern int g_cldrd_tune_attn_fwd2;     // 1: persistent attention forward where it applies, 0: one item per workgroup
 extern int g_cldrd_tune_attn_bwd2;     // the same for the backward
+extern int g_cldrd_tune_nt64;          // 1: one-launch 64 x 64 kernel for small-M, K <= 1024 NT GEMMs, 0: the 128 x 128 kernel (split-K + finish)
 #define CLDRD_CHECK(cond, msg) do { if (!(cond)) return cldrd_set_error(msg); } while (0)
 #define CLDRD_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return cldrd_set_error(hipGetErrorString(e_)); } while (0)

@@ -120,6 +120,137 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmNtArgs p) {
     }
 }
 
+// Round 5: small-M problems with a short K range (K <= 1024: five of the eight GEMMs of a transformer layer) in ONE launch.  M = 256 rows
+// make 12 tiles of 128 x 128 at N = 768: the kernel above either leaves 95 % of the chip idle or splits K over more workgroups and needs a second
+// launch to add the partial sums (10 + 5 us for 0.3 GFLOP).  Here the tile is 64 x 64 (48 workgroups at 256 x 768, 192 at 256 x 3072) and the
+// K loop is latency-hiding instead of wide: eight 16-KiB stages of LDS, SEVEN K tiles requested before the first one is consumed, one barrier per
+// K tile (tile kt + 7 is requested into the slot tile kt - 1 was read from, right behind the barrier that ends those reads).  A workgroup
+// pulls its whole 64 x K + 64 x K operand strip (192 KiB at K = 768) in about one memory latency plus the CU's L2 -> LDS streaming time.
+// Same LDS image, swizzle, MFMA order along K and epilogue as the 128 x 128 kernel: the result is bit-identical to its one-pass form.
+constexpr int SB = 64;
+constexpr int S_TILE = SB * BK * 2;            // 8 KiB per operand tile
+constexpr int S_STAGE = 2 * S_TILE;
+constexpr int S_NST = 8;                       // stages (128 KiB of LDS: one workgroup per CU - the grid has at most one per CU anyway)
+constexpr int S_AHEAD = S_NST - 1;             // K tiles in flight
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <bool F16, bool SPLITK>
+__global__ __launch_bounds__(256, 1) void gemm_nt64_kernel(GemmNtArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntn = (p.N + SB - 1) / SB;
+    const int ntiles = SPLITK ? (int)gridDim.x / p.ksplit : (int)gridDim.x;
+    const int split = SPLITK ? (int)blockIdx.x / ntiles : 0;
+    const int tile = SPLITK ? (int)blockIdx.x % ntiles : xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (tile / ntn) * SB, n0 = (tile % ntn) * SB;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    // LDS-DMA staging: wave w owns pieces 2w, 2w + 1 of each operand tile (piece = 8 rows x 128 B)
+    const int prow = lane >> 3;
+    const int chunk = (lane & 7) ^ prow;
+    const bf16_t* ga[2];
+    const bf16_t* gb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (wid * 2 + i) * 8 + prow;
+        const int ra = min(m0 + r, p.M - 1), rb = min(n0 + r, p.N - 1);
+        ga[i] = p.A + (size_t)ra * p.lda + chunk * 8;
+        gb[i] = p.B + (size_t)rb * p.ldb + chunk * 8;
+    }
+    auto stage = [&](int s, int k0) {
+        char* base = smem + s * S_STAGE + wid * 2048;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(ga[i] + k0), LDS_PTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gb[i] + k0), LDS_PTR(base + S_TILE + i * 1024), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int slot = (4 * s + fq) ^ (frow & 7);
+        a_off[s] = (wm * 32 + frow) * 128 + slot * 16;
+        b_off[s] = S_TILE + (wn * 32 + frow) * 128 + slot * 16;
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // K range of this workgroup (SPLITK: a contiguous share of the K tiles, as in the 128 x 128 kernel)
+    const int nk_all = p.K / BK;
+    const int kper = SPLITK ? (nk_all + p.ksplit - 1) / p.ksplit : nk_all;
+    const int kbeg = split * kper;
+    const int nk = max(0, min(nk_all, kbeg + kper) - kbeg);
+    for (int t = 0; t < S_AHEAD && t < nk; ++t) stage(t, (kbeg + t) * BK);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tiles kt + 1 .. min(nk - 1, kt + 6) may stay in flight (4 requests per wave and tile; they complete in order)
+        switch (min(nk - 1, kt + S_AHEAD - 1) - kt) {
+            case 0: wait_vmcnt<0>(); break;
+            case 1: wait_vmcnt<4>(); break;
+            case 2: wait_vmcnt<8>(); break;
+            case 3: wait_vmcnt<12>(); break;
+            case 4: wait_vmcnt<16>(); break;
+            case 5: wait_vmcnt<20>(); break;
+            default: wait_vmcnt<24>(); break;
+        }
+        __syncthreads();
+        if (kt + S_AHEAD < nk) stage((kt + S_AHEAD) % S_NST, (kbeg + kt + S_AHEAD) * BK);
+        const char* sb = smem + (kt % S_NST) * S_STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = *(const bf16x8*)(sb + a_off[s] + t * 16 * 128);
+                bfr[t] = *(const bf16x8*)(sb + b_off[s] + t * 16 * 128);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[mt][nt] = gemm_mfma<F16 ? EPI_F16IN : 0>(bfr[nt], af[mt], acc[mt][nt]);
+        }
+    }
+    if constexpr (SPLITK) {
+        // raw partial sums of this K range for splitk_finish_kernel (accumulator layout: 4 consecutive columns of one row per lane and tile)
+        float* out = p.slabs + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = m0 + wm * 32 + mt * 16 + (lane & 15);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int n = n0 + wn * 32 + nt * 16 + 4 * (lane >> 4);
+                if (m < p.M && n < p.N) *(f32x4*)(out + (size_t)m * p.N + n) = acc[mt][nt];
+            }
+        }
+    } else {
+        __syncthreads();
+        gemm_nt_epilogue<2, 2, EPI_GENERIC>(p, acc, m0 + wm * 32, n0 + wn * 32, lane, (float*)smem + wid * (32 * 36));
+    }
+}
+
+// Does the 64 x 64 kernel take this shape, and in how many K splits?  0: no; 1: one launch (a grid that fits the chip in one round, a K range its
+// prefetch depth covers: a workgroup has at most 112 KiB in flight, i.e. ~50 GB/s - a longer K range needs more workgroups, not more time);
+// n > 1: n K ranges of at least 8 K tiles + splitk_finish_kernel, where that still fits one round (K = 2304 / 3072 at 256 x 768: 4-5 ranges
+// and 4-5 slabs to add instead of the 128 x 128 kernel's 12).
+static int nt64_splits(int M, int N, int K) {
+    if (g_cldrd_tune_nt64 == 0 || g_cldrd_tune_splitk != 0) return 0;          // a forced split count means the 128 x 128 kernel (tests)
+    if (K % BK != 0 || M >= 1024 || N % 8 != 0) return 0;
+    const long long tiles = (long long)((M + SB - 1) / SB) * ((N + SB - 1) / SB);
+    if (tiles > 256) return 0;
+    if (K <= 1024) return 1;
+    const int nk = K / BK;
+    int ks = (int)(256 / tiles);
+    if (ks > nk / 8) ks = nk / 8;
+    return ks >= 4 ? ks : 0;
+}
+
 // Split-K, second half: every thread owns 8 consecutive columns of a row, sums the ksplit partials in a fixed order and runs the
 // same fused epilogue (run-time flags) as the one-pass kernels.  F16OUT: a 16-bit C is fp16 (the fp16 format of the forward kernels).
 template <bool F16OUT>
@@ -216,6 +347,7 @@ extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int 
 // Bytes of workspace with which cldrd_gemm_nt_bf16_ws splits the K range of this shape over several workgroups (0: it does not)
 extern "C" size_t cldrd_gemm_nt_splitk_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 8 != 0) return 0;
+    if (const int k64 = nt64_splits(M, N, K)) return k64 > 1 ? (size_t)k64 * M * N * sizeof(float) : 0;
     const int ks = splitk_choice(M, N, K);
     return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
 }
@@ -279,6 +411,35 @@ extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int 
     a.c_bf16 = (io_f16 & 2) ? 1 : 0;
     a.tape_f16 = (io_f16 & 4) ? 1 : 0;
     a.c_copy = (bf16_t*)c_copy_bf16;
+    if (const int k64 = (io_f16 && gelu_pre && !(io_f16 & 4)) ? 0 : nt64_splits(M, N, K);
+        k64 == 1 || (k64 > 1 && workspace != nullptr && workspace_bytes >= (size_t)k64 * M * N * sizeof(float) && (uintptr_t)workspace % 16 == 0)) {
+        a.ksplit = k64;
+        a.slabs = workspace;
+        const int nblk = ((M + SB - 1) / SB) * ((N + SB - 1) / SB) * k64;
+        hipStream_t st = (hipStream_t)stream;
+        static bool set64 = false;
+        if (!set64) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_NST * S_STAGE);
+            (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, S_NST * S_STAGE);
+            (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_NST * S_STAGE);
+            (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, S_NST * S_STAGE);
+            set64 = true;
+        }
+        if (k64 == 1) {
+            if (io_f16) hipLaunchKernelGGL((gemm_nt64_kernel<true, false>), dim3(nblk), dim3(256), S_NST * S_STAGE, st, a);
+            else hipLaunchKernelGGL((gemm_nt64_kernel<false, false>), dim3(nblk), dim3(256), S_NST * S_STAGE, st, a);
+            CLDRD_LAUNCH_CHECK();
+            return 0;
+        }
+        if (io_f16) hipLaunchKernelGGL((gemm_nt64_kernel<true, true>), dim3(nblk), dim3(256), S_NST * S_STAGE, st, a);
+        else hipLaunchKernelGGL((gemm_nt64_kernel<false, true>), dim3(nblk), dim3(256), S_NST * S_STAGE, st, a);
+        CLDRD_LAUNCH_CHECK();
+        const size_t nthr = (size_t)M * (N / 8);
+        if (io_f16) hipLaunchKernelGGL(splitk_finish_kernel<true>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(splitk_finish_kernel<false>, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, a);
+        CLDRD_LAUNCH_CHECK();
+        return 0;
+    }
     if (workspace != nullptr && K % BK == 0 && N % 8 == 0 && !(io_f16 && gelu_pre && !(io_f16 & 4))) {
         const int ks = splitk_choice(M, N, K);
         if (ks > 1 && workspace_bytes >= (size_t)ks * M * N * sizeof(float) && (uintptr_t)workspace % 16 == 0) {

@@ -245,7 +245,7 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
     # small-M problems (CLS-only last layer, query tower) are split along K when that fills the chip: fp32 partials in a scratch tensor
     ws, ws_bytes = None, 0
     if M < 1024:
-        key = (M, N, K, _TUNING.get("gemm_splitk", 0))      # the split choice is part of the cache key
+        key = (M, N, K, _TUNING.get("gemm_splitk", 0), _TUNING.get("gemm_nt64", 1))      # the kernel choice is part of the cache key
         ws_bytes = _SPLITK_WS.get(key)
         if ws_bytes is None:
             ws_bytes = _SPLITK_WS[key] = int(_lib.load().cldrd_gemm_nt_splitk_workspace(M, N, K))
@@ -262,7 +262,7 @@ _TUNING = {}
 
 
 def set_tuning(key: str, value: int) -> None:
-    """cldrd_set_tuning: "gemm_splitk" | "attn_fwd2" | "attn_bwd2" (include/cldrd_hip.h).  Process-wide; tests use it to reach the
+    """cldrd_set_tuning: "gemm_splitk" | "gemm_nt64" | "attn_fwd2" | "attn_bwd2" (include/cldrd_hip.h).  Process-wide; tests use it to reach the
     alternative kernels - the library itself reads no environment variable."""
     call("cldrd_set_tuning", key.encode(), int(value))
     _TUNING[key] = int(value)

@@ -29,8 +29,9 @@ const char* cldrd_last_error(void);
 int cldrd_version(void);
 int cldrd_device_ok(void);            /* 1 if device 0 is a gfx950 */
 /* The library reads NO environment variable.  The few kernel choices tests need to reach go through this call (process-wide):
- * key "gemm_splitk" (0 heuristic, 1 never split K, n > 1 n splits of the small-M Linear GEMM), "attn_fwd2" / "attn_bwd2"
- * (1: persistent attention kernels where they apply, 0: one item per workgroup).  Every choice computes the same function. */
+ * key "gemm_splitk" (0 heuristic, 1 never split K, n > 1 n splits of the small-M Linear GEMM), "gemm_nt64" (1: the one-launch
+ * 64 x 64 kernel for small-M GEMMs with K <= 1024 when gemm_splitk is 0, 0: never), "attn_fwd2" / "attn_bwd2" (1: persistent
+ * attention kernels where they apply, 0: one item per workgroup).  Every choice computes the same function. */
 int cldrd_set_tuning(const char* key, int value);
 
 /* ---- encoder Linear layers -------------------------------------------------------------------------------

@@ -108,6 +108,58 @@ def test_gemm_nt_epilogues(M, N, K):
     close(out32, torch.where(keep, base / 0.9, torch.zeros(())) + ln, 1e-5, 1e-4 * math.sqrt(K), "dropout + LayerNorm residual")
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 768, 768), (256, 3072, 768), (100, 520, 832), (1, 8, 64), (640, 1600, 1024), (257, 2304, 768)])
+@pytest.mark.parametrize("flavour", ["plain", "bias_gelu_dpre16", "gelugrad_d16", "bias_drop_res32_f32", "ln_res32_f32", "bf16_res16"])
+def test_gemm_nt_small_m_one_launch_kernel_is_bit_identical(flavour, M, N, K):
+    """Small-M problems with K <= 1024 take the 64 x 64 one-launch kernel (seven K tiles in flight): same MFMA order along K and the same
+    epilogue as the 128 x 128 kernel in its one-pass form (ops.set_tuning("gemm_splitk", 1)), so every output - C, the GELU tape, ragged edges -
+    is bit-identical; rows / columns outside [M, N] are not written."""
+    bf = flavour.startswith("bf16")
+    dt = torch.bfloat16 if bf else torch.float16
+    g = torch.Generator(device=DEV).manual_seed(M * 7 + N + K)
+    A = (torch.randn(M + 3, K, device=DEV, generator=g) * 0.5).to(dt)
+    B = (torch.randn(N, K, device=DEV, generator=g) * 0.5).to(dt)
+    bias = torch.randn(N, device=DEV, generator=g)
+    kw, out_dtype = {}, dt
+    if flavour == "bias_gelu_dpre16":
+        kw.update(bias=bias, preact=True, act=3)
+    if flavour == "gelugrad_d16":
+        kw.update(gelu_pre=torch.rand(M + 3, N, device=DEV, generator=g).half(), act=2)
+    if flavour == "bf16_res16":
+        kw.update(bias=bias, residual=torch.randn(M + 3, N, device=DEV, generator=g).bfloat16())
+    if "res32" in flavour:
+        kw.update(bias=bias, residual=torch.randn(M + 3, N, device=DEV, generator=g))
+        out_dtype = torch.float32
+    if flavour == "bias_drop_res32_f32":
+        kw.update(dropout_p=0.1, seed=(5 << 32) | 9)
+    if flavour == "ln_res32_f32":
+        s32 = kw["residual"]
+        kw["residual_ln"] = (s32.mean(1).contiguous(), (1.0 / torch.sqrt(s32.var(1, unbiased=False) + 1e-12)).contiguous(),
+                             1 + 0.1 * torch.randn(N, device=DEV, generator=g), 0.1 * torch.randn(N, device=DEV, generator=g))
+    assert ops._lib.load().cldrd_gemm_nt_splitk_workspace(M, N, K) == 0        # the one-launch kernel takes these shapes: no partial sums
+    outs = []
+    for forced in (0, 1):
+        ops.set_tuning("gemm_splitk", forced)
+        out = torch.full((M + 3, N), 7.0, dtype=out_dtype, device=DEV)
+        k2 = dict(kw)
+        if k2.get("preact") is True:
+            k2["preact"] = torch.full((M + 3, N), 7.0, dtype=torch.float16, device=DEV)
+        try:
+            ops.gemm_nt(A, B, out, M, **k2)
+            torch.cuda.synchronize()
+        finally:
+            ops.set_tuning("gemm_splitk", 0)
+        outs.append((out, k2.get("preact")))
+    (o64, p64), (o128, p128) = outs
+    assert torch.equal(o64, o128), (o64.float() - o128.float()).abs().max()
+    assert (o64[M:] == 7.0).all() and not torch.isnan(o64.float()).any()
+    if p64 is not None:
+        assert torch.equal(p64, p128) and (p64[M:] == 7.0).all()
+    if flavour == "plain":      # and against fp32 arithmetic
+        ref = A[:M].float() @ B.float().T
+        close(o64[:M].float(), ref, 2e-3, 2e-3 * ref.abs().max().item(), "64 x 64 kernel")
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 768, 3072), (240, 3072, 768), (130, 384, 1024), (512, 768, 768)])
 @pytest.mark.parametrize("flavour", ["bias", "bias_gelu_dpre", "gelugrad_d", "res16", "bias_drop_res32_f32", "ln_res32_f32", "f16_bias_gelu", "f16_res32_f32"])
 def test_gemm_nt_small_m_split_k(flavour, M, N, K):
