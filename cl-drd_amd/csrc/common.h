@@ -97,6 +97,46 @@ __device__ __forceinline__ void gelu_value_grad(float x, float& h, float& dh) {
     dh = fmaf(x * 0.39894228040143268f, e, cdf);
 }
 __device__ __forceinline__ float gelu_grad_f(float x) { float h, d; gelu_value_grad(x, h, d); return d; }
+// The same, TWO elements per call on the packed fp32 operations of gfx950 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per
+// lane and instruction at the rate of one): the polynomial, the products and the final FMA cost half an instruction per element; |x|, max, the
+// select and the two transcendentals stay per element.  Same operations in the same order as the scalar forms: bit-identical results.
+__device__ __forceinline__ cldrd_f32v2 fma2(cldrd_f32v2 a, cldrd_f32v2 b, cldrd_f32v2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ cldrd_f32v2 splat2(float c) { return (cldrd_f32v2){c, c}; }
+__device__ __forceinline__ void add2(float& a0, float& a1, float b0, float b1) {       // one v_pk_add_f32
+    const cldrd_f32v2 r = (cldrd_f32v2){a0, a1} + (cldrd_f32v2){b0, b1};
+    a0 = r.x; a1 = r.y;
+}
+__device__ __forceinline__ void mul2(float& a0, float& a1, float b0, float b1) {       // one v_pk_mul_f32
+    const cldrd_f32v2 r = (cldrd_f32v2){a0, a1} * (cldrd_f32v2){b0, b1};
+    a0 = r.x; a1 = r.y;
+}
+__device__ __forceinline__ void gelu_q2(cldrd_f32v2 ax, cldrd_f32v2& q, cldrd_f32v2& e) {
+    const cldrd_f32v2 d = fma2(splat2(0.3275911f * 0.70710678118654752f), ax, splat2(1.0f));
+    const cldrd_f32v2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const cldrd_f32v2 poly = t * fma2(t, fma2(t, fma2(t, fma2(t, splat2(0.5f * 1.061405429f), splat2(0.5f * -1.453152027f)), splat2(0.5f * 1.421413741f)),
+                                               splat2(0.5f * -0.284496736f)), splat2(0.5f * 0.254829592f));
+    const cldrd_f32v2 w = ax * splat2(0.84932180028801904f);
+    const cldrd_f32v2 nw2 = -w * w;
+    e = (cldrd_f32v2){__builtin_amdgcn_exp2f(nw2.x), __builtin_amdgcn_exp2f(nw2.y)};
+    q = poly * e;
+}
+__device__ __forceinline__ void gelu_f2(float& x0, float& x1) {
+    const cldrd_f32v2 ax = {fabsf(x0), fabsf(x1)};
+    cldrd_f32v2 q, e;
+    gelu_q2(ax, q, e);
+    const cldrd_f32v2 h = fma2(-ax, q, (cldrd_f32v2){fmaxf(x0, 0.f), fmaxf(x1, 0.f)});
+    x0 = h.x; x1 = h.y;
+}
+__device__ __forceinline__ void gelu_value_grad2(float& x0, float& x1, float& d0, float& d1) {
+    const cldrd_f32v2 x = {x0, x1}, ax = {fabsf(x0), fabsf(x1)};
+    cldrd_f32v2 q, e;
+    gelu_q2(ax, q, e);
+    const cldrd_f32v2 h = fma2(-ax, q, (cldrd_f32v2){fmaxf(x0, 0.f), fmaxf(x1, 0.f)});
+    const cldrd_f32v2 omq = splat2(1.0f) - q;
+    const cldrd_f32v2 cdf = {x0 > 0.f ? omq.x : q.x, x1 > 0.f ? omq.y : q.y};
+    const cldrd_f32v2 dh = fma2(x * splat2(0.39894228040143268f), e, cdf);
+    x0 = h.x; x1 = h.y; d0 = dh.x; d1 = dh.y;
+}
 
 // Counter-based dropout, regenerated (never stored) wherever a mask is needed: forward, backward, and the numpy mirror in
 // oracle/dropout_ref.py.  An element is addressed by (row, col) of the tensor the mask applies to:

@@ -130,7 +130,7 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
     }
     if (fl.bias) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bias8[j];
+        for (int j = 0; j < 8; j += 2) add2(v[j], v[j + 1], bias8[j], bias8[j + 1]);
     }
     const size_t crow = (size_t)m * p.ldc + n;
     if (fl.preact && fl.gelu && fl.dgelu) {
@@ -139,7 +139,7 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         // erf and exp again - that epilogue was VALU-bound: 12 us of a 31-us tile round with the MFMA pipe idle)
         float dv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) gelu_value_grad(v[j], v[j], dv[j]);
+        for (int j = 0; j < 8; j += 2) gelu_value_grad2(v[j], v[j + 1], dv[j], dv[j + 1]);
         { const uint4 o = p.tape_f16 ? pack8h(dv) : pack8(dv); if (ok) st16_stream(p.preact + crow, o); }
     } else {
         if (fl.preact) {
@@ -154,14 +154,19 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
         }
         if (fl.gelu) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+            for (int j = 0; j < 8; j += 2) gelu_f2(v[j], v[j + 1]);
         }
     }
     if (fl.gelugrad) {
         float g[8];
         if (p.tape_f16) unpack8h(gp, g); else unpack8(gp, g);
+        if (fl.dgelu) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= fl.dgelu ? g[j] : gelu_grad_f(g[j]);
+            for (int j = 0; j < 8; j += 2) mul2(v[j], v[j + 1], g[j], g[j + 1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_f(g[j]);
+        }
     }
     if (fl.dropout) {
         const uint32_t rk = drop_rowkey(seed_eff, (uint32_t)m);      // n is a multiple of 8: four column pairs
@@ -181,7 +186,7 @@ __device__ __forceinline__ void gemm_nt_apply8(const GemmNtArgs& p, const EpiFla
             unpack8(res, r);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += r[j];
+        for (int j = 0; j < 8; j += 2) add2(v[j], v[j + 1], r[j], r[j + 1]);
     }
     if (fl.f32) {
         float* C = (float*)p.C + crow;

@@ -576,8 +576,13 @@ def test_failed_graph_capture_falls_back_to_a_working_eager_step(monkeypatch):
     assert getattr(tr_b, "_graph_broken", False) and tr_b._state is None
     assert not torch.cuda.is_current_stream_capturing()
     tr_e, loss_e, p_e = run(False)
-    # dropout is off in small_cfg: the two runs are the same arithmetic (embedding-table atomics aside)
-    assert torch.allclose(loss_b, loss_e, rtol=1e-3, atol=1e-6), (loss_b, loss_e)
+    # dropout is off in small_cfg: the two runs are the same arithmetic - embedding-table atomics aside, and those are not negligible here:
+    # the summation order of the float atomics differs from run to run (tools/debug_capture_fallback.py: two EAGER runs of this very loop in
+    # one process give 0.358131 or 0.359187 for the sixth loss), because Adam's first updates are lr * g / |g|: an element whose gradient is
+    # rounding noise around zero moves by +-lr with the sign of the noise.  Up to the step of the failed capture (the fourth) the losses agree to
+    # 1e-4 whatever the order; behind it to 1e-2.  A fallback that trained on unwritten shadows or stale seeds would be off by far more.
+    assert torch.allclose(loss_b[:4], loss_e[:4], rtol=1e-4, atol=1e-6), (loss_b, loss_e)
+    assert torch.allclose(loss_b, loss_e, rtol=1e-2, atol=1e-6), (loss_b, loss_e)
     assert (p_b - p_e).abs().max().item() <= 1e-4 * p_e.abs().max().item()
 
 
