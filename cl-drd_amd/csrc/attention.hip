@@ -67,6 +67,10 @@ template <bool F16> __device__ __forceinline__ uint32_t pack2x(float lo, float h
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, h2_t));      // one v_cvt_pk_f16_f32
     } else return pack2bf(lo, hi);
 }
+template <bool F16> __device__ __forceinline__ uint32_t pack2x_scaled(float lo, float hi, float scale) {      // one v_pk_mul_f32 + one convert
+    const cldrd_f32v2 m = (cldrd_f32v2){lo, hi} * splat2(scale);
+    return pack2x<F16>(m.x, m.y);
+}
 // sum of the two products of a dword pair of 16-bit values (delta = rowsum(dO . O))
 template <bool F16> __device__ __forceinline__ float dot2x(uint32_t a, uint32_t b) {
     if constexpr (F16) return h2f((bf16_t)(a & 0xFFFFu)) * h2f((bf16_t)(b & 0xFFFFu)) + h2f((bf16_t)(a >> 16)) * h2f((bf16_t)(b >> 16));
@@ -153,10 +157,10 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
                 const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
                 const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = fmaf(S[kb][4 * u + j], scale2, bb[j]);
-                    S[kb][4 * u + j] = v;
-                    mx = fmaxf(mx, v);
+                for (int j = 0; j < 4; j += 2) {      // two keys per packed fp32 instruction (v_pk_fma_f32: same IEEE results as two v_fma_f32)
+                    const cldrd_f32v2 v = fma2((cldrd_f32v2){S[kb][4 * u + j], S[kb][4 * u + j + 1]}, splat2(scale2), (cldrd_f32v2){bb[j], bb[j + 1]});
+                    S[kb][4 * u + j] = v.x; S[kb][4 * u + j + 1] = v.y;
+                    mx = fmaxf(mx, fmaxf(v.x, v.y));
                 }
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -164,10 +168,12 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float e = __builtin_amdgcn_exp2f(S[kb][t] - mx);
-                S[kb][t] = e;
-                sum += e;
+            for (int t = 0; t < 16; t += 2) {
+                const cldrd_f32v2 d = (cldrd_f32v2){S[kb][t], S[kb][t + 1]} - splat2(mx);
+                const float e0 = __builtin_amdgcn_exp2f(d.x), e1 = __builtin_amdgcn_exp2f(d.y);
+                S[kb][t] = e0; S[kb][t + 1] = e1;
+                sum += e0;
+                sum += e1;
             }
         sum += __shfl_xor(sum, 32, 64);
         const int q = qb * 32 + r;
@@ -181,13 +187,14 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
             float pv[16];
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
-                float p0 = S[kb][t] * inv, p1 = S[kb][t + 1] * inv;
+                cldrd_f32v2 p = (cldrd_f32v2){S[kb][t], S[kb][t + 1]} * splat2(inv);
                 if (DROP) {
                     const uint32_t hh = drop_pair(rk, (uint32_t)(kb * 32 + rowmap(t, h)));
-                    p0 = drop_keep_lo(hh, drop_thresh) ? p0 * drop_scale : 0.f;
-                    p1 = drop_keep_hi(hh, drop_thresh) ? p1 * drop_scale : 0.f;
+                    p = p * splat2(drop_scale);
+                    p.x = drop_keep_lo(hh, drop_thresh) ? p.x : 0.f;
+                    p.y = drop_keep_hi(hh, drop_thresh) ? p.y : 0.f;
                 }
-                pv[t] = p0; pv[t + 1] = p1;
+                pv[t] = p.x; pv[t + 1] = p.y;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -347,10 +354,10 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
                 const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
                 const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = fmaf(S[kb][4 * u + j], scale2, bb[j]);
-                    S[kb][4 * u + j] = v;
-                    mx = fmaxf(mx, v);
+                for (int j = 0; j < 4; j += 2) {      // two keys per packed fp32 instruction (v_pk_fma_f32: same IEEE results as two v_fma_f32)
+                    const cldrd_f32v2 v = fma2((cldrd_f32v2){S[kb][4 * u + j], S[kb][4 * u + j + 1]}, splat2(scale2), (cldrd_f32v2){bb[j], bb[j + 1]});
+                    S[kb][4 * u + j] = v.x; S[kb][4 * u + j + 1] = v.y;
+                    mx = fmaxf(mx, fmaxf(v.x, v.y));
                 }
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -358,10 +365,12 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const float e = __builtin_amdgcn_exp2f(S[kb][t] - mx);
-                S[kb][t] = e;
-                sum += e;
+            for (int t = 0; t < 16; t += 2) {
+                const cldrd_f32v2 d = (cldrd_f32v2){S[kb][t], S[kb][t + 1]} - splat2(mx);
+                const float e0 = __builtin_amdgcn_exp2f(d.x), e1 = __builtin_amdgcn_exp2f(d.y);
+                S[kb][t] = e0; S[kb][t + 1] = e1;
+                sum += e0;
+                sum += e1;
             }
         sum += __shfl_xor(sum, 32, 64);
         const int q = qb * 32 + r;
@@ -375,13 +384,14 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
             float pv[16];
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
-                float p0 = S[kb][t] * inv, p1 = S[kb][t + 1] * inv;
+                cldrd_f32v2 p = (cldrd_f32v2){S[kb][t], S[kb][t + 1]} * splat2(inv);
                 if (DROP) {       // keys rowmap(t, h), rowmap(t, h) + 1 of block kb: two adjacent bits of the loader's dword
                     const uint32_t w = sBits[kb * Lp + q] >> (4 * h);
-                    p0 = keep_bit(p0 * drop_scale, w, rowmap(t, 0));
-                    p1 = keep_bit(p1 * drop_scale, w, rowmap(t, 0) + 1);
+                    p = p * splat2(drop_scale);
+                    p.x = keep_bit(p.x, w, rowmap(t, 0));
+                    p.y = keep_bit(p.y, w, rowmap(t, 0) + 1);
                 }
-                pv[t] = p0; pv[t + 1] = p1;
+                pv[t] = p.x; pv[t + 1] = p.y;
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
@@ -482,9 +492,10 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
                 const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
                 const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[4 * u + j] = fmaf(S[4 * u + j], scale2, bb[j]);
-                    mloc = fmaxf(mloc, v[4 * u + j]);
+                for (int j = 0; j < 4; j += 2) {      // packed fp32: two keys per instruction
+                    const cldrd_f32v2 w = fma2((cldrd_f32v2){S[4 * u + j], S[4 * u + j + 1]}, splat2(scale2), (cldrd_f32v2){bb[j], bb[j + 1]});
+                    v[4 * u + j] = w.x; v[4 * u + j + 1] = w.y;
+                    mloc = fmaxf(mloc, fmaxf(w.x, w.y));
                 }
             }
             mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
@@ -494,7 +505,8 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
             float psum = 0.f;
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
-                float p0 = __builtin_amdgcn_exp2f(v[t] - mn), p1 = __builtin_amdgcn_exp2f(v[t + 1] - mn);
+                const cldrd_f32v2 dv = (cldrd_f32v2){v[t], v[t + 1]} - splat2(mn);
+                float p0 = __builtin_amdgcn_exp2f(dv.x), p1 = __builtin_amdgcn_exp2f(dv.y);
                 psum += p0 + p1;
                 if (DROP) {
                     const uint32_t hh = drop_pair(rk, (uint32_t)(kb * 32 + rowmap(t, h)));
@@ -507,7 +519,10 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                for (int t = 0; t < 16; ++t) O[dt][t] *= alpha;
+                for (int t = 0; t < 16; t += 2) {
+                    const cldrd_f32v2 o2 = (cldrd_f32v2){O[dt][t], O[dt][t + 1]} * splat2(alpha);
+                    O[dt][t] = o2.x; O[dt][t + 1] = o2.y;
+                }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const bf16x8 pb = pack8x<F16>(v + 8 * s2);
@@ -655,9 +670,10 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
                     const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
                     const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[4 * u + j] = fmaf(S[4 * u + j], scale2, bb[j]);
-                        mloc = fmaxf(mloc, v[4 * u + j]);
+                    for (int j = 0; j < 4; j += 2) {      // packed fp32: two keys per instruction
+                        const cldrd_f32v2 w = fma2((cldrd_f32v2){S[4 * u + j], S[4 * u + j + 1]}, splat2(scale2), (cldrd_f32v2){bb[j], bb[j + 1]});
+                        v[4 * u + j] = w.x; v[4 * u + j + 1] = w.y;
+                        mloc = fmaxf(mloc, fmaxf(w.x, w.y));
                     }
                 }
                 mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
@@ -667,7 +683,8 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
                 float psum = 0.f;
 #pragma unroll
                 for (int t = 0; t < 16; t += 2) {
-                    float p0 = __builtin_amdgcn_exp2f(v[t] - mn), p1 = __builtin_amdgcn_exp2f(v[t + 1] - mn);
+                    const cldrd_f32v2 dv = (cldrd_f32v2){v[t], v[t + 1]} - splat2(mn);
+                    float p0 = __builtin_amdgcn_exp2f(dv.x), p1 = __builtin_amdgcn_exp2f(dv.y);
                     psum += p0 + p1;
                     if (DROP) {
                         const uint32_t hh = drop_pair(rk, (uint32_t)(kb * 32 + rowmap(t, h)));
@@ -680,7 +697,10 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int t = 0; t < 16; ++t) O[dt][t] *= alpha;
+                    for (int t = 0; t < 16; t += 2) {
+                        const cldrd_f32v2 o2 = (cldrd_f32v2){O[dt][t], O[dt][t + 1]} * splat2(alpha);
+                        O[dt][t] = o2.x; O[dt][t + 1] = o2.y;
+                    }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const bf16x8 pb = pack8x<F16>(v + 8 * s2);
@@ -807,17 +827,21 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
                 if (DROP) k4 = *(const uint4*)(sRk + q4);
                 const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; j += 2) {      // two queries per packed fp32 instruction (the same IEEE operations as the scalar form)
                     const int t = 4 * u + j;
-                    const float p = __builtin_amdgcn_exp2f(fmaf(S[t], scale2, bias_k) - ll[j]);
-                    float pdv = p, dp = dP[t];
+                    const cldrd_f32v2 a2 = fma2((cldrd_f32v2){S[t], S[t + 1]}, splat2(scale2), splat2(bias_k)) - (cldrd_f32v2){ll[j], ll[j + 1]};
+                    const cldrd_f32v2 p2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                    cldrd_f32v2 pd2 = p2, dp2 = {dP[t], dP[t + 1]};
                     if (DROP) {
-                        const bool keep = dropout_keep(kk[j], (uint32_t)key, drop_thresh);
-                        pdv = keep ? p * drop_scale : 0.f;
-                        dp = keep ? dp * drop_scale : 0.f;
+                        const bool keep0 = dropout_keep(kk[j], (uint32_t)key, drop_thresh), keep1 = dropout_keep(kk[j + 1], (uint32_t)key, drop_thresh);
+                        pd2 = p2 * splat2(drop_scale);
+                        dp2 = dp2 * splat2(drop_scale);
+                        pd2.x = keep0 ? pd2.x : 0.f; pd2.y = keep1 ? pd2.y : 0.f;
+                        dp2.x = keep0 ? dp2.x : 0.f; dp2.y = keep1 ? dp2.y : 0.f;
                     }
-                    pd[t] = pdv;
-                    ds[t] = p * (dp - dd[j]);
+                    pd[t] = pd2.x; pd[t + 1] = pd2.y;
+                    const cldrd_f32v2 ds2 = p2 * (dp2 - (cldrd_f32v2){dd[j], dd[j + 1]});
+                    ds[t] = ds2.x; ds[t + 1] = ds2.y;
                 }
             }
 #pragma unroll
@@ -842,8 +866,8 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int t = 4 * (u + k);
-                        a[k].x = pack2x<F16>(dK[dt][t] * scale, dK[dt][t + 1] * scale);
-                        a[k].y = pack2x<F16>(dK[dt][t + 2] * scale, dK[dt][t + 3] * scale);
+                        a[k].x = pack2x_scaled<F16>(dK[dt][t], dK[dt][t + 1], scale);
+                        a[k].y = pack2x_scaled<F16>(dK[dt][t + 2], dK[dt][t + 3], scale);
                         b[k].x = pack2x<F16>(dV[dt][t], dV[dt][t + 1]);
                         b[k].y = pack2x<F16>(dV[dt][t + 2], dV[dt][t + 3]);
                     }
@@ -883,16 +907,19 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const int t = 4 * u + j;
-                    const float p0 = __builtin_amdgcn_exp2f(fmaf(ST[t], scale2, bb[j]) - lse_q);
-                    const float p1 = __builtin_amdgcn_exp2f(fmaf(ST[t + 1], scale2, bb[j + 1]) - lse_q);
-                    float dp0 = dPT[t], dp1 = dPT[t + 1];
+                    // packed fp32 (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two keys per instruction, the same IEEE operations as before)
+                    const cldrd_f32v2 a2 = fma2((cldrd_f32v2){ST[t], ST[t + 1]}, splat2(scale2), (cldrd_f32v2){bb[j], bb[j + 1]}) - splat2(lse_q);
+                    const cldrd_f32v2 p2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                    cldrd_f32v2 dp2 = {dPT[t], dPT[t + 1]};
+                    if (DROP) dp2 = dp2 * splat2(drop_scale);
+                    float dp0 = dp2.x, dp1 = dp2.y;
                     if (DROP) {
                         const uint32_t hh = drop_pair(rk_q, (uint32_t)(key4 + j));
-                        dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 * drop_scale : 0.f;
-                        dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 * drop_scale : 0.f;
+                        dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 : 0.f;
+                        dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 : 0.f;
                     }
-                    ds[t] = p0 * (dp0 - delta_q);
-                    ds[t + 1] = p1 * (dp1 - delta_q);
+                    const cldrd_f32v2 ds2 = p2 * ((cldrd_f32v2){dp0, dp1} - splat2(delta_q));
+                    ds[t] = ds2.x; ds[t + 1] = ds2.y;
                 }
             }
 #pragma unroll
@@ -915,8 +942,8 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int t = 4 * (u + k);
-                        a[k].x = pack2x<F16>(dQ[dt][t] * scale, dQ[dt][t + 1] * scale);
-                        a[k].y = pack2x<F16>(dQ[dt][t + 2] * scale, dQ[dt][t + 3] * scale);
+                        a[k].x = pack2x_scaled<F16>(dQ[dt][t], dQ[dt][t + 1], scale);
+                        a[k].y = pack2x_scaled<F16>(dQ[dt][t + 2], dQ[dt][t + 3], scale);
                     }
                     const uint4 w = widen_pair(a[0], a[1]);
                     if (q < L) *(uint4*)(oq + dt * 32 + 8 * (u + h)) = w;
@@ -1073,21 +1100,24 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
 #pragma unroll
                 for (int j = 0; j < 4; j += 2) {
                     const int t = 4 * u + j;
-                    const float p0 = __builtin_amdgcn_exp2f(fmaf(ST[t], scale2, bb[j]) - lse_q);
-                    const float p1 = __builtin_amdgcn_exp2f(fmaf(ST[t + 1], scale2, bb[j + 1]) - lse_q);
-                    float dp0 = dPT[t], dp1 = dPT[t + 1];
+                    // packed fp32 (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two keys per instruction, the same IEEE operations as before)
+                    const cldrd_f32v2 a2 = fma2((cldrd_f32v2){ST[t], ST[t + 1]}, splat2(scale2), (cldrd_f32v2){bb[j], bb[j + 1]}) - splat2(lse_q);
+                    const cldrd_f32v2 p2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                    cldrd_f32v2 dp2 = {dPT[t], dPT[t + 1]};
+                    if (DROP) dp2 = dp2 * splat2(drop_scale);
+                    float dp0 = dp2.x, dp1 = dp2.y;
                     if (DROP) {
                         if constexpr (BITS) {       // keys key4 + j, key4 + j + 1: adjacent bits of the forward's dword [kb][q]
-                            dp0 = keep_bit(dp0 * drop_scale, wbits, 8 * u + j);
-                            dp1 = keep_bit(dp1 * drop_scale, wbits, 8 * u + j + 1);
+                            dp0 = keep_bit(dp0, wbits, 8 * u + j);
+                            dp1 = keep_bit(dp1, wbits, 8 * u + j + 1);
                         } else {
                             const uint32_t hh = drop_pair(rk_q, (uint32_t)(key4 + j));
-                            dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 * drop_scale : 0.f;
-                            dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 * drop_scale : 0.f;
+                            dp0 = drop_keep_lo(hh, drop_thresh) ? dp0 : 0.f;
+                            dp1 = drop_keep_hi(hh, drop_thresh) ? dp1 : 0.f;
                         }
                     }
-                    ds[t] = p0 * (dp0 - delta_q);
-                    ds[t + 1] = p1 * (dp1 - delta_q);
+                    const cldrd_f32v2 ds2 = p2 * ((cldrd_f32v2){dp0, dp1} - splat2(delta_q));
+                    ds[t] = ds2.x; ds[t + 1] = ds2.y;
                 }
             }
 #pragma unroll
@@ -1110,8 +1140,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int t = 4 * (u + k);
-                        a[k].x = pack2x<F16>(dQ[dt][t] * scale, dQ[dt][t + 1] * scale);
-                        a[k].y = pack2x<F16>(dQ[dt][t + 2] * scale, dQ[dt][t + 3] * scale);
+                        a[k].x = pack2x_scaled<F16>(dQ[dt][t], dQ[dt][t + 1], scale);
+                        a[k].y = pack2x_scaled<F16>(dQ[dt][t + 2], dQ[dt][t + 3], scale);
                     }
                     const uint4 w = widen_pair(a[0], a[1]);
                     if (q < L) *(uint4*)(oq + dt * 32 + 8 * (u + h)) = w;
@@ -1146,22 +1176,26 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                 if (DROP) k4 = BITS ? *(const uint4*)(sBits + kb * Lp + q4) : *(const uint4*)(sRk + q4);      // BITS: dwords [kb][q4 .. q4+3], bit = key
                 const uint32_t kk[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 4; j += 2) {      // two queries per packed fp32 instruction (the same IEEE operations as the scalar form)
                     const int t = 4 * u + j;
-                    const float p = __builtin_amdgcn_exp2f(fmaf(S[t], scale2, bias_k) - ll[j]);
-                    float pdv = p, dp = dP[t];
+                    const cldrd_f32v2 a2 = fma2((cldrd_f32v2){S[t], S[t + 1]}, splat2(scale2), splat2(bias_k)) - (cldrd_f32v2){ll[j], ll[j + 1]};
+                    const cldrd_f32v2 p2 = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+                    cldrd_f32v2 pd2 = p2, dp2 = {dP[t], dP[t + 1]};
                     if (DROP) {
+                        pd2 = p2 * splat2(drop_scale);
+                        dp2 = dp2 * splat2(drop_scale);
                         if constexpr (BITS) {
-                            pdv = keep_bit(p * drop_scale, kk[j], r);
-                            dp = keep_bit(dp * drop_scale, kk[j], r);
+                            pd2.x = keep_bit(pd2.x, kk[j], r); pd2.y = keep_bit(pd2.y, kk[j + 1], r);
+                            dp2.x = keep_bit(dp2.x, kk[j], r); dp2.y = keep_bit(dp2.y, kk[j + 1], r);
                         } else {
-                            const bool keep = dropout_keep(kk[j], (uint32_t)key, drop_thresh);
-                            pdv = keep ? p * drop_scale : 0.f;
-                            dp = keep ? dp * drop_scale : 0.f;
+                            const bool keep0 = dropout_keep(kk[j], (uint32_t)key, drop_thresh), keep1 = dropout_keep(kk[j + 1], (uint32_t)key, drop_thresh);
+                            pd2.x = keep0 ? pd2.x : 0.f; pd2.y = keep1 ? pd2.y : 0.f;
+                            dp2.x = keep0 ? dp2.x : 0.f; dp2.y = keep1 ? dp2.y : 0.f;
                         }
                     }
-                    pd[t] = pdv;
-                    ds[t] = p * (dp - dd[j]);
+                    pd[t] = pd2.x; pd[t + 1] = pd2.y;
+                    const cldrd_f32v2 ds2 = p2 * (dp2 - (cldrd_f32v2){dd[j], dd[j + 1]});
+                    ds[t] = ds2.x; ds[t + 1] = ds2.y;
                 }
             }
 #pragma unroll
@@ -1186,8 +1220,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int t = 4 * (u + k);
-                        a[k].x = pack2x<F16>(dK[dt][t] * scale, dK[dt][t + 1] * scale);
-                        a[k].y = pack2x<F16>(dK[dt][t + 2] * scale, dK[dt][t + 3] * scale);
+                        a[k].x = pack2x_scaled<F16>(dK[dt][t], dK[dt][t + 1], scale);
+                        a[k].y = pack2x_scaled<F16>(dK[dt][t + 2], dK[dt][t + 3], scale);
                         b[k].x = pack2x<F16>(dV[dt][t], dV[dt][t + 1]);
                         b[k].y = pack2x<F16>(dV[dt][t + 2], dV[dt][t + 3]);
                     }
