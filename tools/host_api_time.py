@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""Wall time of the reference-shaped host search API (numpy in, numpy out) on one cfg5 shard: FlatIPIndex.search, three calls (the first one
-allocates the pinned result buffers).  Usage: python tools/host_api_time.py [rows] [nq]"""
+"""Wall time of the reference-shaped host search API (numpy in, numpy out) on one cfg5 shard: FlatIPIndex.search, three calls.  Usage: python tools/host_api_time.py [rows] [nq]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -20,7 +19,7 @@ if os.environ.get("PIN_PROBE"):
         h = torch.empty(mb << 18, dtype=torch.float32, pin_memory=True)
         print(f"pinned alloc of {mb} MiB: {(time.perf_counter() - t0) * 1e3:.1f} ms", flush=True)
         del h
-idx.search(q[:256], 1000)        # kernels loaded, workspaces allocated: what is timed below is the API, cold pinned buffers included in call 0
+idx.search(q[:256], 1000)        # kernels loaded, workspaces allocated: what is timed below is the API
 for i in range(3):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
