@@ -37,6 +37,15 @@ __device__ __forceinline__ void st16_stream(void* p, const uint4& v) {
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// LDS-DMA of 16 bytes per lane with a SCALAR base and a 32-bit per-lane byte offset (the SADDR form of global_load_lds_dwordx4): lane l's
+// 16 bytes at sbase + voff land at LDS byte address lds_addr + 16 l.  __builtin_amdgcn_global_load_lds takes a 64-bit per-lane pointer and hipcc
+// builds it with one v_lshl_add_u64 per piece (seven to eight per wave and K tile in the GEMM loops, in front of instructions whose issue is
+// already the K loop's largest non-MFMA cost); here the address arithmetic stays on the scalar unit.  `lds_addr` must be wave-uniform.
+__device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // round-to-nearest-even f32 -> bf16 via the hardware cast (keeps NaN a NaN, MI355X_MICROARCH correctness table)

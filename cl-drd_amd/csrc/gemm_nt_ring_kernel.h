@@ -114,19 +114,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_ring_kernel(GemmNtArgs p) {
 #pragma unroll
     for (int i = 0; i < BPW; ++i)
         ob[i] = (uint32_t)min(n0 + (BPW * wid + i) * 8 + prow, p.N - 1) * (uint32_t)(p.ldb * 2) + schunk * 16;
+    const uint32_t lds0 = lds_addr_of(smem);
     auto stageA = [&](int slot, int kt) {
-        char* base = smem + slot * A_BYTES;
+        const uint32_t base = lds0 + slot * A_BYTES + 4 * wid * 1024;
         const char* pa = (const char*)p.A + kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pa + oa[i]), LDS_PTR(base + (4 * wid + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) lds_dma16(pa, oa[i], base + i * 1024);
     };
     auto stageB = [&](int slot, int kt) {
-        char* base = smem + BRING + slot * B_BYTES;
+        const uint32_t base = lds0 + BRING + slot * B_BYTES + BPW * wid * 1024;
         const char* pb = (const char*)p.B + kt * (BK * 2);
 #pragma unroll
-        for (int i = 0; i < BPW; ++i)
-            __builtin_amdgcn_global_load_lds(GLOBAL_PTR(pb + ob[i]), LDS_PTR(base + (BPW * wid + i) * 1024), 16, 0, 0);
+        for (int i = 0; i < BPW; ++i) lds_dma16(pb, ob[i], base + i * 1024);
     };
     // what a slot recycle at the barrier of K tile kt issues: B of K tile kt + NB into tile kt's B slot, then A of K tile kt + na into its
     // A slot - B first, so that the wait for K tile kt+1 (all of B(kt+1), A(kt+1)) can leave exactly the youngest requests, A(kt+2), in flight
