@@ -72,6 +72,10 @@ SIGNATURES = {
     "cldrd_topk_sort": (ci, [vp, vp, vp, ci, ci, ci, vp, vp, vp]),
     "cldrd_row_sqnorm_max": (ci, [vp, csz, ci, vp, vp]),
     "cldrd_gather_cast_rows": (ci, [vp, vp, csz, csz, ci, vp]),
+    "cldrd_index_col_mean_workspace": (csz, [csz, ci]),
+    "cldrd_index_col_mean": (ci, [vp, csz, ci, vp, vp, csz, vp]),
+    "cldrd_index_center_cast": (ci, [vp, vp, csz, ci, vp, vp, csz, csz, vp, vp, vp]),
+    "cldrd_map_ids": (ci, [vp, vp, C.c_longlong, vp, csz, vp]),
     "cldrd_unpack_rows16": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "cldrd_gather_rows": (ci, [vp, vp, vp, ci, ci, vp]),
     "cldrd_scatter_cls_grad_idx": (ci, [vp, vp, ci, ci, vp, ci, ci, vp]),

@@ -79,16 +79,17 @@ extern "C" void cldrd_set_norm_sink(float* slots, int capacity) {
     g_cldrd_norm_sink_used = 0;
     g_cldrd_norm_sink_bad = 0;
 }
-extern "C" int cldrd_norm_sink_used(void) { return g_cldrd_norm_sink_bad ? -1 : g_cldrd_norm_sink_used; }
+// slots written since cldrd_set_norm_sink; -1: a launch could not contribute (cldrd_norm_sink_miss); -2: the sink was too small for a launch
+extern "C" int cldrd_norm_sink_used(void) { return g_cldrd_norm_sink_bad ? -g_cldrd_norm_sink_bad : g_cldrd_norm_sink_used; }
 // reserve n slots for a launch; null when no sink is set or it is full (the sink is then marked incomplete)
 float* cldrd_norm_sink_take(int n) {
     if (!g_cldrd_norm_sink) return nullptr;
-    if (n <= 0 || g_cldrd_norm_sink_used + n > g_cldrd_norm_sink_cap) { g_cldrd_norm_sink_bad = 1; return nullptr; }
+    if (n <= 0 || g_cldrd_norm_sink_used + n > g_cldrd_norm_sink_cap) { g_cldrd_norm_sink_bad = 2; return nullptr; }
     float* p = g_cldrd_norm_sink + g_cldrd_norm_sink_used;
     g_cldrd_norm_sink_used += n;
     return p;
 }
-void cldrd_norm_sink_miss(void) { if (g_cldrd_norm_sink) g_cldrd_norm_sink_bad = 1; }
+void cldrd_norm_sink_miss(void) { if (g_cldrd_norm_sink && !g_cldrd_norm_sink_bad) g_cldrd_norm_sink_bad = 1; }
 
 namespace {
 __global__ void step_state_kernel(unsigned long long* seeds, unsigned long long s0, unsigned long long s1, float* hyper, float lr, float step_size,

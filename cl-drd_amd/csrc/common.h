@@ -42,7 +42,7 @@ __device__ __forceinline__ void st16_stream(void* p, const uint4& v) {
 // builds it with one v_lshl_add_u64 per piece (seven to eight per wave and K tile in the GEMM loops, in front of instructions whose issue is
 // already the K loop's largest non-MFMA cost); here the address arithmetic stays on the scalar unit.  `lds_addr` must be wave-uniform.
 __device__ __forceinline__ void lds_dma16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p; }
 

@@ -76,7 +76,7 @@ __device__ __forceinline__ int chunk_pos(int c, int m) {
 // the K loop, 1018 TF/s at 4096^3 against 877 for 256 x 128, but no better than 256 x 192 on the encoder shapes once the tile counts
 // are rounded to whole rounds of CUs).
 __device__ __forceinline__ void tn_dma16(uint32_t lds_addr, uint32_t voff, const void* sbase) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 // Round 4: the two transposing reads of a fragment are the BUILTIN again, and every LDS-DMA of the kernel is inline asm instead (the
 // partial-tile path included).  Rounds 1-3 had it the other way round - reads in asm because hipcc, seeing a global_load_lds builtin
@@ -95,7 +95,7 @@ __device__ __forceinline__ void tr_issue(Frag& f, uint32_t addr) {
 __device__ __forceinline__ bf16x8 frag8(const Frag& f) { return __builtin_shufflevector(f.lo, f.hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 // one LDS-DMA piece with a per-lane 64-bit source address (partial last K tile: rows >= M come from the zero page)
 __device__ __forceinline__ void tn_dma16_addr(uint32_t lds_addr, const void* src) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(src) : "memory", "m0");
 }
 
 // ABL != 0 (development build only, tools/tn_ablate.py; WRONG results): 1 no LDS-DMA inside the K loop, 2 no fragment reads inside the

@@ -311,7 +311,7 @@ __device__ __forceinline__ void block_partials(float* smem, RowF& a, RowF& b, Ro
 // the stream carries the loss scale like every other 16-bit gradient tensor; dy_branch and dx2 are fp16 too).  With GS = 2 the stream tensor dx IS
 // the MFMA operand of the next data / weight gradient unless dropout makes the two differ: dx2 may be null, and a LayerNorm backward then moves
 // 250 MB at T = 32768 instead of the 400 MB of the fp32 stream (read 50 + 50 + 100, write 50).  Measured on the reference's fp32 gradients
-// (tools/r05_cos.sh, every ranked tensor of cfg1-4): min cosine 0.99990 / 0.99992 / 0.99994 / 0.99992 / 0.99995 with the stream rounded to
+// (tools/grad_cos_report.py -> profiles/r05_grad_cosines.txt, every ranked tensor of cfg1-4): min cosine 0.99990 / 0.99992 / 0.99994 / 0.99992 / 0.99995 with the stream rounded to
 // fp16 at exactly these points, against 0.99992 / 0.99994 / 0.99998 / 0.99995 / 0.99996 with the fp32 stream (profiles/r05_grad_cosines.txt).
 template <int DC, bool DROP, bool X32, int GS = 0>
 __global__ __launch_bounds__(512) void ln_bwd_kernel(const void* __restrict__ dy_v, const void* __restrict__ x,

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void transpose_cast_kernel(const float* __rest
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
                                                               const long long* __restrict__ desc, const int* __restrict__ tile_prefix,
                                                               int ndesc) {
-    __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];          // 144-byte rows: the column gathers below spread over banks
+    // 128-byte rows, the 16-byte chunk index XOR-swizzled with (row / 8): a column gather below reads rows 8 part .. 8 part + 7 of one column, so
+    // the eight `part`s of a wave land in eight different chunks = disjoint bank quads (the padded [64][72] layout of rounds 2-5 put all of
+    // them on ONE bank - 8 part rows x 36 dwords = 288 = 9 x 32 - and ran with SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.82)
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][64];
     int i = 0;
     while (i + 1 < ndesc && (int)blockIdx.x >= tile_prefix[i + 1]) ++i;
     const long long so = desc[4 * i], dof = desc[4 * i + 1];
@@ -212,15 +215,16 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int r = pass * 32 + line;
-        *(uint4*)&tile[r][part * 8] = *(const uint4*)(src + so + (long long)(r0 + r) * cols + c0 + part * 8);
+        *(uint4*)&tile[r][(part ^ ((r >> 3) & 7)) * 8] = *(const uint4*)(src + so + (long long)(r0 + r) * cols + c0 + part * 8);
     }
     __syncthreads();
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int c = pass * 32 + line;                                    // output line c holds source rows r0 .. r0 + 63
         uint32_t w[4];
+        const int cs = (((c >> 3) ^ part) << 3) | (c & 7);               // column c of rows 8 part .. 8 part + 7 (their swizzle key is `part`)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[part * 8 + 2 * j][c] | ((uint32_t)tile[part * 8 + 2 * j + 1][c] << 16);
+        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)tile[part * 8 + 2 * j][cs] | ((uint32_t)tile[part * 8 + 2 * j + 1][cs] << 16);
         *(uint4*)(dst + dof + (long long)(c0 + c) * rows + r0 + part * 8) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }

@@ -233,6 +233,78 @@ __global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__
     if (bad && flag) atomicOr(flag, 1u);
 }
 
+// ---- attaching a shard (FlatIPIndex._attach): the statistics and shadows of the index in three launches over the fp32 rows ----
+// (until round 5 these were chunks of at::native kernels: mean, subtract, double-precision row norms, casts, a strided gather)
+// 1. column sums in fp64: block b walks rows b, b + grid, ...; thread t owns columns t, t + 256, ... (a row is read as one coalesced segment);
+//    partial[b][d] doubles, reduced in block order by index_mean_finish_kernel -> mu = mean row (fp32), deterministic.
+__global__ __launch_bounds__(256) void index_colsum_kernel(const float* __restrict__ P, size_t rows, int d, double* __restrict__ partial) {
+    constexpr int MAXC = 8;                                    // d <= 2048
+    double acc[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) acc[c] = 0.0;
+    for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* pr = P + r * d;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            const int j = threadIdx.x + 256 * c;
+            if (j < d) acc[c] += (double)pr[j];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int j = threadIdx.x + 256 * c;
+        if (j < d) partial[(size_t)blockIdx.x * d + j] = acc[c];
+    }
+}
+__global__ __launch_bounds__(256) void index_mean_finish_kernel(const double* __restrict__ partial, int nblk, int d, size_t rows, float* __restrict__ mu) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= d) return;
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * d + j];
+    mu[j] = (float)(s / (double)rows);
+}
+// 2. one pass: c = p - mu (fp32, as the scan's operand is defined), fp16 shadow of c, max_r |c_r|^2 (fp64 sum per row, the maximum as the
+//    bit pattern of its fp32 value: non-negative floats order like their bits), the bf16 threshold sample (row r = i * stride for
+//    i < s_rows), range flag.  One wave per row, 16-byte loads, 8-byte stores.
+__global__ __launch_bounds__(256) void index_center_cast_kernel(const float* __restrict__ P, const float* __restrict__ mu, size_t rows, int d,
+                                                                 uint16_t* __restrict__ P16, bf16_t* __restrict__ sample, size_t s_stride,
+                                                                 size_t s_rows, unsigned int* __restrict__ cmax_bits, unsigned int* __restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    double best = 0.0;
+    bool bad = false;
+    for (size_t r = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (size_t)gridDim.x * 4) {
+        const float* pr = P + r * d;
+        uint16_t* o = P16 + r * d;
+        const bool in_sample = sample != nullptr && r % s_stride == 0 && r / s_stride < s_rows;
+        bf16_t* so = in_sample ? sample + (r / s_stride) * d : nullptr;
+        double s = 0.0;
+        for (int j = lane * 4; j < d; j += 256) {
+            const float4 a = *(const float4*)(pr + j);
+            const float4 m = *(const float4*)(mu + j);
+            const float c0 = a.x - m.x, c1 = a.y - m.y, c2 = a.z - m.z, c3 = a.w - m.w;
+            s += (double)c0 * (double)c0 + (double)c1 * (double)c1 + (double)c2 * (double)c2 + (double)c3 * (double)c3;
+            bad |= !(fabsf(c0) <= 65504.f) | !(fabsf(c1) <= 65504.f) | !(fabsf(c2) <= 65504.f) | !(fabsf(c3) <= 65504.f);
+            uint2 u; u.x = pack2h(c0, c1); u.y = pack2h(c2, c3);
+            *(uint2*)(o + j) = u;
+            if (in_sample) { uint2 v; v.x = pack2bf(c0, c1); v.y = pack2bf(c2, c3); *(uint2*)(so + j) = v; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        best = s > best ? s : best;
+    }
+    if (lane == 0 && best > 0.0) atomicMax(cmax_bits, __float_as_uint((float)best));
+    if (bad && flag) atomicOr(flag, 1u);
+}
+// 3. IndexIDMap on the device: row position -> id (ids table, or position + id_offset), -1 stays -1
+__global__ __launch_bounds__(256) void map_ids_kernel(const int* __restrict__ I, const long long* __restrict__ table, long long id_offset,
+                                                       long long* __restrict__ out, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int r = I[i];
+        out[i] = r < 0 ? -1ll : (table ? table[r] : (long long)r + id_offset);
+    }
+}
+
 // one block per query: fp16 + bf16 copies, L2 norm (fp32, fixed order), range flag
 __global__ __launch_bounds__(256) void prep_queries_kernel(const float* __restrict__ q, uint16_t* __restrict__ qh, bf16_t* __restrict__ qb,
                                                             float* __restrict__ qnorm, int d, unsigned int* __restrict__ flag) {
@@ -455,9 +527,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void scan_stream_kernel(c
 #pragma unroll
         for (int j = 0; j < PPW; ++j)
 #if CLDRD_SCAN_NT
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst + j * 1024), "v"(min(soff[j], lim)), "s"(sbase) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(dst + j * 1024), "v"(min(soff[j], lim)), "s"(sbase) : "memory", "m0");
 #else
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + j * 1024), "v"(min(soff[j], lim)), "s"(sbase) : "memory");
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst + j * 1024), "v"(min(soff[j], lim)), "s"(sbase) : "memory", "m0");
 #endif
     };
 
@@ -716,6 +788,45 @@ extern "C" int cldrd_cast_f16(const float* src, void* dst, size_t n, unsigned in
     const size_t n4 = n / 4;
     const int nb = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(cast_f16_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, n4, flag);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+// Attach statistics of an index shard (FlatIPIndex._attach).  cldrd_index_col_mean: mu[d] = mean row of P[rows, d] (fp64 sums, fixed order);
+// workspace = cldrd_index_col_mean_workspace(rows, d) bytes on the device.
+extern "C" size_t cldrd_index_col_mean_workspace(size_t rows, int d) {
+    const size_t nb = rows < 1024 ? rows : 1024;
+    return nb * (size_t)d * sizeof(double);
+}
+extern "C" int cldrd_index_col_mean(const float* P, size_t rows, int d, float* mu, void* workspace, size_t workspace_bytes, void* stream) {
+    CLDRD_CHECK(rows > 0 && d > 0 && d <= 2048, "index_col_mean: rows > 0 and 0 < d <= 2048");
+    CLDRD_CHECK(workspace != nullptr && workspace_bytes >= cldrd_index_col_mean_workspace(rows, d) && (uintptr_t)workspace % 8 == 0, "index_col_mean: workspace too small");
+    const int nb = (int)(rows < 1024 ? rows : 1024);
+    hipLaunchKernelGGL(index_colsum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, P, rows, d, (double*)workspace);
+    CLDRD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(index_mean_finish_kernel, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nb, d, rows, mu);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+// P16[r] = fp16(P[r] - mu); sample[i] = bf16(P[i * s_stride] - mu) for i < s_rows (sample may be null); *cmax_bits (zero it first) = bit pattern
+// of max_r |P[r] - mu|^2 as fp32; *flag |= 1 when a centred value does not fit fp16.
+extern "C" int cldrd_index_center_cast(const float* P, const float* mu, size_t rows, int d, void* P16, void* sample_bf16, size_t s_stride,
+                                       size_t s_rows, unsigned int* cmax_bits, unsigned int* flag, void* stream) {
+    CLDRD_CHECK(rows > 0 && d > 0 && d % 4 == 0 && cmax_bits != nullptr, "index_center_cast: bad arguments");
+    CLDRD_CHECK(sample_bf16 == nullptr || s_stride > 0, "index_center_cast: sample stride");
+    CLDRD_CHECK((uintptr_t)P % 16 == 0 && (uintptr_t)mu % 16 == 0 && (uintptr_t)P16 % 8 == 0, "index_center_cast: aligned operands");
+    const int nb = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+    hipLaunchKernelGGL(index_center_cast_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, P, mu, rows, d, (uint16_t*)P16, (bf16_t*)sample_bf16, s_stride,
+                       s_rows, cmax_bits, flag);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+// out[i] = I[i] < 0 ? -1 : (ids ? ids[I[i]] : I[i] + id_offset): faiss IndexIDMap on the device
+extern "C" int cldrd_map_ids(const int* I, const long long* ids, long long id_offset, long long* out, size_t n, void* stream) {
+    if (n == 0) return 0;
+    CLDRD_CHECK(I != nullptr && out != nullptr, "map_ids: null operands");
+    const int nb = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(map_ids_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, I, ids, id_offset, out, n);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

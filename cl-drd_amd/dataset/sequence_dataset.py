@@ -155,19 +155,31 @@ class SequenceTokenCache:
                 return cls.load(stem, want)
             except ValueError as exc:
                 stale_err = exc            # stale (another collection / tokenizer / length): rank 0 rebuilds it below, the others wait for that
+        marker = stem + ".building"
         if rank == 0:
-            # the metadata file goes FIRST: waiters key on it, and while a rebuild replaces ids / lens / keys one by one nobody may load a
-            # mix of new arrays and old metadata
+            # a marker file FIRST: it tells the waiting ranks that rank 0 has decided to (re)build - from then on a stale metadata file is
+            # rank 0's business and no reason to give up.  Then the metadata file goes: waiters key on it, and while a rebuild replaces
+            # ids / lens / keys one by one nobody may load a mix of new arrays and old metadata
+            with open(marker, "w") as fh:
+                fh.write(str(os.getpid()))
             try:
                 os.remove(stem + ".meta.json")
             except FileNotFoundError:
                 pass
-            return cls.build(path, tokenizer, max_length, stem)
-        # Other ranks wait for rank 0 - but not blindly: a STALE metadata file that rank 0 has not removed within `stale_grace_s` means
-        # rank 0 does not see it as stale (another tokenizer / collection there), has not started, or died: fail with the reason instead of
-        # polling for two hours.  Progress of a build is visible as the growing temporary ids file.
-        stale_grace_s = min(wait_s, 120.0)
+            try:
+                return cls.build(path, tokenizer, max_length, stem)
+            finally:
+                try:
+                    os.remove(marker)
+                except FileNotFoundError:
+                    pass
+        # Other ranks wait for rank 0 - but not blindly: a STALE metadata file with no build marker next to it for `stale_grace_s` in a row
+        # means rank 0 does not see it as stale (another tokenizer / collection there), has not reached this point yet (model load, query
+        # tokenisation: hence ten minutes, not two), or died: fail with the reason instead of polling for two hours.  The clock only runs
+        # while neither the marker nor a fresh metadata file exists; progress of a build is visible as the growing temporary ids file.
+        stale_grace_s = min(wait_s, 600.0)
         t0 = time.time()
+        stale_since = None
         last_err = stale_err
         while time.time() - t0 < wait_s:
             if os.path.exists(stem + ".meta.json"):
@@ -175,9 +187,15 @@ class SequenceTokenCache:
                     return cls.load(stem, want)
                 except ValueError as exc:
                     last_err = exc
-                    if time.time() - t0 > stale_grace_s:
-                        raise ValueError(f"{exc} (rank {rank}: rank 0 has not replaced this cache within {stale_grace_s:.0f} s - does it run with "
-                                         f"the same collection / tokenizer / max_length?)") from exc
+                    if os.path.exists(marker):
+                        stale_since = None
+                    else:
+                        stale_since = time.time() if stale_since is None else stale_since
+                        if time.time() - stale_since > stale_grace_s:
+                            raise ValueError(f"{exc} (rank {rank}: rank 0 has not started to replace this cache within {stale_grace_s:.0f} s - "
+                                             f"does it run with the same collection / tokenizer / max_length?)") from exc
+            else:
+                stale_since = None
             time.sleep(1.0)
         raise TimeoutError(f"sequence token cache {stem}: rank 0 did not finish it within {wait_s:.0f} s"
                            + (f" (last problem: {last_err})" if last_err else ""))

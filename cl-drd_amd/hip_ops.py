@@ -817,6 +817,39 @@ def gather_cast_rows(src32, dst_bf16, n_out, stride):
     call("cldrd_gather_cast_rows", _p(src32), _p(dst_bf16), n_out, stride, src32.shape[1], _stream())
 
 
+def index_col_mean(P32):
+    """mean row of fp32 [rows, d] (fp64 column sums in a fixed order) -> fp32 [d] (cldrd_index_col_mean)"""
+    _chk(P32, F32, "P32", 2)
+    rows, d = P32.shape
+    mu = torch.empty(d, dtype=F32, device=P32.device)
+    nbytes = int(_lib.load().cldrd_index_col_mean_workspace(rows, d))
+    ws = torch.empty(nbytes // 8, dtype=torch.float64, device=P32.device)
+    call("cldrd_index_col_mean", _p(P32), rows, d, _p(mu), _p(ws), nbytes, _stream())
+    return mu
+
+
+def index_center_cast(P32, mu, P16, sample_bf16, s_stride, s_rows, flag):
+    """P16 = fp16(P32 - mu), sample = bf16 of every s_stride-th centred row; returns the DEVICE int32 word holding the bit pattern of
+    max_r |P32[r] - mu|^2 as fp32 (cldrd_index_center_cast) - read it with ``.view(torch.float32).item()``"""
+    _chk(P32, F32, "P32", 2), _chk(mu, F32, "mu", 1), _chk(P16, F16, "P16", 2)
+    if sample_bf16 is not None:
+        _chk(sample_bf16, BF16, "sample_bf16", 2)
+    cmax = torch.zeros(1, dtype=torch.int32, device=P32.device)
+    call("cldrd_index_center_cast", _p(P32), _p(mu), P32.shape[0], P32.shape[1], _p(P16), _p(sample_bf16), int(s_stride), int(s_rows), _p(cmax),
+         _p(flag), _stream())
+    return cmax
+
+
+def map_ids(I32, ids_table, id_offset):
+    """row positions int32 [...] -> ids int64 [...] on the device: the id table when there is one, else position + id_offset; -1 stays -1"""
+    _chk(I32, torch.int32, "I32")
+    if ids_table is not None:
+        _chk(ids_table, torch.int64, "ids_table", 1)
+    out = torch.empty(I32.shape, dtype=torch.int64, device=I32.device)
+    call("cldrd_map_ids", _p(I32), _p(ids_table), int(id_offset), _p(out), I32.numel(), _stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------- merge of shard lists
 
 def merge_topk_host(shard_D, shard_I, k, nthreads=0):

@@ -180,19 +180,16 @@ class FlatIPIndex:
             self._s_rows = min(n, (n + self._s_stride - 1) // self._s_stride)
             # the GEMM wants a column count that is a multiple of 8: zero rows pad the sample (never read by the select)
             self._sample = torch.zeros((self._s_rows + 7) // 8 * 8, d, dtype=torch.bfloat16, device=device)
+            # three launches over the fp32 rows (cldrd_row_sqnorm_max, cldrd_index_col_mean, cldrd_index_center_cast: mean row in fp64, then
+            # centre + fp16 shadow + max centred norm + bf16 sample + range flag in ONE pass); until round 5 this was 17 chunks of
+            # at::native kernels per attach (mean, subtract, double-precision norms, casts, a strided gather)
             raw_max = math.sqrt(ops.row_sqnorm_max(self._p32))
-            mu = self._p32.mean(dim=0, dtype=torch.float64).to(torch.float32) if math.isfinite(raw_max) else torch.zeros(d, device=device)
+            mu = ops.index_col_mean(self._p32) if math.isfinite(raw_max) else torch.zeros(d, dtype=torch.float32, device=device)
             self._mu = mu
-            cmax = torch.zeros((), dtype=torch.float32, device=device)
-            CH = 1 << 16
-            for lo in range(0, n, CH):
-                c = self._p32[lo:lo + CH] - mu
-                cmax = torch.maximum(cmax, (c.double() * c.double()).sum(1).max().float())
-                ops.cast_f16(c.view(-1), self._p16[lo:lo + CH].view(-1), flag)
-            self._sample[:self._s_rows] = (self._p32[::self._s_stride][:self._s_rows] - mu).to(torch.bfloat16)
+            cmax = ops.index_center_cast(self._p32, mu, self._p16, self._sample, self._s_stride, self._s_rows, flag)
             # max |p - mu| for the bound, plus 2^-12 max|p|: the fp32 subtraction p - mu itself rounds (2^-24 |p| per element), which moves a
             # centred score by up to |q| sqrt(d) 2^-24 max|p| < 2^-10 |q| (2^-12 max|p|) - folded into the norm the eps formula multiplies by 2^-10
-            self._max_norm = math.sqrt(float(cmax.item())) * (1.0 + 1e-6) + raw_max * 2.0 ** -12
+            self._max_norm = math.sqrt(float(cmax.view(torch.float32).item())) * (1.0 + 1e-6) + raw_max * 2.0 ** -12
             qt = os.environ.get("CLDRD_QUERY_TILE", "")
             self.query_tile = int(qt) if qt in ("128", "256") else (256 if d == 768 else 128)      # 256: only the d = 768 streaming scan
             if self.query_tile == 256 and d != 768:
@@ -232,12 +229,9 @@ class FlatIPIndex:
         (row position -> id on the device: IndexIDMap).  What a sharded search gathers over RCCL."""
         with torch.cuda.device(self.device):
             Dd, Id, stats = self.search_device(q32, int(k))
-            if self.ids is None:
-                ids64 = torch.where(Id >= 0, Id.to(torch.int64) + int(self.id_offset), torch.full_like(Id, -1, dtype=torch.int64))
-            else:
-                if getattr(self, "_ids_dev", None) is None or self._ids_dev.device != self.device:
-                    self._ids_dev = torch.from_numpy(np.ascontiguousarray(self.ids, dtype=np.int64)).to(self.device)
-                ids64 = torch.where(Id >= 0, self._ids_dev[Id.clamp(min=0).to(torch.int64)], torch.full_like(Id, -1, dtype=torch.int64))
+            if self.ids is not None and (getattr(self, "_ids_dev", None) is None or self._ids_dev.device != self.device):
+                self._ids_dev = torch.from_numpy(np.ascontiguousarray(self.ids, dtype=np.int64)).to(self.device)
+            ids64 = ops.map_ids(Id, self._ids_dev if self.ids is not None else None, int(self.id_offset))     # one launch (cldrd_map_ids)
         self.last_stats = stats
         return Dd, ids64
 
@@ -648,15 +642,91 @@ def merge_shard_results(shard_D, shard_I, k):
     return ops.merge_topk_host(shard_D, shard_I, k)
 
 
+class MultiDeviceFlatIPIndex:
+    """ONE process, several row shards on the devices of a list: what the reference's list branch of ``convert_index_to_gpu`` intends
+    (retriever/retrieval_utils.py:164-182: ``index_cpu_to_gpu_multiple(..., shard=True)``; dead code there - ``gpu_resources`` is undefined).
+    Shard s holds the contiguous row range ``ShardedFlatIPIndex.shard_bounds(n, S, s)`` of the index on ``devices[s]`` (a device may appear
+    more than once: two shards on one GPU, which is how a one-GPU box tests this path).  ``search``: the queries are uploaded to every
+    device, each shard is searched there (its launches are enqueued before any result is awaited, so shards on different GPUs run side by
+    side), the per-shard lists - scores fp32 [nq, k], ids int64 [nq, k], already mapped - are copied device to device onto ``devices[0]``
+    and merged by the same launch a multi-process search uses on rank 0 (``cldrd_merge_topk_device``; more than 8192 candidates per query:
+    the native host merge).  Order: score desc, ties -> shard asc, then list position asc = global row position asc, the single-index rule.
+    The production path for 8 GPUs stays one process per GPU (:class:`ShardedFlatIPIndex`, retrieve_top_passages.py under RANK /
+    WORLD_SIZE): one Python thread enqueues for all devices here."""
+
+    def __init__(self, index: FlatIPIndex, devices):
+        if not devices:
+            raise ValueError("convert_index_to_gpu: empty device list")
+        if index.embeddings is None:
+            raise ValueError("convert_index_to_gpu(index, [devices...]): the index must still hold its rows on the host")
+        self.d, self.ntotal = index.d, index.ntotal
+        self.devices = [torch.device("cuda", d) if isinstance(d, int) else torch.device(d) for d in devices]
+        self.shards = []
+        S = len(self.devices)
+        for s_, dev in enumerate(self.devices):
+            lo, hi = ShardedFlatIPIndex.shard_bounds(index.ntotal, S, s_)
+            sh = FlatIPIndex(index.d)
+            if hi > lo:
+                if index.ids is not None:
+                    sh.add_with_ids(index.embeddings[lo:hi], index.ids[lo:hi])
+                else:
+                    sh.add(index.embeddings[lo:hi])
+                    sh.id_offset = index.id_offset + lo
+                sh.to_gpu(dev)
+            self.shards.append(sh)
+        self.last_stats = {}
+        self.last_merge = {}
+
+    def search(self, queries, k):
+        q = np.ascontiguousarray(queries, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError("queries must be [nq, d]")
+        k = int(k)
+        if k <= 0:
+            raise ValueError("k must be positive")
+        nq = q.shape[0]
+        if nq == 0:
+            return np.full((0, k), -np.inf, dtype=np.float32), np.full((0, k), -1, dtype=np.int64)
+        live = [sh for sh in self.shards if sh.ntotal > 0]
+        dev0 = live[0].device
+        qh = torch.from_numpy(q)
+        lists = []
+        for sh in live:
+            with torch.cuda.device(sh.device):
+                Dd, Id = sh.search_ids_device(qh.to(sh.device, non_blocking=True), k)
+            lists.append((Dd, Id))
+        self.last_stats = {"shards": [sh.last_stats for sh in live]}
+        if len(lists) == 1:
+            return lists[0][0].cpu().numpy(), lists[0][1].cpu().numpy()
+        with torch.cuda.device(dev0):
+            W = len(lists)
+            allD = torch.empty(W, nq, k, dtype=torch.float32, device=dev0)
+            allI = torch.empty(W, nq, k, dtype=torch.int64, device=dev0)
+            for w, (Dd, Id) in enumerate(lists):
+                if Dd.device != dev0:
+                    torch.cuda.current_stream(dev0).wait_stream(torch.cuda.current_stream(Dd.device))      # the shard's search is done
+                allD[w].copy_(Dd, non_blocking=True)        # device to device (xGMI between GPUs of one node)
+                allI[w].copy_(Id, non_blocking=True)
+            if W * k <= CAND_CAP:
+                Dm, Im = ops.merge_topk_device(allD, allI, k)
+                self.last_merge = {"path": "device (cldrd_merge_topk_device)", "shards": W}
+                return Dm.cpu().numpy(), Im.cpu().numpy()
+            self.last_merge = {"path": "host (cldrd_merge_topk)", "shards": W}
+            return ops.merge_topk_host(list(allD.cpu().numpy()), list(allI.cpu().numpy()), k)
+
+
 def convert_index_to_gpu(index, faiss_gpu_index, useFloat16=False):
-    """reference :155-184.  int (or 1-element list): whole index on that GPU.  list of several devices: not supported in one
-    process - shard with one process per GPU and :class:`ShardedFlatIPIndex` instead.  ``useFloat16`` is ignored: the scan
+    """reference :155-184.  int (or 1-element list): whole index on that GPU.  list of several devices: the index is row-sharded over
+    them inside THIS process (:class:`MultiDeviceFlatIPIndex`; the reference's branch, :164-182, is dead code - this is what it
+    intends); the 8-GPU production path is still one process per GPU (:class:`ShardedFlatIPIndex`).  ``useFloat16`` is ignored: the scan
     always reads an fp16 shadow and the returned scores are exact fp32 either way."""
     if type(faiss_gpu_index) == list and len(faiss_gpu_index) == 1:
         faiss_gpu_index = faiss_gpu_index[0]
     if isinstance(faiss_gpu_index, int):
         return index.to_gpu(faiss_gpu_index)
-    raise NotImplementedError("multi-GPU search is one process per GPU: see ShardedFlatIPIndex / retrieve_top_passages.py")
+    if isinstance(faiss_gpu_index, (list, tuple)):
+        return MultiDeviceFlatIPIndex(index, list(faiss_gpu_index))
+    raise TypeError(f"convert_index_to_gpu: a device index or a list of them, got {type(faiss_gpu_index).__name__}")
 
 
 def index_retrieve(index, query_embeddings, topk, batch=None, as_arrays=False):

@@ -127,7 +127,12 @@ class NwayTrainer:
         self.clip = torch.zeros(3, dtype=torch.float32, device=dev)
         # clip-norm partial sums: [0, half) the early piece (sqnorm_partial on the second stream), [half, 2 half) the late piece when it is taken by
         # sqnorm_partial, or [half, half + used) when the kernels that write the passage tower's layer gradients leave them (norm sink, round 5)
-        self.norm_partial = torch.empty(ops.sqnorm_blocks() // 2 + 12288, dtype=torch.float32, device=dev)
+        # sink capacity from the layout: a weight-gradient group's slab reduction takes <= 256 slots per problem (4 per layer + the CLS-only
+        # layer's split projections), a LayerNorm-parameter reduction ceil(3 d / 64) per LayerNorm (2 per layer + embeddings): 12-layer
+        # towers (cfg4) need 13.4 k slots - a fixed 12 288 silently sent them back to the separate norm pass
+        pt = model.towers()[-1].cfg
+        self._sink_cap = 256 * (4 * pt.n_layers + 4) + ((3 * pt.dim + 63) // 64) * (2 * pt.n_layers + 2)
+        self.norm_partial = torch.empty(ops.sqnorm_blocks() // 2 + self._sink_cap, dtype=torch.float32, device=dev)
         self.comm_stream = torch.cuda.Stream(device=dev) if self.distributed else None
         if self.comm_stream is not None:
             self.flat_g.record_stream(self.comm_stream)        # the bucket slices are used on it (the buffer lives as long as the trainer)
@@ -346,7 +351,7 @@ class NwayTrainer:
                 p_hook = self._early_norm_hook(main, side, defer=q_late)
                 if _env_flag("CLDRD_NORM_SINK", "1") != "0":      # "0": the late piece by a separate pass (A/B runs, tests)
                     self._sink_on = True
-                    pe.norm_sink = self.norm_partial[ops.sqnorm_blocks() // 2:]
+                    pe.norm_sink = self.norm_partial[ops.sqnorm_blocks() // 2:ops.sqnorm_blocks() // 2 + self._sink_cap]
             pe.backward_from_cls(p_tape, dp, after_layer=p_hook, accumulate=not write_once)
             if q_late:
                 # (released together with the passage tower's last weight-gradient group instead: +1.4 %, as in round 3's eager measurement)
@@ -393,6 +398,11 @@ class NwayTrainer:
             if used > 0 and self._sink_on:
                 ops.clip_coef(self.norm_partial, half + used, self.max_grad_norm, self.clip)
             else:
+                if self._sink_on and used == -2 and not getattr(self, "_sink_warned", False):
+                    self._sink_warned = True
+                    import warnings
+                    warnings.warn(f"clip norm: the norm sink ({self._sink_cap} slots) is too small for this tower's gradient launches; "
+                                  "taking the late piece with a separate pass")
                 ops.sqnorm_partial(self.flat_g[split:], self.norm_partial[half:2 * half], half)
                 ops.clip_coef(self.norm_partial, 2 * half, self.max_grad_norm, self.clip)
             self._norm_split = None
@@ -469,10 +479,19 @@ class NwayTrainer:
                 batch = dict(batch.items())
                 batch["nway_passages"] = {k: v for k, v in nw.items() if k != "lengths"}
                 lens = None
+        # Data-parallel ranks that may replay captured collectives agree on it ONCE, at call number _DDP_WARM + 1 of EVERY rank: the count
+        # advances here, in front of the per-batch gates below (whether THIS rank's batch is packed depends on its own token fill, so a
+        # count taken behind the gate would reach the agreement step at different global steps on different ranks, or never: the one-off
+        # all-reduce would then meet another rank's bucket all-reduces - a hang).  A rank whose batch is not eligible at that step votes "no".
+        ddp_graph = self.distributed and self._graph_wanted()
+        if ddp_graph:
+            self._ddp_steps += 1
         if self._graph_wanted() and lens is None:      # a packed batch changes its row count every step: eager
             out = self._train_step_graph(batch)
             if out is not None:
                 return out
+        elif ddp_graph and self._ddp_steps == self._DDP_WARM + 1:
+            self._agree_on_capture(False)              # packed batch at the agreement step: every rank stays eager for good
         if self._state is not None:
             # a captured shape exists, so the towers read their seeds (and AdamW its lr) from device memory: an eager step (another
             # batch shape) writes this step's values there first, exactly as a replay does
@@ -502,6 +521,7 @@ class NwayTrainer:
 
     # ---- HIP-graph replay of the step --------------------------------------------------------------------------------------
     _state = None
+    _DDP_WARM = 3               # eager steps in front of the capture (and, under torch.distributed, in front of the agreement step)
 
     def _graph_wanted(self):
         if self.distributed:
@@ -526,7 +546,7 @@ class NwayTrainer:
         entry = graphs.get(key)
         if entry is None:
             entry = graphs[key] = {"seen": 0, "graph": None}
-        warm = 3
+        warm = self._DDP_WARM
         ddp = self.distributed        # (a one-rank forced group, CLDRD_FORCE_DDP, takes the same path: the agreement is then a one-rank all-reduce)
         if ddp:
             # Ranks that replay captured collectives must all do so for the SAME steps, or the collectives of one rank's replay meet another
@@ -536,7 +556,7 @@ class NwayTrainer:
             # one all_reduce(MIN) of the outcome: a single failure anywhere leaves every rank eager for good; (b) afterwards only that ONE
             # shape replays - an eager step of another shape issues the same bucket all-reduces in the same order as a replay does, so
             # mixing the two across ranks is safe, a second capture (another agreement collective at a rank-dependent step) would not be.
-            self._ddp_steps += 1
+            # (`_ddp_steps` is advanced by train_step for every call, eligible for the graph path or not)
             if self._ddp_steps <= warm:
                 entry["seen"] += 1
                 return None

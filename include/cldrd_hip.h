@@ -212,9 +212,9 @@ int cldrd_grad_clip_coef(const float* g, size_t n, float max_norm, float* partia
 int cldrd_sqnorm_partial(const float* g, size_t n, float* partial, int nblk, void* stream);
 /* Clip-norm partial sums from the kernels that WRITE the gradients (round 5): while a sink is set (thread-local, like the loss scale),
  * cldrd_wgrad_group - when it reduces token-split slabs - and cldrd_ln_reduce_group also write one sum of squares per workgroup of the
- * values they wrote to slots[used ...]; cldrd_norm_sink_used() returns the number of slots written since cldrd_set_norm_sink, or -1 when
- * a launch could not contribute (a weight-gradient group without slabs; sink full): the caller then takes that range's norm with
- * cldrd_sqnorm_partial as before.  cldrd_clip_coef reduces the slots like any others.  slots = NULL: off. */
+ * values they wrote to slots[used ...]; cldrd_norm_sink_used() returns the number of slots written since cldrd_set_norm_sink, -1 when
+ * a launch could not contribute (a weight-gradient group without slabs) or -2 when the sink was too small for a launch: the caller then
+ * takes that range's norm with cldrd_sqnorm_partial as before.  cldrd_clip_coef reduces the slots like any others.  slots = NULL: off. */
 void cldrd_set_norm_sink(float* slots, int capacity);
 int cldrd_norm_sink_used(void);
 int cldrd_clip_coef(const float* partial, int nblk_total, float max_norm, float* out, void* stream);
@@ -275,6 +275,18 @@ int cldrd_topk_sort(const int* counts, const int* cand_rows, const float* cand_s
                     int* I, void* stream);
 int cldrd_row_sqnorm_max(const float* P, size_t rows, int d, unsigned int* out, void* stream);
 int cldrd_gather_cast_rows(const float* src, void* dst, size_t n_out, size_t stride, int d, void* stream);
+/* Attaching an index shard to a GPU (what faiss' index_cpu_to_gpu does behind retriever/retrieval_utils.py:155-162 - here: the scan shadow
+ * and its error-bound statistics), three launches over the fp32 rows P[rows, d]:
+ *   cldrd_index_col_mean    mu[d] = mean row (fp64 column sums, fixed order); workspace: cldrd_index_col_mean_workspace(rows, d) device bytes
+ *   cldrd_index_center_cast P16[r] = fp16(P[r] - mu) (the scan's operand), sample[i] = bf16(P[i * s_stride] - mu) for i < s_rows (the threshold
+ *                           sample; may be NULL), *cmax_bits = bit pattern of the fp32 value of max_r |P[r] - mu|^2 (fp64 row sums; zero it
+ *                           first), *flag |= 1 when a centred value is outside the fp16 range
+ *   cldrd_map_ids           out[i] = I[i] < 0 ? -1 : (ids ? ids[I[i]] : I[i] + id_offset): faiss IndexIDMap applied to a result list */
+size_t cldrd_index_col_mean_workspace(size_t rows, int d);
+int cldrd_index_col_mean(const float* P, size_t rows, int d, float* mu, void* workspace, size_t workspace_bytes, void* stream);
+int cldrd_index_center_cast(const float* P, const float* mu, size_t rows, int d, void* P16, void* sample_bf16, size_t s_stride,
+                            size_t s_rows, unsigned int* cmax_bits, unsigned int* flag, void* stream);
+int cldrd_map_ids(const int* I, const long long* ids, long long id_offset, long long* out, size_t n, void* stream);
 
 /* ---- variable-length packing (csrc/pack.hip) -----------------------------------------------------------------------------------
  * The reference pads every sequence of a batch to the longest one (dataset/sequence_dataset.py:50-51, nway_dataset.py:103-107) and the

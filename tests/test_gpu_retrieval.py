@@ -200,6 +200,82 @@ def test_two_shards_merge_equals_global():
     same_ranking(D, I, Dr, Ir)
 
 
+@pytest.mark.parametrize("rows,d,stride", [(10001, 768, 7), (3, 128, 1), (70000, 256, 64), (1, 64, 5)])
+def test_attach_statistics_kernels_equal_the_numpy_restatement(rows, d, stride):
+    """cldrd_index_col_mean / cldrd_index_center_cast / cldrd_map_ids (FlatIPIndex._attach and the id map of a search: torch arithmetic until
+    round 5) against numpy: the mean row to one fp32 ulp of the fp64 mean, the fp16 scan shadow and the bf16 threshold sample of the centred
+    rows BIT FOR BIT (fp32 subtraction, one RNE), the largest centred norm as the fp32 value of the fp64 row sums, the range flag."""
+    rng = np.random.default_rng(rows + d)
+    P = (rng.standard_normal((rows, d)) * 3.0 + 2.5).astype(np.float32)          # a common component, as CLS embeddings have
+    Pd = torch.from_numpy(P).to(DEV)
+    mu = ops.index_col_mean(Pd)
+    mu_ref = P.astype(np.float64).mean(0)
+    assert np.all(np.abs(mu.cpu().numpy().astype(np.float64) - mu_ref) <= np.spacing(np.abs(mu_ref).astype(np.float32)).astype(np.float64))
+    s_rows = min(rows, (rows + stride - 1) // stride)
+    s_rows = max(1, s_rows - 1) if s_rows > 2 else s_rows                          # fewer sample rows than the stride would give: the cut is honoured
+    P16 = torch.empty(rows, d, dtype=torch.float16, device=DEV)
+    sample = torch.zeros((s_rows + 7) // 8 * 8, d, dtype=torch.bfloat16, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    cmax = ops.index_center_cast(Pd, mu, P16, sample, stride, s_rows, flag)
+    c = P - mu.cpu().numpy()[None, :]                                               # fp32 subtraction, as the kernel's
+    assert np.array_equal(P16.cpu().numpy().view(np.uint16), c.astype(np.float16).view(np.uint16))
+    want_s = torch.from_numpy(c[::stride][:s_rows]).to(torch.bfloat16)
+    assert torch.equal(sample[:s_rows].cpu().view(torch.int16), want_s.view(torch.int16)) and not sample[s_rows:].any()
+    want_max = np.float32((c.astype(np.float64) ** 2).sum(1).max())
+    assert cmax.view(torch.float32).item() == want_max and int(flag.item()) == 0
+    # a centred value outside the fp16 range raises the flag
+    P2 = P.copy()
+    P2[rows // 2, d // 2] = 1e6
+    ops.index_center_cast(torch.from_numpy(P2).to(DEV), mu, P16, None, 1, 0, flag)
+    assert int(flag.item()) == 1
+    # id map: table or offset, -1 stays -1
+    I = torch.from_numpy(rng.integers(-1, rows, size=(5, 9)).astype(np.int32)).to(DEV)
+    table = torch.from_numpy((np.arange(rows, dtype=np.int64) * 7 + 3)).to(DEV)
+    In = I.cpu().numpy().astype(np.int64)
+    assert np.array_equal(ops.map_ids(I, table, 0).cpu().numpy(), np.where(In >= 0, In * 7 + 3, -1))
+    assert np.array_equal(ops.map_ids(I, None, 1000).cpu().numpy(), np.where(In >= 0, In + 1000, -1))
+
+
+@pytest.mark.parametrize("devices,with_ids", [([0, 0], True), ([0, 0, 0], False)])
+def test_convert_index_to_gpu_device_list_shards_in_one_process(devices, with_ids):
+    """The reference's LIST form, ``convert_index_to_gpu(index, [d0, d1, ...])`` (retriever/retrieval_utils.py:164-182: sharded clone, dead
+    code there): one process, one row shard per list entry, per-shard search + cldrd_merge_topk_device.  One GPU per box, so the list names
+    device 0 several times - the shard split, the id mapping, the device-to-device gather and the merge are what a [0..7] list runs.  Equal
+    to the oracle's search of the whole index, incl. duplicated rows that land in DIFFERENT shards (tie -> global row position asc) and a
+    k larger than one shard's contribution."""
+    n = 10001
+    emb = syn.corpus_embeddings(21, n, 128)
+    emb[9000] = emb[7]                   # the same row in the first and the last shard
+    emb[5000] = emb[7]
+    ids = (np.arange(n, dtype=np.int64) * 3 + 11) if with_ids else None
+    index = RU.construct_flatindex_from_embeddings(emb, ids)
+    multi = RU.convert_index_to_gpu(index, devices, False)
+    assert isinstance(multi, RU.MultiDeviceFlatIPIndex) and len(multi.shards) == len(devices) and multi.ntotal == n
+    assert sum(sh.ntotal for sh in multi.shards) == n
+    q = np.concatenate([emb[7:8], syn.corpus_embeddings(22, 40, 128)])
+    for k in (5, 300):
+        D, I = RU.index_retrieve(multi, q, k, batch=None)
+        Dr, Ir = R.flat_ip_search(emb, ids, q, k)
+        same_ranking(D, I, Dr, Ir)
+    D, I = multi.search(q[:1], 3)
+    want = [7, 5000, 9000] if ids is None else [7 * 3 + 11, 5000 * 3 + 11, 9000 * 3 + 11]
+    assert I[0].tolist() == want and D[0, 0] == D[0, 1] == D[0, 2]
+    assert multi.last_merge["path"].startswith("device")
+    # the single-device forms are unchanged
+    one = RU.convert_index_to_gpu(RU.construct_flatindex_from_embeddings(emb, ids), [0], False)
+    assert isinstance(one, RU.FlatIPIndex)
+    D1, I1 = one.search(q, 300)
+    Dm, Im = multi.search(q, 300)
+    assert np.array_equal(I1, Im) and np.array_equal(D1, Dm)          # sharded in one process == the whole index on one device, bit for bit
+    with pytest.raises(TypeError):
+        RU.convert_index_to_gpu(index, "cuda:0")
+    # a list longer than the index has rows: the empty shards are skipped
+    tiny = RU.convert_index_to_gpu(RU.construct_flatindex_from_embeddings(emb[:2], None), [0, 0, 0], False)
+    Dt, It = tiny.search(q[:2], 4)
+    Drt, Irt = R.flat_ip_search(emb[:2], None, q[:2], 4)
+    same_ranking(Dt, It, Drt, Irt)
+
+
 @pytest.mark.parametrize("world,nq,k,tie_levels,short", [(8, 300, 1000, 16, ()), (8, 64, 1000, 1, (1, 5)), (2, 33, 50, 4, (1,)), (3, 17, 2000, 0, ()),
                                                         (8, 40, 1024, 2, (0, 1, 2, 3, 4, 5, 6, 7))])
 def test_device_merge_of_shard_lists_equals_oracle_merge(world, nq, k, tie_levels, short):

@@ -106,9 +106,17 @@ def test_waiting_rank_fails_fast_on_a_stale_cache_that_rank0_never_replaces(tmp_
     clock = {"t": 1000.0}
     monkeypatch.setattr(_time, "time", lambda: clock["t"])
     monkeypatch.setattr(_time, "sleep", lambda s: clock.__setitem__("t", clock["t"] + 30.0))
-    with pytest.raises(ValueError, match="rank 0 has not replaced"):
+    with pytest.raises(ValueError, match="rank 0 has not started to replace"):
         SequenceTokenCache.open_or_build(str(tmp_path), COLLECTION, tok, 12, rank=1, world=2, wait_s=7200.0)
-    assert clock["t"] - 1000.0 <= 200.0           # gave up after the grace period, not after wait_s
+    assert clock["t"] - 1000.0 <= 700.0           # gave up after the grace period (10 min without a build marker), not after wait_s
+    # once rank 0 has dropped its ".building" marker the stale metadata is its business - the waiter keeps waiting however late
+    # rank 0 arrived, and only the overall wait_s ends the poll
+    open(stem + ".building", "w").write("1")
+    clock["t"] = 1000.0
+    with pytest.raises(TimeoutError):
+        SequenceTokenCache.open_or_build(str(tmp_path), COLLECTION, tok, 12, rank=1, world=2, wait_s=3000.0)
+    assert clock["t"] - 1000.0 >= 3000.0
+    os.remove(stem + ".building")
     monkeypatch.undo()
     # rank 0: the stale metadata disappears before anything else is replaced
     seen = {}
@@ -116,7 +124,9 @@ def test_waiting_rank_fails_fast_on_a_stale_cache_that_rank0_never_replaces(tmp_
 
     def spy(cls, *a, **k):
         seen["meta_present_at_build"] = os.path.exists(stem + ".meta.json")
+        seen["marker_at_build"] = os.path.exists(stem + ".building")
         return real_build(cls, *a, **k)
     monkeypatch.setattr(SequenceTokenCache, "build", classmethod(spy))
     again = SequenceTokenCache.open_or_build(str(tmp_path), COLLECTION, tok, 12, rank=0, world=2)
     assert seen["meta_present_at_build"] is False and len(again) == meta["rows"]
+    assert seen["marker_at_build"] is True and not os.path.exists(stem + ".building")          # the marker lives exactly as long as the build
