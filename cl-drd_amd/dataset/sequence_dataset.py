@@ -208,6 +208,7 @@ class CachedSequenceDataset(torch.utils.data.Dataset):
     def __init__(self, cache: SequenceTokenCache, lo: int = 0, hi: int | None = None, batch_size: int = 512, pad_id: int = 0):
         self.cache, self.lo, self.hi = cache, int(lo), int(len(cache) if hi is None else hi)
         self.batch_size, self.pad_id = int(batch_size), int(pad_id)
+        self.n_rows = self.hi - self.lo          # get_embeddings_from_scratch allocates its [n, D] result once when a dataset says this
 
     def __len__(self):
         return (self.hi - self.lo + self.batch_size - 1) // self.batch_size
@@ -234,6 +235,7 @@ class SyntheticSequenceDataset(torch.utils.data.Dataset):
     def __init__(self, n, max_length, seed=99, vocab=syn.VOCAB, ragged=True, first_id=0, batch_size=512):
         self.n, self.max_length, self.seed, self.vocab, self.ragged = int(n), int(max_length), seed, vocab, ragged
         self.first_id, self.batch_size = first_id, batch_size
+        self.n_rows = self.n
 
     def __len__(self):
         return (self.n + self.batch_size - 1) // self.batch_size

@@ -33,6 +33,8 @@ _FLAGS = {
     "share_weights": dict(action="store_true", default=False),
     "synthetic_rows": dict(type=int, default=0),          # ours: encode N generated MSMARCO-shaped passages
     "token_cache_dir": dict(default=""),                  # ours: tokenise the collection once (dataset.SequenceTokenCache), memory-map it afterwards
+    "token_cache_stem": dict(default=""),                 # ours: memory-map an EXISTING token cache by its file stem (no collection / tokenizer opened)
+    "loader_workers": dict(type=int, default=2),          # ours: DataLoader workers of the token-cache path
 }
 
 
@@ -72,18 +74,32 @@ def collection_loader(path, tokenizer, max_length, is_query, token_cache_dir, ra
 
 
 def main(args):
+    import time
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    timings = {}
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        timings[name] = timings.get(name, 0.0) + now - t_last[0]
+        t_last[0] = now
     model = NwayDualEncoder(args.model_name_or_path, share_weights=args.share_weights)
     print("************************* share weights = {} *************************".format(args.share_weights))
     if args.resume:
         print(f"load model from ==> {args.resume}")
         load_checkpoint_into(model, args.resume, args.is_parallel)
     model.cuda()
+    lap("model_load_s")
 
-    if args.synthetic_rows:
+    if getattr(args, "token_cache_stem", ""):
+        cache = SequenceTokenCache.load(args.token_cache_stem, {"max_length": args.max_length})
+        lo, hi = ShardedFlatIPIndex.shard_bounds(len(cache), world, rank)
+        text_loader = CachedSequenceDataset(cache, lo, hi, batch_size=512).loader(num_workers=int(getattr(args, "loader_workers", 2)))
+    elif args.synthetic_rows:
         lo, hi = ShardedFlatIPIndex.shard_bounds(args.synthetic_rows, world, rank)
         dataset = SyntheticSequenceDataset(hi - lo, args.max_length, first_id=lo)
         text_loader = dataset.loader()
@@ -92,15 +108,23 @@ def main(args):
         tokenizer = AutoTokenizer.from_pretrained(args.tokenizer_name_or_path)
         text_loader = collection_loader(args.passages_path, tokenizer, args.max_length, args.is_query, args.token_cache_dir, rank, world)
 
+    lap("open_collection_s")
     text_embs, text_ids = get_embeddings_from_scratch(model, text_loader, use_fp16=True, is_query=args.is_query, show_progress_bar=True)
+    lap("encode_s")
     text_id_to_idx = {tid: idx for idx, tid in enumerate(text_ids)}
     print("embs dtype: ", text_embs.dtype)
     index = construct_flatindex_from_embeddings(text_embs, np.array(text_ids))
+    lap("index_build_s")
     stem = Path(args.resume).stem.split(".")[0] if args.resume else "random_init"
     index_path = os.path.join(args.index_dir, stem + (f".shard{rank}of{world}" if world > 1 else "") + ".index")
     write_index(index, index_path)
+    lap("index_write_s")
     with open(os.path.join(args.index_dir, "meta.pkl" if world == 1 else f"meta.shard{rank}.pkl"), "wb") as f:
         pickle.dump({"text_ids": np.array(text_ids), "text_id_to_idx": text_id_to_idx}, f)
+    lap("meta_pkl_s")
+    timings["encode_host_phases"] = dict(getattr(get_embeddings_from_scratch, "last_timings", {}))
+    main.last_timings = timings
+    print("timings: " + " ".join(f"{k}={v:.3f}" for k, v in timings.items() if not isinstance(v, dict)))
     return index_path
 
 

@@ -74,12 +74,41 @@ def get_embeddings_from_scratch(model, dataloader, use_fp16, is_query, show_prog
     """Encode every batch of ``dataloader`` ({"seq": {input_ids, attention_mask}, "id": list[int]}) with the query or
     passage tower in eval mode -> (np.float32 [n, D], list[int]).  ``use_fp16`` is accepted for signature compatibility:
     the towers always run 16-bit MFMA compute (evaluation: fp16 operands in the FFN / out-projection GEMMs, bf16 QKV / attention) with fp32
-    accumulate, fp32 residual stream and fp32 CLS output (the reference's output is fp32 too, :56)."""
+    accumulate, fp32 residual stream and fp32 CLS output (the reference's output is fp32 too, :56).
+
+    The host side of the loop is timed (``get_embeddings_from_scratch.last_timings``, seconds): ``load_s`` waiting for the loader (tokens
+    from the cache / tokeniser), ``h2d_enqueue_s`` moving the batch and enqueuing the encode, ``d2h_wait_s`` waiting for the PREVIOUS
+    batch's embeddings (the GPU's encode of it, as far as the host sees it: one batch of D2H stays in flight), ``gather_s`` collecting the
+    rows.  When the loader knows its row count (``dataset.n_rows``: the token-cache and synthetic datasets) the [n, D] result is allocated
+    once and filled in place; the reference appends per-batch arrays and concatenates 27 GB at the end (:51)."""
+    import time
+    tm = {"load_s": 0.0, "h2d_enqueue_s": 0.0, "d2h_wait_s": 0.0, "gather_s": 0.0, "batches": 0}
     embeddings, embeddings_ids = [], []
     model.eval()
     dev = next(model.parameters()).device
+    n_rows = getattr(getattr(dataloader, "dataset", None), "n_rows", None)
+    out, filled = None, 0
     pending = None
+
+    def collect(p):
+        nonlocal out, filled
+        t0 = time.perf_counter()
+        p[1].synchronize()
+        t1 = time.perf_counter()
+        a = p[0].numpy()
+        if n_rows is not None:
+            if out is None:
+                out = np.empty((int(n_rows), a.shape[1]), dtype=np.float32)
+            out[filled:filled + a.shape[0]] = a
+            filled += a.shape[0]
+        else:
+            embeddings.append(a.copy())
+        tm["d2h_wait_s"] += t1 - t0
+        tm["gather_s"] += time.perf_counter() - t1
+    t_prev = time.perf_counter()
     for _, batch in enumerate(dataloader):
+        t0 = time.perf_counter()
+        tm["load_s"] += t0 - t_prev
         with torch.no_grad():
             batch = batch_to_device(batch, dev)
             reps = model.query_embs(batch["seq"]) if is_query else model.passage_embs(batch["seq"])
@@ -89,16 +118,25 @@ def get_embeddings_from_scratch(model, dataloader, use_fp16, is_query, show_prog
         host.copy_(reps, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
+        tm["h2d_enqueue_s"] += time.perf_counter() - t0
         if pending is not None:
-            pending[1].synchronize()
-            embeddings.append(pending[0].numpy().copy())
+            collect(pending)
         pending = (host, ev)
         assert isinstance(text_ids, list)
         embeddings_ids.extend(text_ids)
+        tm["batches"] += 1
+        t_prev = time.perf_counter()
     if pending is not None:
-        pending[1].synchronize()
-        embeddings.append(pending[0].numpy().copy())
-    embeddings = np.concatenate(embeddings)
+        collect(pending)
+    t0 = time.perf_counter()
+    if n_rows is not None and out is not None:
+        if filled != out.shape[0]:
+            raise RuntimeError(f"the loader announced {out.shape[0]} rows and delivered {filled}")
+        embeddings = out
+    else:
+        embeddings = np.concatenate(embeddings)
+    tm["gather_s"] += time.perf_counter() - t0
+    get_embeddings_from_scratch.last_timings = tm
     assert len(embeddings_ids) == embeddings.shape[0]
     assert isinstance(embeddings_ids[0], int)
     print(f"# nan in embeddings: {np.sum(np.isnan(embeddings))}")

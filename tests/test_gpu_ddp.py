@@ -248,3 +248,77 @@ def test_captured_ddp_step_replays_bit_for_bit_200_times(tmp_path):
     out = str(tmp_path / "ok")
     mp.spawn(_rccl_replay_worker, args=(_free_port(), out), nprocs=1, join=True)
     assert open(out).read().startswith("ok 200")
+
+
+def _rccl_agreement_worker(rank, port, out):
+    """the one-off capture agreement of data-parallel ranks happens at train_step CALL number warm + 1 on every rank,
+    whatever that rank's batches looked like - the count advances in front of the packed / padded gate.  A rank whose batch at that call is
+    packed (its own token fill decides that), or that saw packed batches before, votes "no"; nobody reaches the all-reduce at another call
+    or never (which would pair it with another rank's bucket all-reduces: a hang).  One rank over ProcessGroupNCCL: what is checked is WHEN
+    the agreement collective is issued and with which vote."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", CLDRD_FORCE_DDP="1", CLDRD_DDP_GRAPH="1",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    import cldrd_amd.synthetic as syn
+    import selftest
+    from cldrd_amd.encoder import EncoderConfig
+    from cldrd_amd.trainer import NwayTrainer
+    from cldrd_amd.trainer.nway_listwise import batch_to_device
+
+    cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=2,
+                        max_position_embeddings=64, dropout=0.0, attention_dropout=0.0)
+
+    def batch(seed, packed):
+        b = syn.nway_batch(seed, 4, 16, 10, 64, vocab=cfg.vocab_size, ragged=False, label_kind="teacher")
+        if packed:       # ~45 % token fill: the encoder packs it (would_pack), so the step cannot be a graph replay
+            lens = 20 + (torch.arange(64) % 20)
+            m = (torch.arange(64)[None, :] < lens[:, None]).to(torch.int64).view(4, 16, 64)
+            b["nway_passages"]["attention_mask"] = m
+            b["nway_passages"]["input_ids"] = b["nway_passages"]["input_ids"] * m
+        return batch_to_device(b, torch.device("cuda", 0))
+
+    def scenario(pattern):
+        m = selftest.build_tiny_model(cfg, seed=3).cuda()
+        m.train()
+        tr = NwayTrainer(m, loss="kl_div", learning_rate=1e-4, warmup_steps=0, total_steps=1000)
+        votes, real = [], tr._agree_on_capture
+
+        def spy(ok):
+            votes.append((tr._ddp_steps, bool(ok)))
+            return real(ok)
+        tr._agree_on_capture = spy
+        for i, packed in enumerate(pattern):
+            bt = batch(100 + i, packed)
+            if packed:
+                assert "lengths" in bt["nway_passages"]
+            tr.train_step(bt)
+        torch.cuda.synchronize()
+        return tr, votes
+    W = NwayTrainer._DDP_WARM
+    # every call padded: captured at call W + 1, replayed afterwards
+    tr, votes = scenario([False] * (W + 3))
+    assert votes == [(W + 1, True)], votes
+    assert any(e["graph"] is not None for e in tr._graphs.values()) and not getattr(tr, "_graph_broken", False)
+    # the batch of call W + 1 is packed: this rank still votes at call W + 1 ("no"), and never again
+    tr, votes = scenario([False] * W + [True, False, False, True])
+    assert votes == [(W + 1, False)], votes
+    assert tr._graph_broken and not any(e["graph"] is not None for e in getattr(tr, "_graphs", {}).values())
+    # packed batches BEFORE the agreement step: the padded batch of call W + 1 has not been seen `warm` times -> "no", at call W + 1
+    tr, votes = scenario([True, True, False, False, False, False])
+    assert votes == [(W + 1, False)], votes
+    assert tr._graph_broken
+    # always packed: the vote still happens, at the same call
+    tr, votes = scenario([True] * (W + 2))
+    assert votes == [(W + 1, False)], votes
+    open(out, "w").write("ok agreement")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_capture_agreement_happens_at_a_fixed_call_on_every_rank(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "ok")
+    mp.spawn(_rccl_agreement_worker, args=(_free_port(), out), nprocs=1, join=True)
+    assert open(out).read().startswith("ok agreement")

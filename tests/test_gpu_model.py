@@ -185,6 +185,121 @@ def test_trainer_step_matches_oracle_update():
     assert t._t_fresh and torch.equal(t.ht(0, "f2").float(), w2.T.contiguous().to(t.flat_t.dtype).float())      # fp16 in the all-fp16 mode
 
 
+def _oracle_trajectory(model, cfg, batches, order, loss_kind, *, lr0, warmup, total, wd, max_norm):
+    """The reference's step loop (trainer/multistep-curriculum/nway_listwise_1.py:328-367) restated over the oracle: fp32 forward + autograd
+    (oracle/encoder_ref.py), closed-form loss gradient (losses_ref.py), clip_grad_norm_ + legacy AdamW + linear schedule in float64
+    (optim_ref.py), parameters rounded to fp32 after every step as a torch optimizer leaves them.  GradScaler semantics for a non-finite
+    step (:355-359): the optimizer step is skipped - no change of p / m / v, Adam's own step counter does not advance - the scheduler
+    steps all the same.  Returns (losses, params {tower: {name: fp32 array}}, applied steps)."""
+    qp, pp = selftest.oracle_params(model)
+    towers = [("q", qp), ("p", pp)]
+    ocfg = selftest.oracle_cfg(cfg)
+    fn = {"margin_mse": LR.margin_mse, "kl_div": LR.kl_div, "lambda_mrr": LR.lambda_mrr, "ranknet": LR.ranknet}[loss_kind]
+    mom = {t: {n: (np.zeros(tuple(v.shape)), np.zeros(tuple(v.shape))) for n, v in d.items()} for t, d in towers}
+    prefix = {"q": "query_encoder.", "p": "passage_encoder."}
+    losses, applied = [], 0
+    for step, bi in enumerate(order):
+        b = batches[bi]
+        for _, d in towers:
+            for v in d.values():
+                v.grad = None
+                v.requires_grad_(True)
+        logits = E.nway_forward(qp, pp, ocfg, b["query"], b["nway_passages"])
+        with np.errstate(all="ignore"):
+            val, dl = fn(logits.detach().numpy(), b["labels"].numpy())
+        losses.append(float(val))
+        logits.backward(torch.from_numpy(np.asarray(dl)).float())
+        grads = [v.grad.numpy() for _, d in towers for v in d.values()]
+        total_norm, coef = O.clip_coef(grads, max_norm)
+        lr = lr0 * O.linear_schedule_factor(step, warmup, total)
+        if np.isfinite(total_norm):
+            applied += 1
+            for t, d in towers:
+                for n, v in d.items():
+                    m, vv = mom[t][n]
+                    decay = 0.0 if O.no_decay(prefix[t] + n) else wd
+                    p1, m1, v1 = O.adamw_step(v.detach().numpy(), v.grad.numpy().astype(np.float64) * coef, m, vv, lr=lr, step=applied, weight_decay=decay)
+                    mom[t][n] = (m1, v1)
+                    with torch.no_grad():
+                        v.copy_(torch.from_numpy(p1.astype(np.float32)))
+    return losses, {t: {n: v.detach().numpy().copy() for n, v in d.items()} for t, d in towers}, applied
+
+
+@pytest.mark.parametrize("graph", [True, False])
+@pytest.mark.parametrize("arch,loss_kind", [("distilbert", "kl_div"), ("bert", "margin_mse")])
+def test_forty_step_trajectory_matches_the_oracle_loop(arch, loss_kind, graph, monkeypatch):
+    """not one step from m = v = 0 but a TRAJECTORY - 40 steps over 8 rotating batches of one shape, warm-up 5 then
+    linear decay, clip active, weight decay on, one poisoned (non-finite) batch in the middle - of NwayTrainer.train_step, with the HIP-graph
+    replay on and off, against the reference's loop restated over the oracle (reference nway_listwise_1.py:328-367).  The class of bug this
+    catches and a one-step test cannot: stale weight shadows after a replay, a bias-correction exponent that counts skipped steps, lr /
+    seeds / step size frozen at their capture-time values, moments of one tower applied to the other.
+    Bars: per-step loss within 2 % (fp16 operands against an fp32 loop on a tiny model whose weights are 5 x the HF init scale; measured
+    values are printed); final parameters cosine >= 0.9999 per tensor; the 40-step UPDATE p40 - p0 of every weight matrix cosine >= 0.97 and
+    its norm within 10 % (Adam normalises every element's step to ~lr, so elements whose gradient is rounding noise move by +-lr either
+    way: the update is the sensitive quantity, the parameters are not); Adam's step in the checkpoint = applied steps = 39."""
+    monkeypatch.setenv("CLDRD_GRAPH", "1" if graph else "0")
+    cfg = small_cfg(arch)
+    model = selftest.build_tiny_model(cfg, std=0.1).cuda()
+    model.train()
+    STEPS, NB, POISON = 40, 8, 17
+    label_kind = "teacher"
+    batches = [syn.nway_batch(4680 + i, 3, 6, 10, 40, vocab=cfg.vocab_size, ragged=True, label_kind=label_kind) for i in range(NB)]
+    bad = {k: ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v.clone()) for k, v in batches[POISON % NB].items()}
+    bad["labels"][1, 2] = float("inf")                           # a non-finite teacher score: loss, dlogits and every gradient are NaN
+    batches.append(bad)
+    order = [(NB if i == POISON else i % NB) for i in range(STEPS)]
+    hp = dict(lr0=2e-4, warmup=5, total=STEPS + 10, wd=0.01, max_norm=1.0)
+    ref_losses, ref_params, applied = _oracle_trajectory(model, cfg, batches, order, loss_kind, **hp)
+    assert applied == STEPS - 1
+    p0 = {t: {n: v.detach().float().cpu().numpy().copy() for n, v in tw.named_flat()} for t, tw in (("q", model.query_encoder), ("p", model.passage_encoder))}
+    tr = NwayTrainer(model, loss=loss_kind, learning_rate=hp["lr0"], weight_decay=hp["wd"], max_grad_norm=hp["max_norm"], warmup_steps=hp["warmup"],
+                     total_steps=hp["total"])
+    dev = [{k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in b.items()} for b in batches]
+    got_losses, clips = [], []
+    for bi in order:
+        out = tr.train_step(dev[bi])
+        got_losses.append(out[0:1].clone())
+        clips.append(tr.clip[1:2].clone())
+    torch.cuda.synchronize()
+    got_losses = torch.cat(got_losses).cpu().numpy()
+    clips = torch.cat(clips).cpu().numpy()
+    if graph:
+        assert any(e["graph"] is not None for e in tr._graphs.values()) and not getattr(tr, "_graph_broken", False)
+    else:
+        assert not any(e["graph"] is not None for e in getattr(tr, "_graphs", {}).values())
+    assert not np.isfinite(got_losses[POISON]) and not np.isfinite(ref_losses[POISON])
+    ok = np.arange(STEPS) != POISON
+    rel = np.abs(got_losses[ok] - np.asarray(ref_losses)[ok]) / np.maximum(np.abs(np.asarray(ref_losses)[ok]), 1e-3)
+    print(f"{arch}/{loss_kind}/graph={graph}: per-step loss error max {rel.max():.2e} median {np.median(rel):.2e}; clip coefficient min {np.nanmin(clips):.3f} "
+          f"(active on {(clips[ok] < 1).sum()} of {ok.sum()} steps); loss {ref_losses[0]:.4f} -> {ref_losses[-1]:.4f}")
+    assert rel.max() <= 2e-2, (rel.max(), int(np.argmax(rel)))
+    assert (clips[ok] < 1).sum() >= 10, "the clip must be active on this trajectory"
+    assert tr.skipped_steps() == 1 and tr.global_step == STEPS
+    worst_p, worst_u, worst_n = 1.0, 1.0, 0.0
+    for t, tw in (("q", model.query_encoder), ("p", model.passage_encoder)):
+        for n, v in tw.named_flat():
+            have, want, start = v.detach().float().cpu().numpy(), ref_params[t][n], p0[t][n]
+            c = cos(have, want)
+            worst_p = min(worst_p, c)
+            assert c >= 0.9999, f"{t}.{n}: final parameters cosine {c:.6f}"
+            du, dw = have - start, want - start
+            if have.ndim == 2 and "embeddings" not in n and np.linalg.norm(dw) > 0:
+                cu, rn = cos(du, dw), np.linalg.norm(du) / np.linalg.norm(dw)
+                worst_u, worst_n = min(worst_u, cu), max(worst_n, abs(rn - 1.0))
+                assert cu >= 0.97 and abs(rn - 1.0) <= 0.10, f"{t}.{n}: 40-step update cosine {cu:.4f}, norm ratio {rn:.4f}"
+    print(f"{arch}/{loss_kind}/graph={graph}: final parameters cosine >= {worst_p:.7f}; weight-matrix updates cosine >= {worst_u:.4f}, norm within {worst_n:.3f}")
+    sd = tr.optimizer_state_dict()
+    steps = {int(st["step"]) for st in sd["state"].values()}
+    assert steps == {applied}, steps                             # Adam's own counter: the skipped step is not in it (scaler.step semantics)
+    # an evaluation forward after the trajectory sees the CURRENT weights (shadows refreshed / marked stale by every replay)
+    model.eval()
+    with torch.no_grad():
+        q_eval = model.query_embs(dev[0]["query"]).cpu().numpy()
+    qp_now = {n: torch.from_numpy(ref_params["q"][n]) for n in ref_params["q"]}
+    q_ref = E.cls_embs(qp_now, selftest.oracle_cfg(cfg), batches[0]["query"]).numpy()
+    assert np.abs(q_eval - q_ref).max() <= 2e-2 * np.abs(q_ref).max()
+
+
 @pytest.mark.parametrize("arch", ["distilbert", "bert"])
 def test_write_once_gradients_equal_zeroed_accumulation(arch, monkeypatch):
     """The trainer zeroes only the embedding tables and lets every other gradient be WRITTEN once per step: the gradient buffer
