@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic")
     ap.add_argument("--no-retrieve", action="store_true")
     ap.add_argument("--no-ragged", action="store_true", help="skip the MSMARCO-shaped (padded / packed) extra legs")
-    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the extra timing of the step in the bf16-operand training mode (CLDRD_AMP=bf16)")
+    ap.add_argument("--no-bf16-leg", action="store_true", help="skip the extra timing of the step in the all-bf16 mode (CLDRD_AMP=bf16)")
     ap.add_argument("--no-ddp1", action="store_true", help="skip the child run of the data-parallel code path over RCCL with one rank")
     ap.add_argument("--ddp1-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--retrieve-rows", type=int, default=1105228, help="index rows per GPU (8 841 823 / 8)")
@@ -270,7 +270,7 @@ def main():
     except Exception as exc:
         ragged = None if args.no_ragged else {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
-    # ---- the same step with BF16 MFMA operands in the backward and the tape (CLDRD_AMP=bf16: the round 1-3 mode; BASELINE.json words cfg2 as
+    # ---- the same step with BF16 operands in EVERY MFMA (CLDRD_AMP=bf16, the all-bf16 mode of round 6; BASELINE.json words cfg2 as
     # "bf16").  The headline runs the framework's default, fp16 operands with a loss-scaled backward - what the reference itself trains in
     # (trainer/multistep-curriculum/nway_listwise_1.py:129,328-352: use_fp16 default True, amp.autocast + GradScaler); both formats are 16-bit
     # operands at the same MFMA rate, fp32 accumulate / residual stream / gradient stream / master weights.  One GPU only.
@@ -299,7 +299,8 @@ def main():
                 else:
                     os.environ["CLDRD_AMP"] = old_amp
             bf16_mode = {"samples_per_s": round(B * args.steps / db, 2), "ms_per_step": round(1e3 * db / args.steps, 3), "final_loss": float(lb_[0].item()),
-                         "mode": "CLDRD_AMP=bf16: bf16 tape + backward operands, fp16 forward FFN / query-tower pass (the round-3 configuration)"}
+                         "mode": "CLDRD_AMP=bf16: EVERY MFMA operand bf16 - forward, tape and backward of both towers (the wording of BASELINE.json cfg2); "
+                                 "fp32 accumulate / residual stream / gradient-path arithmetic / master weights, no loss scale"}
             del trainer_b, model_b
             torch.cuda.empty_cache()
         except Exception as exc:
@@ -642,7 +643,7 @@ def main():
             "config": {"workload": f"cfg2: DistilBERT-6L dual encoder (2 unshared towers), N={N}, {args.loss}, seq_len={L}, q_len={Lq}, "
                                    f"per-GPU batch {B}, dropout {args.dropout:g}, fwd+loss+bwd+allreduce+clip+AdamW; "
                                    + ("fp16 MFMA operands (16-bit, same MFMA rate as bf16; the reference's own use_fp16 autocast mode), loss-scaled backward, "
-                                      if amp16 else "bf16 MFMA operands (forward FFN GEMMs: fp16 operands, same rate), ")
+                                      if amp16 else "bf16 MFMA operands in every GEMM and in attention, ")
                                    + "fp32 accumulate / residual stream / gradient stream / master weights",
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "model_tflop_per_sample": round(flops_per_sample / 1e12, 4),

@@ -16,7 +16,7 @@ import os as _os
 # towers: 13.2 instead of 12.6 ms per cfg2 step with ProcessGroupNCCL initialised on one rank; eight queues restore it.  A REPLAYED HIP graph
 # is the other way round: 12.3 ms with the default four queues, 15.1 ms with eight (its branches spread over more queues and pay for the
 # cross-queue dependencies).  Data-parallel ranks can replay the step as a graph too, RCCL collectives captured inside
-# (profiles/r04_microbench.txt: tools/ddp_graph_ab.sh) - the default for a ONE-rank process group, opt-in (CLDRD_DDP_GRAPH=1) for real
+# (profiles/r04_microbench.txt) - the default for a ONE-rank process group, opt-in (CLDRD_DDP_GRAPH=1) for real
 # multi-rank jobs (trainer/nway_listwise.py: _graph_wanted).  So eight queues for ranks that will NOT replay a graph: CLDRD_GRAPH=0, or a
 # multi-rank job without CLDRD_DDP_GRAPH=1, or CLDRD_DDP_GRAPH=0.  Read by the HIP runtime when it initialises: this works only before the first GPU call of the process - importing
 # the package first is enough; an explicit setting wins.

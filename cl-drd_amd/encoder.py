@@ -237,6 +237,47 @@ class _Pack:
         return pk
 
 
+def _drain(gen):
+    """run a generator to its end; its return value"""
+    try:
+        while True:
+            next(gen)
+    except StopIteration as stop:
+        return stop.value
+
+
+class Stepper:
+    """A forward or backward of one tower that is enqueued PIECE BY PIECE: ``step(n)`` enqueues the next n groups of launches (a group = a few
+    dependent kernels: a projection + attention, an out-projection + LayerNorm, an FFN GEMM, ...), ``finish()`` the rest and returns the
+    result.  The trainer uses it to enqueue the query tower's ~130 small launches in slices, each slice released by an event of the passage
+    tower's stream at the start of one of ITS HBM-bound kernels (LayerNorm, attention): next to those the small GEMMs cost nothing, next
+    to a large GEMM - whose grid is sized to whole rounds of 256 CUs - each of them delays a round (training step).
+    ``contexts``: factories of the thread-local launch contexts (hip_ops.seed_base / loss_scale) the launches need; every step re-enters them,
+    so two towers' steppers can be advanced alternately from one thread."""
+
+    def __init__(self, gen, contexts=()):
+        self._gen, self._contexts, self.done, self.result = gen, tuple(contexts), False, None
+
+    def step(self, n: int = 1) -> bool:
+        if self.done:
+            return True
+        from contextlib import ExitStack
+        with ExitStack() as stack:
+            for make in self._contexts:
+                stack.enter_context(make())
+            try:
+                for _ in range(n):
+                    next(self._gen)
+            except StopIteration as stop:
+                self.done, self.result = True, stop.value
+        return self.done
+
+    def finish(self):
+        while not self.step(1 << 20):
+            pass
+        return self.result
+
+
 class HipEncoder(nn.Module):
     """One encoder tower.  ``encode(ids, mask)`` -> CLS embeddings fp32 [M, d]."""
 
@@ -259,41 +300,30 @@ class HipEncoder(nn.Module):
             _attach(self, name, nn.Parameter(self.flat_p[off:off + _numel(shape)].view(shape)))
         self.reset_parameters(seed)
         self.step_seed = 0
-        # last layer: compute only the CLS row after the K/V projection (CLDRD_CLS_ONLY=0 restores the full layer)
-        self.cls_only_last = os.environ.get("CLDRD_CLS_ONLY", "1") != "0"
-        # residual stream: fp32 (default) keeps every LayerNorm input (pre-LN sum) and output in fp32 between kernels, as the
-        # reference's autocast does (LayerNorm / residual adds run in fp32 there, nway_listwise_1.py:334); the GEMMs still read bf16
-        # copies.  CLDRD_RESIDUAL=bf16 stores them in bf16 (round-1 behaviour: ~7 % faster, 2.4x the reference's own
-        # mixed-precision logit drift instead of 0.7x - tools/drift_emulation.py).
-        self.stream32 = os.environ.get("CLDRD_RESIDUAL", "fp32") != "bf16"
-        # FFN forward GEMMs on fp16 operands (default with the fp32 residual stream; CLDRD_FFN_FP16=0: bf16 like every other GEMM).
-        # Of all 16-bit rounding points of a layer, the operands of ffn.lin1 / ffn.lin2 carry the logit drift: emulated on the cfg1
-        # golden, max|dlogit| is 0.234 with every operand in bf16, 0.051 with the FFN operands in fp16 and 0.024
-        # with everything in fp16 - the reference's own fp16 autocast drifts by 0.036.  Same MFMA rate; the training forward keeps a
-        # bf16 copy of the LayerNorm output and of h for the backward's MFMAs (fp16 activations x bf16 gradients do not mix).
-        self.ffn_fp16 = self.stream32 and os.environ.get("CLDRD_FFN_FP16", "1") != "0"
-        # gradient stream of the backward (the residual path: gradient of every LayerNorm input / output): fp32 (default with the fp32
-        # residual stream) or bf16 (CLDRD_GRAD_STREAM=bf16, the behaviour until round 3).  The stream is no MFMA operand - the LayerNorm
-        # backward leaves a bf16 copy for the data-gradient GEMMs next to it - but every parameter gradient that is a SUM over tokens
-        # (biases, LayerNorm, position rows) reads it directly and the roundings accumulate through the layers: on the cfg1 golden the
-        # worst per-tensor cosine against the fp32 reference goes 0.9978 -> 0.9997 (weights) and 0.986 -> 0.992+ (sum-type) with an fp32
-        # stream (CPU emulation of the rounding points); the reference's own fp16 autocast reaches 0.9999.
-        self.grad_stream32 = self.stream32 and os.environ.get("CLDRD_GRAD_STREAM", "fp32") != "bf16"
-        # Round 4, "amp16" (default; CLDRD_AMP=bf16 restores the bf16-base backward of rounds 1-3): a TRAINING pass (a forward that keeps a tape, and its backward) runs every MFMA on fp16 operands,
-        # like the reference's own mode - fp16 autocast + GradScaler, nway_listwise_1.py:334-359.  The forward is the high-precision pass with
-        # a tape: activations, q / k / v, the context, h and gelu'(x) are fp16 and exist ONCE (the bf16-base mode keeps bf16 copies of the
-        # LayerNorm output, h and the context for the backward next to the fp16 ones: 1.5 GB written per cfg2 step); the backward's 16-bit
-        # tensors are fp16 and carry the loss scale (hip_ops.loss_scale: born in score_bwd, removed where parameter gradients are
-        # written), the gradient stream and every parameter gradient stay fp32.  Needs the fp32 residual and gradient streams.
-        self._amp_fp16 = os.environ.get("CLDRD_AMP", "fp16") != "bf16"
-        # Round 5: in the all-fp16 mode the gradient stream itself is fp16 between kernels (CLDRD_GRAD_STREAM=fp32 keeps the round-3/4 fp32
-        # stream).  It carries the loss scale like every 16-bit gradient tensor; each LayerNorm backward still forms dy = stream + branch and
-        # its whole arithmetic in fp32 and rounds dx once.  A LayerNorm backward then moves 250-300 MB at T = 32768 instead of 400 (twelve of
-        # them per cfg2 step: 1.22 ms at the HBM roof).  Gradient directions against the reference's fp32 gradients, every ranked tensor of
-        # cfg1-4: min cosine 0.99990-0.99995 with the stream rounded at exactly these points, against 0.99992-0.99998 with the fp32 stream
-        # (profiles/r05_grad_cosines.txt) - the level of the reference's own fp16 autocast (>= 0.9999).  The CLS-only last layer keeps its
-        # (256-row) stream in fp32.
-        self._grad_stream16 = os.environ.get("CLDRD_GRAD_STREAM", "fp16") == "fp16"
+        # last layer: compute only the CLS row after the K/V projection (a test hook: `cls_only_last = False` computes the full layer)
+        self.cls_only_last = True
+        # ---- arithmetic mode: ONE switch, CLDRD_AMP, read when the tower is built ---------------------------------------------------
+        #   "fp16" (default): the reference's own mode (fp16 autocast + loss scale, nway_listwise_1.py:129,334-359).  A TRAINING pass runs
+        #       every MFMA of forward and backward on fp16 operands with an fp16 tape and an fp16 gradient stream that carry a power-of-two
+        #       loss scale (hip_ops.loss_scale); an EVALUATION pass reads fp16 operands in the FFN / out-projection GEMMs and in the whole
+        #       query tower, bf16 in QKV / attention (fp16 QKV operands on towers deeper than 6 layers).
+        #   "bf16": EVERY MFMA operand of every pass is bf16 - forward, tape, backward, both towers (BASELINE.json words cfg2-4 as bf16) -
+        #       no loss scale (bf16 has fp32's range).  8-bit significands: logit drift at the level of the reference's own bf16 autocast,
+        #       gradient cosines 0.99+ (tests/test_gpu_model.py states the bars of each mode).
+        # Both modes keep what the reference's autocast keeps in fp32: master weights, the residual stream (pre-LN sums, LayerNorm statistics),
+        # softmax, the CLS output; the gradient of the residual path is fp32 in bf16 mode (fp16 + loss scale in fp16 mode) and every
+        # parameter gradient is fp32.  The operand-format sub-switches of rounds 3-5 (CLDRD_FFN_FP16, _OUT_FP16, _QKV_FP16, _QUERY_FP16,
+        # _RESIDUAL, _GRAD_STREAM, _LN_ON_THE_FLY) are gone: the hybrid "bf16 tape, fp16 forward" mode they spanned is not a supported mode.
+        mode = os.environ.get("CLDRD_AMP", "fp16")
+        if mode not in ("fp16", "bf16"):
+            raise ValueError(f"CLDRD_AMP must be fp16 or bf16, got {mode!r}")
+        self.amp_mode = mode
+        self._amp_fp16 = mode == "fp16"
+        self.stream32 = True                  # fp32 residual stream (pre-LN sums) in both modes
+        self.grad_stream32 = True             # fp32 arithmetic on the residual path of the backward in both modes
+        self.ffn_fp16 = self._amp_fp16        # evaluation pass of the fp16 mode: FFN / out-projection (and deep towers' QKV) GEMMs on fp16 operands
+        self._grad_stream16 = True            # fp16 mode: the gradient stream is stored in fp16 between kernels (test hook: False keeps it fp32)
+        self.ln_defer = True                  # LayerNorm-parameter gradients reduced by one grouped launch per flush (test hook: False = immediately)
 
     # ------------------------------------------------------------------ parameters
     def named_flat(self):
@@ -581,32 +611,41 @@ class HipEncoder(nn.Module):
                save: bool = False, seed: int | None = None, fp16: bool | None = None, lengths=None, device_seed: bool = False):
         """CLS embeddings fp32 [M, d] (== HF ``model(**enc)[0][:, 0, :]``).  With ``save`` also returns the tape.
 
-        ``fp16`` (default: ``self.hp_forward``, which NwayDualEncoder sets on the QUERY tower): high-precision forward - the same
-        kernels with fp16 instead of bf16 MFMA operands (11-bit significands, same rate; forward activations of a BERT encoder are
+        ``fp16`` (default: ``self.hp_forward``, which NwayDualEncoder sets on the QUERY tower in the fp16 mode): the evaluation pass runs
+        every GEMM and the attention on fp16 operands (11-bit significands, same MFMA rate; forward activations of a BERT encoder are
         far inside the fp16 range, and the reference itself runs fp16 autocast on its GPUs).  Why the query tower: a logit error is
         dq.p + q.dp, there are N passages per query, and with CLS vectors that share a large common component every logit of a row
-        inherits the SAME dq.p term - B draws dominate max|dlogit| - while the query tower is ~1 % of the FLOPs and runs on a side
-        stream.  The backward needs bf16 operands, so with ``save`` the bf16 forward runs as well (it fills the tape; same dropout
-        masks: same seed) and only the returned CLS comes from the fp16 pass.
+        inherits the SAME dq.p term - B draws dominate max|dlogit| - while the query tower is ~1 % of the FLOPs.  Ignored in the bf16 mode.
 
         ``lengths`` (host-side ints, one per sequence: the number of leading 1s of its mask row): with them a padded batch is PACKED -
         the Linear / LayerNorm / weight-gradient kernels run on the real tokens only (the reference pads every sequence to the longest of
         the batch and computes on the padding: ~40 % of the rows of an MS MARCO batch); attention keeps the padded layout; the CLS output
         is the same up to the order of fp32 summation.  Without them nothing is packed (finding the row count would cost a host sync)."""
+        return self.encode_steps(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=fp16, lengths=lengths,
+                                 device_seed=device_seed).finish()
+
+    def encode_steps(self, input_ids, attention_mask, *, train=None, save=False, seed=None, fp16=None, lengths=None, device_seed=False,
+                     window=None) -> Stepper:
+        """:meth:`encode` as a :class:`Stepper` (``.finish()`` -> what encode returns).  ``window(kind)`` (optional) is called right before
+        each HBM-bound launch of the pass - kind "ln" (LayerNorm / embedding kernels) or "attn" - on the stream the pass is enqueued on: the
+        hook at which a trainer releases a slice of the OTHER tower's stepper."""
         fp16 = self.hp_forward if fp16 is None else fp16
         base = getattr(self, "seed_base_ptr", None) if (device_seed and seed is None) else None
         if base:
             # graph mode, NwayTrainer only (`device_seed`): the per-step part of the seed lives in device memory at `seed_base_ptr` (the
             # trainer advances step_seed and writes next_seed() there before each step); the launches carry offsets only.  Any other
             # caller (encode_autograd, an explicit seed) gets a by-value seed as before - the device word is only advanced by the trainer.
-            with ops.seed_base(base):
-                out = self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=0, fp16=fp16, lengths=lengths)
-            if save:
-                out[1].device_seed = True           # the backward adds the same device word
-            return out
+            gen = self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=0, fp16=fp16, lengths=lengths, window=window)
+
+            def mark(gen=gen):
+                out = yield from gen
+                if save:
+                    out[1].device_seed = True           # the backward adds the same device word
+                return out
+            return Stepper(mark(), [lambda: ops.seed_base(base)])
         if seed is None:
             seed = self.next_seed()
-        return self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=fp16, lengths=lengths)
+        return Stepper(self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=fp16, lengths=lengths, window=window))
 
     def would_pack(self, lengths, M, L, has_mask=True, fp16=False) -> bool:
         """Whether encode() packs a batch with these host-side token counts (CLDRD_PACK=0 turns packing off; a batch with less than
@@ -627,19 +666,22 @@ class HipEncoder(nn.Module):
         self.step_seed += 1
         return (self.step_seed * 0x9E3779B1) & 0x7FFFFFFFFFFF
 
-    def _encode_pair(self, input_ids, attention_mask, *, train, save, seed, fp16, lengths=None):
-        if self.amp16 and save:
-            # the all-fp16 training pass: one forward (the query tower's bf16 tape pass next to its fp16 pass is gone), fp16 tape
-            return self._encode(input_ids, attention_mask, train=train, save=True, seed=seed, fp16=True, lengths=lengths)
-        if fp16 and self.stream32 and self.hp_forward and input_ids.dim() == 2 and input_ids.shape[1] <= 128:
-            tape = None
+    def _encode_pair(self, input_ids, attention_mask, *, train, save, seed, fp16, lengths=None, window=None):
+        """The generator of the pass that runs (see __init__, CLDRD_AMP).  fp16 mode: a pass that keeps a tape is the all-fp16 pass; an
+        evaluation pass of the query tower (``fp16``: hp_forward) is the all-fp16 pass too, any other evaluation pass reads fp16 operands in
+        the FFN / out-projection GEMMs and bf16 in QKV / attention.  bf16 mode: one pass, every operand bf16 (``fp16`` is ignored)."""
+        if self.amp16:
             if save:
-                _, tape = self._encode(input_ids, attention_mask, train=train, save=True, seed=seed, fp16=False)
-            cls = self._encode(input_ids, attention_mask, train=train, save=False, seed=seed, fp16=True)
-            return (cls, tape) if save else cls
-        return self._encode(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=False, lengths=lengths)
+                return self._encode_gen(input_ids, attention_mask, train=train, save=True, seed=seed, fp16=True, lengths=lengths, window=window)
+            if fp16 and self.hp_forward and input_ids.dim() == 2 and input_ids.shape[1] <= 128:
+                return self._encode_gen(input_ids, attention_mask, train=train, save=False, seed=seed, fp16=True, window=window)
+        return self._encode_gen(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=False, lengths=lengths, window=window)
 
     def _encode(self, input_ids, attention_mask, *, train, save, seed, fp16, lengths=None):
+        return _drain(self._encode_gen(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=fp16, lengths=lengths))
+
+    def _encode_gen(self, input_ids, attention_mask, *, train, save, seed, fp16, lengths=None, window=None):
+        """one forward pass as a generator: a ``yield`` behind every group of launches (:class:`Stepper`); returns cls or (cls, tape)"""
         cfg = self.cfg
         train = self.training if train is None else train
         if input_ids.dim() != 2:
@@ -672,39 +714,39 @@ class HipEncoder(nn.Module):
         f32 = dict(dtype=torch.float32, device=dev)
         S32 = self.stream32
         sdt = torch.float32 if S32 else torch.bfloat16         # storage type of the pre-LN sums
-        # QKV16: the QKV projection reads fp16 operands too (bf16 q / k / v out: the attention kernels are bf16).  With the FFN pair in
-        # fp16, x_in / Wqkv are the next largest source of logit drift (emulated on the BERT-base cfg4 golden: 8.3e-3 -> 5.2e-3 relative);
-        # x then exists in fp16 (`xh`: the GEMM operand) and, when a tape is kept, in bf16 (`x`: the weight gradient's operand).
-        # Default: towers deeper than 6 layers (BERT-base; measured cfg4 0.190 -> 0.116).  The 6-layer DistilBERT configs are at 2-3.5e-3
-        # without it and would only pay its +0.9 % step time (profiles/r03_microbench.txt); CLDRD_QKV_FP16=1 / 0 forces it on / off.
-        qkv_env = _env_flag("CLDRD_QKV_FP16", "auto")
-        QKV16 = self.ffn_fp16 and S32 and not fp16 and (qkv_env == "1" or (qkv_env not in ("0", "1") and cfg.n_layers > 6))
+        # QKV16 (evaluation pass of the fp16 mode, towers deeper than 6 layers): the QKV projection reads fp16 operands too (bf16 q / k / v
+        # out: that pass's attention kernels are bf16).  With the FFN pair in fp16, x_in / Wqkv are the next largest source of logit drift
+        # (BERT-base cfg4 golden: 0.190 -> 0.116); the 6-layer configs are at 2-3.5e-3 without it and would only pay for it.
+        QKV16 = self.ffn_fp16 and S32 and not fp16 and cfg.n_layers > 6
         x = self._buf(T, d, dev, dt16) if (save or not QKV16) else None
         xh = self._buf(T, d, dev, torch.float16) if QKV16 else None
         x32 = self._buf(T, d, dev, torch.float32) if S32 else None      # fp32 copy of the layer input: the residual operand
         mean0, rstd0 = torch.empty(T, **f32), torch.empty(T, **f32)
         type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
+        if window is not None:
+            window("ln")
         ops.embed_ln_fwd(ids.view(-1), self.w("embeddings.word_embeddings.weight"),
                          self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
                          self.w("embeddings.LayerNorm.bias"), xh if QKV16 else x, mean0, rstd0, T, L, cfg.eps, p_h, seed, out32=x32,
                          pos_idx=pk.pos if pk is not None else None, out_copy=x if QKV16 else None)
         if save:
             tape.mean0, tape.rstd0 = mean0, rstd0
+        yield
         cls = torch.empty(M, d, **f32)
         p_out = p_h if cfg.arch == "bert" else 0.0          # DistilBERT has no dropout after out_lin
         # fp32 residual stream: a LayerNorm's fp32 output is consumed exactly once, as the residual operand of the next out-projection /
         # FFN2 epilogue.  It is not stored: that epilogue reads the pre-LN sum (which the backward keeps anyway) and applies mean / rstd /
         # gamma / beta on the fly (`residual_ln`) - 100 MB less written per LayerNorm at cfg2, the same bytes read.
         res_ln = None                                        # LayerNorm still to be applied to x32 (None: x32 is the value itself)
-        LNF = S32 and _env_flag("CLDRD_LN_ON_THE_FLY", "1") != "0"          # "0": store every fp32 LayerNorm output (A/B runs)
-        FFN16 = self.ffn_fp16 and S32 and not fp16                           # a bf16 pass whose FFN GEMMs read fp16 operands
-        OUT16 = FFN16 and LNF and _env_flag("CLDRD_OUT_FP16", "1") != "0"    # ... and whose out-projection does (fp16 context from the attention kernel)
+        LNF = S32                                                            # the residual operand is LayerNorm(pre-LN sum) applied on the fly
+        FFN16 = self.ffn_fp16 and S32 and not fp16                           # fp16 mode, evaluation pass: the FFN GEMMs read fp16 operands
+        OUT16 = FFN16 and LNF                                                # ... and so does the out-projection (fp16 context from the attention kernel)
         for i in range(cfg.n_layers):
             W = self._layer_weights(i, fp16)
             W16 = self._layer_weights(i, True) if FFN16 else None
             s_l = seed + 7919 * (i + 1)
             if i == cfg.n_layers - 1 and self.cls_only_last:
-                self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16, W16, pk, xh, out16=OUT16)
+                yield from self._last_layer_cls_fwd(x, x32, W, mask, M, L, T, p_h, p_a, p_out, s_l, save, tape, cls, dt16, W16, pk, xh, out16=OUT16)
                 break
             qkv = self._buf(T, 3 * d, dev, dt16)
             if QKV16:
@@ -721,6 +763,9 @@ class HipEncoder(nn.Module):
             ctx16 = self._buf(T, d, dev, torch.float16) if OUT16 else None
             if pk is None:
                 ctx = self._buf(T, d, dev, dt16) if (save or not OUT16) else None
+                yield
+                if window is not None:
+                    window("attn")
                 ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16, full_family=fp16 and self.amp16)
             else:
                 # packed batch: attention works on the padded [M * L, .] layout (one item = one sequence x head, keys >= len masked): move
@@ -729,6 +774,9 @@ class HipEncoder(nn.Module):
                 ops.unpack_rows16(qkv_p, qkv, pk.cu, M, L)
                 ctx_pad = self._buf(TP, d, dev, dt16) if (save or not OUT16) else None
                 ctx16_pad = self._buf(TP, d, dev, torch.float16) if OUT16 else None
+                yield
+                if window is not None:
+                    window("attn")
                 ops.attention_fwd(qkv, mask, ctx_pad, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16_pad, full_family=fp16 and self.amp16)
                 ctx = None
                 if ctx_pad is not None:
@@ -737,10 +785,14 @@ class HipEncoder(nn.Module):
                 if OUT16:
                     ops.gather_rows(ctx16_pad, pk.tok_idx, ctx16, T)
                 del qkv_p, ctx16_pad
+            yield
             s1 = self._buf(T, d, dev, sdt)
             ops.gemm_nt(ctx16 if OUT16 else ctx, (W16 if OUT16 else W)["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out,
                         seed=s_l + 2, residual_ln=res_ln)
             del ctx16
+            yield
+            if window is not None:
+                window("ln")
             mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
             x1_32 = self._buf(T, d, dev, torch.float32) if (S32 and not LNF) else None
             F16 = FFN16 and LNF                                  # the FFN pair on fp16 operands (the fp16 FFN2 flavours add LayerNorm on the fly)
@@ -749,19 +801,23 @@ class HipEncoder(nn.Module):
                 x1h = self._buf(T, d, dev, torch.float16)
                 x1 = self._buf(T, d, dev) if save else None
                 ops.layernorm_fwd(s1, W["g1"], W["b1"], x1h, mean1, rstd1, T, cfg.eps, out_copy=x1)
+                yield
                 hh = self._buf(T, f, dev, torch.float16)
                 hbuf = self._buf(T, f, dev) if save else None
                 pre = self._buf(T, f, dev) if save else None
                 ops.gemm_nt(x1h, W16["W1"], hh, T, bias=W["bf1"], preact=pre, act=3 if save else 1, out_copy=hbuf)
+                yield
                 s2 = self._buf(T, d, dev, sdt)
                 ops.gemm_nt(hh, W16["W2"], s2, T, bias=W["bf2"], residual=s1, dropout_p=p_h, seed=s_l + 3, residual_ln=(mean1, rstd1, W["g1"], W["b1"]))
                 del x1h, hh
             else:
                 x1 = self._buf(T, d, dev, dt16)
                 ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps, out32=x1_32)
+                yield
                 hbuf = self._buf(T, f, dev, dt16)
                 pre = self._buf(T, f, dev, dt16) if save else None
                 ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=3 if save else 1)     # the tape keeps gelu'(pre-activation)
+                yield
                 s2 = self._buf(T, d, dev, sdt)
                 ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=(s1 if LNF else x1_32) if S32 else x1, dropout_p=p_h, seed=s_l + 3,
                             residual_ln=(mean1, rstd1, W["g1"], W["b1"]) if LNF else None)
@@ -772,6 +828,9 @@ class HipEncoder(nn.Module):
             need32 = S32 and not last and ((i + 1 == cfg.n_layers - 1 and self.cls_only_last) or not LNF)
             xo32 = self._buf(T, d, dev, torch.float32) if need32 else None
             mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
+            yield
+            if window is not None:
+                window("ln")
             ops.layernorm_fwd(s2, W["g2"], W["b2"], xoh if QKV16 else xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32,
                               out_copy=xo if QKV16 else None)
             if save:
@@ -780,6 +839,7 @@ class HipEncoder(nn.Module):
             x, xh = xo, xoh
             if S32:
                 x32, res_ln = (xo32, None) if need32 else (s2, (mean2, rstd2, W["g2"], W["b2"]))
+            yield
         if cfg.n_layers == 0:
             src = x if x is not None else xh
             cls.copy_(src.view(ops.pad_rows(T), d)[:T].view(M, L, d)[:, 0].float())
@@ -801,6 +861,7 @@ class HipEncoder(nn.Module):
             ops.gemm_nt(xh, W16["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
         else:
             ops.gemm_nt(x, W["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
+        yield
         S32 = x32 is not None
         sdt = torch.float32 if S32 else torch.bfloat16
         if pk is None:
@@ -834,9 +895,11 @@ class HipEncoder(nn.Module):
         ctxc16 = self._buf(M, d, dev, torch.float16) if out16 else None
         probs = torch.empty(M, H, L, **f32)
         ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1, ctx16=ctxc16)
+        yield
         s1 = self._buf(M, d, dev, sdt)
         ops.gemm_nt(ctxc16 if out16 else ctxc, (W16 if out16 else W)["Wo"], s1, M, bias=W["bo"], residual=xc32 if S32 else xc, dropout_p=p_out,
                     seed=s_l + 2)
+        yield
         x1_32 = self._buf(M, d, dev, torch.float32) if S32 else None
         mean1, rstd1 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
         if W16 is not None and S32:         # the FFN pair on fp16 operands, as in the full layers (bf16 copies for the backward)
@@ -857,6 +920,7 @@ class HipEncoder(nn.Module):
             ops.gemm_nt(x1, W["W1"], hbuf, M, bias=W["bf1"], preact=pre, act=3 if save else 1)
             s2 = self._buf(M, d, dev, sdt)
             ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
+        yield
         xo = self._buf(M, d, dev, dt16)
         mean2, rstd2 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
         ops.layernorm_fwd(s2, W["g2"], W["b2"], xo, mean2, rstd2, M, cfg.eps, cls, 1)
@@ -890,6 +954,7 @@ class HipEncoder(nn.Module):
         own = (lambda: torch.empty(ops.ln_partial_elems(M, d), **f32)) if lnq is not None else (lambda: partial)
         ops.layernorm_bwd(gc, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], own(), M, p_h, s_l + 3,
                           accumulate=self._acc, defer=lnq)
+        yield
         dF = ds2m if ds2m is not None else ds2
         self._wq.add(dF, a["h"], G["W2"], M)
         dpre = buf(M, f, dev)
@@ -897,6 +962,7 @@ class HipEncoder(nn.Module):
         self._wq.add(dpre, a["x1"], G["W1"], M, dbias=G["bf1"])
         dx1 = buf(M, d, dev, sdt)
         ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, M, residual=ds2)
+        yield
         ds1 = buf(M, d, dev, sdt)
         ds1m = buf(M, d, dev) if (p_out > 0 or GS) else None
         ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), M, p_out, s_l + 2,
@@ -905,6 +971,7 @@ class HipEncoder(nn.Module):
         self._wq.add(dA, a["ctx"], G["Wo"], M)
         dctx = buf(M, d, dev)
         ops.gemm_nt(dA, self.ht(i, "o"), dctx, M)
+        yield
         dqc = buf(M, d, dev)
         pk = tape.pack
         dkv = buf(M * L, 2 * d, dev)
@@ -915,6 +982,7 @@ class HipEncoder(nn.Module):
             del dkv_pad
         self._wq.add(dqc, a["xc"], G["Wqkv"][:d], M, dbias=G["bqkv"][:d])
         self._wq.add(dkv, a["x_in"], G["Wqkv"][d:], T, dbias=G["bqkv"][d:])
+        yield
         wt = self.ht(i, "qkv")                                      # [d, 3d] = Wqkv^T
         # the [T, d] gradient this layer hands down: fp32 - or fp16 with the fp16 gradient stream (the layer's own M-row stream stays fp32:
         # the CLS rows are added from the fp32 gq with one rounding)
@@ -940,17 +1008,18 @@ class HipEncoder(nn.Module):
         to, so ``flat_g`` needs no zeroing except the embedding tables (scatter-add by atomics).
 
         ``before_last_wgrad()`` (optional) is called once, right before the LAST group of deferred weight gradients is launched:
-        from there on this stream runs one long launch that is on nobody's critical path - the place where the trainer puts
-        the other tower's latency-bound backward."""
+        from there on this stream runs one long launch that is on nobody's critical path."""
+        return self.backward_steps(tape, dcls, after_layer=after_layer, accumulate=accumulate, check_grads=check_grads,
+                                   before_last_wgrad=before_last_wgrad).finish()
+
+    def backward_steps(self, tape: _Tape, dcls: torch.Tensor, after_layer=None, accumulate: bool = True, check_grads: bool = False,
+                       before_last_wgrad=None, window=None) -> Stepper:
+        """:meth:`backward_from_cls` as a :class:`Stepper`; ``window(kind)`` as in :meth:`encode_steps` (before LayerNorm / attention backward
+        launches)."""
+        contexts = []
         base = getattr(self, "seed_base_ptr", None) if getattr(tape, "device_seed", False) else None
-        if base and not getattr(self, "_in_seed_ctx", False):
-            self._in_seed_ctx = True
-            try:
-                with ops.seed_base(base):
-                    return self.backward_from_cls(tape, dcls, after_layer=after_layer, accumulate=accumulate, check_grads=check_grads,
-                                                  before_last_wgrad=before_last_wgrad)
-            finally:
-                self._in_seed_ctx = False
+        if base:
+            contexts.append(lambda: ops.seed_base(base))
         if (self.amp16 and getattr(ops._TLS, "loss_scale", None) is None and tape.layers and tape.layers[-1] is not None
                 and tape.layers[-1]["h"].dtype == torch.float16):
             # an fp16 tape outside the trainer (the autograd bridge of the reference-style loop: dL/dCLS arrives unscaled): this tower scales
@@ -960,9 +1029,10 @@ class HipEncoder(nn.Module):
                 st = self.__dict__["_own_scale"] = ops.new_loss_scale_state(self.flat_p.device)
             dcls = dcls.contiguous().clone()
             ops.loss_scale_adapt(dcls, None, st)
-            with ops.loss_scale(st.data_ptr()):
-                return self.backward_from_cls(tape, dcls, after_layer=after_layer, accumulate=accumulate, check_grads=check_grads,
-                                              before_last_wgrad=before_last_wgrad)
+            contexts.append(lambda: ops.loss_scale(st.data_ptr()))
+        return Stepper(self._backward_gen(tape, dcls, after_layer, accumulate, check_grads, before_last_wgrad, window), contexts)
+
+    def _backward_gen(self, tape, dcls, after_layer, accumulate, check_grads, before_last_wgrad, window):
         self._acc = bool(accumulate)
         cfg = self.cfg
         self.ensure_grads(check_all=check_grads)
@@ -975,7 +1045,7 @@ class HipEncoder(nn.Module):
         # them all.  Bit-identical and 22 launches fewer per step.  Round 2 kept it off (±0 at cfg2, slower on the then enqueue-bound
         # cfg1); measured again in round 3 with the step replayed as a HIP graph: -1.0 % step time at cfg2, twice on one box
         # (profiles/r03_microbench.txt): on by default, CLDRD_LN_DEFER=0 restores the immediate reductions.
-        self._lnq = ops.LnReduceQueue() if _env_flag("CLDRD_LN_DEFER", "1") == "1" else None
+        self._lnq = ops.LnReduceQueue() if self.ln_defer else None
         flush_every = int(getattr(self, "wgrad_flush_layers", 0) or 0)
         waiting = []
 
@@ -1015,9 +1085,10 @@ class HipEncoder(nn.Module):
         for i in reversed(range(cfg.n_layers)):
             W, G, a = self._layer_weights(i), self._layer_grads(i), tape.layers[i]
             if a.get("cls_only"):
-                g = self._last_layer_cls_bwd(i, a, tape, dcls, partial)
+                g = yield from self._last_layer_cls_bwd(i, a, tape, dcls, partial)
                 tape.layers[i] = None
                 layer_done(i)
+                yield
                 continue
             GS = self.grad_stream32 and a["s2"].dtype == torch.float32  # fp32 residual sums on the tape: the stream is added in the LayerNorm backward
             bdt = a["h"].dtype                                          # 16-bit format of this backward = the tape's (fp16 in amp16)
@@ -1040,12 +1111,16 @@ class HipEncoder(nn.Module):
             own = (lambda: torch.empty(ops.ln_partial_elems(T, d), **f32)) if lnq is not None else (lambda: partial)
             # fp32 stream: the gradient of a LayerNorm output is `g` (fp32: the residual path) + `gb` (bf16: the plain output of the
             # branch's last data-gradient GEMM), added inside layernorm_bwd - not in that GEMM's epilogue (200 MB less per GEMM)
+            if window is not None:
+                window("ln")
             ops.layernorm_bwd(g, a["s2"], a["mean2"], a["rstd2"], W["g2"], ds2, ds2m, G["g2"], G["b2"], G["bf2"], own(), T,
                               p_h, s_l + 3, accumulate=self._acc, defer=lnq, dy_branch=gb)
+            yield
             dF = ds2m if ds2m is not None else ds2
             self._wq.add(dF, a["h"], G["W2"], T)
             dpre = buf(T, f, dev)
             ops.gemm_nt(dF, self.ht(i, "f2"), dpre, T, gelu_pre=a["pre"], act=2)
+            yield
             self._wq.add(dpre, a["x1"], G["W1"], T, dbias=G["bf1"])
             dx1 = buf(T, d, dev)
             if GS:
@@ -1055,13 +1130,20 @@ class HipEncoder(nn.Module):
             # --- attention-output LayerNorm + attention ---
             ds1 = buf(T, d, dev, sdt)
             ds1m = buf(T, d, dev) if (p_out > 0 or (GS and not G16)) else None
+            yield
+            if window is not None:
+                window("ln")
             ops.layernorm_bwd(ds2 if GS else dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), T,
                               p_out, s_l + 2, accumulate=self._acc, defer=lnq, dy_branch=dx1 if GS else None)
             dA = ds1m if ds1m is not None else ds1
             self._wq.add(dA, a["ctx"], G["Wo"], T)
             dctx = buf(T, d, dev)
+            yield
             ops.gemm_nt(dA, self.ht(i, "o"), dctx, T)
             pk = tape.pack
+            yield
+            if window is not None:
+                window("attn")
             if pk is None:
                 dqkv = buf(T, 3 * d, dev)
                 ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1, drop_bits=a.get("dbits"))
@@ -1076,6 +1158,7 @@ class HipEncoder(nn.Module):
                 ops.gather_rows(dqkv_pad, pk.tok_idx, dqkv, T)
                 del dctx_pad, dqkv_pad
             self._wq.add(dqkv, a["x_in"], G["Wqkv"], T, dbias=G["bqkv"])
+            yield
             if GS:
                 gb = buf(T, d, dev)
                 ops.gemm_nt(dqkv, self.ht(i, "qkv"), gb, T)             # the attention branch alone
@@ -1085,14 +1168,18 @@ class HipEncoder(nn.Module):
                 ops.gemm_nt(dqkv, self.ht(i, "qkv"), g, T, residual=ds1)
             tape.layers[i] = None        # this layer's activations: the deferred weight-gradient jobs keep what they still need
             layer_done(i)
+            yield
         type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
         dtype0 = self.g("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
+        if window is not None:
+            window("ln")
         ops.embed_ln_bwd(g, tape.ids.view(-1), self.w("embeddings.word_embeddings.weight"),
                          self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
                          tape.mean0, tape.rstd0, self.g("embeddings.word_embeddings.weight"),
                          self.g("embeddings.position_embeddings.weight"), dtype0, self.g("embeddings.LayerNorm.weight"),
                          self.g("embeddings.LayerNorm.bias"), partial, T, L, tape.p_embed, tape.seed, accumulate=self._acc,
                          pos_idx=tape.pack.pos if tape.pack is not None else None, dy_branch=gb)
+        yield
         layer_done(-1, force=True)
 
     # ------------------------------------------------------------------ HF-style call surface

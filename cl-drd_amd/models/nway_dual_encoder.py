@@ -45,11 +45,10 @@ class NwayDualEncoder(nn.Module):
             self.passage_encoder = self.query_encoder
         else:
             self.passage_encoder = HipEncoder.from_pretrained(model_name_or_path)
-        # The query side runs its FORWARD with fp16 MFMA operands (HipEncoder.encode: 8x finer operand rounding at no cost - the
-        # query tower is ~1 % of the FLOPs - and it removes the dq.p term that every logit of a row shares).  CLDRD_QUERY_FP16=0
-        # keeps it in bf16.  With shared weights the one tower keeps an fp16 shadow too and only query calls use it.
-        import os
-        self.query_fp16 = os.environ.get("CLDRD_QUERY_FP16", "1") != "0"
+        # fp16 mode (the default, encoder.HipEncoder: CLDRD_AMP): the query side runs its whole FORWARD on fp16 MFMA operands, evaluation
+        # included (the query tower is ~1 % of the FLOPs, and a query's rounding error is shared by every logit of its row).  bf16 mode:
+        # bf16 like everything else.  With shared weights the one tower keeps an fp16 shadow too and only query calls use it.
+        self.query_fp16 = self.query_encoder.amp_mode == "fp16"
         self.query_encoder.hp_forward = self.query_fp16
 
     # -- reference call surface -------------------------------------------------------------------------------

@@ -156,6 +156,8 @@ class FlatIPIndex:
         self._p32 = self._p16 = self._sample = None
         self.last_stats = {}
         self.profile = False          # bench.py: time the search with HIP events and count candidates
+        self.probe = True             # first pass of a long search sizes the kept-set buffer of the rest (test hook: False)
+        self.query_tile_request = None
 
     # -- construction -----------------------------------------------------------------------------------------
     def add_with_ids(self, embeddings, ids):
@@ -228,10 +230,9 @@ class FlatIPIndex:
             # max |p - mu| for the bound, plus 2^-12 max|p|: the fp32 subtraction p - mu itself rounds (2^-24 |p| per element), which moves a
             # centred score by up to |q| sqrt(d) 2^-24 max|p| < 2^-10 |q| (2^-12 max|p|) - folded into the norm the eps formula multiplies by 2^-10
             self._max_norm = math.sqrt(float(cmax.view(torch.float32).item())) * (1.0 + 1e-6) + raw_max * 2.0 ** -12
-            qt = os.environ.get("CLDRD_QUERY_TILE", "")
-            self.query_tile = int(qt) if qt in ("128", "256") else (256 if d == 768 else 128)      # 256: only the d = 768 streaming scan
-            if self.query_tile == 256 and d != 768:
-                self.query_tile = 128
+            # queries per pass over the index bytes: 256 at d = 768 (the streaming scan's two-batch form), else the reference's 128
+            # (`query_tile_request`: a test hook that asks for 128 at d = 768)
+            self.query_tile = 256 if (d == 768 and self.query_tile_request != 128) else 128
             if int(flag.item()) or not math.isfinite(self._max_norm):
                 raise ValueError("FlatIPIndex: embeddings must be finite and inside the fp16 range (|x| <= 65504) for the scan shadow")
 
@@ -319,7 +320,7 @@ class FlatIPIndex:
         # notes).  A search of more than two passes therefore runs its first pass as a PROBE with the default buffer, reads that pass's
         # kept-set sizes (one extra host sync per search) and sizes the buffer of the remaining passes from them - instead of
         # overflowing it query after query and scanning those a second time.
-        probe = 0 if (exhaustive or nq <= 2 * QT or os.environ.get("CLDRD_TOPK_PROBE", "1") == "0") else QT
+        probe = 0 if (exhaustive or nq <= 2 * QT or not self.probe) else QT
         if probe:
             st_p, cnt_p, n2_p, kh_p = self._run(q32[:probe], qh[:probe], thr[:probe], eps[:probe], k, self._workspace(cap2), D[:probe], I[:probe], False)
             pr = torch.stack([st_p, n2_p]).cpu().numpy()

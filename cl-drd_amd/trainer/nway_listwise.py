@@ -142,6 +142,10 @@ class NwayTrainer:
         self.l_stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._pending = []
         self._sink_on = False
+        # test hooks (tests/test_gpu_model.py, test_gpu_amp16.py prove the default path equal to the plain one they select; not configuration):
+        self.zero_all_grads = False        # True: zero the whole gradient buffer and accumulate instead of writing every gradient once
+        self.use_norm_sink = True          # False: the late clip-norm piece by a separate pass over the gradients
+        self.window_schedule = True        # False: the query tower runs free on the second stream (the schedule of rounds 2-5)
         # CLDRD_AMP=fp16 towers (encoder.py: amp16): the loss scale lives in device memory (hip_ops.new_loss_scale_state).  It is set every
         # step from dL/dCLS (ops.loss_scale_adapt: a power of two that puts the largest entering gradient at 2^11..2^12); what is kept of
         # torch.cuda.amp.GradScaler (the reference: nway_listwise_1.py:355-359) is its safety net: a non-finite gradient norm skips the step
@@ -215,6 +219,24 @@ class NwayTrainer:
             self._norm_split = split
         return hook
 
+    # groups of the query tower's stepper (encoder.Stepper: one group = one GEMM / attention / LayerNorm launch, plus its split-K finish) released
+    # per window of the passage tower: an attention kernel lasts ~55 us forward / ~107 us backward at cfg2, a LayerNorm kernel 29-50 us, a small
+    # query-tower launch 7-10 us; one passage layer then releases seven groups = one query layer
+    FWD_SLICE = {"attn": 3, "ln": 2}
+    BWD_SLICE = {"attn": 3, "ln": 2}
+
+    @staticmethod
+    def _window(main, side, stepper, slices):
+        def window(kind):
+            if stepper.done:
+                return
+            ev = torch.cuda.Event()
+            ev.record(main)                  # fires when the main stream reaches the HBM-bound kernel enqueued right after this call
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                stepper.step(slices[kind])
+        return window
+
     def _finish_early_norm(self, side):
         d = getattr(self, "_norm_deferred", None)
         self._norm_deferred = None
@@ -246,11 +268,11 @@ class NwayTrainer:
         qe, pe = model.query_encoder, model.passage_encoder
         q, nw = batch["query"], batch["nway_passages"]
         bz, nway, L = nw["input_ids"].shape
-        write_once = not model.share_weights and _env_flag("CLDRD_GRAD_ZERO", "") != "full"      # "full": A/B runs
+        write_once = not model.share_weights and not self.zero_all_grads      # (test hook: zero_all_grads = True zeroes + accumulates)
         main = torch.cuda.current_stream()
         # The query tower is ~1 % of the FLOPs but dozens of small, latency-bound launches: it runs on its own stream
         # next to the passage tower (forward and backward) instead of in front of it.
-        side = self.q_stream if (not model.share_weights and _env_flag("CLDRD_Q_SIDE", "1") != "0") else main      # "0": A/B runs
+        side = self.q_stream if (not model.share_weights and self.q_stream is not None) else main
         if side is not main:
             side.wait_stream(main)
         # Step preamble that nothing in the passage tower's FORWARD depends on - on the second stream, next to that forward instead of in
@@ -269,10 +291,25 @@ class NwayTrainer:
             for tower in model.towers():
                 if not getattr(tower, "_t_fresh", False):
                     tower.refresh_transposed()
-        with torch.cuda.stream(side):
-            q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True, fp16=model.query_fp16, device_seed=True)
-        p_cls, p_tape = pe.encode(nw["input_ids"].reshape(bz * nway, L), nw["attention_mask"].reshape(bz * nway, L),
-                                  train=True, save=True, fp16=False, lengths=_lengths(nw), device_seed=True)      # "lengths" given: a packed batch
+        # Round 6: the query tower is enqueued in SLICES, each released by an event the main stream records at the start of one of the passage
+        # tower's HBM-bound kernels (LayerNorm, attention: `window`), instead of running free next to everything.  Its ~130 launches are 1 % of
+        # the FLOPs, but a 64 x 64-tile GEMM that lands next to one of the passage tower's large GEMMs takes up to 48 CUs for 7-10 us out of a grid
+        # sized to whole rounds of 256 CUs (0.32 ms per step of interference, profiles/r05_microbench.txt section 14); next to a kernel that
+        # waits for HBM it costs nothing.  Same launches, same arithmetic, another enqueue order (test hook: window_schedule = False).
+        windows = side is not main and self.window_schedule
+        self._windows_on = windows
+        p_ids, p_mask = nw["input_ids"].reshape(bz * nway, L), nw["attention_mask"].reshape(bz * nway, L)
+        if windows:
+            with torch.cuda.stream(side):
+                q_step = qe.encode_steps(q["input_ids"], q.get("attention_mask"), train=True, save=True, fp16=model.query_fp16, device_seed=True)
+            p_cls, p_tape = pe.encode_steps(p_ids, p_mask, train=True, save=True, fp16=False, lengths=_lengths(nw), device_seed=True,
+                                            window=self._window(main, side, q_step, self.FWD_SLICE)).finish()
+            with torch.cuda.stream(side):
+                q_cls, q_tape = q_step.finish()          # whatever is left (nothing, when the slices kept pace)
+        else:
+            with torch.cuda.stream(side):
+                q_cls, q_tape = qe.encode(q["input_ids"], q.get("attention_mask"), train=True, save=True, fp16=model.query_fp16, device_seed=True)
+            p_cls, p_tape = pe.encode(p_ids, p_mask, train=True, save=True, fp16=False, lengths=_lengths(nw), device_seed=True)      # "lengths" given: a packed batch
         if side is not main:
             main.wait_stream(side)
             q_cls.record_stream(main)
@@ -284,7 +321,7 @@ class NwayTrainer:
         # the passage tower's backward - the critical path - started only when that run was over: 0.62 ms of 5-10-us kernels with the rest of
         # the chip idle (kernel trace of the replayed step, profiles/r04_microbench.txt section 14).  A run that contains nothing but the loss
         # ends where both towers' backward begin.
-        lst = self.l_stream if (side is not main and self.l_stream is not None and _env_flag("CLDRD_L_STREAM", "1") != "0") else main
+        lst = self.l_stream if (side is not main and self.l_stream is not None) else main
         if lst is not main:
             lst.wait_stream(main)
         with torch.cuda.stream(lst):
@@ -339,24 +376,40 @@ class NwayTrainer:
             # (the critical path) sat idle for 0.62 ms behind the loss in every replayed step (kernel trace, profiles/r04_microbench.txt
             # section 14).  So a captured step enqueues the passage tower first; the query tower's chain is released ~1.8 ms behind the loss
             # and still ends 4 ms before the join.
-            q_late = side is not main and torch.cuda.is_current_stream_capturing() and _env_flag("CLDRD_Q_BWD_LATE", "1") != "0"
-            if not q_late:
+            windows = side is not main and getattr(self, "_windows_on", False)
+            q_late = side is not main and (torch.cuda.is_current_stream_capturing() or windows)
+            q_bstep = None
+            if windows:
+                # sliced like the forward: the query tower's backward is created here (inside the loss-scale context) and enqueued by the
+                # passage tower's backward windows; what is left follows the passage tower's last weight-gradient group
+                side.wait_stream(lst if (lst is not None and lst is not main) else main)
+                dq.record_stream(side)
+                with torch.cuda.stream(side):
+                    q_bstep = qe.backward_steps(q_tape, dq, after_layer=self._bucket_hook(0), accumulate=not write_once)
+            elif not q_late:
                 query_backward()
             self._norm_split = None
             self._norm_deferred = None
             p_hook = self._bucket_hook(1)
             self._sink_on = False
             pe.norm_sink, pe.norm_sink_used = None, -1
-            if p_hook is None and side is not main and write_once and _env_flag("CLDRD_NORM_SPLIT", "1") != "0":
+            if p_hook is None and side is not main and write_once:
                 p_hook = self._early_norm_hook(main, side, defer=q_late)
-                if _env_flag("CLDRD_NORM_SINK", "1") != "0":      # "0": the late piece by a separate pass (A/B runs, tests)
+                if self.use_norm_sink:      # (test hook: False takes the late piece by a separate pass)
                     self._sink_on = True
                     pe.norm_sink = self.norm_partial[ops.sqnorm_blocks() // 2:ops.sqnorm_blocks() // 2 + self._sink_cap]
-            pe.backward_from_cls(p_tape, dp, after_layer=p_hook, accumulate=not write_once)
-            if q_late:
-                # (released together with the passage tower's last weight-gradient group instead: +1.4 %, as in round 3's eager measurement)
-                query_backward()
+            if q_bstep is not None:
+                pe.backward_steps(p_tape, dp, after_layer=p_hook, accumulate=not write_once,
+                                  window=self._window(main, side, q_bstep, self.BWD_SLICE)).finish()
+                with torch.cuda.stream(side):
+                    q_bstep.finish()
                 self._finish_early_norm(side)
+            else:
+                pe.backward_from_cls(p_tape, dp, after_layer=p_hook, accumulate=not write_once)
+                if q_late:
+                    # (released together with the passage tower's last weight-gradient group instead: +1.4 %, as in round 3's eager measurement)
+                    query_backward()
+                    self._finish_early_norm(side)
             main.wait_stream(side)
             if self.distributed:
                 self._wait_pending()
@@ -414,19 +467,18 @@ class NwayTrainer:
         shadow = self._joint_shadow()
         # all-fp16 training: no pass of a training step reads the bf16 shadow (forward, backward and the transposed copies come from the fp16
         # one), so AdamW does not write it; the towers remember it is stale and an evaluation forward casts it first
-        skip_h = self.amp16 and all(t.amp16 for t in towers) and _env_flag("CLDRD_ADAM_SKIP_BF16", "1") != "0"
+        skip_h = self.amp16 and all(t.amp16 for t in towers)
         # ... and the fp16 shadow of the towers whose forward reads fp16 weights (the FFN GEMMs of every tower by default, the whole
         # high-precision pass of the query tower): one contiguous range of the joint buffer
         s16, r16 = self._joint_shadow16()
-        fused16 = s16 is not None and _env_flag("CLDRD_ADAM_H16", "1") != "0"
+        fused16 = s16 is not None
         self._last_skip_h = bool(skip_h and fused16)
         with ops.optim_hyper(hyper.data_ptr() if hyper is not None else None):
             ops.adamw_step(self.flat_p, self.flat_g, self.m, self.v, self.decay_flags, None if (skip_h and fused16) else shadow, lr=lr, beta1=self.betas[0],
                            beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=adam_step, clip=self.clip,
                            shadow16=s16[r16[0]:r16[1]] if fused16 else None, h16_range=r16 if fused16 else None)
         # the transposed copies wait for the next step's preamble on the second stream (forward_backward) when there is one
-        defer_t = not self.model.share_weights and self.q_stream is not None and _env_flag("CLDRD_Q_SIDE", "1") != "0" \
-            and _env_flag("CLDRD_T_DEFER", "1") != "0"
+        defer_t = not self.model.share_weights and self.q_stream is not None
         for t in towers:
             t.refresh_shadows(need_transposed=not defer_t, cast=False, cast16=not fused16, h_stale=skip_h and fused16)
 

@@ -51,18 +51,16 @@ def cfg_of(arch, layers):
                          dropout=0.1, attention_dropout=0.1)
 
 
-@pytest.mark.parametrize("arch,layers", [("distilbert", 3), ("bert", 2), ("distilbert", 1)])
-@pytest.mark.parametrize("ffn16,qkv16,out16", [("1", "1", "1"), ("1", "0", "1"), ("1", "auto", "0"), ("0", "0", "1")])
+@pytest.mark.parametrize("arch,layers", [("distilbert", 3), ("bert", 2), ("distilbert", 1), ("bert", 7)])
 @pytest.mark.parametrize("packed", [False, True])
-@pytest.mark.parametrize("gs,amp", [("fp32", "fp16"), ("fp32", "bf16"), ("bf16", "fp16")])
-def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, ffn16, qkv16, out16, packed, gs, amp):
+@pytest.mark.parametrize("amp,stream16", [("fp16", True), ("fp16", False), ("bf16", True)])
+def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, packed, amp, stream16):
+    """CLDRD_AMP = fp16 (all-fp16 training pass; evaluation with fp16 FFN / out-projection operands, fp16 QKV operands on towers deeper than 6
+    layers: the 7-layer case) and bf16 (every operand bf16), the fp16 mode also with its fp32 gradient stream (test hook)."""
     monkeypatch.setenv("CLDRD_AMP", amp)
-    monkeypatch.setenv("CLDRD_FFN_FP16", ffn16)
-    monkeypatch.setenv("CLDRD_QKV_FP16", qkv16)
-    monkeypatch.setenv("CLDRD_OUT_FP16", out16)
-    monkeypatch.setenv("CLDRD_GRAD_STREAM", gs)
     enc = HipEncoder(cfg_of(arch, layers), seed=1)
-    assert enc.amp16 == (amp == "fp16" and gs == "fp32")        # the all-fp16 training mode needs the fp32 gradient stream
+    enc._grad_stream16 = stream16
+    assert enc.amp16 == (amp == "fp16") and enc.grad_stream16 == (amp == "fp16" and stream16) and enc.needs_h16 == (amp == "fp16")
     t16 = torch.float16 if enc.amp16 else torch.bfloat16
     M, L = 6, 24
     lens = np.array([24, 3, 10, 17, 5, 8])
@@ -74,8 +72,7 @@ def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, f
         cls = enc.encode(ids, mask, train=False, save=False, lengths=lengths)
         assert cls.shape == (M, 128) and cls.dtype == torch.float32
         cls, tape = enc.encode(ids, mask, train=True, save=True, lengths=lengths)
-        # the dual-pass (fp16 + bf16 tape) forward of the query tower is never packed; the all-fp16 mode has one pass for both towers
-        pk = packed and (enc.amp16 or not hp)
+        pk = packed                                 # one pass per mode for both towers: a training pass packs whenever it is given lengths
         assert (tape.pack is not None) == pk and tape.T == (int(lens.sum()) if pk else M * L)
         for a in tape.layers:                       # what the backward's MFMAs read: one 16-bit format per mode
             for k in ("x_in", "ctx", "x1", "h", "pre"):
@@ -98,7 +95,6 @@ def test_trainer_step_walks_with_stubbed_kernels(stubbed, monkeypatch):
     monkeypatch.setattr(torch.cuda, "stream", lambda s: _Null())
     monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: _FakeStream())
     monkeypatch.setenv("CLDRD_GRAPH", "0")
-    monkeypatch.setenv("CLDRD_Q_SIDE", "0")
     model = NwayDualEncoder(cfg_of("distilbert", 2), share_weights=False)
     tr = TL.NwayTrainer(model, loss="kl_div")
     tr.q_stream = None
@@ -108,6 +104,47 @@ def test_trainer_step_walks_with_stubbed_kernels(stubbed, monkeypatch):
     n0 = len(stubbed)
     tr.train_step(moved)
     assert tr.global_step == 1 and "cldrd_adamw_step_h16" in stubbed[n0:] and "cldrd_loss_fwd_bwd" in stubbed[n0:]
+
+
+def test_window_scheduled_step_walks_and_interleaves_the_two_towers(stubbed, monkeypatch):
+    """Round 6: the query tower is enqueued in slices released at the passage tower's LayerNorm / attention launches (encoder.Stepper,
+    NwayTrainer._window).  With stubbed kernels and fake streams: the launch sequence of a step must contain every launch of the free-running
+    schedule exactly once (same multiset), the query tower's launches must be INTERLEAVED with the passage tower's (not all in front), and
+    forward and backward must each have drained their stepper."""
+    from cldrd_amd.trainer import nway_listwise as TL
+    monkeypatch.setattr(TL.NwayTrainer, "_require_gpu", staticmethod(lambda dev: None))
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _MAIN)
+    monkeypatch.setattr(torch.cuda, "stream", lambda s_: _Null())
+    monkeypatch.setattr(torch.cuda, "Stream", lambda *a, **k: _FakeStream())
+    monkeypatch.setattr(torch.cuda, "Event", lambda *a, **k: _FakeEvent())
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    monkeypatch.setattr(torch.Tensor, "record_stream", lambda self, s_: None)
+    monkeypatch.setenv("CLDRD_GRAPH", "0")
+    seqs = {}
+    for windows in (False, True):
+        torch.manual_seed(0)
+        model = NwayDualEncoder(cfg_of("distilbert", 3), share_weights=False)
+        tr = TL.NwayTrainer(model, loss="kl_div")
+        tr.q_stream, tr.l_stream = _FakeStream(), _FakeStream()
+        tr.window_schedule = windows
+        batch = syn.nway_batch(5, 2, 3, 6, 20, vocab=512, ragged=False, label_kind="teacher")
+        n0 = len(stubbed)
+        tr.train_step(batch)
+        seqs[windows] = list(stubbed[n0:])
+        assert tr.global_step == 1
+    assert sorted(seqs[True]) == sorted(seqs[False]) and seqs[True] != seqs[False]
+    # free-running: the query tower's whole forward (its embedding kernel first) is enqueued before the passage tower's first launch;
+    # windowed: the passage tower's embedding kernel comes first and the two towers' attention launches alternate
+    first_attn = [i for i, n in enumerate(seqs[True]) if n.startswith("cldrd_attention_fwd")]
+    assert len(first_attn) >= 4
+    emb = [i for i, n in enumerate(seqs[True]) if n == "cldrd_embed_ln_fwd"]
+    assert len(emb) == 2 and emb[1] - emb[0] <= 3           # both embedding launches at the very start of the windowed forward
+
+
+
+class _FakeEvent:
+    def record(self, stream=None):
+        pass
 
 
 class _Null:
@@ -141,3 +178,6 @@ def test_would_pack_rules():
     assert not enc.would_pack([10] * M, M, L)         # 640 tokens < 1024 <= 2048 padded rows: stays padded
     assert enc.would_pack([10] * 16, 16, L)           # 160 of 512: both small-M
     assert not enc.would_pack([31] * M, M, L)         # 3 % padding: not worth the row moves
+
+
+_MAIN = _FakeStream()

@@ -137,7 +137,7 @@ def test_attention_fp16_dropout_bits_match_the_hash(nseq, L, H, p):
     assert torch.equal(outs[0], outs[1])
     # bits vs hash: dQ and dK bit for bit.  dV differs in the LAST fp16 bit of <0.5 % of its elements: with the hash the compiler rounds
     # p * 1/(1-p_drop) to fp16 ONCE (v_fma_mix), with the bits the AND sits between the fp32 multiply and the conversion (two roundings), so
-    # about one probability in 2^14 differs by an fp16 ulp (tools/attn_bits_debug.py: 431 of 73728 (key, head) rows, max |diff| one ulp).
+    # about one probability in 2^14 differs by an fp16 ulp (measured in round 4: 431 of 73728 (key, head) rows, max |diff| one ulp).
     # A wrong keep bit would move dV by p * dO ~ 1e-2, forty ulps.
     assert torch.equal(outs[1][:, :2 * d], outs[2][:, :2 * d])
     dv1, dv2 = outs[1][:, 2 * d:].float(), outs[2][:, 2 * d:].float()
@@ -297,13 +297,13 @@ def test_non_finite_gradients_skip_the_step_and_training_continues(monkeypatch):
         tr.norm_partial[ops.sqnorm_blocks() // 2] = float("nan")
         real()
     tr._norm_launches = poisoned
-    monkeypatch.setenv("CLDRD_NORM_SINK", "0")      # the late piece by a separate pass: it then sees the poisoned flat_g
+    tr.use_norm_sink = False      # (test hook) the late piece by a separate pass: it then sees the poisoned flat_g
     tr.train_step(batch)
     torch.cuda.synchronize()
     assert tr.clip[2].item() == 1.0 and torch.equal(tr.flat_p, p1) and torch.equal(tr.m, m1)
     assert tr._scale_state[3].item() == 1.0 and tr._scale_state[4].item() == -2.0
     tr._norm_launches = real
-    monkeypatch.delenv("CLDRD_NORM_SINK")
+    tr.use_norm_sink = True
     tr.train_step(batch)
     torch.cuda.synchronize()
     assert tr.clip[2].item() == 0.0 and not torch.equal(tr.flat_p, p1) and torch.isfinite(tr.flat_p).all()
@@ -424,13 +424,13 @@ def test_skipped_steps_do_not_advance_adams_bias_correction(graph, monkeypatch):
         Bt.flat_g[-1] = float("nan")
         real()
     Bt._norm_launches = poisoned
-    monkeypatch.setenv("CLDRD_NORM_SINK", "0")      # the poisoned step takes the separate norm pass (which re-reads flat_g)
+    Bt.use_norm_sink = False      # (test hook) the poisoned step takes the separate norm pass (which re-reads flat_g)
     p0 = Bt.flat_p.clone()
     Bt.train_step(batch)                    # skipped
     torch.cuda.synchronize()
     assert torch.equal(Bt.flat_p, p0) and Bt.skipped_steps() == 1
     Bt._norm_launches = real
-    monkeypatch.delenv("CLDRD_NORM_SINK")
+    Bt.use_norm_sink = True
     for _ in range(3):
         Bt.train_step(batch)
     torch.cuda.synchronize()
@@ -449,7 +449,7 @@ def test_skipped_steps_do_not_advance_adams_bias_correction(graph, monkeypatch):
 
 @pytest.mark.parametrize("T,d,p,branch", [(300, 768, 0.0, True), (1000, 768, 0.1, True), (130, 128, 0.1, False), (2050, 768, 0.0, False)])
 def test_layernorm_bwd_fp16_gradient_stream(T, d, p, branch):
-    """Round 5: the gradient stream itself is fp16 (dy in, dx out; CLDRD_GRAD_STREAM=fp16, the default of the all-fp16 mode).  Same arithmetic as the
+    """Round 5: the gradient stream itself is fp16 (dy in, dx out; the default of the fp16 mode).  Same arithmetic as the
     fp32-stream kernel on the same (fp16-representable) inputs: dx equals the fp32-stream dx rounded once to fp16, the dropped operand copy and the
     parameter-gradient sums are bit-identical; without dropout no second tensor is written at all."""
     x = rnd(51, (T, d))
@@ -513,16 +513,17 @@ def test_fp16_stream_row_helpers():
 
 
 def test_fp16_and_fp32_gradient_streams_agree_end_to_end(monkeypatch):
-    """The whole backward of a small model with the fp16 stream (default) and with CLDRD_GRAD_STREAM=fp32 from the same state: every
+    """The whole backward of a small model with the fp16 stream (default) and with the fp32 stream (test hook `_grad_stream16 = False`) from the same state: every
     parameter-gradient tensor agrees to fp16 rounding noise (cosine >= 0.99999 per tensor, norms to 1e-3)."""
     cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=3, max_position_embeddings=64,
                         dropout=0.1, attention_dropout=0.1)
     batch = syn.nway_batch(4680, 4, 6, 10, 40, vocab=cfg.vocab_size, ragged=True, label_kind="teacher")
     grads = {}
     for mode in ("fp16", "fp32"):
-        monkeypatch.setenv("CLDRD_GRAD_STREAM", mode)
         monkeypatch.setenv("CLDRD_GRAPH", "0")
         model = selftest.build_tiny_model(cfg, seed=5).cuda().train()
+        for t in model.towers():
+            t._grad_stream16 = mode == "fp16"
         tr = NwayTrainer(model, loss="kl_div", learning_rate=1e-4, warmup_steps=0, total_steps=10)
         assert tr.amp16 and all(t.grad_stream16 == (mode == "fp16") for t in model.towers())
         for t in model.towers():
@@ -549,7 +550,7 @@ def test_clip_norm_from_the_kernels_that_write_the_gradients(graph, monkeypatch)
     """Round 5 (norm sink): the passage tower's layer gradients are complete only behind its last weight-gradient group; their share of the clip
     norm now comes from that group's slab reduction and from the LayerNorm-parameter reduction (sums of squares of what they write) instead of
     a separate pass.  DistilBERT-width model at a token count where the group splits the tokens (slabs): the sink must be in use, the norm
-    must equal the norm of the whole gradient buffer, and the step must equal the step taken with the separate pass (CLDRD_NORM_SINK=0)
+    must equal the norm of the whole gradient buffer, and the step must equal the step taken with the separate pass (`use_norm_sink = False`)
     outside the embedding atomics."""
     monkeypatch.setenv("CLDRD_GRAPH", graph)
     cfg = EncoderConfig(arch="distilbert", vocab_size=2048, dim=768, n_heads=12, hidden_dim=3072, n_layers=2, max_position_embeddings=128,
@@ -558,9 +559,9 @@ def test_clip_norm_from_the_kernels_that_write_the_gradients(graph, monkeypatch)
     batch = {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in batch.items()}
     res = {}
     for sink in ("1", "0"):
-        monkeypatch.setenv("CLDRD_NORM_SINK", sink)
         model = selftest.build_tiny_model(cfg, seed=2).cuda().train()
         tr = NwayTrainer(model, loss="kl_div", learning_rate=1e-4, warmup_steps=0, total_steps=100)
+        tr.use_norm_sink = sink == "1"
         for _ in range(5):
             tr.train_step(batch)
         torch.cuda.synchronize()

@@ -116,25 +116,25 @@ def test_flat_ip_search_matches_oracle(n, d, nq, k):
     assert st["exhaustive"] or st["scans"] >= (nq + index.query_tile - 1) // index.query_tile
 
 
-@pytest.mark.parametrize("env", [{}, {"CLDRD_TOPK_PROBE": "0"}, {"CLDRD_QUERY_TILE": "128"}])
-def test_multi_pass_search_switches_give_the_same_answer(env, monkeypatch):
-    """A search of several passes (more than two query tiles) with the probe pass off / with 128-query tiles: the exact result cannot
-    depend on how the thresholds were found or how the queries were tiled - scores and ids against the oracle, and equal to the default's."""
+@pytest.mark.parametrize("hook", [{}, {"probe": False}, {"query_tile_request": 128}])
+def test_multi_pass_search_switches_give_the_same_answer(hook):
+    """A search of several passes (more than two query tiles) with the probe pass off / with 128-query tiles (test hooks of FlatIPIndex, set
+    before the shard is attached): the exact result cannot depend on how the thresholds were found or how the queries were tiled - scores
+    and ids against the oracle, and equal to the default's."""
     n, d, nq, k = 60000, 768, 700, 100
     emb = syn.corpus_embeddings(21, n, d)
     q = syn.corpus_embeddings(22, nq, d)
     ids = np.arange(n, dtype=np.int64)
-    for kk, vv in env.items():
-        monkeypatch.setenv(kk, vv)
     index = RU.construct_flatindex_from_embeddings(emb, ids)
+    for kk, vv in hook.items():
+        setattr(index, kk, vv)
     RU.convert_index_to_gpu(index, 0, False)
+    assert index.query_tile == (128 if hook.get("query_tile_request") == 128 else 256)
     D, I = index.search(q, k)
     st = dict(index.last_stats)
     assert not st["exhaustive"] and st["scans"] >= 3
     Dr, Ir = R.flat_ip_search(emb, ids, q[:64], k)
     same_ranking(D[:64], I[:64], Dr, Ir)
-    for kk in env:
-        monkeypatch.delenv(kk)
     index2 = RU.construct_flatindex_from_embeddings(emb, ids)
     RU.convert_index_to_gpu(index2, 0, False)
     D2, I2 = index2.search(q, k)
