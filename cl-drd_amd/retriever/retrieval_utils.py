@@ -354,6 +354,9 @@ class FlatIPIndex:
             stats["candidates"] = int(c_all.clamp(max=CAND_CAP).sum().item())
         bad = np.nonzero(status)[0]
         stats["unproven_first_pass"] = int(bad.size)
+        # why (status bits of cldrd_flatip_search): 1 too few candidates, 2 candidate list overflowed, 4 the scan dropped hits, 8 threshold above
+        # t^ - 2 eps, 16 the kept set (k + the 2 eps band) does not fit its buffer
+        stats["status_bits_first_pass"] = {int(b): int(((status & b) != 0).sum()) for b in (1, 2, 4, 8, 16) if ((status & b) != 0).any()}
         stats["fallback_queries"] = 0
         attempt = 0
         thr_h = eps_h = None
