@@ -222,10 +222,15 @@ class CachedSequenceDataset(torch.utils.data.Dataset):
         mask = (np.arange(width)[None, :] < lens[:, None]).astype(np.int64)
         if self.pad_id != 0:
             ids = np.where(mask == 1, ids, self.pad_id)
-        return {"seq": {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask)}, "id": [int(k) for k in self.cache.keys[a:z]]}
+        # "lengths" (host-side token counts): what lets the encoder pack the batch; given here so that nobody has to derive them from the mask
+        return {"seq": {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "lengths": lens.astype(np.int64).tolist()},
+                "id": np.asarray(self.cache.keys[a:z]).tolist()}
 
-    def loader(self, num_workers: int = 2):
-        return torch.utils.data.DataLoader(self, batch_size=None, shuffle=False, num_workers=num_workers)
+    def loader(self, num_workers: int = 2, pin_memory: bool = False):
+        """whole batches (already collated); ``pin_memory``: the loader's pinning thread stages them, so the H2D copies of the encode loop are
+        asynchronous (retriever.index_text uses it)"""
+        kw = dict(prefetch_factor=4, persistent_workers=False) if num_workers > 0 else {}
+        return torch.utils.data.DataLoader(self, batch_size=None, shuffle=False, num_workers=num_workers, pin_memory=bool(pin_memory) and torch.cuda.is_available(), **kw)
 
 
 class SyntheticSequenceDataset(torch.utils.data.Dataset):

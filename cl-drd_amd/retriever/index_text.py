@@ -66,7 +66,7 @@ def collection_loader(path, tokenizer, max_length, is_query, token_cache_dir, ra
     if token_cache_dir:
         cache = SequenceTokenCache.open_or_build(token_cache_dir, path, tokenizer, max_length, rank, world)
         lo, hi = ShardedFlatIPIndex.shard_bounds(len(cache), world, rank)
-        return CachedSequenceDataset(cache, lo, hi, batch_size=512, pad_id=int(getattr(tokenizer, "pad_token_id", 0) or 0)).loader()
+        return CachedSequenceDataset(cache, lo, hi, batch_size=512, pad_id=int(getattr(tokenizer, "pad_token_id", 0) or 0)).loader(pin_memory=True)
     dataset = SequenceDataset.create_from_seqs_file(path, tokenizer, max_length, is_query=is_query)
     lo, hi = ShardedFlatIPIndex.shard_bounds(len(dataset), world, rank)
     dataset.ids, dataset.seqs = dataset.ids[lo:hi], dataset.seqs[lo:hi]
@@ -98,7 +98,7 @@ def main(args):
     if getattr(args, "token_cache_stem", ""):
         cache = SequenceTokenCache.load(args.token_cache_stem, {"max_length": args.max_length})
         lo, hi = ShardedFlatIPIndex.shard_bounds(len(cache), world, rank)
-        text_loader = CachedSequenceDataset(cache, lo, hi, batch_size=512).loader(num_workers=int(getattr(args, "loader_workers", 2)))
+        text_loader = CachedSequenceDataset(cache, lo, hi, batch_size=512).loader(num_workers=int(getattr(args, "loader_workers", 2)), pin_memory=True)
     elif args.synthetic_rows:
         lo, hi = ShardedFlatIPIndex.shard_bounds(args.synthetic_rows, world, rank)
         dataset = SyntheticSequenceDataset(hi - lo, args.max_length, first_id=lo)

@@ -46,6 +46,7 @@ QUERY_TILE = 128             # the reference searches in batches of 128 (retriev
                              # share one pass over the index (FlatIPIndex.query_tile = 256: the index bytes are read once per 256 queries)
 EST_CHUNK = 1024             # queries per threshold-estimate GEMM
 MAX_ATTEMPTS = 12
+PROGRESS_HOOK = None         # tools: callable(timings dict) every 500 batches of get_embeddings_from_scratch
 
 
 def batch_to_device(batch, target_device: torch.device):
@@ -62,11 +63,11 @@ def batch_to_device(batch, target_device: torch.device):
             seq["lengths"] = lens.tolist()
     for key in batch:
         if isinstance(batch[key], torch.Tensor):
-            batch[key] = batch[key].to(target_device)
+            batch[key] = batch[key].to(target_device, non_blocking=True)          # asynchronous when the loader pinned the batch
         if isinstance(batch[key], dict) or hasattr(batch[key], "keys"):
             for sub_key in batch[key]:
                 if isinstance(batch[key][sub_key], torch.Tensor):
-                    batch[key][sub_key] = batch[key][sub_key].to(target_device)
+                    batch[key][sub_key] = batch[key][sub_key].to(target_device, non_blocking=True)
     return batch
 
 
@@ -125,6 +126,8 @@ def get_embeddings_from_scratch(model, dataloader, use_fp16, is_query, show_prog
         assert isinstance(text_ids, list)
         embeddings_ids.extend(text_ids)
         tm["batches"] += 1
+        if PROGRESS_HOOK is not None and tm["batches"] % 500 == 0:
+            PROGRESS_HOOK(tm)
         t_prev = time.perf_counter()
     if pending is not None:
         collect(pending)

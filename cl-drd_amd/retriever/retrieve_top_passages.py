@@ -138,6 +138,7 @@ def main(args):
         print("timings: " + " ".join(f"{k}={v:.3f}" for k, v in timings.items()) +
               f" | search stats: scans={st.get('scans')} rescans={st.get('rescans')} fallback={st.get('fallback_queries')}")
     main.last_timings = timings
+    main.last_search_stats = dict(getattr(index.local, "last_stats", {}) or {})
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

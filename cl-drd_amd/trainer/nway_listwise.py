@@ -145,7 +145,8 @@ class NwayTrainer:
         # test hooks (tests/test_gpu_model.py, test_gpu_amp16.py prove the default path equal to the plain one they select; not configuration):
         self.zero_all_grads = False        # True: zero the whole gradient buffer and accumulate instead of writing every gradient once
         self.use_norm_sink = True          # False: the late clip-norm piece by a separate pass over the gradients
-        self.window_schedule = True        # False: the query tower runs free on the second stream (the schedule of rounds 2-5)
+        self.window_schedule = False       # True: the query tower enqueued in slices released at the passage tower's LayerNorm / attention launches
+                                           # (round 6, measured and NOT adopted: 11.58-11.92 ms per cfg2 step against 11.01 free-running, see forward_backward)
         # CLDRD_AMP=fp16 towers (encoder.py: amp16): the loss scale lives in device memory (hip_ops.new_loss_scale_state).  It is set every
         # step from dL/dCLS (ops.loss_scale_adapt: a power of two that puts the largest entering gradient at 2^11..2^12); what is kept of
         # torch.cuda.amp.GradScaler (the reference: nway_listwise_1.py:355-359) is its safety net: a non-finite gradient norm skips the step
@@ -291,11 +292,15 @@ class NwayTrainer:
             for tower in model.towers():
                 if not getattr(tower, "_t_fresh", False):
                     tower.refresh_transposed()
-        # Round 6: the query tower is enqueued in SLICES, each released by an event the main stream records at the start of one of the passage
-        # tower's HBM-bound kernels (LayerNorm, attention: `window`), instead of running free next to everything.  Its ~130 launches are 1 % of
-        # the FLOPs, but a 64 x 64-tile GEMM that lands next to one of the passage tower's large GEMMs takes up to 48 CUs for 7-10 us out of a grid
-        # sized to whole rounds of 256 CUs (0.32 ms per step of interference, profiles/r05_microbench.txt section 14); next to a kernel that
-        # waits for HBM it costs nothing.  Same launches, same arithmetic, another enqueue order (test hook: window_schedule = False).
+        # Round 6 experiment, OFF by default (`window_schedule`): the query tower enqueued in SLICES, each released by an event the main stream
+        # records at the start of one of the passage tower's HBM-bound kernels (LayerNorm, attention), instead of running free next to everything -
+        # the idea being that a 64 x 64-tile GEMM next to a kernel that waits for HBM costs nothing, while next to a large GEMM (a grid sized to
+        # whole rounds of 256 CUs) it delays a round (0.32 ms of interference per step, profiles/r05_microbench.txt section 14).  Measured on one
+        # box, interleaved rounds (profiles/r06_microbench.txt section 1): free-running 11.01 ms per step; slices of 3 / 2 groups per attention /
+        # LayerNorm window 11.66; 2 / 1: 11.92; 4 / 3: 11.72; 7 / 7: 11.58.  The tighter the gating the slower: a gated chain of ~130 dependent
+        # small launches finishes late (every release waits for the main stream to REACH a window, and the chain then still needs its own
+        # 7-10 us per launch), so the join in front of the loss / the last weight-gradient group waits for it - that costs more than the
+        # interference it avoids.  The stepping API (encoder.Stepper) stays: encode / backward are built on it.
         windows = side is not main and self.window_schedule
         self._windows_on = windows
         p_ids, p_mask = nw["input_ids"].reshape(bz * nway, L), nw["attention_mask"].reshape(bz * nway, L)

@@ -11,7 +11,41 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 
 
+def trace(rows, workers):
+    """the encode loop at scale with a progress line every 500 batches: host phase deltas + the caching allocator's state"""
+    import time_cfg5_full as T
+    d = "/tmp/cldrd_hostprof"
+    os.makedirs(d, exist_ok=True)
+    stem = d + "/s.L256.seqcache"
+    T.build_token_cache(stem, rows, 256, procs=24)
+    import torch
+    from cldrd_amd.dataset import CachedSequenceDataset, SequenceTokenCache
+    from cldrd_amd.encoder import EncoderConfig
+    from cldrd_amd.models import NwayDualEncoder
+    from cldrd_amd.retriever import retrieval_utils as RU
+    cache = SequenceTokenCache.load(stem, {"max_length": 256})
+    torch.manual_seed(0)
+    model = NwayDualEncoder(EncoderConfig(arch="distilbert"), share_weights=False).cuda().eval()
+    last = {"t": time.perf_counter(), "tm": {}}
+
+    def hook(tm):
+        now = time.perf_counter()
+        st = torch.cuda.memory_stats()
+        d_ = {k: tm[k] - last["tm"].get(k, 0.0) for k in ("load_s", "h2d_enqueue_s", "d2h_wait_s", "gather_s")}
+        print(f"batch {tm['batches']:6d}: {500 * 512 / (now - last['t']):8.0f} passages/s | per batch ms: load {2 * d_['load_s']:.2f} enqueue {2 * d_['h2d_enqueue_s']:.2f} "
+              f"gpu-wait {2 * d_['d2h_wait_s']:.2f} gather {2 * d_['gather_s']:.2f} | reserved {st['reserved_bytes.all.current'] / 2**30:.1f} GiB allocated "
+              f"{st['allocated_bytes.all.current'] / 2**30:.1f} GiB, device mallocs {st['num_device_alloc']} frees {st['num_device_free']} retries {st['num_alloc_retries']}", flush=True)
+        last["t"], last["tm"] = now, dict(tm)
+    RU.PROGRESS_HOOK = hook
+    t0 = time.perf_counter()
+    RU.get_embeddings_from_scratch(model, CachedSequenceDataset(cache, 0, None, 512).loader(num_workers=workers, pin_memory=True), True, False)
+    print(f"total: {rows / (time.perf_counter() - t0):.0f} passages/s; {RU.get_embeddings_from_scratch.last_timings}")
+    shutil.rmtree(d, ignore_errors=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "trace":
+        return trace(int(sys.argv[2]) if len(sys.argv) > 2 else 2500000, int(sys.argv[3]) if len(sys.argv) > 3 else 4)
     rows = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     import time_cfg5_full as T

@@ -2,9 +2,9 @@
 """What parts of the training step cost on the critical path: the cfg2 step (graph replay) with parts SKIPPED (timing only, wrong
 results): the query tower's forward / backward (side stream), the AdamW + norm tail.  One process, interleaved rounds.
 
-Modes: full (the default step: query tower in window-released slices, round 6) | free (the query tower running free on the second stream, the
-schedule of rounds 2-5) | win<a><l> (window schedule releasing a / l groups per attention / LayerNorm window, e.g. win32 = the default,
-win21, win43, win77) | no_q_bwd | no_q | no_opt (parts skipped; these run on the free schedule) | opt_side (AdamW moved to the head of the next step on
+Modes: full (the default step: the query tower runs free on the second stream) | win<a><l> (round-6 experiment: the query tower in slices of
+a / l groups released at the passage tower's attention / LayerNorm launches, e.g. win32, win21, win43, win77) | no_q_bwd | no_q | no_opt
+(parts skipped) | opt_side (AdamW moved to the head of the next step on
 the second stream: timing only)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,9 +23,8 @@ def build(mode):
     model = NwayDualEncoder(EncoderConfig(arch="distilbert"), share_weights=False).to(dev).train()
     tr = NwayTrainer(model, loss="kl_div", T=1.0, learning_rate=7e-6, warmup_steps=4000, total_steps=100000)
     qe = model.query_encoder
-    if mode == "free" or mode.startswith("no_"):
-        tr.window_schedule = False
     if mode.startswith("win") and len(mode) == 5:
+        tr.window_schedule = True
         tr.FWD_SLICE = tr.BWD_SLICE = {"attn": int(mode[3]), "ln": int(mode[4])}
     if mode in ("no_q", "no_q_bwd"):
         real_enc, real_bwd = qe.encode, qe.backward_from_cls
@@ -62,7 +61,7 @@ def build(mode):
 
 batch = syn.nway_batch(4680, B, N, Lq, L, ragged=False, label_kind="teacher")
 batch = {k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v.to(dev)) for k, v in batch.items()}
-modes = [a for a in sys.argv[1:] if not a.isdigit()] or ["full", "free", "no_q_bwd", "no_q", "no_opt"]
+modes = [a for a in sys.argv[1:] if not a.isdigit()] or ["full", "no_q_bwd", "no_q", "no_opt"]
 ROUNDS = next((int(a) for a in sys.argv[1:] if a.isdigit()), 3)
 trs = {m: build(m) for m in modes}
 for m, tr in trs.items():

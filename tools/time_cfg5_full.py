@@ -81,7 +81,8 @@ def main():
     ap.add_argument("--top_k", type=int, default=1000)
     ap.add_argument("--workdir", default="/tmp/cldrd_cfg5_full")
     ap.add_argument("--out", default="")
-    ap.add_argument("--workers", type=int, default=4)
+    ap.add_argument("--workers", type=int, default=8)
+    ap.add_argument("--init_std", type=float, default=0.06)
     ap.add_argument("--force", action="store_true")
     a = ap.parse_args()
     os.makedirs(a.workdir, exist_ok=True)
@@ -113,7 +114,11 @@ def main():
     print(lines[-1], flush=True)
 
     torch.manual_seed(0)
-    model = NwayDualEncoder(EncoderConfig(arch="distilbert"), share_weights=False)
+    # weights drawn 3 x wider than the HF init (0.06 instead of 0.02): the random encoder's CLS vectors are then as diverse as a trained dual
+    # encoder's (pairwise cosine 0.87, q.p spread ~19 % of its mean; the reference model: 17 +- 2).  At the HF init scale they are
+    # near-duplicates (cosine 0.993, q.p = 759 +- 0.6: a spread of 8e-4, below what ANY 16-bit scan resolves) and every query takes the exact
+    # fp32 fallback: measured 110 s for the search phase (profiles/r06_cfg5_full.txt, first run)
+    model = NwayDualEncoder(EncoderConfig(arch="distilbert", initializer_range=a.init_std), share_weights=False)
     mdir = os.path.join(a.workdir, "model")
     model.query_encoder.save_pretrained(mdir)
     ckpt = os.path.join(a.workdir, "checkpoint_1.pth.tar")
@@ -157,6 +162,7 @@ def main():
                      ("index_to_gpu_s", "attach: H2D of the fp32 rows + mean / centre / fp16 shadow / sample"),
                      ("search_and_merge_s", f"search ({a.queries} x top-{a.top_k}, whole index on this GPU) + result download"), ("run_file_s", "run file")):
         lines.append(f"  {label:<72s} {tr.get(k, float('nan')):9.2f} s")
+    lines.append(f"  search statistics: {getattr(RTP.main, 'last_search_stats', None)}")
     nlines = sum(1 for _ in open(out))
     lines.append(f"  run file: {os.path.getsize(out) / 1e6:.1f} MB, {nlines} lines")
     lines.append("")
