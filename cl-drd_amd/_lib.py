@@ -19,12 +19,12 @@ SIGNATURES = {
     "cldrd_version": (ci, []),
     "cldrd_device_ok": (ci, []),
     "cldrd_set_tuning": (ci, [C.c_char_p, ci]),
-    "cldrd_gemm_nt_bf16": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp]),
-    "cldrd_gemm_nt_bf16_ln": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp, vp, vp, vp, vp]),
+    "cldrd_gemm_nt16": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp]),
+    "cldrd_gemm_nt16_ln": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp, vp, vp, vp, vp]),
     "cldrd_gemm_nt_splitk_workspace": (csz, [ci, ci, ci]),
-    "cldrd_gemm_nt_bf16_ws": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp, vp, vp, vp, vp, vp, csz, vp]),
+    "cldrd_gemm_nt16_ws": (ci, [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, cf, cf, cull, ci, ci, ci, vp, vp, vp, vp, vp, vp, csz, vp]),
     "cldrd_wgrad_splits": (ci, [ci, ci, ci]),
-    "cldrd_wgrad_bf16": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, csz, ci, vp]),
+    "cldrd_wgrad16": (ci, [vp, vp, vp, vp, ci, ci, ci, ci, ci, vp, csz, ci, vp]),
     "cldrd_wgrad_group_workspace": (csz, [vp, vp, vp, ci]),
     "cldrd_wgrad_group": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, csz, ci, vp]),
     "cldrd_attention_fwd": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),

@@ -333,18 +333,18 @@ int cldrd_gemm_nt_ring_scan(const GemmNtArgs& a, hipStream_t st);               
 int cldrd_topk_scan_stream(const void* Q, const void* P, int nq, long long rows, int d, const float* thr, int* counts, int* cand_rows,
                            float* cand_scores, int cap, int f16, hipStream_t st);   // topk.hip
 
-extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+extern "C" int cldrd_gemm_nt16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                      const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
                                      const float* ln_beta, void* c_copy_bf16, float* workspace, size_t workspace_bytes, void* stream);
-extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+extern "C" int cldrd_gemm_nt16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                      const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
                                      const float* ln_beta, void* stream);
 
-// Bytes of workspace with which cldrd_gemm_nt_bf16_ws splits the K range of this shape over several workgroups (0: it does not)
+// Bytes of workspace with which cldrd_gemm_nt16_ws splits the K range of this shape over several workgroups (0: it does not)
 extern "C" size_t cldrd_gemm_nt_splitk_workspace(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK != 0 || N % 8 != 0) return 0;
     if (const int k64 = nt64_splits(M, N, K)) return k64 > 1 ? (size_t)k64 * M * N * sizeof(float) : 0;
@@ -352,28 +352,28 @@ extern "C" size_t cldrd_gemm_nt_splitk_workspace(int M, int N, int K) {
     return ks > 1 ? (size_t)ks * M * N * sizeof(float) : 0;
 }
 
-extern "C" int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+extern "C" int cldrd_gemm_nt16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                   const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                   int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                   int io_f16, void* stream) {
-    return cldrd_gemm_nt_bf16_ln(A, B, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, preact, gelu_pre, act, alpha, dropout_p, seed,
+    return cldrd_gemm_nt16_ln(A, B, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, preact, gelu_pre, act, alpha, dropout_p, seed,
                                  out_f32, res_f32, io_f16, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 // The same with the fp32 residual given as a LayerNorm still to be applied (GemmNtArgs::ln_*): all four pointers or none.
-extern "C" int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+extern "C" int cldrd_gemm_nt16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                      const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,
                                      const float* ln_beta, void* stream) {
-    return cldrd_gemm_nt_bf16_ws(A, B, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, preact, gelu_pre, act, alpha, dropout_p, seed, out_f32,
+    return cldrd_gemm_nt16_ws(A, B, C, M, N, K, lda, ldb, ldc, bias, residual, ldr, preact, gelu_pre, act, alpha, dropout_p, seed, out_f32,
                                  res_f32, io_f16, ln_mean, ln_rstd, ln_gamma, ln_beta, nullptr, nullptr, 0, stream);
 }
 
 // The same with a workspace: small-M problems whose one-pass grid would leave most CUs idle (the CLS-only last layer, the query
 // tower: M = 256 rows, K up to 3072 -> 12 workgroups walking 48 K tiles each) are split along K over cldrd_gemm_nt_splitk_workspace()
 // bytes of fp32 partials and finished by a second launch (fixed summation order; same epilogue).  workspace = null: one pass.
-extern "C" int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+extern "C" int cldrd_gemm_nt16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                                      const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
                                      int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32,
                                      int io_f16, const float* ln_mean, const float* ln_rstd, const float* ln_gamma,

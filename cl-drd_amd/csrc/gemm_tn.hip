@@ -640,7 +640,7 @@ extern "C" int cldrd_wgrad_group(const void* const* A, const void* const* B, flo
 }
 
 // the single-problem form (a group of one).  workspace floats needed: cldrd_wgrad_splits(M, N1, N2) * (N1*N2 + N1)
-extern "C" int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, float* dbias, int M, int N1, int N2, int lda, int ldb,
+extern "C" int cldrd_wgrad16(const void* A, const void* B, float* dW, float* dbias, int M, int N1, int N2, int lda, int ldb,
                                 float* workspace, size_t workspace_bytes, int accumulate, void* stream) {
     return cldrd_wgrad_group(&A, &B, &dW, &dbias, &M, &N1, &N2, &lda, &ldb, 1, workspace, workspace_bytes, accumulate, stream);
 }

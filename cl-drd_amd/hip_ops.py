@@ -251,7 +251,7 @@ def gemm_nt(A, B, out, M=None, *, bias=None, residual=None, preact=None, gelu_pr
             ws_bytes = _SPLITK_WS[key] = int(_lib.load().cldrd_gemm_nt_splitk_workspace(M, N, K))
         if ws_bytes:
             ws = torch.empty(ws_bytes // 4, dtype=F32, device=A.device)
-    call("cldrd_gemm_nt_bf16_ws", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
+    call("cldrd_gemm_nt16_ws", _p(A), _p(B), _p(out), M, N, K, A.stride(0), B.stride(0), out.stride(0), _p(bias),
          _p(residual), residual.stride(0) if residual is not None else 0, _p(preact), _p(gelu_pre), act, alpha, dropout_p, seed,
          out_f32, res_f32, io_f16, _p(mean), _p(rstd), _p(gamma), _p(beta), _p(out_copy), _p(ws), ws_bytes, _stream())
     return out
@@ -283,7 +283,7 @@ def wgrad(dY, X, dW, M, workspace, accumulate=False, dbias=None):
         raise ValueError("wgrad: operands have fewer than M rows")
     if dbias is not None:
         _chk(dbias, F32, "dbias", 1)
-    call("cldrd_wgrad_bf16", _p(dY), _p(X), _p(dW), _p(dbias), M, N1, N2, dY.stride(0), X.stride(0), _p(workspace),
+    call("cldrd_wgrad16", _p(dY), _p(X), _p(dW), _p(dbias), M, N1, N2, dY.stride(0), X.stride(0), _p(workspace),
          workspace.numel() * 4, (1 if accumulate else 0) | (2 if f16 else 0), _stream())
     return dW
 

@@ -46,33 +46,36 @@ int cldrd_set_tuning(const char* key, int value);
  *   K % 64 == 0; A/B/C 16-byte aligned; out_f32 != 0 stores fp32 instead of bf16; res_f32 != 0: `residual` is fp32
  *   (the fp32 residual stream: out-projection / FFN2 add the fp32 LayerNorm output and store the fp32 pre-LN sum, as the
  *   reference's autocast does - trainer/multistep-curriculum/nway_listwise_1.py:334).
- *   io_f16 = 1: A, B and a 16-bit C are fp16 instead of bf16 (same MFMA rate, 11-bit significands); io_f16 = 3: fp16 A and B, bf16 C
- *   (the QKV projection of a forward whose attention kernels are bf16); the forward kernels
- *   (this one for M < 1024, attention_fwd for L <= 128, attention_cls_fwd, layernorm_fwd, embed_ln_fwd) take this format for the
- *   high-precision forward of the query tower; the backward entry points are bf16 only. */
-int cldrd_gemm_nt_bf16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+ *   fmt (enum cldrd_fmt16 below): the 16-bit format of A, B, a 16-bit C and the GELU tape.  The entry points are named "16", not "bf16": both
+ *   formats run at the same MFMA rate and fp16 is the DEFAULT arithmetic mode of the package (the reference's own, CLDRD_AMP in README.md). */
+enum cldrd_fmt16 {
+    CLDRD_FMT_BF16 = 0,          /* A, B, 16-bit C, preact / gelu_pre: bf16 (CLDRD_AMP=bf16: every operand of every pass) */
+    CLDRD_FMT_F16 = 1,           /* A, B and a 16-bit C: fp16 (evaluation passes of the fp16 mode; no preact / gelu_pre) */
+    CLDRD_FMT_F16_C_BF16 = 3,    /* fp16 A and B, bf16 C: the QKV projection of an evaluation pass whose attention kernels are bf16 */
+    CLDRD_FMT_F16_TAPE = 5       /* fp16 everywhere incl. preact / gelu_pre: a training pass of the fp16 mode */
+};
+int cldrd_gemm_nt16(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                        const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
-                       int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int io_f16,
+                       int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int fmt,
                        void* stream);
 
 /* The same GEMM with the fp32 residual given as a LayerNorm still to be applied: `residual` holds the pre-LN sum s (fp32, res_f32 = 1) and
  * the epilogue adds (s - ln_mean[m]) * ln_rstd[m] * ln_gamma[n] + ln_beta[n] - exactly what cldrd_layernorm_fwd would have written
  * as its fp32 output, which it then need not write (HF: hidden = LayerNorm(...); out = dense(x) + hidden).  All four ln_* or none. */
-int cldrd_gemm_nt_bf16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+int cldrd_gemm_nt16_ln(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                           const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
-                          int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int io_f16,
+                          int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int fmt,
                           const float* ln_mean, const float* ln_rstd, const float* ln_gamma, const float* ln_beta, void* stream);
 
 /* The same with a workspace: problems of fewer than 1024 rows whose one-pass grid would leave most CUs idle (CLS-only last layer, query
  * tower) are split along K: fp32 partials in `workspace` (cldrd_gemm_nt_splitk_workspace() bytes; 0 = this shape is not split), summed in
- * a fixed order and finished with the same epilogue by a second launch.  workspace = NULL: cldrd_gemm_nt_bf16_ln.
- * io_f16 here also serves M >= 1024 for the forward FFN flavours (bias + GELU [+ tape], bias [+ dropout] + fp32 LayerNorm-on-the-fly
- * residual -> fp32): csrc/gemm_nt_ring16.hip.  c_copy_bf16 (optional, with io_f16 and a 16-bit C): a bf16 copy of C - the tape entry the
- * backward's bf16 MFMAs read when the forward GEMM ran on fp16 operands (FFN1 writes h in fp16 for FFN2 and in bf16 for the weight gradient). */
+ * a fixed order and finished with the same epilogue by a second launch.  workspace = NULL: cldrd_gemm_nt16_ln.
+ * fmt != CLDRD_FMT_BF16 here also serves M >= 1024 (csrc/gemm_nt_ring16.hip).  c_copy_bf16: NULL (a bf16 copy of an fp16 C for the removed
+ * "bf16 tape under an fp16 forward" mode of rounds 3-5; kept in the signature, rejected when non-NULL with any format but CLDRD_FMT_F16). */
 size_t cldrd_gemm_nt_splitk_workspace(int M, int N, int K);
-int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
+int cldrd_gemm_nt16_ws(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc,
                           const float* bias, const void* residual, int ldr, void* preact, const void* gelu_pre,
-                          int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int io_f16,
+                          int act, float alpha, float dropout_p, unsigned long long seed, int out_f32, int res_f32, int fmt,
                           const float* ln_mean, const float* ln_rstd, const float* ln_gamma, const float* ln_beta,
                           void* c_copy_bf16, float* workspace, size_t workspace_bytes, void* stream);
 
@@ -85,7 +88,7 @@ int cldrd_gemm_nt_bf16_ws(const void* A, const void* B, void* C, int M, int N, i
  * workspace (floats): cldrd_wgrad_group_workspace(...) for a group (0 when no token split is chosen),
  * cldrd_wgrad_splits(M,N1,N2) * (N1 * N2 + N1) for the single-problem form. */
 int cldrd_wgrad_splits(int M, int N1, int N2);
-int cldrd_wgrad_bf16(const void* A, const void* B, float* dW, float* dbias, int M, int N1, int N2, int lda, int ldb,
+int cldrd_wgrad16(const void* A, const void* B, float* dW, float* dbias, int M, int N1, int N2, int lda, int ldb,
                      float* workspace, size_t workspace_bytes, int accumulate, void* stream);
 size_t cldrd_wgrad_group_workspace(const int* M, const int* N1, const int* N2, int n);
 int cldrd_wgrad_group(const void* const* A, const void* const* B, float* const* dW, float* const* dbias, const int* M,
@@ -96,7 +99,7 @@ int cldrd_wgrad_group(const void* const* A, const void* const* B, float* const* 
  * qkv: bf16 [nseq*L, 3*H*64] = Q | K | V;  mask: int64 [nseq, L], 0 = padded key, or NULL;
  * ctx: bf16 [nseq*L, H*64];  lse: fp32 [nseq, H, L] (NULL allowed in forward-only use). */
 int cldrd_attention_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
-                        float dropout_p, unsigned long long seed, int io_f16, void* stream);
+                        float dropout_p, unsigned long long seed, int fmt, void* stream);
 int cldrd_attention_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                         void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
 
@@ -108,13 +111,13 @@ long long cldrd_attention_bits_words(int nseq, int L, int H, float dropout_p);
 /* ctx_f16_copy (optional, bf16 pass only): the same context vectors in fp16 - the A operand of an fp16-operand out-projection GEMM (round 3:
  * the out-projection's operands carry most of the remaining logit drift of a 12-layer tower); ctx may then be NULL (no bf16 tape wanted). */
 int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
-                             float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy, void* stream);
+                             float dropout_p, unsigned long long seed, int fmt, void* drop_bits_out, void* ctx_f16_copy, void* stream);
 int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                              void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
                              void* stream);
-/* the same with a format flag: io_f16 != 0 - q / k / v, ctx, dctx and dqkv are fp16 (the all-fp16 training mode) */
+/* the same with a format: fmt != CLDRD_FMT_BF16 - q / k / v, ctx, dctx and dqkv are fp16 (a training pass of the fp16 mode) */
 int cldrd_attention_bwd_x(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
-                             void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits, int io_f16,
+                             void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits, int fmt,
                              void* stream);
 
 /* CLS-only attention of the LAST layer (the reference pools last_hidden_state[:, 0, :], models/nway_dual_encoder.py:52,56,64):
@@ -122,11 +125,11 @@ int cldrd_attention_bwd_x(const void* qkv, const long long* mask, const void* ct
  * probs: fp32 [nseq, H, L] (softmax row, saved for the backward); dkv: bf16 [nseq*L, 2*H*64] (every row written).
  * cldrd_add_rows_strided: dst[m * stride_rows] += src[m] for bf16 rows of d elements (puts the CLS-row gradients back). */
 int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L,
-                            int H, float dropout_p, unsigned long long seed, int io_f16, void* ctx_f16_copy, void* stream);
+                            int H, float dropout_p, unsigned long long seed, int fmt, void* ctx_f16_copy, void* stream);
 int cldrd_attention_cls_bwd(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
                             int nseq, int L, int H, float dropout_p, unsigned long long seed, void* stream);
 int cldrd_attention_cls_bwd_x(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
-                            int nseq, int L, int H, float dropout_p, unsigned long long seed, int io_f16, void* stream);
+                            int nseq, int L, int H, float dropout_p, unsigned long long seed, int fmt, void* stream);
 int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, int f32, void* stream);   /* f32: fp32 rows (fp32 gradient stream) */
 
 /* ---- embeddings + LayerNorm (HF Embeddings.forward, sa_layer_norm / output_layer_norm) --------------------

@@ -82,7 +82,7 @@ def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, p
         enc.backward_from_cls(tape, torch.zeros(M, 128), after_layer=hooks.append, accumulate=False)
         assert sorted(hooks) == list(range(-1, layers))        # every bucket reported once (the embedding block before the last weight-gradient group)
     kinds = set(stubbed)
-    assert "cldrd_gemm_nt_bf16_ws" in kinds and "cldrd_wgrad_group" in kinds and "cldrd_embed_ln_bwd" in kinds
+    assert "cldrd_gemm_nt16_ws" in kinds and "cldrd_wgrad_group" in kinds and "cldrd_embed_ln_bwd" in kinds
     assert ("cldrd_unpack_rows16" in kinds) == packed
 
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised check of cldrd_gemm_nt_bf16* against fp64 on the same rounded inputs: random M (1 .. 6000: both kernels, tails), N (multiples of 8),
+"""Randomised check of cldrd_gemm_nt16* against fp64 on the same rounded inputs: random M (1 .. 6000: both kernels, tails), N (multiples of 8),
 K (multiples of 64), operand format (bf16 / fp16), and every epilogue the encoder uses (bias, GELU with / without the tape, GELU gradient,
 bf16 / fp32 residual, LayerNorm on the fly, dropout, fp32 out, fp16 -> bf16 result, bf16 tape copy).  usage: tools/gemm_fuzz.py [cases] [seed]"""
 import os, sys, math

@@ -1,4 +1,5 @@
-# rocprofv3 --kernel-trace --stats of the index leg (L = 128 and L = 256) and of the retrieve leg; summaries -> gpurun_out/r05_*_summary.txt
+# rocprofv3 --kernel-trace --stats of the index leg (L = 128 and L = 256) and of the retrieve leg; summaries -> gpurun_out/<tag>_*_summary.txt
+export TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for L in 128 256; do
@@ -7,7 +8,8 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_ret -o r -- python3 $R/tools/retrieve_prof.py > $R/gpurun_out/prof_ret.log 2>&1
 cd $R
 python3 - <<'PY'
-import csv, glob
+import csv, glob, os
+TAG = os.environ.get('TAG', 'r06')
 out = []
 for L in (128, 256):
     f = glob.glob(f'gpurun_out/prof_idx{L}/**/*kernel_stats.csv', recursive=True)[0]
@@ -21,7 +23,7 @@ for L in (128, 256):
     for r in rows[:18]:
         out.append(f"{r['Name'][:92]:92s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['AverageNs'])/1e3:9.1f} {100*float(r['TotalDurationNs'])/tot:5.1f}%")
     out.append("")
-open('gpurun_out/r05_index_leg_summary.txt', 'w').write("\n".join(out) + "\n")
+open(f'gpurun_out/{TAG}_index_leg_summary.txt', 'w').write("\n".join(out) + "\n")
 print("\n".join(out))
 f = glob.glob('gpurun_out/prof_ret/**/*kernel_stats.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
@@ -31,7 +33,7 @@ out = ["# rocprofv3 --kernel-trace --stats -- python3 tools/retrieve_prof.py: 3 
        "", f"{'kernel':92s} {'calls':>6s} {'total_ms':>9s} {'avg_us':>9s} {'share':>6s}"]
 for r in rows[:16]:
     out.append(f"{r['Name'][:92]:92s} {int(r['Calls']):6d} {float(r['TotalDurationNs'])/1e6:9.2f} {float(r['AverageNs'])/1e3:9.1f} {100*float(r['TotalDurationNs'])/tot:5.1f}%")
-open('gpurun_out/r05_retrieve_summary.txt', 'w').write("\n".join(out) + "\n")
+open(f'gpurun_out/{TAG}_retrieve_summary.txt', 'w').write("\n".join(out) + "\n")
 print("\n".join(out))
 PY
 tail -1 gpurun_out/prof_ret.log

@@ -126,10 +126,21 @@ def main():
     del model
 
     idir = os.path.join(a.workdir, "index")
+    from cldrd_amd.retriever import retrieval_utils as RU
+    prog = {"t": time.perf_counter(), "tm": {}}
+
+    def progress(tm):          # every 500 batches (stdout only): does the loop's rate hold over 17 000 batches?
+        now = time.perf_counter()
+        d = {k: tm[k] - prog["tm"].get(k, 0.0) for k in ("load_s", "h2d_enqueue_s", "d2h_wait_s", "gather_s")}
+        print(f"  batch {tm['batches']:6d}: {500 * 512 / (now - prog['t']):8.0f} passages/s | per batch ms: loader {2 * d['load_s']:.2f} H2D+enqueue {2 * d['h2d_enqueue_s']:.2f} "
+              f"GPU wait {2 * d['d2h_wait_s']:.2f} gather {2 * d['gather_s']:.2f}", flush=True)
+        prog["t"], prog["tm"] = now, dict(tm)
+    RU.PROGRESS_HOOK = progress
     t0 = time.perf_counter()
     ipath = IT.main(IT.get_args(["--resume", ckpt, "--model_name_or_path", mdir, "--max_length", str(a.max_length), "--index_dir", idir,
                                  "--token_cache_stem", stem, "--loader_workers", str(a.workers)]))
     t_index = time.perf_counter() - t0
+    RU.PROGRESS_HOOK = None
     ti = IT.main.last_timings
     host = ti.get("encode_host_phases", {})
     lines.append("")
