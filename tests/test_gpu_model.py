@@ -446,7 +446,9 @@ def test_full_size_configs_match_reference_goldens(name, mode, monkeypatch):
             rel_bar = 3e-3 if tr.amp16 else 4e-3
             assert err <= rel_bar * np.abs(ref).max(), f"{name}: max|dlogit| {err:.4f} above {rel_bar:g} x max|logit| = {rel_bar * np.abs(ref).max():.4f}"
             if "logits_autocast_fp16" in g.files:
-                kmax, krms = (1.25, 1.25) if tr.amp16 else (1.5, 1.5)
+                # round 6 (keep the old bar where it holds): measured max / rms ratios cfg1 0.82 / 0.66, cfg2 0.67 / 0.66, cfg3 0.77 / 0.76,
+                # cfg4 0.64 / 0.62 - every config is back under the 1.0 x of rounds 3-4, which is asserted again (round 5 had loosened it to 1.25 x)
+                kmax, krms = (1.0, 1.0) if tr.amp16 else (1.5, 1.5)
                 assert err <= kmax * a16.max() and rms <= krms * np.sqrt(np.mean(a16 ** 2)), f"{name}: more than {kmax} x / {krms} x the reference's fp16-autocast drift"
         if "loss" in g.files:                                # cfg1 golden (round 1 layout)
             ref_loss, names, vals = float(g["loss"]), [str(n) for n in g["grad_norm_names"]], g["grad_norm_values"]
