@@ -55,6 +55,7 @@ SIGNATURES = {
     "cldrd_sqnorm_partial": (ci, [vp, csz, vp, ci, vp]),
     "cldrd_clip_coef": (ci, [vp, ci, cf, vp, vp]),
     "cldrd_copy_segments": (ci, [vp, vp, vp, ci, vp]),
+    "cldrd_zero_segments": (ci, [vp, vp, ci, vp]),
     "cldrd_adamw_step": (ci, [vp, vp, vp, vp, vp, vp, csz, cf, cf, cf, cf, cf, ci, vp, vp]),
     "cldrd_adamw_step_h16": (ci, [vp, vp, vp, vp, vp, vp, csz, cf, cf, cf, cf, cf, ci, vp, vp, csz, csz, vp]),
     "cldrd_cast_bf16": (ci, [vp, vp, csz, vp]),

@@ -150,6 +150,39 @@ extern "C" int cldrd_copy_segments(const void* const* src, void* const* dst, con
     return 0;
 }
 
+namespace {
+struct ZeroSegs { void* dst[8]; unsigned long long bytes[8]; int n; };
+__global__ __launch_bounds__(256) void zero_segments_kernel(ZeroSegs z) {
+    const int seg = blockIdx.y;
+    if (seg >= z.n) return;
+    uint4* d = (uint4*)z.dst[seg];
+    const size_t n16 = z.bytes[seg] / 16, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) d[i] = make_uint4(0, 0, 0, 0);
+}
+}  // namespace
+
+// n <= 8 device ranges set to zero in ONE launch (16-byte aligned, sizes multiples of 16): the embedding-table gradients of both towers at
+// the start of a training step (everything else of the gradient buffer is written, not accumulated; two FillFunctor launches until round 5).
+extern "C" int cldrd_zero_segments(void* const* dst, const size_t* bytes, int n, void* stream) {
+    CLDRD_CHECK(n >= 1 && n <= 8, "zero_segments: 1..8 segments");
+    ZeroSegs z;
+    size_t biggest = 0;
+    for (int i = 0; i < 8; ++i) {
+        z.dst[i] = i < n ? dst[i] : nullptr; z.bytes[i] = i < n ? bytes[i] : 0;
+        if (i < n) {
+            CLDRD_CHECK(dst[i] != nullptr && ((uintptr_t)dst[i] % 16 == 0) && bytes[i] % 16 == 0, "zero_segments: 16-byte aligned ranges");
+            biggest = biggest > bytes[i] ? biggest : bytes[i];
+        }
+    }
+    z.n = n;
+    size_t blocks = (biggest / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_segments_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, (hipStream_t)stream, z);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
 // One tiny launch that writes this step's values (two seed words, lr, Adam step size for bias-correction step `adam_step`) to device
 // memory, in stream order in front of the replay that reads them.
 // scale_state (optional): the float[72] loss-scale block; the bias-correction exponent becomes adam_step - skipped steps (state[3]), read on the device.

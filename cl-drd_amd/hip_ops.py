@@ -184,6 +184,21 @@ def copy_segments(dsts, srcs):
     call("cldrd_copy_segments", src, dst, nb, n, _stream())
 
 
+def zero_segments(tensors):
+    """up to 8 contiguous device tensors (16-byte aligned, byte sizes multiples of 16) set to zero in one launch (cldrd_zero_segments)"""
+    import ctypes as C
+    n = len(tensors)
+    if not 1 <= n <= 8:
+        raise ValueError("zero_segments: 1..8 tensors")
+    for t in tensors:
+        _chk(t, t.dtype, "zero_segments")
+        if not t.is_contiguous():
+            raise ValueError("zero_segments: contiguous tensors")
+    dst = (C.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    nb = (C.c_size_t * n)(*[t.numel() * t.element_size() for t in tensors])
+    call("cldrd_zero_segments", dst, nb, n, _stream())
+
+
 def pad_rows(rows: int) -> int:
     """Activation / gradient buffers are allocated with rows rounded up to 64 (allocation granularity only: no kernel reads the
     rows past M any more - the weight-gradient kernel fetches them from a zero page)."""

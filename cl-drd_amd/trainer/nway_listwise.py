@@ -286,9 +286,8 @@ class NwayTrainer:
             else:
                 # every weight / bias / LayerNorm gradient is written exactly once per step (accumulate=False below); only the
                 # embedding tables are scatter-added into and need zeros (2 x 94 MB instead of the whole 531 MB buffer)
-                for tower, toff in zip(model.towers(), model._tower_offsets):
-                    a, b = tower.layout.embed_range
-                    self.flat_g[toff + a:toff + b].zero_()
+                ops.zero_segments([self.flat_g[toff + t.layout.embed_range[0]:toff + t.layout.embed_range[1]]
+                                   for t, toff in zip(model.towers(), model._tower_offsets)])      # one launch for both towers' tables
             for tower in model.towers():
                 if not getattr(tower, "_t_fresh", False):
                     tower.refresh_transposed()

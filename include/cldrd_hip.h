@@ -324,6 +324,9 @@ void cldrd_set_loss_scale(const float* scale, int growth_interval);
 int cldrd_loss_scale_adapt(float* a, size_t na, float* b, size_t nb, float* state, void* stream);
 /* n <= 8 small device-to-device copies in one launch (host arrays of pointers / byte counts): the inputs of a captured step. */
 int cldrd_copy_segments(const void* const* src, void* const* dst, const size_t* bytes, int n, void* stream);
+/* n <= 8 device ranges (16-byte aligned, sizes multiples of 16) set to zero in one launch: what optimizer.zero_grad() is reduced to - only the
+ * embedding tables' gradients are accumulated into (reference nway_listwise_1.py:365 zeroes every gradient). */
+int cldrd_zero_segments(void* const* dst, const size_t* bytes, int n, void* stream);
 int cldrd_write_step_state(unsigned long long* seeds, unsigned long long seed0, unsigned long long seed1, float* hyper, float lr,
                            float beta1, float beta2, int adam_step, const float* scale_state, void* stream);
 

@@ -929,6 +929,23 @@ def test_copy_segments_copies_up_to_eight_buffers_in_one_launch():
         ops.copy_segments([], [])
 
 
+def test_zero_segments_clears_exactly_the_given_ranges():
+    """cldrd_zero_segments (the trainer's zero_grad: the embedding-table gradient ranges of both towers in one launch): the ranges are zero,
+    their neighbours untouched; unaligned ranges are refused."""
+    buf = torch.full((3_000_000,), 7.0, device=DEV)
+    a, b, c = buf[64:64 + 1_000_000], buf[1_500_032:1_500_032 + 400_000], buf[2_999_996:3_000_000]
+    ops.zero_segments([a, b, c])
+    keep = torch.ones_like(buf, dtype=torch.bool)
+    keep[64:64 + 1_000_000] = False
+    keep[1_500_032:1_500_032 + 400_000] = False
+    keep[2_999_996:] = False
+    assert not buf[~keep].any() and (buf[keep] == 7.0).all()
+    with pytest.raises(Exception):
+        ops.zero_segments([buf[1:5]])                 # 4-byte offset: not 16-byte aligned
+    with pytest.raises(ValueError):
+        ops.zero_segments([])
+
+
 def test_adamw_step_writes_the_fp16_shadow_of_a_sub_range():
     """The fused step leaves the fp16 copy of parameters [lo, hi) (what cast_f16 of the updated parameters gives) and changes
     nothing else: p, m, v and the bf16 shadow are bit-identical to the step without it; a skipped step still refreshes the copy."""
