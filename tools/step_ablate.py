@@ -23,6 +23,10 @@ def build(mode):
     model = NwayDualEncoder(EncoderConfig(arch="distilbert"), share_weights=False).to(dev).train()
     tr = NwayTrainer(model, loss="kl_div", T=1.0, learning_rate=7e-6, warmup_steps=4000, total_steps=100000)
     qe = model.query_encoder
+    if mode.startswith("qprio"):
+        # the second (query tower) stream at another HIP stream priority: qprio-1 high, qprio1 low (round 3 tried high: no change)
+        tr.q_stream = torch.cuda.Stream(device=dev, priority=int(mode[5:]))
+        tr.flat_g.record_stream(tr.q_stream)
     if mode.startswith("win") and len(mode) == 5:
         tr.window_schedule = True
         tr.FWD_SLICE = tr.BWD_SLICE = {"attn": int(mode[3]), "ln": int(mode[4])}
