@@ -203,28 +203,68 @@ class SequenceTokenCache:
 
 class CachedSequenceDataset(torch.utils.data.Dataset):
     """Whole encode batches of rows [lo, hi) of a :class:`SequenceTokenCache` with the ``collate_fn`` layout of the reference
-    (dataset/sequence_dataset.py:44-55): ``input_ids`` / ``attention_mask`` int64 padded to the longest row OF THE BATCH, ``id`` list[int]."""
+    (dataset/sequence_dataset.py:44-55): ``input_ids`` / ``attention_mask`` int64 padded to the longest row OF THE BATCH, ``id`` list[int].
 
-    def __init__(self, cache: SequenceTokenCache, lo: int = 0, hi: int | None = None, batch_size: int = 512, pad_id: int = 0):
+    ``bucket_window`` > 0 (round 6; retriever.index_text turns it on): the batches are no longer 512 consecutive rows but LENGTH BUCKETS.  The
+    cache knows every row's token count, so inside each window of ``bucket_window`` consecutive rows the rows are sorted by length and cut
+    into chunks whose padded size (rows x longest row) is at most ``token_budget`` (and ``max_rows`` rows): a chunk's rows have about the same
+    length - its padded layout, which the attention kernels work on, is nearly all real tokens - and its row count sits just under 256 x 256,
+    so the Linear layers run whole rounds of 256-row tiles on the 256 CUs.  A passage's embedding does not depend on what it is batched with; every batch
+    carries ``"row"`` (positions in [0, hi - lo)) and ``get_embeddings_from_scratch`` puts the rows back in collection order.  Measured on the
+    full MS MARCO-shaped collection: DESIGN.md section 6."""
+
+    def __init__(self, cache: SequenceTokenCache, lo: int = 0, hi: int | None = None, batch_size: int = 512, pad_id: int = 0,
+                 bucket_window: int = 0, token_budget: int = 65536, max_rows: int = 2048):
         self.cache, self.lo, self.hi = cache, int(lo), int(len(cache) if hi is None else hi)
         self.batch_size, self.pad_id = int(batch_size), int(pad_id)
         self.n_rows = self.hi - self.lo          # get_embeddings_from_scratch allocates its [n, D] result once when a dataset says this
+        self.chunks = None
+        if bucket_window > 0 and self.n_rows > 0:
+            self.chunks = self.length_buckets(np.asarray(cache.lens[self.lo:self.hi]), int(bucket_window), int(token_budget), int(max_rows))
+
+    @staticmethod
+    def length_buckets(lens, window: int, token_budget: int, max_rows: int):
+        """[int64 arrays of row positions]: per window of consecutive rows, rows in (length, position) order cut greedily so that a chunk's PADDED
+        size - rows x its longest row, what the encoder computes on when a batch is too full to be worth packing - stays within the budget"""
+        chunks = []
+        lens = np.maximum(np.asarray(lens, dtype=np.int64), 1)
+        for w0 in range(0, lens.shape[0], window):
+            wl = lens[w0:w0 + window]
+            order = np.argsort(wl, kind="stable")
+            sl = wl[order]
+            start = 0
+            while start < order.shape[0]:
+                cand = sl[start:start + max_rows]
+                fits = np.nonzero(np.arange(1, cand.shape[0] + 1) * cand <= token_budget)[0]      # ascending lengths: rows x longest is monotone
+                end = start + (int(fits[-1]) + 1 if fits.size else 1)
+                chunks.append(np.sort(order[start:end]) + w0)       # ascending positions: sequential reads of the memory map
+                start = end
+        return chunks
 
     def __len__(self):
+        if self.chunks is not None:
+            return len(self.chunks)
         return (self.hi - self.lo + self.batch_size - 1) // self.batch_size
 
-    def __getitem__(self, b):
-        a = self.lo + b * self.batch_size
-        z = min(self.hi, a + self.batch_size)
-        lens = np.asarray(self.cache.lens[a:z])
-        width = int(lens.max()) if z > a else 0
-        ids = np.asarray(self.cache.ids[a:z, :width]).astype(np.int64)
+    def _batch(self, rows_abs, lens):
+        width = int(lens.max()) if lens.shape[0] else 0
+        ids = np.asarray(self.cache.ids[rows_abs, :width] if not isinstance(rows_abs, slice) else self.cache.ids[rows_abs, :width]).astype(np.int64)
         mask = (np.arange(width)[None, :] < lens[:, None]).astype(np.int64)
         if self.pad_id != 0:
             ids = np.where(mask == 1, ids, self.pad_id)
         # "lengths" (host-side token counts): what lets the encoder pack the batch; given here so that nobody has to derive them from the mask
-        return {"seq": {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "lengths": lens.astype(np.int64).tolist()},
-                "id": np.asarray(self.cache.keys[a:z]).tolist()}
+        return {"input_ids": torch.from_numpy(ids), "attention_mask": torch.from_numpy(mask), "lengths": lens.astype(np.int64).tolist()}
+
+    def __getitem__(self, b):
+        if self.chunks is not None:
+            rows = self.chunks[b]
+            rows_abs = rows + self.lo
+            lens = np.asarray(self.cache.lens[rows_abs])
+            return {"seq": self._batch(rows_abs, lens), "id": np.asarray(self.cache.keys[rows_abs]).tolist(), "row": rows.tolist()}
+        a = self.lo + b * self.batch_size
+        z = min(self.hi, a + self.batch_size)
+        lens = np.asarray(self.cache.lens[a:z])
+        return {"seq": self._batch(slice(a, z), lens), "id": np.asarray(self.cache.keys[a:z]).tolist()}
 
     def loader(self, num_workers: int = 2, pin_memory: bool = False):
         """whole batches (already collated); ``pin_memory``: the loader's pinning thread stages them, so the H2D copies of the encode loop are

@@ -35,6 +35,7 @@ _FLAGS = {
     "token_cache_dir": dict(default=""),                  # ours: tokenise the collection once (dataset.SequenceTokenCache), memory-map it afterwards
     "token_cache_stem": dict(default=""),                 # ours: memory-map an EXISTING token cache by its file stem (no collection / tokenizer opened)
     "loader_workers": dict(type=int, default=2),          # ours: DataLoader workers of the token-cache path
+    "bucket_window": dict(type=int, default=16384),       # ours (token-cache path): rows are batched by LENGTH inside windows of this many rows (0: 512 consecutive rows)
 }
 
 
@@ -59,14 +60,15 @@ def load_checkpoint_into(model, path, is_parallel=True):
     model.load_state_dict(sd)
 
 
-def collection_loader(path, tokenizer, max_length, is_query, token_cache_dir, rank, world):
+def collection_loader(path, tokenizer, max_length, is_query, token_cache_dir, rank, world, bucket_window=0):
     """Batches of 512 rows of this rank's contiguous row range (reference index_text.py:84: bs 512, 4 workers).  With a token cache
     the rank memory-maps the tokenised collection and reads only its own rows; without, it parses the TSV and tokenises per batch as the
     reference does."""
     if token_cache_dir:
         cache = SequenceTokenCache.open_or_build(token_cache_dir, path, tokenizer, max_length, rank, world)
         lo, hi = ShardedFlatIPIndex.shard_bounds(len(cache), world, rank)
-        return CachedSequenceDataset(cache, lo, hi, batch_size=512, pad_id=int(getattr(tokenizer, "pad_token_id", 0) or 0)).loader(pin_memory=True)
+        return CachedSequenceDataset(cache, lo, hi, batch_size=512, pad_id=int(getattr(tokenizer, "pad_token_id", 0) or 0),
+                                     bucket_window=bucket_window).loader(pin_memory=True)
     dataset = SequenceDataset.create_from_seqs_file(path, tokenizer, max_length, is_query=is_query)
     lo, hi = ShardedFlatIPIndex.shard_bounds(len(dataset), world, rank)
     dataset.ids, dataset.seqs = dataset.ids[lo:hi], dataset.seqs[lo:hi]
@@ -98,7 +100,8 @@ def main(args):
     if getattr(args, "token_cache_stem", ""):
         cache = SequenceTokenCache.load(args.token_cache_stem, {"max_length": args.max_length})
         lo, hi = ShardedFlatIPIndex.shard_bounds(len(cache), world, rank)
-        text_loader = CachedSequenceDataset(cache, lo, hi, batch_size=512).loader(num_workers=int(getattr(args, "loader_workers", 2)), pin_memory=True)
+        text_loader = CachedSequenceDataset(cache, lo, hi, batch_size=512, bucket_window=int(getattr(args, "bucket_window", 0))).loader(
+            num_workers=int(getattr(args, "loader_workers", 2)), pin_memory=True)
     elif args.synthetic_rows:
         lo, hi = ShardedFlatIPIndex.shard_bounds(args.synthetic_rows, world, rank)
         dataset = SyntheticSequenceDataset(hi - lo, args.max_length, first_id=lo)
@@ -106,7 +109,8 @@ def main(args):
     else:
         from transformers import AutoTokenizer
         tokenizer = AutoTokenizer.from_pretrained(args.tokenizer_name_or_path)
-        text_loader = collection_loader(args.passages_path, tokenizer, args.max_length, args.is_query, args.token_cache_dir, rank, world)
+        text_loader = collection_loader(args.passages_path, tokenizer, args.max_length, args.is_query, args.token_cache_dir, rank, world,
+                                        bucket_window=int(getattr(args, "bucket_window", 0)))
 
     lap("open_collection_s")
     text_embs, text_ids = get_embeddings_from_scratch(model, text_loader, use_fp16=True, is_query=args.is_query, show_progress_bar=True)

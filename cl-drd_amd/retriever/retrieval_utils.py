@@ -91,8 +91,10 @@ def get_embeddings_from_scratch(model, dataloader, use_fp16, is_query, show_prog
     out, filled = None, 0
     pending = None
 
+    out_ids = None
+
     def collect(p):
-        nonlocal out, filled
+        nonlocal out, filled, out_ids
         t0 = time.perf_counter()
         p[1].synchronize()
         t1 = time.perf_counter()
@@ -100,7 +102,15 @@ def get_embeddings_from_scratch(model, dataloader, use_fp16, is_query, show_prog
         if n_rows is not None:
             if out is None:
                 out = np.empty((int(n_rows), a.shape[1]), dtype=np.float32)
-            out[filled:filled + a.shape[0]] = a
+            if p[2] is not None:
+                # a length-bucketed batch (CachedSequenceDataset(bucket_window=...)): its rows go back to their positions in the collection
+                rows = np.asarray(p[2], dtype=np.int64)
+                if out_ids is None:
+                    out_ids = np.full(int(n_rows), -1, dtype=np.int64)
+                out[rows] = a
+                out_ids[rows] = np.asarray(p[3], dtype=np.int64)
+            else:
+                out[filled:filled + a.shape[0]] = a
             filled += a.shape[0]
         else:
             embeddings.append(a.copy())
@@ -122,9 +132,11 @@ def get_embeddings_from_scratch(model, dataloader, use_fp16, is_query, show_prog
         tm["h2d_enqueue_s"] += time.perf_counter() - t0
         if pending is not None:
             collect(pending)
-        pending = (host, ev)
+        rows = batch.get("row") if (n_rows is not None and hasattr(batch, "get")) else None
+        pending = (host, ev, rows, text_ids if rows is not None else None)
         assert isinstance(text_ids, list)
-        embeddings_ids.extend(text_ids)
+        if rows is None:
+            embeddings_ids.extend(text_ids)
         tm["batches"] += 1
         if PROGRESS_HOOK is not None and tm["batches"] % 500 == 0:
             PROGRESS_HOOK(tm)
@@ -136,6 +148,10 @@ def get_embeddings_from_scratch(model, dataloader, use_fp16, is_query, show_prog
         if filled != out.shape[0]:
             raise RuntimeError(f"the loader announced {out.shape[0]} rows and delivered {filled}")
         embeddings = out
+        if out_ids is not None:
+            if embeddings_ids:
+                raise RuntimeError("a loader must deliver either every batch with row positions or none")
+            embeddings_ids = out_ids.tolist()
     else:
         embeddings = np.concatenate(embeddings)
     tm["gather_s"] += time.perf_counter() - t0

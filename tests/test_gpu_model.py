@@ -962,6 +962,35 @@ def test_packed_index_encode_matches_padded(monkeypatch):
     assert np.abs(e1 - e0).max() <= 2e-3 * np.abs(e0).max()
 
 
+def test_length_bucketed_index_encode_equals_the_plain_batches():
+    """Round 6: the token-cache path of index_text batches rows by LENGTH (CachedSequenceDataset(bucket_window=...)) and
+    get_embeddings_from_scratch puts them back in collection order.  Against the plain 512-consecutive-row batches of the same cache: ids in the
+    same (file) order, and every passage's embedding the same - a passage's CLS vector does not depend on what it is batched with."""
+    from cldrd_amd.dataset import CachedSequenceDataset, SequenceTokenCache
+    from cldrd_amd.retriever import retrieval_utils as RU
+    cfg = small_cfg("distilbert", 3)
+    model = selftest.build_tiny_model(cfg).cuda().eval()
+    rng = np.random.default_rng(11)
+    n, L = 3000, 48
+    lens = np.clip(np.round(rng.lognormal(2.6, 0.5, n)), 2, L).astype(np.int32)
+    ids = np.zeros((n, L), dtype=np.uint16)
+    for r in range(n):
+        ids[r, :lens[r]] = rng.integers(5, cfg.vocab_size, lens[r])
+        ids[r, 0] = 1
+    cache = SequenceTokenCache(np.arange(n, dtype=np.int64) * 3 + 7, ids, lens, {"rows": n, "max_length": L})
+    plain = CachedSequenceDataset(cache, 40, 2900, batch_size=512)
+    e0, i0 = RU.get_embeddings_from_scratch(model, plain.loader(num_workers=0), True, False)
+    buck = CachedSequenceDataset(cache, 40, 2900, batch_size=512, bucket_window=1024, token_budget=4096)
+    assert len(buck) > len(plain)
+    e1, i1 = RU.get_embeddings_from_scratch(model, buck.loader(num_workers=2), True, False)
+    assert i1 == i0 == (np.arange(40, 2900) * 3 + 7).tolist()
+    same = np.all(e1 == e0, axis=1).mean()
+    print(f"length-bucketed index encode: identical rows {same:.3f}, max rel diff {np.abs(e1 - e0).max() / np.abs(e0).max():.2e}")
+    # (packed and padded batches of different shapes: the same arithmetic per row; the Linear layers of a small chunk may take the small-M GEMM
+    # kernel, whose K split sums in another order - hence a bar at fp32 rounding of the 16-bit pipeline, not bit equality)
+    assert np.abs(e1 - e0).max() <= 2e-3 * np.abs(e0).max()
+
+
 @pytest.mark.parametrize("arch", ["distilbert", "bert"])
 def test_deferred_layernorm_parameter_gradients_equal_the_immediate_ones(arch, monkeypatch):
     """The deferred LayerNorm-parameter gradients (the gamma / beta and preceding-bias gradients of a tower are reduced by one grouped

@@ -130,3 +130,40 @@ def test_waiting_rank_fails_fast_on_a_stale_cache_that_rank0_never_replaces(tmp_
     again = SequenceTokenCache.open_or_build(str(tmp_path), COLLECTION, tok, 12, rank=0, world=2)
     assert seen["meta_present_at_build"] is False and len(again) == meta["rows"]
     assert seen["marker_at_build"] is True and not os.path.exists(stem + ".building")          # the marker lives exactly as long as the build
+
+
+def test_length_buckets_cover_every_row_once_within_the_token_budget(tmp_path):
+    """CachedSequenceDataset(bucket_window=...): inside each window the rows are cut into chunks by length - every row of [lo, hi) exactly once,
+    chunk padded sizes (rows x longest row) within the budget, rows of a chunk within a narrow length band, chunks confined to their window, positions ascending;
+    each batch carries the collate layout, its token counts and its row positions."""
+    rng = np.random.default_rng(5)
+    n, L = 5000, 64
+    lens = np.clip(np.round(rng.lognormal(3.0, 0.5, n)), 1, L).astype(np.int32)
+    ids = np.zeros((n, L), dtype=np.uint16)
+    for r in range(n):
+        ids[r, :lens[r]] = rng.integers(5, 500, lens[r])
+    keys = (np.arange(n, dtype=np.int64) * 7 + 3)
+    cache = SequenceTokenCache(keys, ids, lens, {"rows": n, "max_length": L})
+    lo, hi = 100, 4700
+    ds = CachedSequenceDataset(cache, lo, hi, batch_size=512, bucket_window=1024, token_budget=4096, max_rows=300)
+    assert ds.n_rows == hi - lo and len(ds) == len(ds.chunks) > (hi - lo) // 512
+    seen = np.zeros(hi - lo, dtype=np.int64)
+    for i, rows in enumerate(ds.chunks):
+        seen[rows] += 1
+        cl = lens[lo:hi][rows]
+        assert (len(rows) * cl.max() <= 4096 or len(rows) == 1) and len(rows) <= 300 and np.all(np.diff(rows) > 0)
+        assert rows.min() // 1024 == rows.max() // 1024                      # one window
+        b = ds[i]
+        assert b["row"] == rows.tolist() and b["id"] == keys[rows + lo].tolist() and b["seq"]["lengths"] == cl.tolist()
+        w = int(cl.max())
+        assert tuple(b["seq"]["input_ids"].shape) == (len(rows), w)
+        assert torch.equal(b["seq"]["input_ids"], torch.from_numpy(ids[rows + lo, :w].astype(np.int64)))
+        assert torch.equal(b["seq"]["attention_mask"].sum(1), torch.from_numpy(cl.astype(np.int64)))
+    assert np.all(seen == 1)
+    # the buckets are tight: the padded layout of a chunk is mostly real tokens (the plain 512-row batches of this length mix: ~45 %)
+    fill = np.mean([lens[lo:hi][r].sum() / (len(r) * lens[lo:hi][r].max()) for r in ds.chunks if len(r) > 8])
+    plain = np.mean([lens[a:a + 512].sum() / (min(512, hi - a) * lens[a:min(hi, a + 512)].max()) for a in range(lo, hi, 512)])
+    assert fill > 0.8 and plain < 0.5, (fill, plain)
+    # a row longer than the budget still gets a chunk of its own
+    ds2 = CachedSequenceDataset(cache, 0, 50, bucket_window=50, token_budget=8)
+    assert sorted(int(r) for c in ds2.chunks for r in c) == list(range(50))

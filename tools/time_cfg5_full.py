@@ -83,13 +83,15 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--workers", type=int, default=8)
     ap.add_argument("--init_std", type=float, default=0.06)
+    ap.add_argument("--bucket_window", type=int, default=16384, help="0: batches of 512 consecutive rows, as the reference forms them")
     ap.add_argument("--force", action="store_true")
     a = ap.parse_args()
     os.makedirs(a.workdir, exist_ok=True)
     need_disk = a.rows * (768 * 4 + a.max_length * 2 + 16) / 1e9 + 1.0
     need_mem = a.rows * 768 * 4 * 2.3 / 1e9 + 8.0
     free_disk = shutil.disk_usage(a.workdir).free / 1e9
-    lines = [f"cfg5 end to end, one GPU: {a.rows} passages x max_length {a.max_length}, {a.queries} queries, top-{a.top_k}",
+    lines = [f"cfg5 end to end, one GPU: {a.rows} passages x max_length {a.max_length}, {a.queries} queries, top-{a.top_k}; batches: "
+             + (f"length buckets inside windows of {a.bucket_window} rows" if a.bucket_window else "512 consecutive rows"),
              f"host: {os.cpu_count()} CPUs ({len(os.sched_getaffinity(0))} usable), {mem_gb():.0f} GB available memory, {free_disk:.0f} GB free in {a.workdir} "
              f"(needs ~{need_disk:.0f} GB disk, ~{need_mem:.0f} GB memory)"]
     print(lines[-1], flush=True)
@@ -132,13 +134,13 @@ def main():
     def progress(tm):          # every 500 batches (stdout only): does the loop's rate hold over 17 000 batches?
         now = time.perf_counter()
         d = {k: tm[k] - prog["tm"].get(k, 0.0) for k in ("load_s", "h2d_enqueue_s", "d2h_wait_s", "gather_s")}
-        print(f"  batch {tm['batches']:6d}: {500 * 512 / (now - prog['t']):8.0f} passages/s | per batch ms: loader {2 * d['load_s']:.2f} H2D+enqueue {2 * d['h2d_enqueue_s']:.2f} "
+        print(f"  batch {tm['batches']:6d}: {500 / (now - prog['t']):6.1f} batches/s | per batch ms: loader {2 * d['load_s']:.2f} H2D+enqueue {2 * d['h2d_enqueue_s']:.2f} "
               f"GPU wait {2 * d['d2h_wait_s']:.2f} gather {2 * d['gather_s']:.2f}", flush=True)
         prog["t"], prog["tm"] = now, dict(tm)
     RU.PROGRESS_HOOK = progress
     t0 = time.perf_counter()
     ipath = IT.main(IT.get_args(["--resume", ckpt, "--model_name_or_path", mdir, "--max_length", str(a.max_length), "--index_dir", idir,
-                                 "--token_cache_stem", stem, "--loader_workers", str(a.workers)]))
+                                 "--token_cache_stem", stem, "--loader_workers", str(a.workers), "--bucket_window", str(a.bucket_window)]))
     t_index = time.perf_counter() - t0
     RU.PROGRESS_HOOK = None
     ti = IT.main.last_timings
@@ -151,7 +153,7 @@ def main():
                      ("meta_pkl_s", "meta.pkl (text_ids + the reference's 8.8 M-entry dict)")):
         lines.append(f"  {label:<72s} {ti.get(k, float('nan')):9.2f} s")
     if host:
-        lines.append(f"  host side of the encode loop ({host.get('batches', 0)} batches of 512): waiting for the loader {host['load_s']:.1f} s | batch H2D + enqueue "
+        lines.append(f"  host side of the encode loop ({host.get('batches', 0)} batches; bucket_window {a.bucket_window}): waiting for the loader {host['load_s']:.1f} s | batch H2D + enqueue "
                      f"{host['h2d_enqueue_s']:.1f} s | waiting for the GPU (encode + D2H of the previous batch) {host['d2h_wait_s']:.1f} s | gather into [n, 768] {host['gather_s']:.1f} s")
     isize = sum(os.path.getsize(os.path.join(idir, f)) for f in os.listdir(idir)) / 1e9
     lines.append(f"  index directory: {isize:.1f} GB")
