@@ -401,6 +401,28 @@ def main():
                         torch.cuda.synchronize()
                         index[f"l256_ragged_{tag}_s"] = time.perf_counter() - t1
                     index["l256_ragged_fill"], index["l256_longest"] = float(il2.sum()) / (512 * lg2), lg2
+                    # the same MSMARCO-shaped passages batched the way retriever/index_text.py batches a token cache since round 6: 8 192 rows cut
+                    # into LENGTH BUCKETS (dataset.CachedSequenceDataset.length_buckets: padded size <= 65 536 token slots per chunk) instead of
+                    # 16 batches of 512 consecutive rows - same embeddings bit for bit, the attention kernels' padded layout nearly all real tokens
+                    from cldrd_amd.dataset import CachedSequenceDataset
+                    rb3 = syn.seq_rows(499 + rank, 0, 8192, L2, ragged=True)["seq"]
+                    m3 = rb3["attention_mask"]
+                    il3 = m3.sum(-1).numpy()
+                    chunks = []
+                    for rows in CachedSequenceDataset.length_buckets(il3, 8192, 65536, 2048):
+                        w3 = int(il3[rows].max())
+                        rt = torch.from_numpy(rows)
+                        chunks.append({"input_ids": (rb3["input_ids"][rt, :w3] * m3[rt, :w3]).contiguous().to(dev), "attention_mask": m3[rt, :w3].contiguous().to(dev),
+                                       "lengths": il3[rows].tolist()})
+                    for c in chunks:
+                        model.passage_embs(c)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(2):
+                        for c in chunks:
+                            model.passage_embs(c)
+                    torch.cuda.synchronize()
+                    index["l256_bucketed_s"], index["l256_bucketed_rows"], index["l256_bucketed_chunks"] = time.perf_counter() - t1, 2 * 8192, len(chunks)
     except Exception as exc:      # a secondary leg must not take the headline line down with it
         index = {"error": f"{type(exc).__name__}: {exc}"[:300]}
     if not args.no_index:         # the collective sits outside the try: every rank reaches it whatever happened above
@@ -427,6 +449,9 @@ def main():
                     l256["msmarco_shaped"] = {"token_fill_of_padded_batch": round(index["l256_ragged_fill"], 3), "longest": index["l256_longest"],
                                               "padded_passages_per_s": round(world * 512 * index["l256_it"] / index["l256_ragged_padded_s"], 1),
                                               "packed_passages_per_s": round(world * 512 * index["l256_it"] / index["l256_ragged_packed_s"], 1)}
+                    if "l256_bucketed_s" in index:
+                        l256["msmarco_shaped"]["length_bucketed_passages_per_s"] = round(world * index["l256_bucketed_rows"] / index["l256_bucketed_s"], 1)
+                        l256["msmarco_shaped"]["length_buckets"] = f"8192 passages in {index['l256_bucketed_chunks']} chunks of <= 65536 padded token slots (what index_text does with a token cache)"
             index = {"value": round(pps, 1), "unit": "passages/s", "batch": 512, "seq_len": L,
                      "mfma_frac": round(pps * flops_seq_fwd(L) / (world * PEAK_BF16_TFLOPS * 1e12), 4), **extra, "l256": l256}
         elif "error" not in index:
