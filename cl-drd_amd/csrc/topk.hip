@@ -235,25 +235,35 @@ __global__ __launch_bounds__(256) void cast_f16_kernel(const float* __restrict__
 
 // ---- attaching a shard (FlatIPIndex._attach): the statistics and shadows of the index in three launches over the fp32 rows ----
 // (until round 5 these were chunks of at::native kernels: mean, subtract, double-precision row norms, casts, a strided gather)
-// 1. column sums in fp64: block b walks rows b, b + grid, ...; thread t owns columns t, t + 256, ... (a row is read as one coalesced segment);
+// 1. column sums in fp64: block b walks rows b, b + grid, ...; thread t owns four adjacent columns (a row is read as one coalesced segment);
 //    partial[b][d] doubles, reduced in block order by index_mean_finish_kernel -> mu = mean row (fp32), deterministic.
 __global__ __launch_bounds__(256) void index_colsum_kernel(const float* __restrict__ P, size_t rows, int d, double* __restrict__ partial) {
-    constexpr int MAXC = 8;                                    // d <= 2048
-    double acc[MAXC];
+    // thread t owns the 4 columns 4 t .. 4 t + 3 (+ 1024 per further group): one 16-byte load per row and group (the first version read 4 bytes
+    // per lane: 2.2 TB/s, profiles/r06_retrieve_summary.txt); d % 4 == 0, d <= 2048
+    constexpr int MAXG = 2;
+    double acc[MAXG][4];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) acc[c] = 0.0;
+    for (int g = 0; g < MAXG; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[g][j] = 0.0;
     for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const float* pr = P + r * d;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) {
-            const int j = threadIdx.x + 256 * c;
-            if (j < d) acc[c] += (double)pr[j];
+        for (int g = 0; g < MAXG; ++g) {
+            const int c = 4 * threadIdx.x + 1024 * g;
+            if (c < d) {
+                const float4 v = *(const float4*)(pr + c);
+                acc[g][0] += (double)v.x; acc[g][1] += (double)v.y; acc[g][2] += (double)v.z; acc[g][3] += (double)v.w;
+            }
         }
     }
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int j = threadIdx.x + 256 * c;
-        if (j < d) partial[(size_t)blockIdx.x * d + j] = acc[c];
+    for (int g = 0; g < MAXG; ++g) {
+        const int c = 4 * threadIdx.x + 1024 * g;
+        if (c < d) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) partial[(size_t)blockIdx.x * d + c + j] = acc[g][j];
+        }
     }
 }
 __global__ __launch_bounds__(256) void index_mean_finish_kernel(const double* __restrict__ partial, int nblk, int d, size_t rows, float* __restrict__ mu) {
@@ -799,7 +809,7 @@ extern "C" size_t cldrd_index_col_mean_workspace(size_t rows, int d) {
     return nb * (size_t)d * sizeof(double);
 }
 extern "C" int cldrd_index_col_mean(const float* P, size_t rows, int d, float* mu, void* workspace, size_t workspace_bytes, void* stream) {
-    CLDRD_CHECK(rows > 0 && d > 0 && d <= 2048, "index_col_mean: rows > 0 and 0 < d <= 2048");
+    CLDRD_CHECK(rows > 0 && d > 0 && d <= 2048 && d % 4 == 0 && (uintptr_t)P % 16 == 0, "index_col_mean: rows > 0, 0 < d <= 2048, d % 4 == 0, 16-byte aligned rows");
     CLDRD_CHECK(workspace != nullptr && workspace_bytes >= cldrd_index_col_mean_workspace(rows, d) && (uintptr_t)workspace % 8 == 0, "index_col_mean: workspace too small");
     const int nb = (int)(rows < 1024 ? rows : 1024);
     hipLaunchKernelGGL(index_colsum_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, P, rows, d, (double*)workspace);

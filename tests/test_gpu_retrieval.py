@@ -200,7 +200,7 @@ def test_two_shards_merge_equals_global():
     same_ranking(D, I, Dr, Ir)
 
 
-@pytest.mark.parametrize("rows,d,stride", [(10001, 768, 7), (3, 128, 1), (70000, 256, 64), (1, 64, 5)])
+@pytest.mark.parametrize("rows,d,stride", [(10001, 768, 7), (3, 128, 1), (70000, 256, 64), (1, 64, 5), (777, 1280, 3)])
 def test_attach_statistics_kernels_equal_the_numpy_restatement(rows, d, stride):
     """cldrd_index_col_mean / cldrd_index_center_cast / cldrd_map_ids (FlatIPIndex._attach and the id map of a search: torch arithmetic until
     round 5) against numpy: the mean row to one fp32 ulp of the fp64 mean, the fp16 scan shadow and the bf16 threshold sample of the centred
