@@ -712,15 +712,16 @@ class HipEncoder(nn.Module):
             tape.M, tape.L, tape.T, tape.ids, tape.mask, tape.seed, tape.layers = M, L, T, ids, mask, seed, []
             tape.p_embed, tape.pack, tape.device_seed = p_h, pk, False
         f32 = dict(dtype=torch.float32, device=dev)
-        S32 = self.stream32
-        sdt = torch.float32 if S32 else torch.bfloat16         # storage type of the pre-LN sums
+        sdt = torch.float32                                     # storage type of the pre-LN sums: the fp32 residual stream
         # QKV16 (evaluation pass of the fp16 mode, towers deeper than 6 layers): the QKV projection reads fp16 operands too (bf16 q / k / v
         # out: that pass's attention kernels are bf16).  With the FFN pair in fp16, x_in / Wqkv are the next largest source of logit drift
         # (BERT-base cfg4 golden: 0.190 -> 0.116); the 6-layer configs are at 2-3.5e-3 without it and would only pay for it.
-        QKV16 = self.ffn_fp16 and S32 and not fp16 and cfg.n_layers > 6
-        x = self._buf(T, d, dev, dt16) if (save or not QKV16) else None
+        QKV16 = self.ffn_fp16 and not fp16 and cfg.n_layers > 6
+        if QKV16 and save:
+            raise RuntimeError("a pass that keeps a tape runs one operand format (fp16 or bf16), never the evaluation pass's mixed one")
+        x = self._buf(T, d, dev, dt16) if not QKV16 else None
         xh = self._buf(T, d, dev, torch.float16) if QKV16 else None
-        x32 = self._buf(T, d, dev, torch.float32) if S32 else None      # fp32 copy of the layer input: the residual operand
+        x32 = self._buf(T, d, dev, torch.float32)           # fp32 copy of the layer input: the residual operand
         mean0, rstd0 = torch.empty(T, **f32), torch.empty(T, **f32)
         type0 = self.w("embeddings.token_type_embeddings.weight")[0] if cfg.arch == "bert" else None
         if window is not None:
@@ -728,7 +729,7 @@ class HipEncoder(nn.Module):
         ops.embed_ln_fwd(ids.view(-1), self.w("embeddings.word_embeddings.weight"),
                          self.w("embeddings.position_embeddings.weight"), type0, self.w("embeddings.LayerNorm.weight"),
                          self.w("embeddings.LayerNorm.bias"), xh if QKV16 else x, mean0, rstd0, T, L, cfg.eps, p_h, seed, out32=x32,
-                         pos_idx=pk.pos if pk is not None else None, out_copy=x if QKV16 else None)
+                         pos_idx=pk.pos if pk is not None else None)
         if save:
             tape.mean0, tape.rstd0 = mean0, rstd0
         yield
@@ -738,9 +739,10 @@ class HipEncoder(nn.Module):
         # FFN2 epilogue.  It is not stored: that epilogue reads the pre-LN sum (which the backward keeps anyway) and applies mean / rstd /
         # gamma / beta on the fly (`residual_ln`) - 100 MB less written per LayerNorm at cfg2, the same bytes read.
         res_ln = None                                        # LayerNorm still to be applied to x32 (None: x32 is the value itself)
-        LNF = S32                                                            # the residual operand is LayerNorm(pre-LN sum) applied on the fly
-        FFN16 = self.ffn_fp16 and S32 and not fp16                           # fp16 mode, evaluation pass: the FFN GEMMs read fp16 operands
-        OUT16 = FFN16 and LNF                                                # ... and so does the out-projection (fp16 context from the attention kernel)
+        FFN16 = self.ffn_fp16 and not fp16              # fp16 mode, evaluation pass: the FFN and out-projection GEMMs read fp16 operands (the
+        OUT16 = FFN16                                   # attention kernel leaves its context in fp16 for the out-projection)
+        if FFN16 and save:
+            raise RuntimeError("a pass that keeps a tape runs one operand format (fp16 or bf16), never the evaluation pass's mixed one")
         for i in range(cfg.n_layers):
             W = self._layer_weights(i, fp16)
             W16 = self._layer_weights(i, True) if FFN16 else None
@@ -787,58 +789,51 @@ class HipEncoder(nn.Module):
                 del qkv_p, ctx16_pad
             yield
             s1 = self._buf(T, d, dev, sdt)
-            ops.gemm_nt(ctx16 if OUT16 else ctx, (W16 if OUT16 else W)["Wo"], s1, T, bias=W["bo"], residual=x32 if S32 else x, dropout_p=p_out,
+            ops.gemm_nt(ctx16 if OUT16 else ctx, (W16 if OUT16 else W)["Wo"], s1, T, bias=W["bo"], residual=x32, dropout_p=p_out,
                         seed=s_l + 2, residual_ln=res_ln)
             del ctx16
             yield
             if window is not None:
                 window("ln")
-            mean1, rstd1 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
-            x1_32 = self._buf(T, d, dev, torch.float32) if (S32 and not LNF) else None
-            F16 = FFN16 and LNF                                  # the FFN pair on fp16 operands (the fp16 FFN2 flavours add LayerNorm on the fly)
-            if F16:
-                # LayerNorm -> fp16 (FFN1's operand) [+ bf16 copy for the weight gradient]; FFN1 -> h in fp16 (FFN2's operand) [+ bf16 copy]
+            mean1, rstd1 = torch.empty(T, **f32), torch.empty(T, **f32)
+            if FFN16:
+                # evaluation pass of the fp16 mode: LayerNorm -> fp16 (FFN1's operand); FFN1 -> h in fp16 (FFN2's operand); no tape
+                x1 = hbuf = pre = None
                 x1h = self._buf(T, d, dev, torch.float16)
-                x1 = self._buf(T, d, dev) if save else None
-                ops.layernorm_fwd(s1, W["g1"], W["b1"], x1h, mean1, rstd1, T, cfg.eps, out_copy=x1)
+                ops.layernorm_fwd(s1, W["g1"], W["b1"], x1h, mean1, rstd1, T, cfg.eps)
                 yield
                 hh = self._buf(T, f, dev, torch.float16)
-                hbuf = self._buf(T, f, dev) if save else None
-                pre = self._buf(T, f, dev) if save else None
-                ops.gemm_nt(x1h, W16["W1"], hh, T, bias=W["bf1"], preact=pre, act=3 if save else 1, out_copy=hbuf)
+                ops.gemm_nt(x1h, W16["W1"], hh, T, bias=W["bf1"], act=1)
                 yield
                 s2 = self._buf(T, d, dev, sdt)
                 ops.gemm_nt(hh, W16["W2"], s2, T, bias=W["bf2"], residual=s1, dropout_p=p_h, seed=s_l + 3, residual_ln=(mean1, rstd1, W["g1"], W["b1"]))
                 del x1h, hh
             else:
                 x1 = self._buf(T, d, dev, dt16)
-                ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps, out32=x1_32)
+                ops.layernorm_fwd(s1, W["g1"], W["b1"], x1, mean1, rstd1, T, cfg.eps)
                 yield
                 hbuf = self._buf(T, f, dev, dt16)
                 pre = self._buf(T, f, dev, dt16) if save else None
                 ops.gemm_nt(x1, W["W1"], hbuf, T, bias=W["bf1"], preact=pre, act=3 if save else 1)     # the tape keeps gelu'(pre-activation)
                 yield
                 s2 = self._buf(T, d, dev, sdt)
-                ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=(s1 if LNF else x1_32) if S32 else x1, dropout_p=p_h, seed=s_l + 3,
-                            residual_ln=(mean1, rstd1, W["g1"], W["b1"]) if LNF else None)
-            xo = self._buf(T, d, dev, dt16) if (save or not QKV16) else None
+                ops.gemm_nt(hbuf, W["W2"], s2, T, bias=W["bf2"], residual=s1, dropout_p=p_h, seed=s_l + 3, residual_ln=(mean1, rstd1, W["g1"], W["b1"]))
+            xo = self._buf(T, d, dev, dt16) if not QKV16 else None
             xoh = self._buf(T, d, dev, torch.float16) if QKV16 else None
             last = i == cfg.n_layers - 1
             # the CLS-only last layer gathers its fp32 residual rows from a stored copy: the layer before it still writes one
-            need32 = S32 and not last and ((i + 1 == cfg.n_layers - 1 and self.cls_only_last) or not LNF)
+            need32 = not last and i + 1 == cfg.n_layers - 1 and self.cls_only_last
             xo32 = self._buf(T, d, dev, torch.float32) if need32 else None
-            mean2, rstd2 = (torch.empty(T, **f32), torch.empty(T, **f32)) if (save or S32) else (None, None)
+            mean2, rstd2 = torch.empty(T, **f32), torch.empty(T, **f32)
             yield
             if window is not None:
                 window("ln")
-            ops.layernorm_fwd(s2, W["g2"], W["b2"], xoh if QKV16 else xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32,
-                              out_copy=xo if QKV16 else None)
+            ops.layernorm_fwd(s2, W["g2"], W["b2"], xoh if QKV16 else xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32)
             if save:
                 tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, ctx_pad=ctx_pad, lse=lse, dbits=dbits, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
                                         h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h, p_a=p_a, p_out=p_out))
             x, xh = xo, xoh
-            if S32:
-                x32, res_ln = (xo32, None) if need32 else (s2, (mean2, rstd2, W["g2"], W["b2"]))
+            x32, res_ln = (xo32, None) if need32 else (s2, (mean2, rstd2, W["g2"], W["b2"]))
             yield
         if cfg.n_layers == 0:
             src = x if x is not None else xh
@@ -862,26 +857,24 @@ class HipEncoder(nn.Module):
         else:
             ops.gemm_nt(x, W["Wqkv"][d:], kv, T, bias=W["bqkv"][d:])
         yield
-        S32 = x32 is not None
-        sdt = torch.float32 if S32 else torch.bfloat16
+        sdt = torch.float32
         if pk is None:
             # the CLS rows are rows 0, L, 2L, ... of the layer input: STRIDED VIEWS (row pitch L * d), no copies - every consumer (the Q
             # projection's A operand, its weight gradient's X operand, the out-projection's fp32 residual) takes a row pitch.  Until round 5
             # two or three 6-us gather launches sat here, on the critical path between the towers' forward and the loss
             xc = x[:T].view(M, L * d)[:, :d] if x is not None else None
             xch = xh[:T].view(M, L * d)[:, :d] if Q16 else None
-            xc32 = x32[:T].view(M, L * d)[:, :d] if S32 else None
+            xc32 = x32[:T].view(M, L * d)[:, :d]
         else:
             xc = self._buf(M, d, dev, dt16) if x is not None else None          # 16-bit CLS rows: the weight gradient's operand (and, without Q16, the GEMM's)
             xch = self._buf(M, d, dev, torch.float16) if Q16 else None
-            xc32 = self._buf(M, d, dev, torch.float32) if S32 else None
+            xc32 = self._buf(M, d, dev, torch.float32)
             # packed batch: the CLS token of sequence m is row cu[m]; K / V go to the padded layout the CLS attention kernel reads
             if xc is not None:
                 ops.gather_rows(x, pk.cls_idx, xc, M)
             if Q16:
                 ops.gather_rows(xh, pk.cls_idx, xch, M)
-            if S32:
-                ops.gather_rows(x32, pk.cls_idx, xc32, M)
+            ops.gather_rows(x32, pk.cls_idx, xc32, M)
             kv_p, kv = kv, self._buf(M * L, 2 * d, dev, dt16)
             ops.unpack_rows16(kv_p, kv, pk.cu, M, L)
             del kv_p
@@ -890,26 +883,23 @@ class HipEncoder(nn.Module):
             ops.gemm_nt(xch, W16["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
         else:
             ops.gemm_nt(xc, W["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
-        out16 = out16 and W16 is not None and S32            # out-projection on fp16 operands (see _encode)
+        out16 = out16 and W16 is not None                    # out-projection on fp16 operands (see _encode_gen)
         ctxc = self._buf(M, d, dev, dt16) if (save or not out16) else None
         ctxc16 = self._buf(M, d, dev, torch.float16) if out16 else None
         probs = torch.empty(M, H, L, **f32)
         ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1, ctx16=ctxc16)
         yield
         s1 = self._buf(M, d, dev, sdt)
-        ops.gemm_nt(ctxc16 if out16 else ctxc, (W16 if out16 else W)["Wo"], s1, M, bias=W["bo"], residual=xc32 if S32 else xc, dropout_p=p_out,
-                    seed=s_l + 2)
+        ops.gemm_nt(ctxc16 if out16 else ctxc, (W16 if out16 else W)["Wo"], s1, M, bias=W["bo"], residual=xc32, dropout_p=p_out, seed=s_l + 2)
         yield
-        x1_32 = self._buf(M, d, dev, torch.float32) if S32 else None
+        x1_32 = self._buf(M, d, dev, torch.float32)
         mean1, rstd1 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
-        if W16 is not None and S32:         # the FFN pair on fp16 operands, as in the full layers (bf16 copies for the backward)
+        if W16 is not None:                 # evaluation pass of the fp16 mode: the FFN pair on fp16 operands, as in the full layers (no tape)
+            x1 = hbuf = pre = None
             x1h = self._buf(M, d, dev, torch.float16)
-            x1 = self._buf(M, d, dev) if save else None
-            ops.layernorm_fwd(s1, W["g1"], W["b1"], x1h, mean1, rstd1, M, cfg.eps, out32=x1_32, out_copy=x1)
+            ops.layernorm_fwd(s1, W["g1"], W["b1"], x1h, mean1, rstd1, M, cfg.eps, out32=x1_32)
             hh = self._buf(M, f, dev, torch.float16)
-            hbuf = self._buf(M, f, dev) if save else None
-            pre = self._buf(M, f, dev) if save else None
-            ops.gemm_nt(x1h, W16["W1"], hh, M, bias=W["bf1"], preact=pre, act=3 if save else 1, out_copy=hbuf)
+            ops.gemm_nt(x1h, W16["W1"], hh, M, bias=W["bf1"], act=1)
             s2 = self._buf(M, d, dev, sdt)
             ops.gemm_nt(hh, W16["W2"], s2, M, bias=W["bf2"], residual=x1_32, dropout_p=p_h, seed=s_l + 3)
         else:
@@ -919,7 +909,7 @@ class HipEncoder(nn.Module):
             pre = self._buf(M, f, dev, dt16) if save else None
             ops.gemm_nt(x1, W["W1"], hbuf, M, bias=W["bf1"], preact=pre, act=3 if save else 1)
             s2 = self._buf(M, d, dev, sdt)
-            ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1_32 if S32 else x1, dropout_p=p_h, seed=s_l + 3)
+            ops.gemm_nt(hbuf, W["W2"], s2, M, bias=W["bf2"], residual=x1_32, dropout_p=p_h, seed=s_l + 3)
         yield
         xo = self._buf(M, d, dev, dt16)
         mean2, rstd2 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
@@ -938,17 +928,12 @@ class HipEncoder(nn.Module):
         dev = self.flat_p.device
         W, G = self._layer_weights(i), self._layer_grads(i)
         s_l, p_h, p_a, p_out = a["seed"], a["p_h"], a["p_a"], a["p_out"]
-        GS = self.grad_stream32 and a["s2"].dtype == torch.float32      # fp32 gradient stream (needs the fp32 pre-LN sums on the tape)
-        sdt = torch.float32 if GS else torch.bfloat16
-        bdt = a["h"].dtype                                              # the backward's 16-bit format = the tape's (fp16 in amp16)
+        sdt = torch.float32                                             # this layer's M-row gradient stream stays fp32 in both modes
+        bdt = a["h"].dtype                                              # the backward's 16-bit format = the tape's (fp16 or bf16)
         buf = lambda r, c, dv, dt=None: self._buf(r, c, dv, bdt if dt is None else dt)
-        if GS:
-            gc = dcls.contiguous()                                      # dL/dCLS is the stream's first tensor: no rounding at all
-        else:
-            gc = buf(M, d, dev)
-            ops.scatter_cls_grad(dcls.contiguous(), gc, M, 1, M)
+        gc = dcls.contiguous()                                          # dL/dCLS is the stream's first tensor: no rounding at all
         ds2 = buf(M, d, dev, sdt)
-        ds2m = buf(M, d, dev) if (p_h > 0 or GS) else None       # bf16 MFMA operand of the next data-gradient GEMM
+        ds2m = buf(M, d, dev)                                    # 16-bit MFMA operand of the next data-gradient GEMM
         lnq = getattr(self, "_lnq", None)
         f32 = dict(dtype=torch.float32, device=dev)
         own = (lambda: torch.empty(ops.ln_partial_elems(M, d), **f32)) if lnq is not None else (lambda: partial)
@@ -964,7 +949,7 @@ class HipEncoder(nn.Module):
         ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, M, residual=ds2)
         yield
         ds1 = buf(M, d, dev, sdt)
-        ds1m = buf(M, d, dev) if (p_out > 0 or GS) else None
+        ds1m = buf(M, d, dev)
         ops.layernorm_bwd(dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), M, p_out, s_l + 2,
                           accumulate=self._acc, defer=lnq)
         dA = ds1m if ds1m is not None else ds1
@@ -986,7 +971,7 @@ class HipEncoder(nn.Module):
         wt = self.ht(i, "qkv")                                      # [d, 3d] = Wqkv^T
         # the [T, d] gradient this layer hands down: fp32 - or fp16 with the fp16 gradient stream (the layer's own M-row stream stays fp32:
         # the CLS rows are added from the fp32 gq with one rounding)
-        g = buf(T, d, dev, torch.float16 if (GS and self.grad_stream16 and bdt == torch.float16) else sdt)
+        g = buf(T, d, dev, torch.float16 if (self.grad_stream16 and bdt == torch.float16) else sdt)
         ops.gemm_nt(dkv, wt[:, d:], g, T)                           # through K and V: every token
         gq = buf(M, d, dev, sdt)
         ops.gemm_nt(dqc, wt[:, :d], gq, M, residual=ds1)            # through Q and the residual: CLS rows only
@@ -1090,10 +1075,11 @@ class HipEncoder(nn.Module):
                 layer_done(i)
                 yield
                 continue
-            GS = self.grad_stream32 and a["s2"].dtype == torch.float32  # fp32 residual sums on the tape: the stream is added in the LayerNorm backward
             bdt = a["h"].dtype                                          # 16-bit format of this backward = the tape's (fp16 in amp16)
-            G16 = GS and self.grad_stream16 and bdt == torch.float16    # ... and is itself fp16 between kernels (round 5, see __init__)
-            sdt = torch.float16 if G16 else (torch.float32 if GS else torch.bfloat16)
+            # the gradient stream (residual path): its arithmetic is fp32 inside the LayerNorm backward, where stream and branch are added;
+            # BETWEEN kernels it is stored in fp16 in the fp16 mode (round 5, see __init__), in fp32 in the bf16 mode
+            G16 = self.grad_stream16 and bdt == torch.float16
+            sdt = torch.float16 if G16 else torch.float32
             buf = lambda r, c, dv, dt=None: self._buf(r, c, dv, bdt if dt is None else dt)
             if g is None:
                 g = buf(T, d, dev, sdt)
@@ -1106,7 +1092,7 @@ class HipEncoder(nn.Module):
             ds2 = buf(T, d, dev, sdt)
             # the 16-bit MFMA operand of the FFN2 data / weight gradients: a tensor of its own when dropout separates it from the stream, or
             # when the stream is fp32; with the fp16 stream and no dropout the stream tensor serves
-            ds2m = buf(T, d, dev) if (p_h > 0 or (GS and not G16)) else None
+            ds2m = buf(T, d, dev) if (p_h > 0 or not G16) else None
             lnq = self._lnq
             own = (lambda: torch.empty(ops.ln_partial_elems(T, d), **f32)) if lnq is not None else (lambda: partial)
             # fp32 stream: the gradient of a LayerNorm output is `g` (fp32: the residual path) + `gb` (bf16: the plain output of the
@@ -1123,18 +1109,15 @@ class HipEncoder(nn.Module):
             yield
             self._wq.add(dpre, a["x1"], G["W1"], T, dbias=G["bf1"])
             dx1 = buf(T, d, dev)
-            if GS:
-                ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T)             # the FFN branch alone; the residual path is ds2
-            else:
-                ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T, residual=ds2)
+            ops.gemm_nt(dpre, self.ht(i, "f1"), dx1, T)                 # the FFN branch alone; the residual path is ds2
             # --- attention-output LayerNorm + attention ---
             ds1 = buf(T, d, dev, sdt)
-            ds1m = buf(T, d, dev) if (p_out > 0 or (GS and not G16)) else None
+            ds1m = buf(T, d, dev) if (p_out > 0 or not G16) else None
             yield
             if window is not None:
                 window("ln")
-            ops.layernorm_bwd(ds2 if GS else dx1, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), T,
-                              p_out, s_l + 2, accumulate=self._acc, defer=lnq, dy_branch=dx1 if GS else None)
+            ops.layernorm_bwd(ds2, a["s1"], a["mean1"], a["rstd1"], W["g1"], ds1, ds1m, G["g1"], G["b1"], G["bo"], own(), T,
+                              p_out, s_l + 2, accumulate=self._acc, defer=lnq, dy_branch=dx1)
             dA = ds1m if ds1m is not None else ds1
             self._wq.add(dA, a["ctx"], G["Wo"], T)
             dctx = buf(T, d, dev)
@@ -1159,13 +1142,9 @@ class HipEncoder(nn.Module):
                 del dctx_pad, dqkv_pad
             self._wq.add(dqkv, a["x_in"], G["Wqkv"], T, dbias=G["bqkv"])
             yield
-            if GS:
-                gb = buf(T, d, dev)
-                ops.gemm_nt(dqkv, self.ht(i, "qkv"), gb, T)             # the attention branch alone
-                g = ds1                                                 # the residual path
-            else:
-                g = buf(T, d, dev)
-                ops.gemm_nt(dqkv, self.ht(i, "qkv"), g, T, residual=ds1)
+            gb = buf(T, d, dev)
+            ops.gemm_nt(dqkv, self.ht(i, "qkv"), gb, T)                 # the attention branch alone
+            g = ds1                                                     # the residual path
             tape.layers[i] = None        # this layer's activations: the deferred weight-gradient jobs keep what they still need
             layer_done(i)
             yield
