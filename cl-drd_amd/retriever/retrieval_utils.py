@@ -212,7 +212,12 @@ class FlatIPIndex:
         if device.type != "cuda":
             raise RuntimeError("FlatIPIndex.search runs on the GPU only (no CPU path)")
         with torch.cuda.device(device):
-            self._attach(torch.from_numpy(np.ascontiguousarray(self.embeddings)).to(device))
+            import warnings
+            with warnings.catch_warnings():
+                # a memory-mapped index file is read-only; the host tensor is only the source of this one upload and is never written through
+                warnings.filterwarnings("ignore", message="The given NumPy array is not writable")
+                host = torch.from_numpy(np.ascontiguousarray(self.embeddings))
+            self._attach(host.to(device))
         return self
 
     def _attach(self, p32: torch.Tensor):
