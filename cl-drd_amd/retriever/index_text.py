@@ -17,7 +17,7 @@ import torch
 
 from ..dataset import CachedSequenceDataset, SequenceDataset, SequenceTokenCache, SyntheticSequenceDataset
 from ..models.nway_dual_encoder import NwayDualEncoder
-from .retrieval_utils import ShardedFlatIPIndex, construct_flatindex_from_embeddings, get_embeddings_from_scratch, write_index
+from .retrieval_utils import ShardedFlatIPIndex, cap_host_threads, construct_flatindex_from_embeddings, get_embeddings_from_scratch, write_index
 
 
 # flag name -> argparse keyword arguments: names and defaults of the reference's command line (index_text.py:30-41)
@@ -81,6 +81,7 @@ def main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    cap_host_threads()
     timings = {}
     t_last = [time.perf_counter()]
 

@@ -49,15 +49,25 @@ MAX_ATTEMPTS = 12
 PROGRESS_HOOK = None         # tools: callable(timings dict) every 500 batches of get_embeddings_from_scratch
 
 
+def cap_host_threads(limit: int = 8):
+    """The host side of every batch is a handful of tiny CPU tensor ops between kernel launches.  torch sizes its intra-op pool to the
+    machine (128 threads on a 256-CPU MI355X host): waking that pool costs MILLISECONDS per op (an int64 sum over a 32 k-element mask:
+    18 ms, measured, profiles/r06_microbench.txt section 8), and eight rank processes would each own such a pool.  The command lines
+    (trainer, index_text, retrieve_top_passages) cap it; a library user's process is left alone."""
+    if torch.get_num_threads() > limit:
+        torch.set_num_threads(limit)
+
+
 def batch_to_device(batch, target_device: torch.device):
     seq = batch.get("seq") if hasattr(batch, "get") else None
     if seq is not None and hasattr(seq, "keys") and "lengths" not in seq and isinstance(seq.get("attention_mask"), torch.Tensor) \
             and not seq["attention_mask"].is_cuda:
         # token counts while the mask is still on the host: the encoder packs the batch (HipEncoder.encode) - the tokenizer pads every
         # sequence to the longest of its batch of 512, about half of the rows of an MS MARCO batch
-        m = seq["attention_mask"]
-        lens = m.sum(-1).reshape(-1)
-        if m.dim() == 2 and torch.equal(m != 0, torch.arange(m.shape[1])[None, :] < lens[:, None]):       # right-padded, as HF tokenizers pad
+        # (numpy on the zero-copy view: one thread; torch's intra-op pool on a 256-CPU host takes milliseconds to wake for such a reduction)
+        m = seq["attention_mask"].numpy()
+        lens = np.count_nonzero(m, axis=-1).reshape(-1)
+        if m.ndim == 2 and np.array_equal(m != 0, np.arange(m.shape[1])[None, :] < lens[:, None]):       # right-padded, as HF tokenizers pad
             seq = dict(seq.items())
             batch["seq"] = seq
             seq["lengths"] = lens.tolist()

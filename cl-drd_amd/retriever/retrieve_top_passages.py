@@ -14,7 +14,7 @@ import torch
 from ..dataset import SequenceDataset, SyntheticSequenceDataset
 from ..models.nway_dual_encoder import NwayDualEncoder
 from .index_text import load_checkpoint_into
-from .retrieval_utils import ShardedFlatIPIndex, convert_index_to_gpu, get_embeddings_from_scratch, index_retrieve, read_index
+from .retrieval_utils import ShardedFlatIPIndex, cap_host_threads, convert_index_to_gpu, get_embeddings_from_scratch, index_retrieve, read_index
 
 
 # names and defaults of the reference's command line (retrieve_top_passages.py:28-40) + ours
@@ -88,6 +88,7 @@ def main(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
+    cap_host_threads()
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -27,8 +27,10 @@ import torch
 import torch.distributed as dist
 
 from .. import hip_ops as ops
+from ..dataset.nway_dataset import attach_lengths
 from ..encoder import _env_flag
 from ..models.nway_dual_encoder import NwayDualEncoder, _lengths, score_mode
+from ..retriever.retrieval_utils import cap_host_threads
 
 LOSS_KINDS = ("lambda_mrr", "ranknet", "kl_div", "margin_mse")
 
@@ -881,8 +883,11 @@ def get_args(argv=None):
     ap.add_argument("--local_rank", default=-1, type=int)
     ap.add_argument("--loss", default="lambda_mrr", choices=LOSS_KINDS)
     ap.add_argument("--token_cache_dir", default=None)
+    ap.add_argument("--loader_workers", default=4, type=int, help="collate (tokenise / gather from the token cache) worker processes; "
+                    "batches arrive in pinned memory, a few steps ahead of the GPU")
     ap.add_argument("--synthetic_steps", default=0, type=int, help="steps per epoch on generated batches (no dataset files needed)")
     ap.add_argument("--synthetic_nway", default=30, type=int)
+    ap.add_argument("--synthetic_fixed", action="store_true", default=False, help="every synthetic passage passage_max_len tokens long (default: MS MARCO-shaped lengths)")
     ap.add_argument("--synthetic_model", default="distilbert", choices=("distilbert", "tiny"),
                     help="random-init architecture for --synthetic_steps runs without a model directory (tiny: encoder.tiny_config)")
     args = ap.parse_args(argv)
@@ -906,6 +911,7 @@ def set_env(args):
         args.nranks, args.distributed = 1, False
     args.device = torch.device("cuda", max(args.local_rank, 0))
     args.rank = dist.get_rank() if args.distributed else 0
+    cap_host_threads()
     return args
 
 
@@ -977,12 +983,16 @@ def build_dataloader(args):
     assert args.train_batch_size % args.nranks == 0
     g = torch.Generator()
     g.manual_seed(args.seed + args.rank)
-    return ds, torch.utils.data.DataLoader(ds, batch_size=args.train_batch_size // args.nranks, shuffle=True, num_workers=1,
-                                           collate_fn=ds.collate_fn, drop_last=True, generator=g)
+    nw = max(int(getattr(args, "loader_workers", 1)), 0)
+    return ds, torch.utils.data.DataLoader(ds, batch_size=args.train_batch_size // args.nranks, shuffle=True, num_workers=nw,
+                                           collate_fn=ds.collate_fn, drop_last=True, generator=g, pin_memory=True,
+                                           **(dict(prefetch_factor=4, persistent_workers=True) if nw else {}))
 
 
-class _SyntheticLoader:
-    """``--synthetic_steps`` batches of the collate_fn layout from the portable generator (synthetic.nway_batch)."""
+class _SyntheticBatches(torch.utils.data.Dataset):
+    """``--synthetic_steps`` batches of the collate_fn layout from the portable generator (synthetic.nway_batch): item i IS batch i (a
+    function of (seed, rank, i) only), so the loader below hands them out with ``batch_size=None`` from worker processes, pinned, like the
+    real one."""
 
     def __init__(self, args):
         self.args = args
@@ -990,13 +1000,19 @@ class _SyntheticLoader:
     def __len__(self):
         return self.args.synthetic_steps
 
-    def __iter__(self):
+    def __getitem__(self, i):
         from .. import synthetic as syn
         a = self.args
-        for i in range(a.synthetic_steps):
-            yield syn.nway_batch(a.seed + 1000 * a.rank + i, a.train_batch_size // a.nranks, a.synthetic_nway, a.query_max_len,
-                                 a.passage_max_len, vocab=getattr(a, "synthetic_vocab", syn.VOCAB), ragged=True,
-                                 label_kind="teacher" if a.loss in ("kl_div", "margin_mse") else "mode9")
+        b = syn.nway_batch(a.seed + 1000 * a.rank + i, a.train_batch_size // a.nranks, a.synthetic_nway, a.query_max_len,
+                           a.passage_max_len, vocab=getattr(a, "synthetic_vocab", syn.VOCAB), ragged=not getattr(a, "synthetic_fixed", False),
+                           label_kind="teacher" if a.loss in ("kl_div", "margin_mse") else "mode9")
+        return attach_lengths(b)
+
+
+def _synthetic_loader(args):
+    nw = max(int(getattr(args, "loader_workers", 1)), 0)
+    return torch.utils.data.DataLoader(_SyntheticBatches(args), batch_size=None, shuffle=False, num_workers=nw, pin_memory=True,
+                                       **(dict(prefetch_factor=4, persistent_workers=True) if nw else {}))
 
 
 def common_steps_per_epoch(local_steps: int, distributed: bool, dev=None, group=None) -> int:
@@ -1011,17 +1027,8 @@ def common_steps_per_epoch(local_steps: int, distributed: bool, dev=None, group=
 
 
 def batch_to_device(batch, dev):
-    """Move a collated batch to the device.  The passages' token counts are taken from the attention mask while it is still on the host
-    ("lengths": what lets the encoder pack the batch without a device -> host sync; CLDRD_PACK=0 turns packing off)."""
-    nw = batch.get("nway_passages")
-    if hasattr(nw, "items") and "lengths" not in nw and isinstance(nw.get("attention_mask"), torch.Tensor) and not nw["attention_mask"].is_cuda:
-        m = nw["attention_mask"]
-        lens = m.sum(-1)
-        if torch.equal(m != 0, torch.arange(m.shape[-1]).expand_as(m) < lens.unsqueeze(-1)):       # right-padded, as HF tokenizers pad
-            nw = dict(nw.items())
-            nw["lengths"] = lens.reshape(-1)
-            batch = dict(batch.items())
-            batch["nway_passages"] = nw
+    """Move a collated batch to the device (asynchronously when the loader pinned it); "lengths" stay on the host."""
+    batch = attach_lengths(batch)
     out = {}
     for k, v in batch.items():
         if isinstance(v, torch.Tensor):
@@ -1039,7 +1046,7 @@ def train(args):
     import numpy as np
     dev = args.device
     if args.synthetic_steps > 0:
-        loader, n_examples = _SyntheticLoader(args), args.synthetic_steps * args.train_batch_size
+        loader, n_examples = _synthetic_loader(args), args.synthetic_steps * args.train_batch_size
     else:
         ds, loader = build_dataloader(args)
         n_examples = len(ds)

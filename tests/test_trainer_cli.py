@@ -46,6 +46,57 @@ def test_schedule_and_sharding_helpers():
     assert not T.no_decay("passage_encoder.transformer.layer.0.sa_layer_norm.weight")
 
 
+def test_lengths_come_from_the_host_mask_without_torch_reductions():
+    """attach_lengths (collate functions in the loader's workers, batch_to_device for anything else): token counts of right-padded masks, none
+    for a mask that is not right-padded, untouched when the loader already gave them; numpy on the tensor's memory (on a 256-CPU host torch's
+    intra-op pool took 18 ms per step for this sum: profiles/r06_microbench.txt section 8)."""
+    from cldrd_amd import synthetic as syn
+    from cldrd_amd.dataset.nway_dataset import attach_lengths
+    b = syn.nway_batch(11, 3, 5, 8, 128, vocab=512, ragged=True)
+    out = attach_lengths(b)
+    m = b["nway_passages"]["attention_mask"]
+    assert 0 < int(m.sum()) < m.numel()
+    assert out["nway_passages"]["lengths"].dtype == torch.int64 and out["nway_passages"]["lengths"].tolist() == m.sum(-1).reshape(-1).tolist()
+    assert "lengths" not in b["nway_passages"]                         # the caller's dict is not modified
+    assert attach_lengths(out) is out
+    left = {k: (dict(v) if isinstance(v, dict) else v) for k, v in b.items()}
+    left["nway_passages"]["attention_mask"] = m.flip(-1).contiguous()
+    assert "lengths" not in attach_lengths(left)["nway_passages"]
+    full = attach_lengths(syn.nway_batch(11, 3, 5, 8, 24, vocab=512, ragged=False))
+    assert full["nway_passages"]["lengths"].tolist() == [24] * 15
+    moved = T.batch_to_device(b, torch.device("cpu"))
+    assert moved["nway_passages"]["lengths"].tolist() == out["nway_passages"]["lengths"].tolist()
+
+
+def test_synthetic_loader_hands_out_whole_batches_from_workers():
+    """--synthetic_steps: item i of the dataset IS batch i (a function of seed, rank and i), so worker processes can produce them ahead of the GPU
+    like the real loader; --synthetic_fixed gives the one-shape batches of the headline benchmark; the command line caps torch's host pool."""
+    from cldrd_amd import synthetic as syn
+    a = T.get_args(["--synthetic_steps", "5", "--synthetic_nway", "4", "--query_max_len", "8", "--passage_max_len", "24", "--train_batch_size", "2",
+                    "--loss", "kl_div", "--loader_workers", "2"])
+    assert T.get_args([]).loader_workers == 4 and not a.synthetic_fixed
+    a.rank, a.nranks, a.synthetic_vocab = 0, 1, 512
+    ds = T._SyntheticBatches(a)
+    want = syn.nway_batch(a.seed + 3, 2, 4, 8, 24, vocab=512, ragged=True, label_kind="teacher")
+    got = ds[3]
+    assert len(ds) == 5 and torch.equal(got["nway_passages"]["input_ids"], want["nway_passages"]["input_ids"])
+    assert torch.equal(got["labels"], want["labels"]) and got["nway_passages"]["lengths"].numel() == 8
+    loader = torch.utils.data.DataLoader(ds, batch_size=None, shuffle=False, num_workers=2)
+    seen = [b["nway_passages"]["input_ids"] for b in loader]
+    assert len(seen) == 5 and torch.equal(seen[3], want["nway_passages"]["input_ids"])
+    a.synthetic_fixed = True
+    assert T._SyntheticBatches(a)[0]["nway_passages"]["lengths"].tolist() == [24] * 8
+    n0 = torch.get_num_threads()
+    try:
+        torch.set_num_threads(max(n0, 2))
+        T.cap_host_threads(1)
+        assert torch.get_num_threads() == 1
+        T.cap_host_threads(64)                                          # a cap never raises the count
+        assert torch.get_num_threads() == 1
+    finally:
+        torch.set_num_threads(n0)
+
+
 @pytest.mark.gpu
 def test_logit_norm_regulariser_matches_torch():
     from cldrd_amd import hip_ops as ops
