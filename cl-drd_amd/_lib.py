@@ -36,6 +36,10 @@ SIGNATURES = {
     "cldrd_attention_cls_fwd": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp]),
     "cldrd_attention_cls_bwd": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp]),
     "cldrd_attention_cls_bwd_x": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
+    "cldrd_attention_fwd_varlen": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp, vp]),
+    "cldrd_attention_bwd_varlen": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp, ci, vp]),
+    "cldrd_attention_cls_fwd_varlen": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp]),
+    "cldrd_attention_cls_bwd_varlen": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
     "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, ci, vp]),
     "cldrd_ln_partial_blocks": (ci, [ci]),
     "cldrd_embed_ln_fwd": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, cull, vp, ci, vp, vp, vp]),

@@ -94,6 +94,16 @@ __device__ __forceinline__ uint4 widen_pair(const uint2& g0, const uint2& g1) {
     return make_uint4(rx[0], ry[0], rx[1], ry[1]);
 }
 
+// Packed ("varlen") batches: with `cu` given, the rows of sequence `seq` are rows cu[seq] .. cu[seq + 1] of qkv / ctx / dctx / dqkv (pack.hip's
+// layout: Tp = sum of the lengths rows, no padding rows anywhere) instead of rows seq * L .. seq * L + L of the padded layout; keys and queries
+// >= the sequence's length arrive in LDS as zero rows and are masked, exactly what the padded layout holds after cldrd_unpack_rows16 - so the two
+// layouts give the same bits - and are neither read nor written.  LSE, keep bits and probabilities stay [nseq, H, L(, ..)] (small).
+struct SeqRows { int row0, len; };
+__device__ __forceinline__ SeqRows seq_rows(const int* __restrict__ cu, int seq, int L) {
+    if (cu) { const int c0 = cu[seq]; return {c0, cu[seq + 1] - c0}; }
+    return {seq * L, L};
+}
+
 // copy a [L, 64] bf16 head slice (row stride ld elements) into an LDS tile of Lp rows, zero-filling rows >= L
 __device__ __forceinline__ void load_tile(char* tile, const bf16_t* src, int ld, int L, int Lp) {
     for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
@@ -113,7 +123,7 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
-                                                        bf16_t* __restrict__ ctx16) {
+                                                        bf16_t* __restrict__ ctx16, const int* __restrict__ cu) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -123,12 +133,14 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
     float* sBias = (float*)(sV + Lp * RSB);
     const int seq = blockIdx.x / H, hd = blockIdx.x % H;
     const int dm = H * 64, ld = 3 * dm;
-    const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
-    load_tile(sQ, base, ld, L, Lp);
-    load_tile(sK, base + dm, ld, L, Lp);
-    load_tile(sV, base + 2 * dm, ld, L, Lp);
+    const SeqRows sr = seq_rows(cu, seq, L);
+    const int len = sr.len;
+    const bf16_t* base = qkv + (size_t)sr.row0 * ld + hd * 64;
+    load_tile(sQ, base, ld, len, Lp);
+    load_tile(sK, base + dm, ld, len, Lp);
+    load_tile(sV, base + 2 * dm, ld, len, Lp);
     for (int k = threadIdx.x; k < Lp; k += blockDim.x)
-        sBias[k] = (k < L && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
+        sBias[k] = (k < len && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
         // 32 (+ 32) two-byte ones.  (Round 2 tried the transposed form with 8-byte stores and found it 8 % slower; round 5, with the widened
         // stores: profiles/r05_microbench.txt section 6.)
         {
-            const size_t orow = ((size_t)seq * L + q) * dm + hd * 64;
+            const size_t orow = ((size_t)sr.row0 + q) * dm + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -225,11 +237,11 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
                     }
                     if (ctx) {       // ctx: the kernel's own format (may be absent); ctx16: an fp16 copy of a bf16 pass (out-projection operand)
                         const uint4 w = widen_pair(o[0], o[1]);
-                        if (q < L) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
+                        if (q < len) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                     if (ctx16) {
                         const uint4 w = widen_pair(o16[0], o16[1]);
-                        if (q < L) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
+                        if (q < len) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                 }
         }
@@ -246,7 +258,7 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                          bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                          float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
-                                                         uint32_t* __restrict__ bits_out, bf16_t* __restrict__ ctx16) {
+                                                         uint32_t* __restrict__ bits_out, bf16_t* __restrict__ ctx16, const int* __restrict__ cu) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -264,19 +276,20 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
     float p_bias = 0.f;
     auto issue = [&](int item) {
         const int seq = item / H, hd = item % H;
-        const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
+        const SeqRows nr = seq_rows(cu, seq, L);
+        const bf16_t* base = qkv + (size_t)nr.row0 * ld + hd * 64;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int idx = tb + 256 * j, row = idx >> 3, ch = idx & 7;
             pq[j] = pk[j] = pv[j] = make_uint4(0, 0, 0, 0);
-            if (row < L) {
+            if (row < nr.len) {
                 const bf16_t* rp = base + (size_t)row * ld + ch * 8;
                 pq[j] = *(const uint4*)rp;
                 pk[j] = *(const uint4*)(rp + dm);
                 pv[j] = *(const uint4*)(rp + 2 * dm);
             }
         }
-        if (tb < Lp) p_bias = (tb < L && (!mask || mask[(size_t)seq * L + tb] != 0)) ? 0.f : NEG_BIG;
+        if (tb < Lp) p_bias = (tb < nr.len && (!mask || mask[(size_t)seq * L + tb] != 0)) ? 0.f : NEG_BIG;
     };
     auto commit = [&](int b) {
         char* base = smem + b * BUF;
@@ -324,6 +337,8 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
         const float* sBias = (const float*)(sV + TILE);
         const uint32_t* sBits = (const uint32_t*)(sBias + Lp);
         const int seq = item / H, hd = item % H;
+        const SeqRows sr = seq_rows(cu, seq, L);
+        const int len = sr.len;
         const int t_ = opaque(tid);
         const int lane = t_ & 63, r = lane & 31, h = lane >> 5;
         tb = t_ & 255;
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
         // 32 (+ 32) two-byte ones.  (Round 2 tried the transposed form with 8-byte stores and found it 8 % slower; round 5, with the widened
         // stores: profiles/r05_microbench.txt section 6.)
         {
-            const size_t orow = ((size_t)seq * L + q) * dm + hd * 64;
+            const size_t orow = ((size_t)sr.row0 + q) * dm + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -422,11 +437,11 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
                     }
                     if (ctx) {       // ctx: the kernel's own format (may be absent); ctx16: an fp16 copy of a bf16 pass (out-projection operand)
                         const uint4 w = widen_pair(o[0], o[1]);
-                        if (q < L) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
+                        if (q < len) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                     if (ctx16) {
                         const uint4 w = widen_pair(o16[0], o16[1]);
-                        if (q < L) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
+                        if (q < len) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                 }
         }
@@ -447,7 +462,7 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
-                                                        bf16_t* __restrict__ ctx16) {
+                                                        bf16_t* __restrict__ ctx16, const int* __restrict__ cu) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -458,12 +473,14 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
     float* sBias = (float*)(sV + Lp * RSB);
     const int seq = blockIdx.x / H, hd = blockIdx.x % H;
     const int dm = H * 64, ld = 3 * dm;
-    const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
-    load_tile(sQ, base, ld, L, Lp);
-    load_tile(sK, base + dm, ld, L, Lp);
-    load_tile(sV, base + 2 * dm, ld, L, Lp);
+    const SeqRows sr = seq_rows(cu, seq, L);
+    const int len = sr.len;
+    const bf16_t* base = qkv + (size_t)sr.row0 * ld + hd * 64;
+    load_tile(sQ, base, ld, len, Lp);
+    load_tile(sK, base + dm, ld, len, Lp);
+    load_tile(sV, base + 2 * dm, ld, len, Lp);
     for (int k = threadIdx.x; k < Lp; k += blockDim.x)
-        sBias[k] = (k < L && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
+        sBias[k] = (k < len && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -535,7 +552,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
         if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (m + __log2f(l)) * LN2;
         const float inv = (DROP ? drop_scale : 1.0f) / l;
         {
-            const size_t orow = ((size_t)seq * L + q) * dm + hd * 64;
+            const size_t orow = ((size_t)sr.row0 + q) * dm + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -552,11 +569,11 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
                     }
                     if (ctx) {
                         const uint4 w = widen_pair(o[0], o[1]);
-                        if (q < L) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
+                        if (q < len) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                     if (ctx16) {       // fp16 copy (out-projection operand)
                         const uint4 w = widen_pair(o16[0], o16[1]);
-                        if (q < L) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
+                        if (q < len) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                 }
         }
@@ -576,7 +593,7 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                          bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                          float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
-                                                         bf16_t* __restrict__ ctx16) {
+                                                         bf16_t* __restrict__ ctx16, const int* __restrict__ cu) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -589,6 +606,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
     u32x4 pk[NCH], pv[NCH];          // (first-class vector values: as `uint4` structs hipcc kept the two arrays in scratch memory)
     bf16x8 qn[4];
     long long pm = 0;
+    int p_len = 0;                   // row count of the prefetched item (L, or its length in the packed layout)
     // Every load of issue() is UNCONDITIONAL on a clamped row (no exec-masked region, no branch): the compiler can then count its vmcnt waits -
     // the pieces are consumed at commit(), behind this item's ctx stores, and must not wait for those (vmcnt counts stores too).  A row >= L
     // therefore arrives as a copy of row L - 1 instead of zeros: a K row that the key bias masks (score + -1e30 is -1e30 whatever the score),
@@ -596,18 +614,20 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
     const long long* mask_or_any = mask ? (const long long*)mask : (const long long*)qkv;      // null mask: the value loaded is ignored
     auto issue = [&](int item) {
         const int seq = item / H, hd = item % H;
-        const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
+        const SeqRows nr = seq_rows(cu, seq, L);
+        p_len = nr.len;
+        const bf16_t* base = qkv + (size_t)nr.row0 * ld + hd * 64;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            const int idx = tid + 512 * j, row = min(idx >> 3, L - 1), ch = idx & 7;
+            const int idx = tid + 512 * j, row = min(idx >> 3, nr.len - 1), ch = idx & 7;
             const bf16_t* rp = base + (size_t)row * ld + ch * 8;
             pk[j] = *(const u32x4*)(rp + dm);
             pv[j] = *(const u32x4*)(rp + 2 * dm);
         }
-        pm = mask_or_any[(size_t)seq * L + min(tid, L - 1)];
+        pm = mask_or_any[mask ? (size_t)seq * L + min(tid, L - 1) : (size_t)0];
         // this wave's Q block of the item: row 32 qb + r, 16-byte pieces 2 s + h (row_frag's layout)
         const int lane = tid & 63, r = lane & 31, h = lane >> 5, qb = min(tid >> 6, NKB - 1);
-        const int qrow = min(qb * 32 + r, L - 1);
+        const int qrow = min(qb * 32 + r, nr.len - 1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) qn[s] = *(const bf16x8*)(base + (size_t)qrow * ld + (2 * s + h) * 8);
     };
@@ -622,7 +642,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
                 *(u32x4*)(base + TILE + off) = pv[j];
             }
         }
-        if (tid < Lp) ((float*)(base + 2 * TILE))[tid] = (tid < L && (!mask || pm != 0)) ? 0.f : NEG_BIG;
+        if (tid < Lp) ((float*)(base + 2 * TILE))[tid] = (tid < p_len && (!mask || pm != 0)) ? 0.f : NEG_BIG;
     };
     int item = blockIdx.x;
     bf16x8 qf[4];
@@ -648,6 +668,8 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
         const char* sV = sK + TILE;
         const float* sBias = (const float*)(sV + TILE);
         const int seq = item / H, hd = item % H;
+        const SeqRows sr = seq_rows(cu, seq, L);
+        const int len = sr.len;
         const int lane = tid & 63, wid = tid >> 6;
         const int r = lane & 31, h = lane >> 5;
         if (wid < NKB) {
@@ -712,7 +734,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
             const float l = lsum + __shfl_xor(lsum, 32, 64);
             if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (m + __log2f(l)) * LN2;
             const float inv = (DROP ? drop_scale : 1.0f) / l;
-            const size_t orow = ((size_t)seq * L + q) * dm + hd * 64;
+            const size_t orow = ((size_t)sr.row0 + q) * dm + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -729,11 +751,11 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
                     }
                     if (ctx) {
                         const uint4 w = widen_pair(o[0], o[1]);
-                        if (q < L) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
+                        if (q < len) *(uint4*)(ctx + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                     if (ctx16) {       // fp16 copy (out-projection operand)
                         const uint4 w = widen_pair(o16[0], o16[1]);
-                        if (q < L) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
+                        if (q < len) *(uint4*)(ctx16 + orow + dt * 32 + 8 * (u + h)) = w;
                     }
                 }
         }
@@ -749,7 +771,8 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
-                                                        float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+                                                        float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
+                                                        const int* __restrict__ cu) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -764,17 +787,19 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
     uint32_t* sRk = (uint32_t*)(sDelta + Lp);          // dropout row key of every query row (common.h)
     const int seq = blockIdx.x / H, hd = blockIdx.x % H;
     const int dm = H * 64, ld = 3 * dm;
-    const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
-    load_tile(sQ, base, ld, L, Lp);
-    load_tile(sK, base + dm, ld, L, Lp);
-    load_tile(sV, base + 2 * dm, ld, L, Lp);
+    const SeqRows sr = seq_rows(cu, seq, L);
+    const int len = sr.len;
+    const bf16_t* base = qkv + (size_t)sr.row0 * ld + hd * 64;
+    load_tile(sQ, base, ld, len, Lp);
+    load_tile(sK, base + dm, ld, len, Lp);
+    load_tile(sV, base + 2 * dm, ld, len, Lp);
     {   // dO tile + delta[q] = sum_d dO[q][d] * O[q][d]
-        const bf16_t* dob = dctx + (size_t)seq * L * dm + hd * 64;
-        const bf16_t* ob = ctx + (size_t)seq * L * dm + hd * 64;
+        const bf16_t* dob = dctx + (size_t)sr.row0 * dm + hd * 64;
+        const bf16_t* ob = ctx + (size_t)sr.row0 * dm + hd * 64;
         for (int idx = threadIdx.x; idx < Lp * 8; idx += blockDim.x) {
             const int row = idx >> 3, ch = idx & 7;
             uint4 v = make_uint4(0, 0, 0, 0), o = make_uint4(0, 0, 0, 0);
-            if (row < L) {
+            if (row < len) {
                 v = *(const uint4*)(dob + (size_t)row * dm + ch * 8);
                 o = *(const uint4*)(ob + (size_t)row * dm + ch * 8);
             }
@@ -788,7 +813,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
         }
     }
     for (int k = threadIdx.x; k < Lp; k += blockDim.x) {
-        sBias[k] = (k < L && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
+        sBias[k] = (k < len && (!mask || mask[(size_t)seq * L + k] != 0)) ? 0.f : NEG_BIG;
         sLse[k] = k < L ? lse[((size_t)seq * H + hd) * L + k] * LOG2E : 1.0e30f;      // log2 domain; rows >= L: P = 2^-inf = 0
         sRk[k] = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + k));
     }
@@ -856,7 +881,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
         }
         // dV[dt][t] = dV[key][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
         {
-            bf16_t* ok = dqkv + ((size_t)seq * L + key) * ld + dm + hd * 64;
+            bf16_t* ok = dqkv + ((size_t)sr.row0 + key) * ld + dm + hd * 64;
             bf16_t* ov = ok + dm;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -873,7 +898,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
                     }
                     const uint4 wa = widen_pair(a[0], a[1]), wb = widen_pair(b[0], b[1]);      // 16 contiguous bytes per lane (see widen_pair)
                     const int d0 = dt * 32 + 8 * (u + h);
-                    if (key < L) {
+                    if (key < len) {
                         *(uint4*)(ok + d0) = wa;
                         *(uint4*)(ov + d0) = wb;
                     }
@@ -933,7 +958,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
             }
         }
         {                 // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
-            bf16_t* oq = dqkv + ((size_t)seq * L + q) * ld + hd * 64;
+            bf16_t* oq = dqkv + ((size_t)sr.row0 + q) * ld + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -946,7 +971,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
                         a[k].y = pack2x_scaled<F16>(dQ[dt][t + 2], dQ[dt][t + 3], scale);
                     }
                     const uint4 w = widen_pair(a[0], a[1]);
-                    if (q < L) *(uint4*)(oq + dt * 32 + 8 * (u + h)) = w;
+                    if (q < len) *(uint4*)(oq + dt * 32 + 8 * (u + h)) = w;
                 }
         }
     }
@@ -968,7 +993,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                                                          const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
                                                          float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
-                                                         const uint32_t* __restrict__ drop_bits) {
+                                                         const uint32_t* __restrict__ drop_bits, const int* __restrict__ cu) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -992,17 +1017,20 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
     // with them for the twenty tile loads issued just before: the "issue early, write late" prefetch waited for itself.)
     long long p_mask = 1;
     float p_lse = 0.f;
+    int p_len = 0;                   // row count of the prefetched item (L, or its length in the packed layout)
     uint32_t pbits[NBW > 0 ? NBW : 1];
     auto issue = [&](int item) {
         const int seq = item / H, hd = item % H;
-        const bf16_t* base = qkv + (size_t)seq * L * ld + hd * 64;
-        const bf16_t* dob = dctx + (size_t)seq * L * dm + hd * 64;
-        const bf16_t* ob = ctx + (size_t)seq * L * dm + hd * 64;
+        const SeqRows nr = seq_rows(cu, seq, L);
+        p_len = nr.len;
+        const bf16_t* base = qkv + (size_t)nr.row0 * ld + hd * 64;
+        const bf16_t* dob = dctx + (size_t)nr.row0 * dm + hd * 64;
+        const bf16_t* ob = ctx + (size_t)nr.row0 * dm + hd * 64;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int idx = tb + 256 * j, row = idx >> 3, ch = idx & 7;
             pq[j] = pk[j] = pv[j] = pdo[j] = po[j] = make_uint4(0, 0, 0, 0);
-            if (row < L) {
+            if (row < nr.len) {
                 const bf16_t* rp = base + (size_t)row * ld + ch * 8;
                 pq[j] = ld16_stream(rp);                          // q, k, v, o: the forward's tape, read once (common.h)
                 pk[j] = ld16_stream(rp + dm);
@@ -1041,7 +1069,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             if (ch == 0) fl[2 * Lp + row] = dsum;
         }
         if (tb < Lp) {
-            fl[tb] = (tb < L && p_mask != 0) ? 0.f : NEG_BIG;
+            fl[tb] = (tb < p_len && p_mask != 0) ? 0.f : NEG_BIG;
             fl[Lp + tb] = tb < L ? p_lse * LOG2E : 1.0e30f;
             ((uint32_t*)fl)[3 * Lp + tb] = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + tb));
         }
@@ -1068,6 +1096,8 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         const uint32_t* sRk = (const uint32_t*)(sDelta + Lp);
         const uint32_t* sBits = sRk + Lp;
         const int seq = item / H, hd = item % H;
+        const SeqRows sr = seq_rows(cu, seq, L);
+        const int len = sr.len;
         const int t_ = opaque(tid);
         const int lane = t_ & 63, r = lane & 31, h = lane >> 5;
         tb = t_ & 255;
@@ -1131,7 +1161,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
             }
         }
         {                 // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
-            bf16_t* oq = dqkv + ((size_t)seq * L + q) * ld + hd * 64;
+            bf16_t* oq = dqkv + ((size_t)sr.row0 + q) * ld + hd * 64;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -1144,7 +1174,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                         a[k].y = pack2x_scaled<F16>(dQ[dt][t + 2], dQ[dt][t + 3], scale);
                     }
                     const uint4 w = widen_pair(a[0], a[1]);
-                    if (q < L) *(uint4*)(oq + dt * 32 + 8 * (u + h)) = w;
+                    if (q < len) *(uint4*)(oq + dt * 32 + 8 * (u + h)) = w;
                 }
         }
                 }
@@ -1210,7 +1240,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         }
         // dV[dt][t] = dV[key][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
         {
-            bf16_t* ok = dqkv + ((size_t)seq * L + key) * ld + dm + hd * 64;
+            bf16_t* ok = dqkv + ((size_t)sr.row0 + key) * ld + dm + hd * 64;
             bf16_t* ov = ok + dm;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -1227,7 +1257,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                     }
                     const uint4 wa = widen_pair(a[0], a[1]), wb = widen_pair(b[0], b[1]);      // 16 contiguous bytes per lane (see widen_pair)
                     const int d0 = dt * 32 + 8 * (u + h);
-                    if (key < L) {
+                    if (key < len) {
                         *(uint4*)(ok + d0) = wa;
                         *(uint4*)(ov + d0) = wb;
                     }
@@ -1244,24 +1274,24 @@ bool attn_fwd2_enabled(int nseq, int L, int H);
 
 template <int NKB, bool DROP>
 int launch_fwd_f16(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-                   unsigned long long seed, hipStream_t st) {      // fp16 in, fp16 out: no second copy
+                   unsigned long long seed, hipStream_t st, const int* cu) {      // fp16 in, fp16 out: no second copy
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
     (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP, true>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)nullptr);
+                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)nullptr, cu);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 template <int NKB>
 int launch_fwd_h(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-                 unsigned long long seed, hipStream_t st) {
-    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_f16<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, st)
-                                              : launch_fwd_f16<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, st);
+                 unsigned long long seed, hipStream_t st, const int* cu) {
+    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_f16<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, st, cu)
+                                              : launch_fwd_f16<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, st, cu);
 }
 
 template <int NKB, bool DROP, bool F16 = false>
 int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-                 unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st) {
+                 unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st, const int* cu) {
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
     if constexpr (NKB <= 4) {
         // many items: the persistent loader / compute kernel (CLDRD_ATTN_FWD2=0 keeps the one-item-per-workgroup kernel: A/B runs and tests)
@@ -1271,13 +1301,13 @@ int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, 
             (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipLaunchKernelGGL((attn_fwd2_kernel<NKB, DROP, F16>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems,
-                               bits_out, (bf16_t*)ctx16);
+                               bits_out, (bf16_t*)ctx16, cu);
             CLDRD_LAUNCH_CHECK();
             return 0;
         }
         (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16);
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16, cu);
     } else {
         // many items at 128 < L <= 256: the persistent streaming kernel (K / V double-buffered, Q from global memory); cldrd_set_tuning("attn_fwd2", 0)
         // keeps the one-item-per-workgroup kernel (tests: the two are bit-identical)
@@ -1287,22 +1317,22 @@ int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, 
             (void)hipFuncSetAttribute((const void*)attn_fwd3_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
             hipLaunchKernelGGL((attn_fwd3_kernel<NKB, DROP, F16>), dim3(cus), dim3(512), lds3, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems,
-                               (bf16_t*)ctx16);
+                               (bf16_t*)ctx16, cu);
             CLDRD_LAUNCH_CHECK();
             return 0;
         }
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(512), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16);
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16, cu);
     }
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 template <int NKB, bool F16 = false>
 int launch_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-               unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st) {
-    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, bits_out, ctx16, st)
-                                              : launch_fwd_d<NKB, false, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, nullptr, ctx16, st);
+               unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st, const int* cu) {
+    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, bits_out, ctx16, st, cu)
+                                              : launch_fwd_d<NKB, false, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, nullptr, ctx16, st, cu);
 }
 int attn_num_cus() {
     static int n = 0;
@@ -1320,7 +1350,7 @@ bool attn_fwd2_enabled(int nseq, int L, int H) {
 
 template <int NKB, bool DROP, bool F16 = false>
 int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
-                 int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st) {
+                 int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st, const int* cu) {
     if constexpr (NKB <= 4) {
         // many items: the persistent two-role kernel (cldrd_set_tuning("attn_bwd2", 0) keeps the one-item-per-workgroup kernel: tests)
         const int nitems = nseq * H, cus = attn_num_cus();
@@ -1331,12 +1361,12 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
                 (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
                 hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, DROP, F16>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                    (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, drop_bits);
+                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, drop_bits, cu);
             } else {
                 (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
                 hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, false, F16>), dim3(cus), dim3(512), 2 * lds1, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                    (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, (const uint32_t*)nullptr);
+                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, (const uint32_t*)nullptr, cu);
             }
             CLDRD_LAUNCH_CHECK();
             return 0;
@@ -1346,16 +1376,16 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                        (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                       DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed));
+                       DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), cu);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 template <int NKB, bool F16 = false>
 int launch_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
-               int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st) {
+               int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st, const int* cu) {
     return p > 0.f && dropout_thresh16(p) > 0
-               ? launch_bwd_d<NKB, true, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, p, seed, drop_bits, st)
-               : launch_bwd_d<NKB, false, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, 0.f, seed, nullptr, st);
+               ? launch_bwd_d<NKB, true, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, p, seed, drop_bits, st, cu)
+               : launch_bwd_d<NKB, false, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, 0.f, seed, nullptr, st, cu);
 }
 
 }  // namespace
@@ -1380,9 +1410,25 @@ extern "C" int cldrd_attention_fwd(const void* qkv, const long long* mask, void*
 // drop_bits_out (optional, cldrd_attention_bits_words() words): receives the dropout keep bits for cldrd_attention_bwd_bits.
 // ctx_f16_copy (optional, bf16 pass only): the same context in fp16 - the operand of an fp16 out-projection GEMM; ctx itself may then be null
 // (an evaluation forward keeps no bf16 tape).
+static int attention_fwd_impl(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float dropout_p,
+                              unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy, const int* cu, void* stream);
 extern "C" int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
                                         float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy,
                                         void* stream) {
+    return attention_fwd_impl(qkv, mask, ctx, lse, nseq, L, H, dropout_p, seed, io_f16, drop_bits_out, ctx_f16_copy, nullptr, stream);
+}
+// The same on a PACKED batch (pack.hip): qkv [Tp, 3*H*64] and ctx [Tp, H*64] hold the rows cu_rows[m] .. cu_rows[m + 1] of sequence m
+// (cu_rows: int32 [nseq + 1] on the device, every length in 1 .. L); keys >= a sequence's length are masked (right padding, what an HF
+// tokenizer's attention mask says), no mask tensor is read.  lse [nseq, H, L] and the keep bits keep their padded shapes.  Bit for bit what
+// cldrd_unpack_rows16 -> cldrd_attention_fwd_bits -> cldrd_gather_rows give, without the two row moves and without loading padding rows.
+extern "C" int cldrd_attention_fwd_varlen(const void* qkv_packed, const int* cu_rows, void* ctx_packed, float* lse, int nseq, int L, int H,
+                                          float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy,
+                                          void* stream) {
+    CLDRD_CHECK(cu_rows != nullptr, "attention_fwd_varlen: cu_rows is required");
+    return attention_fwd_impl(qkv_packed, nullptr, ctx_packed, lse, nseq, L, H, dropout_p, seed, io_f16, drop_bits_out, ctx_f16_copy, cu_rows, stream);
+}
+static int attention_fwd_impl(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float dropout_p,
+                              unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy, const int* cu, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_fwd: need 0 < L <= 256");
     CLDRD_CHECK(ctx != nullptr || ctx_f16_copy != nullptr, "attention_fwd: no output");
     CLDRD_CHECK(!(io_f16 && (ctx_f16_copy != nullptr || ctx == nullptr)), "attention_fwd: the fp16 pass writes ctx only");
@@ -1392,34 +1438,34 @@ extern "C" int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, 
     hipStream_t st = (hipStream_t)stream;
     if (io_f16 == 5) {            // fp16 activations through the whole kernel family (round 4: the all-fp16 training mode)
         switch (nkb) {
-            case 1: return launch_fwd<1, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
-            case 2: return launch_fwd<2, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
-            case 3: return launch_fwd<3, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
-            case 4: return launch_fwd<4, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
-            case 5: return launch_fwd<5, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
-            case 6: return launch_fwd<6, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
-            case 7: return launch_fwd<7, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
-            default: return launch_fwd<8, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st);
+            case 1: return launch_fwd<1, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
+            case 2: return launch_fwd<2, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
+            case 3: return launch_fwd<3, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
+            case 4: return launch_fwd<4, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
+            case 5: return launch_fwd<5, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
+            case 6: return launch_fwd<6, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
+            case 7: return launch_fwd<7, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
+            default: return launch_fwd<8, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
         }
     }
     if (io_f16) {                 // fp16 activations: the all-scores-in-registers kernel only (L <= 128)
         CLDRD_CHECK(L <= 128, "attention_fwd: the fp16 forward handles L <= 128");
         switch (nkb) {
-            case 1: return launch_fwd_h<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-            case 2: return launch_fwd_h<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-            case 3: return launch_fwd_h<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
-            default: return launch_fwd_h<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st);
+            case 1: return launch_fwd_h<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu);
+            case 2: return launch_fwd_h<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu);
+            case 3: return launch_fwd_h<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu);
+            default: return launch_fwd_h<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu);
         }
     }
     switch (nkb) {
-        case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
-        case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
-        case 3: return launch_fwd<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
-        case 4: return launch_fwd<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
-        case 5: return launch_fwd<5>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
-        case 6: return launch_fwd<6>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
-        case 7: return launch_fwd<7>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
-        default: return launch_fwd<8>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st);
+        case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
+        case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
+        case 3: return launch_fwd<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
+        case 4: return launch_fwd<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
+        case 5: return launch_fwd<5>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
+        case 6: return launch_fwd<6>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
+        case 7: return launch_fwd<7>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
+        default: return launch_fwd<8>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
     }
 }
 
@@ -1440,9 +1486,23 @@ extern "C" int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, 
     return cldrd_attention_bwd_x(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p, seed, drop_bits, 0, stream);
 }
 // io_f16 != 0: q / k / v, ctx, dctx and dqkv are fp16 (the all-fp16 training mode: gradients carry the loss scale)
+static int attention_bwd_impl(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
+                              int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits, int io_f16, const int* cu, void* stream);
 extern "C" int cldrd_attention_bwd_x(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                                      void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
                                      int io_f16, void* stream) {
+    return attention_bwd_impl(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p, seed, drop_bits, io_f16, nullptr, stream);
+}
+// The backward on a PACKED batch (see cldrd_attention_fwd_varlen): qkv, ctx, dctx, dqkv are [Tp, .]; rows of dqkv that do not exist in the
+// packed layout (padding) are not written - in the padded layout they receive zeros.
+extern "C" int cldrd_attention_bwd_varlen(const void* qkv_packed, const int* cu_rows, const void* ctx_packed, const void* dctx_packed,
+                                          const float* lse, void* dqkv_packed, int nseq, int L, int H, float dropout_p, unsigned long long seed,
+                                          const void* drop_bits, int io_f16, void* stream) {
+    CLDRD_CHECK(cu_rows != nullptr, "attention_bwd_varlen: cu_rows is required");
+    return attention_bwd_impl(qkv_packed, nullptr, ctx_packed, dctx_packed, lse, dqkv_packed, nseq, L, H, dropout_p, seed, drop_bits, io_f16, cu_rows, stream);
+}
+static int attention_bwd_impl(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
+                              int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits, int io_f16, const int* cu, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_bwd: need 0 < L <= 256");
     CLDRD_CHECK(lse != nullptr, "attention_bwd: lse is required");
     const float scale = 0.125f;
@@ -1450,25 +1510,25 @@ extern "C" int cldrd_attention_bwd_x(const void* qkv, const long long* mask, con
     hipStream_t st = (hipStream_t)stream;
     if (io_f16) {
         switch (nkb) {
-            case 1: return launch_bwd<1, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-            case 2: return launch_bwd<2, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-            case 3: return launch_bwd<3, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-            case 4: return launch_bwd<4, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-            case 5: return launch_bwd<5, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-            case 6: return launch_bwd<6, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-            case 7: return launch_bwd<7, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-            default: return launch_bwd<8, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+            case 1: return launch_bwd<1, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+            case 2: return launch_bwd<2, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+            case 3: return launch_bwd<3, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+            case 4: return launch_bwd<4, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+            case 5: return launch_bwd<5, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+            case 6: return launch_bwd<6, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+            case 7: return launch_bwd<7, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+            default: return launch_bwd<8, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
         }
     }
     switch (nkb) {
-        case 1: return launch_bwd<1>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-        case 2: return launch_bwd<2>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-        case 3: return launch_bwd<3>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-        case 4: return launch_bwd<4>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-        case 5: return launch_bwd<5>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-        case 6: return launch_bwd<6>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-        case 7: return launch_bwd<7>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
-        default: return launch_bwd<8>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st);
+        case 1: return launch_bwd<1>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+        case 2: return launch_bwd<2>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+        case 3: return launch_bwd<3>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+        case 4: return launch_bwd<4>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+        case 5: return launch_bwd<5>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+        case 6: return launch_bwd<6>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+        case 7: return launch_bwd<7>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+        default: return launch_bwd<8>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
     }
 }
 
@@ -1483,7 +1543,8 @@ template <bool F16>
 __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
                                                            const int64_t* __restrict__ mask, bf16_t* __restrict__ ctx,
                                                            float* __restrict__ probs, int L, int H, float scale,
-                                                           uint32_t drop_thresh, float drop_scale, SeedArg seed_a, bf16_t* __restrict__ ctx16) {
+                                                           uint32_t drop_thresh, float drop_scale, SeedArg seed_a, bf16_t* __restrict__ ctx16,
+                                                           const int* __restrict__ cu) {
     const uint64_t seed = seed_a.get();
     __shared__ float sp[256];
     __shared__ float sq[64];
@@ -1491,7 +1552,9 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
     const int dm = H * 64;
     sq[lane] = x2f<F16>(qc[(size_t)seq * dm + hd * 64 + lane]);
     __syncthreads();
-    const bf16_t* kb = kv + (size_t)seq * L * 2 * dm + hd * 64;
+    const SeqRows sr = seq_rows(cu, seq, L);          // packed K | V rows: see seq_rows
+    const int len = sr.len;
+    const bf16_t* kb = kv + (size_t)sr.row0 * 2 * dm + hd * 64;
     const bf16_t* vb = kb + dm;
     float sc[4];
     float mx = -3.0e38f;
@@ -1499,7 +1562,7 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
     for (int i = 0; i < 4; ++i) {
         const int key = lane + 64 * i;
         float s = -1.0e30f;
-        if (key < L && (!mask || mask[(size_t)seq * L + key] != 0)) {
+        if (key < len && (!mask || mask[(size_t)seq * L + key] != 0)) {
             const bf16_t* kr = kb + (size_t)key * 2 * dm;
             float a = 0.f;
 #pragma unroll
@@ -1540,9 +1603,9 @@ __global__ __launch_bounds__(64) void attn_cls_fwd_kernel(const bf16_t* __restri
     float o8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o8[j] = 0.f;
-    for (int k0 = 0; k0 < L; k0 += 8) {
+    for (int k0 = 0; k0 < len; k0 += 8) {           // keys >= len: p = 0 and (padded layout) zero rows: + 0.0f, skipped
         const int key = k0 + g;
-        if (key < L) {
+        if (key < len) {
             const float pk = sp[key];
             const uint4 u = *(const uint4*)(vb + (size_t)key * 2 * dm + c8 * 8);
             const uint32_t w[4] = {u.x, u.y, u.z, u.w};
@@ -1568,7 +1631,8 @@ template <bool F16>
 __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restrict__ qc, const bf16_t* __restrict__ kv,
                                                            const float* __restrict__ probs, const bf16_t* __restrict__ dctx,
                                                            bf16_t* __restrict__ dqc, bf16_t* __restrict__ dkv, int L, int H,
-                                                           float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a) {
+                                                           float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
+                                                           const int* __restrict__ cu) {
     const uint64_t seed = seed_a.get();
     __shared__ float sds[256], spd[256], sdo[64];
     const int seq = blockIdx.x / H, hd = blockIdx.x % H, lane = threadIdx.x;
@@ -1576,14 +1640,16 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
     sdo[lane] = x2f<F16>(dctx[(size_t)seq * dm + hd * 64 + lane]);
     const float qd = x2f<F16>(qc[(size_t)seq * dm + hd * 64 + lane]);
     __syncthreads();
-    const bf16_t* kb = kv + (size_t)seq * L * 2 * dm + hd * 64;
+    const SeqRows sr = seq_rows(cu, seq, L);
+    const int len = sr.len;
+    const bf16_t* kb = kv + (size_t)sr.row0 * 2 * dm + hd * 64;
     const bf16_t* vb = kb + dm;
     float p[4], dp[4], dot = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int key = lane + 64 * i;
         p[i] = dp[i] = 0.f;
-        if (key < L) {
+        if (key < len) {
             p[i] = probs[((size_t)seq * H + hd) * L + key];
             const bf16_t* vr = vb + (size_t)key * 2 * dm;
             float a = 0.f;
@@ -1610,7 +1676,7 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int key = lane + 64 * i;
-        if (key < L) sds[key] = p[i] * (dp[i] - dot) * scale;
+        if (key < len) sds[key] = p[i] * (dp[i] - dot) * scale;
     }
     __syncthreads();
     // dq = sum_key ds[key] K[key]; dK[key] = ds[key] q; dV[key] = p_drop[key] dO.  Eight lanes per key row (16 bytes = 8 features
@@ -1619,14 +1685,14 @@ __global__ __launch_bounds__(64) void attn_cls_bwd_kernel(const bf16_t* __restri
     __shared__ float sqd[64];
     sqd[lane] = qd;
     __syncthreads();
-    bf16_t* dkb = dkv + (size_t)seq * L * 2 * dm + hd * 64;
+    bf16_t* dkb = dkv + (size_t)sr.row0 * 2 * dm + hd * 64;
     const int c8 = lane & 7, g = lane >> 3;
     float q8[8], do8[8], dq8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { q8[j] = sqd[c8 * 8 + j]; do8[j] = sdo[c8 * 8 + j]; dq8[j] = 0.f; }
-    for (int k0 = 0; k0 < L; k0 += 8) {
+    for (int k0 = 0; k0 < len; k0 += 8) {
         const int key = k0 + g;
-        if (key < L) {
+        if (key < len) {
             const float ds = sds[key], pd = spd[key];
             const uint4 u = *(const uint4*)(kb + (size_t)key * 2 * dm + c8 * 8);
             const uint32_t w[4] = {u.x, u.y, u.z, u.w};
@@ -1668,32 +1734,57 @@ __global__ __launch_bounds__(256) void add_rows_strided_kernel(void* __restrict_
 }  // namespace
 
 // qc: bf16 [nseq, H*64] (CLS queries); kv: bf16 [nseq*L, 2*H*64] = K | V; ctx: bf16 [nseq, H*64]; probs: fp32 [nseq, H, L]
+static int attention_cls_fwd_impl(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L, int H,
+                                  float dropout_p, unsigned long long seed, int io_f16, void* ctx_f16_copy, const int* cu, void* stream);
 extern "C" int cldrd_attention_cls_fwd(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L,
                                        int H, float dropout_p, unsigned long long seed, int io_f16, void* ctx_f16_copy, void* stream) {
+    return attention_cls_fwd_impl(qc, kv, mask, ctx, probs, nseq, L, H, dropout_p, seed, io_f16, ctx_f16_copy, nullptr, stream);
+}
+// kv PACKED: [Tp, 2*H*64], rows cu_rows[m] .. cu_rows[m + 1] of sequence m (see cldrd_attention_fwd_varlen); probs stays [nseq, H, L]
+extern "C" int cldrd_attention_cls_fwd_varlen(const void* qc, const void* kv_packed, const int* cu_rows, void* ctx, float* probs, int nseq, int L,
+                                              int H, float dropout_p, unsigned long long seed, int io_f16, void* ctx_f16_copy, void* stream) {
+    CLDRD_CHECK(cu_rows != nullptr, "attention_cls_fwd_varlen: cu_rows is required");
+    return attention_cls_fwd_impl(qc, kv_packed, nullptr, ctx, probs, nseq, L, H, dropout_p, seed, io_f16, ctx_f16_copy, cu_rows, stream);
+}
+static int attention_cls_fwd_impl(const void* qc, const void* kv, const long long* mask, void* ctx, float* probs, int nseq, int L, int H,
+                                  float dropout_p, unsigned long long seed, int io_f16, void* ctx_f16_copy, const int* cu, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0 && probs != nullptr, "attention_cls_fwd: need 0 < L <= 256 and a probs buffer");
     CLDRD_CHECK((ctx != nullptr || ctx_f16_copy != nullptr) && !(io_f16 && (ctx_f16_copy != nullptr || ctx == nullptr)), "attention_cls_fwd: outputs");
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     if (io_f16)
         hipLaunchKernelGGL(attn_cls_fwd_kernel<true>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
-                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), (bf16_t*)nullptr);
+                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), (bf16_t*)nullptr, cu);
     else
         hipLaunchKernelGGL(attn_cls_fwd_kernel<false>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv,
-                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), (bf16_t*)ctx_f16_copy);
+                           (const int64_t*)mask, (bf16_t*)ctx, probs, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), (bf16_t*)ctx_f16_copy, cu);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 
 // dqc: bf16 [nseq, H*64]; dkv: bf16 [nseq*L, 2*H*64] (every row written)
+static int attention_cls_bwd_impl(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv, int nseq, int L,
+                                  int H, float dropout_p, unsigned long long seed, int io_f16, const int* cu, void* stream);
 extern "C" int cldrd_attention_cls_bwd_x(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv,
                                          int nseq, int L, int H, float dropout_p, unsigned long long seed, int io_f16, void* stream) {
+    return attention_cls_bwd_impl(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p, seed, io_f16, nullptr, stream);
+}
+// kv and dkv PACKED: [Tp, 2*H*64] (every row of dkv written)
+extern "C" int cldrd_attention_cls_bwd_varlen(const void* qc, const void* kv_packed, const int* cu_rows, const float* probs, const void* dctx,
+                                              void* dqc, void* dkv_packed, int nseq, int L, int H, float dropout_p, unsigned long long seed,
+                                              int io_f16, void* stream) {
+    CLDRD_CHECK(cu_rows != nullptr, "attention_cls_bwd_varlen: cu_rows is required");
+    return attention_cls_bwd_impl(qc, kv_packed, probs, dctx, dqc, dkv_packed, nseq, L, H, dropout_p, seed, io_f16, cu_rows, stream);
+}
+static int attention_cls_bwd_impl(const void* qc, const void* kv, const float* probs, const void* dctx, void* dqc, void* dkv, int nseq, int L,
+                                  int H, float dropout_p, unsigned long long seed, int io_f16, const int* cu, void* stream) {
     CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_cls_bwd: need 0 < L <= 256");
     const uint32_t th = dropout_p > 0.f ? dropout_thresh16(dropout_p) : 0u;
     if (io_f16)
         hipLaunchKernelGGL(attn_cls_bwd_kernel<true>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv, probs,
-                           (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
+                           (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), cu);
     else
         hipLaunchKernelGGL(attn_cls_bwd_kernel<false>, dim3(nseq * H), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)qc, (const bf16_t*)kv, probs,
-                           (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed));
+                           (const bf16_t*)dctx, (bf16_t*)dqc, (bf16_t*)dkv, L, H, 0.125f, th, 1.0f / (1.0f - dropout_p), seed_arg(seed), cu);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

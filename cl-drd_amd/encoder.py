@@ -695,7 +695,6 @@ class HipEncoder(nn.Module):
         ids = input_ids.to(device=dev, dtype=torch.int64).contiguous()
         mask = None if attention_mask is None else attention_mask.to(device=dev, dtype=torch.int64).contiguous()
         T, d, f, H = M * L, cfg.dim, cfg.hidden_dim, cfg.n_heads
-        TP = T                                                   # rows of the padded layout (attention); T becomes the packed row count
         p_h = cfg.dropout if train else 0.0
         p_a = cfg.attention_dropout if train else 0.0
         dt16 = torch.float16 if fp16 else torch.bfloat16         # 16-bit activation format of this pass
@@ -757,36 +756,21 @@ class HipEncoder(nn.Module):
                 ops.gemm_nt(x, W["Wqkv"], qkv, T, bias=W["bqkv"])
             lse = torch.empty(M, H, L, **f32) if save else None
             dbits = ops.attention_drop_bits(M, L, H, p_a, dev) if (save and (dt16 == torch.bfloat16 or self.amp16)) else None      # dropout keep bits for the backward
-            ctx_pad = None
             # OUT16: the out-projection on fp16 operands too - the attention kernel leaves its context in fp16 next to (training) or
             # instead of (evaluation) the bf16 tensor the backward's MFMAs read.  With the FFN pair already on fp16 operands this is the
             # rounding point that carries most of what is left of the logit drift (CPU emulation on the goldens, DESIGN.md section 2:
             # BERT-base 5.25e-3 -> 2.08e-3 of the logit scale, DistilBERT 2.98e-3 -> 2.05e-3).
             ctx16 = self._buf(T, d, dev, torch.float16) if OUT16 else None
-            if pk is None:
-                ctx = self._buf(T, d, dev, dt16) if (save or not OUT16) else None
-                yield
-                if window is not None:
-                    window("attn")
-                ops.attention_fwd(qkv, mask, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16, full_family=fp16 and self.amp16)
-            else:
-                # packed batch: attention works on the padded [M * L, .] layout (one item = one sequence x head, keys >= len masked): move
-                # the rows there (zeros in the padding: a masked key contributes exp(-inf) * v = 0 only for finite v) and the context back
-                qkv_p, qkv = qkv, self._buf(TP, 3 * d, dev, dt16)
-                ops.unpack_rows16(qkv_p, qkv, pk.cu, M, L)
-                ctx_pad = self._buf(TP, d, dev, dt16) if (save or not OUT16) else None
-                ctx16_pad = self._buf(TP, d, dev, torch.float16) if OUT16 else None
-                yield
-                if window is not None:
-                    window("attn")
-                ops.attention_fwd(qkv, mask, ctx_pad, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16_pad, full_family=fp16 and self.amp16)
-                ctx = None
-                if ctx_pad is not None:
-                    ctx = self._buf(T, d, dev, dt16)
-                    ops.gather_rows(ctx_pad, pk.tok_idx, ctx, T)
-                if OUT16:
-                    ops.gather_rows(ctx16_pad, pk.tok_idx, ctx16, T)
-                del qkv_p, ctx16_pad
+            # packed batch: the attention kernels find a sequence's rows through cu (keys beyond its length masked, padding rows neither
+            # loaded nor stored: cldrd_attention_*_varlen) - bit for bit what moving the rows to the padded [M * L, .] layout and back
+            # gave until round 6 (two row moves per layer and pass, 0.56 ms of an 8.3-ms MS MARCO-shaped training step)
+            cu = pk.cu if pk is not None else None
+            ctx = self._buf(T, d, dev, dt16) if (save or not OUT16) else None
+            yield
+            if window is not None:
+                window("attn")
+            ops.attention_fwd(qkv, mask if pk is None else None, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16,
+                              full_family=fp16 and self.amp16, cu=cu)
             yield
             s1 = self._buf(T, d, dev, sdt)
             ops.gemm_nt(ctx16 if OUT16 else ctx, (W16 if OUT16 else W)["Wo"], s1, T, bias=W["bo"], residual=x32, dropout_p=p_out,
@@ -830,7 +814,7 @@ class HipEncoder(nn.Module):
                 window("ln")
             ops.layernorm_fwd(s2, W["g2"], W["b2"], xoh if QKV16 else xo, mean2, rstd2, T, cfg.eps, cls if last else None, L, out32=xo32)
             if save:
-                tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, ctx_pad=ctx_pad, lse=lse, dbits=dbits, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
+                tape.layers.append(dict(x_in=x, qkv=qkv, ctx=ctx, lse=lse, dbits=dbits, s1=s1, mean1=mean1, rstd1=rstd1, x1=x1, pre=pre,
                                         h=hbuf, s2=s2, mean2=mean2, rstd2=rstd2, seed=s_l, p_h=p_h, p_a=p_a, p_out=p_out))
             x, xh = xo, xoh
             x32, res_ln = (xo32, None) if need32 else (s2, (mean2, rstd2, W["g2"], W["b2"]))
@@ -869,15 +853,12 @@ class HipEncoder(nn.Module):
             xc = self._buf(M, d, dev, dt16) if x is not None else None          # 16-bit CLS rows: the weight gradient's operand (and, without Q16, the GEMM's)
             xch = self._buf(M, d, dev, torch.float16) if Q16 else None
             xc32 = self._buf(M, d, dev, torch.float32)
-            # packed batch: the CLS token of sequence m is row cu[m]; K / V go to the padded layout the CLS attention kernel reads
+            # packed batch: the CLS token of sequence m is row cu[m]; the CLS attention kernel reads the packed K / V rows through cu
             if xc is not None:
                 ops.gather_rows(x, pk.cls_idx, xc, M)
             if Q16:
                 ops.gather_rows(xh, pk.cls_idx, xch, M)
             ops.gather_rows(x32, pk.cls_idx, xc32, M)
-            kv_p, kv = kv, self._buf(M * L, 2 * d, dev, dt16)
-            ops.unpack_rows16(kv_p, kv, pk.cu, M, L)
-            del kv_p
         qc = self._buf(M, d, dev, dt16)
         if Q16:
             ops.gemm_nt(xch, W16["Wqkv"][:d], qc, M, bias=W["bqkv"][:d])
@@ -887,7 +868,8 @@ class HipEncoder(nn.Module):
         ctxc = self._buf(M, d, dev, dt16) if (save or not out16) else None
         ctxc16 = self._buf(M, d, dev, torch.float16) if out16 else None
         probs = torch.empty(M, H, L, **f32)
-        ops.attention_cls_fwd(qc, kv, mask, ctxc, probs, M, L, H, p_a, s_l + 1, ctx16=ctxc16)
+        ops.attention_cls_fwd(qc, kv, mask if pk is None else None, ctxc, probs, M, L, H, p_a, s_l + 1, ctx16=ctxc16,
+                              cu=pk.cu if pk is not None else None)
         yield
         s1 = self._buf(M, d, dev, sdt)
         ops.gemm_nt(ctxc16 if out16 else ctxc, (W16 if out16 else W)["Wo"], s1, M, bias=W["bo"], residual=xc32, dropout_p=p_out, seed=s_l + 2)
@@ -959,12 +941,8 @@ class HipEncoder(nn.Module):
         yield
         dqc = buf(M, d, dev)
         pk = tape.pack
-        dkv = buf(M * L, 2 * d, dev)
-        ops.attention_cls_bwd(a["qc"], a["kv"], a["probs"], dctx, dqc, dkv, M, L, H, p_a, s_l + 1)
-        if pk is not None:                                          # padded -> packed rows (T = the packed row count)
-            dkv_pad, dkv = dkv, buf(T, 2 * d, dev)
-            ops.gather_rows(dkv_pad, pk.tok_idx, dkv, T)
-            del dkv_pad
+        dkv = buf(T, 2 * d, dev)                                    # (T = the packed row count of a packed batch)
+        ops.attention_cls_bwd(a["qc"], a["kv"], a["probs"], dctx, dqc, dkv, M, L, H, p_a, s_l + 1, cu=pk.cu if pk is not None else None)
         self._wq.add(dqc, a["xc"], G["Wqkv"][:d], M, dbias=G["bqkv"][:d])
         self._wq.add(dkv, a["x_in"], G["Wqkv"][d:], T, dbias=G["bqkv"][d:])
         yield
@@ -1127,19 +1105,9 @@ class HipEncoder(nn.Module):
             yield
             if window is not None:
                 window("attn")
-            if pk is None:
-                dqkv = buf(T, 3 * d, dev)
-                ops.attention_bwd(a["qkv"], tape.mask, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1, drop_bits=a.get("dbits"))
-            else:
-                # packed batch: the context gradient goes to the padded layout attention works on (zero rows in the padding), the
-                # q / k / v gradients come back packed
-                dctx_pad = buf(M * L, d, dev)
-                ops.unpack_rows16(dctx, dctx_pad, pk.cu, M, L)
-                dqkv_pad = buf(M * L, 3 * d, dev)
-                ops.attention_bwd(a["qkv"], tape.mask, a["ctx_pad"], dctx_pad, a["lse"], dqkv_pad, M, L, H, p_a, s_l + 1, drop_bits=a.get("dbits"))
-                dqkv = buf(T, 3 * d, dev)
-                ops.gather_rows(dqkv_pad, pk.tok_idx, dqkv, T)
-                del dctx_pad, dqkv_pad
+            dqkv = buf(T, 3 * d, dev)
+            ops.attention_bwd(a["qkv"], tape.mask if pk is None else None, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1,
+                              drop_bits=a.get("dbits"), cu=pk.cu if pk is not None else None)
             self._wq.add(dqkv, a["x_in"], G["Wqkv"], T, dbias=G["bqkv"])
             yield
             gb = buf(T, d, dev)

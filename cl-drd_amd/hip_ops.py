@@ -352,9 +352,26 @@ def attention_drop_bits(nseq, L, H, dropout_p, device):
     return torch.empty(n, dtype=torch.int32, device=device) if n > 0 else None
 
 
-def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, ctx16=None, full_family=False):
-    """``ctx16`` (fp16, bf16 pass only): the same context in fp16, for an fp16-operand out-projection; ``ctx`` may then be None."""
+def _cu_rows(cu, nseq, mask, what):
+    """``cu`` (int32 [nseq + 1] on the device): the PACKED layout - sequence m owns rows cu[m] .. cu[m + 1] of every [Tp, .] tensor, keys beyond
+    its length are masked (no mask tensor is read)."""
+    _chk(cu, torch.int32, "cu", 1)
+    if cu.numel() != nseq + 1 or not cu.is_contiguous():
+        raise ValueError(f"{what}: cu must be contiguous int32 [nseq + 1]")
+    if mask is not None:
+        raise ValueError(f"{what}: a packed batch takes its key mask from cu (pass mask=None)")
+    return cu
+
+
+def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, ctx16=None, full_family=False, cu=None):
+    """``ctx16`` (fp16, bf16 pass only): the same context in fp16, for an fp16-operand out-projection; ``ctx`` may then be None.
+    ``cu``: qkv / ctx / ctx16 are packed [Tp, .] (see _cu_rows); ``lse`` and ``drop_bits`` keep their padded shapes."""
     io_f16 = _fmt16(qkv, "qkv")
+    entry = "cldrd_attention_fwd_bits"
+    if cu is not None:
+        entry, mask_arg = "cldrd_attention_fwd_varlen", _p(_cu_rows(cu, nseq, mask, "attention_fwd"))
+    else:
+        mask_arg = _p(mask)
     _chk(qkv, F16 if io_f16 else BF16, "qkv", 2)
     if ctx16 is not None:
         if io_f16:
@@ -365,7 +382,7 @@ def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_b
         if ctx is None:
             if mask is not None:
                 _chk(mask, torch.int64, "mask", 2)
-            call("cldrd_attention_fwd_bits", _p(qkv), _p(mask), None, _p(lse), nseq, L, H, dropout_p, seed, 0, _p(drop_bits), _p(ctx16), _stream())
+            call(entry, _p(qkv), mask_arg, None, _p(lse), nseq, L, H, dropout_p, seed, 0, _p(drop_bits), _p(ctx16), _stream())
             return ctx16
     _chk(ctx, F16 if io_f16 else BF16, "ctx", 2)
     if mask is not None:
@@ -382,11 +399,12 @@ def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_b
             raise ValueError("attention_fwd: drop_bits must come from attention_drop_bits() for the same shape")
     if io_f16 and (drop_bits is not None or L > 128 or full_family):
         io_f16 = 5                    # fp16 through the whole kernel family of the bf16 path (persistent kernel, keep bits, L > 128)
-    call("cldrd_attention_fwd_bits", _p(qkv), _p(mask), _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _p(drop_bits), _p(ctx16), _stream())
+    call(entry, _p(qkv), mask_arg, _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _p(drop_bits), _p(ctx16), _stream())
     return ctx
 
 
-def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None):
+def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, cu=None):
+    """``cu``: qkv / ctx / dctx / dqkv are packed [Tp, .] (see _cu_rows)."""
     io_f16 = _fmt16(qkv, "qkv")       # fp16 everywhere (the all-fp16 training mode) or bf16 everywhere
     for t, n in ((qkv, "qkv"), (ctx, "ctx"), (dctx, "dctx"), (dqkv, "dqkv")):
         _chk(t, F16 if io_f16 else BF16, n, 2)
@@ -395,12 +413,17 @@ def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, se
     _chk(lse, F32, "lse")
     if drop_bits is not None:
         _chk(drop_bits, torch.int32, "drop_bits", 1)
+    if cu is not None:
+        call("cldrd_attention_bwd_varlen", _p(qkv), _p(_cu_rows(cu, nseq, mask, "attention_bwd")), _p(ctx), _p(dctx), _p(lse), _p(dqkv), nseq, L, H,
+             dropout_p, seed, _p(drop_bits), io_f16, _stream())
+        return dqkv
     call("cldrd_attention_bwd_x", _p(qkv), _p(mask), _p(ctx), _p(dctx), _p(lse), _p(dqkv), nseq, L, H, dropout_p, seed,
          _p(drop_bits), io_f16, _stream())
     return dqkv
 
 
-def attention_cls_fwd(qc, kv, mask, ctx, probs, nseq, L, H, dropout_p=0.0, seed=0, ctx16=None):
+def attention_cls_fwd(qc, kv, mask, ctx, probs, nseq, L, H, dropout_p=0.0, seed=0, ctx16=None, cu=None):
+    """``cu``: kv is packed [Tp, 2*H*64] (see _cu_rows); probs stays [nseq, H, L]."""
     io_f16 = _fmt16(qc, "qc")
     dt16 = F16 if io_f16 else BF16
     _chk(qc, dt16, "qc", 2), _chk(kv, dt16, "kv", 2), _chk(probs, F32, "probs")
@@ -414,15 +437,24 @@ def attention_cls_fwd(qc, kv, mask, ctx, probs, nseq, L, H, dropout_p=0.0, seed=
         raise ValueError("attention_cls_fwd: no output")
     if kv.shape[1] != 2 * H * 64 or not kv.is_contiguous() or not qc.is_contiguous() or any(t is not None and not t.is_contiguous() for t in (ctx, ctx16)):
         raise ValueError("attention_cls: kv must be contiguous [T, 2*H*64]")
+    if cu is not None:
+        call("cldrd_attention_cls_fwd_varlen", _p(qc), _p(kv), _p(_cu_rows(cu, nseq, mask, "attention_cls_fwd")), _p(ctx), _p(probs), nseq, L, H,
+             dropout_p, seed, io_f16, _p(ctx16), _stream())
+        return
     call("cldrd_attention_cls_fwd", _p(qc), _p(kv), _p(mask), _p(ctx), _p(probs), nseq, L, H, dropout_p, seed, io_f16, _p(ctx16), _stream())
 
 
-def attention_cls_bwd(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p=0.0, seed=0):
+def attention_cls_bwd(qc, kv, probs, dctx, dqc, dkv, nseq, L, H, dropout_p=0.0, seed=0, cu=None):
+    """``cu``: kv and dkv are packed [Tp, 2*H*64] (see _cu_rows)."""
     io_f16 = _fmt16(qc, "qc")
     for t, n in ((qc, "qc"), (kv, "kv"), (dctx, "dctx"), (dqc, "dqc"), (dkv, "dkv")):
         _chk(t, F16 if io_f16 else BF16, n, 2)
         if not t.is_contiguous():
             raise ValueError(f"attention_cls_bwd: {n} must be contiguous")
+    if cu is not None:
+        call("cldrd_attention_cls_bwd_varlen", _p(qc), _p(kv), _p(_cu_rows(cu, nseq, None, "attention_cls_bwd")), _p(probs), _p(dctx), _p(dqc), _p(dkv),
+             nseq, L, H, dropout_p, seed, io_f16, _stream())
+        return
     call("cldrd_attention_cls_bwd_x", _p(qc), _p(kv), _p(probs), _p(dctx), _p(dqc), _p(dkv), nseq, L, H, dropout_p, seed, io_f16, _stream())
 
 

@@ -132,6 +132,22 @@ int cldrd_attention_cls_bwd_x(const void* qc, const void* kv, const float* probs
                             int nseq, int L, int H, float dropout_p, unsigned long long seed, int fmt, void* stream);
 int cldrd_add_rows_strided(void* dst, const void* src, int M, int d, int stride_rows, int f32, void* stream);   /* f32: fp32 rows (fp32 gradient stream) */
 
+/* The four attention calls on a PACKED batch (round 6; layout of "packed batches" below: sequence m owns rows cu_rows[m] .. cu_rows[m + 1] of every
+ * [Tp, .] tensor, Tp = cu_rows[nseq]; cu_rows: int32 [nseq + 1] on the device, every length in 1 .. L).  The reference pads every sequence of a batch
+ * to the longest (dataset/nway_dataset.py:105-106, dataset/sequence_dataset.py:50-51) and HF attention then computes on the padding; here keys
+ * beyond a sequence's length are masked (right padding: what the tokenizer's attention_mask says; no mask tensor is read) and padding rows are
+ * neither loaded nor stored.  qkv / ctx / dctx / dqkv / kv / dkv are [Tp, .]; lse, probs and the keep bits keep their [nseq, H, L(, ..)] shapes.
+ * Results are bit for bit those of cldrd_unpack_rows16 -> the padded call -> cldrd_gather_rows. */
+int cldrd_attention_fwd_varlen(const void* qkv_packed, const int* cu_rows, void* ctx_packed, float* lse, int nseq, int L, int H,
+                               float dropout_p, unsigned long long seed, int fmt, void* drop_bits_out, void* ctx_f16_copy, void* stream);
+int cldrd_attention_bwd_varlen(const void* qkv_packed, const int* cu_rows, const void* ctx_packed, const void* dctx_packed, const float* lse,
+                               void* dqkv_packed, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
+                               int fmt, void* stream);
+int cldrd_attention_cls_fwd_varlen(const void* qc, const void* kv_packed, const int* cu_rows, void* ctx, float* probs, int nseq, int L, int H,
+                                   float dropout_p, unsigned long long seed, int fmt, void* ctx_f16_copy, void* stream);
+int cldrd_attention_cls_bwd_varlen(const void* qc, const void* kv_packed, const int* cu_rows, const float* probs, const void* dctx, void* dqc,
+                                   void* dkv_packed, int nseq, int L, int H, float dropout_p, unsigned long long seed, int fmt, void* stream);
+
 /* ---- embeddings + LayerNorm (HF Embeddings.forward, sa_layer_norm / output_layer_norm) --------------------
  * d <= 1024, d % 4 == 0.  `partial` scratch: cldrd_ln_partial_blocks(T) * 3 * d floats. */
 int cldrd_ln_partial_blocks(int T);
@@ -294,7 +310,8 @@ int cldrd_map_ids(const int* I, const long long* ids, long long id_offset, long 
 /* ---- variable-length packing (csrc/pack.hip) -----------------------------------------------------------------------------------
  * The reference pads every sequence of a batch to the longest one (dataset/sequence_dataset.py:50-51, nway_dataset.py:103-107) and the
  * encoder computes on the padding.  Packed layout: tokens of sequence m = rows cu[m] .. cu[m+1] of a [Tp, features] matrix (cu: device
- * int32 [nseq + 1]); Linear / LayerNorm / weight gradients run on the Tp real rows, attention on the padded [nseq * L, .] layout.
+ * int32 [nseq + 1]); Linear / LayerNorm / weight gradients run on the Tp real rows, attention on the same rows through the
+ * cldrd_attention_*_varlen calls above (until round 6: on the padded [nseq * L, .] layout, rows moved by the two calls below).
  * cldrd_embed_ln_fwd / _bwd take pos_idx (device int32 [T], the position of every row inside its sequence; NULL: row % L).
  *   unpack_rows16: dst[m * L + j] = j < len[m] ? src[cu[m] + j] : 0  (16-bit rows of w elements);  gather_rows: dst[p] = src[idx[p]]
  *   (rows of row_bytes bytes: packing, CLS rows);  scatter_cls_grad_idx: g = 0, g[idx[r]] = bf16(dcls[r]);  add_rows_idx: dst[idx[m]] += src[m]. */

@@ -83,7 +83,9 @@ def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, p
         assert sorted(hooks) == list(range(-1, layers))        # every bucket reported once (the embedding block before the last weight-gradient group)
     kinds = set(stubbed)
     assert "cldrd_gemm_nt16_ws" in kinds and "cldrd_wgrad_group" in kinds and "cldrd_embed_ln_bwd" in kinds
-    assert ("cldrd_unpack_rows16" in kinds) == packed
+    assert ("cldrd_attention_cls_fwd_varlen" in kinds) == packed and ("cldrd_attention_cls_bwd_varlen" in kinds) == packed
+    assert ("cldrd_attention_fwd_varlen" in kinds) == (packed and layers > 1) and ("cldrd_attention_bwd_varlen" in kinds) == (packed and layers > 1)
+    assert "cldrd_unpack_rows16" not in kinds                      # round 6: attention reads the packed rows through cu, no row moves
 
 
 def test_trainer_step_walks_with_stubbed_kernels(stubbed, monkeypatch):

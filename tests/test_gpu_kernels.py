@@ -581,6 +581,79 @@ def test_attention_fwd_streaming_persistent_kernel(nseq, L, H, p, f16, masked):
         close(outs[1][0][valid], ref.to(DEV)[valid], 1 / 64, 2e-2, "streaming persistent forward vs fp64")
 
 
+@pytest.mark.parametrize("nseq,L,H,p,f16", [(48, 128, 12, 0.1, True), (48, 128, 12, 0.0, False), (90, 100, 6, 0.1, False), (200, 30, 3, 0.1, True),
+                                             (7, 128, 12, 0.1, True), (5, 77, 2, 0.0, False), (48, 256, 12, 0.1, True), (64, 161, 8, 0.0, False),
+                                             (6, 256, 12, 0.1, False), (9, 200, 4, 0.1, True)])
+def test_attention_on_packed_rows_equals_the_padded_layout(nseq, L, H, p, f16):
+    """Round 6: cldrd_attention_{fwd,bwd,cls_fwd,cls_bwd}_varlen read and write the PACKED rows of a batch through cu (sequence m = rows cu[m] ..
+    cu[m + 1]) instead of the padded [nseq * L, .] layout the encoder used to move them to and from (cldrd_unpack_rows16 / cldrd_gather_rows: 0.56 ms of
+    an 8.3-ms MS MARCO-shaped training step).  Same kernels, same arithmetic, zero rows where the padded layout held zeros: context, LSE, keep bits,
+    q / k / v gradients, CLS context, probabilities and K / V gradients must equal the padded path bit for bit - few and many items (the
+    one-item-per-workgroup and the persistent kernels), L <= 128 and 128 < L <= 256, bf16 and fp16 families, with and without dropout; lengths include
+    1 and L; a packed buffer exactly Tp rows long (a read or write past a sequence's rows lands in the next sequence or past the end)."""
+    d = H * 64
+    g = torch.Generator(device=DEV).manual_seed(nseq * L + H + 13)
+    dt = torch.float16 if f16 else torch.bfloat16
+    lens = torch.randint(1, L + 1, (nseq,), device=DEV, generator=g)
+    lens[0], lens[-1] = L, 1
+    cu = torch.zeros(nseq + 1, dtype=torch.int32, device=DEV)
+    cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    Tp = int(cu[-1])
+    mask = (torch.arange(L, device=DEV)[None, :] < lens[:, None]).to(torch.int64).contiguous()
+    tok = torch.nonzero(mask.reshape(-1)).reshape(-1).to(torch.int32)          # padded row of every packed row
+    qkv_p = torch.randn(Tp, 3 * d, device=DEV, generator=g).to(dt)
+    dctx_p = torch.randn(Tp, d, device=DEV, generator=g).to(dt)
+
+    def padded(t_p):
+        out = torch.full((nseq * L, t_p.shape[1]), float("nan"), dtype=dt, device=DEV)
+        ops.unpack_rows16(t_p, out, cu, nseq, L)
+        return out
+
+    def packed(t_pad):
+        out = torch.empty(Tp, t_pad.shape[1], dtype=t_pad.dtype, device=DEV)
+        ops.gather_rows(t_pad, tok, out, Tp)
+        return out
+    qkv = padded(qkv_p)
+    res = {}
+    for kind in ("padded", "packed"):
+        pk = kind == "packed"
+        rows = Tp if pk else nseq * L
+        ctx = torch.full((rows, d), float("nan"), dtype=dt, device=DEV)
+        c16 = None if f16 else torch.full((rows, d), float("nan"), dtype=torch.float16, device=DEV)
+        lse = torch.full((nseq, H, L), float("nan"), dtype=torch.float32, device=DEV)
+        bits = ops.attention_drop_bits(nseq, L, H, p, DEV)
+        ops.attention_fwd(qkv_p if pk else qkv, None if pk else mask, ctx, lse, nseq, L, H, dropout_p=p, seed=77, drop_bits=bits, ctx16=c16,
+                          full_family=f16, cu=cu if pk else None)
+        dqkv = torch.full((rows, 3 * d), float("nan"), dtype=dt, device=DEV)
+        ops.attention_bwd(qkv_p if pk else qkv, None if pk else mask, ctx if pk else ctx, dctx_p if pk else padded(dctx_p), lse, dqkv, nseq, L, H,
+                          dropout_p=p, seed=77, drop_bits=bits, cu=cu if pk else None)
+        # the CLS-only last layer: queries of token 0, K | V of every token
+        qc = (qkv_p[cu[:-1].long(), :d] if pk else qkv.view(nseq, L, 3 * d)[:, 0, :d]).contiguous()
+        kv = (qkv_p if pk else qkv)[:, d:].contiguous()
+        cctx = torch.full((nseq, d), float("nan"), dtype=dt, device=DEV)
+        probs = torch.full((nseq, H, L), float("nan"), dtype=torch.float32, device=DEV)
+        ops.attention_cls_fwd(qc, kv, None if pk else mask, cctx, probs, nseq, L, H, dropout_p=p, seed=78, cu=cu if pk else None)
+        dqc = torch.full((nseq, d), float("nan"), dtype=dt, device=DEV)
+        dkv = torch.full((rows, 2 * d), float("nan"), dtype=dt, device=DEV)
+        ops.attention_cls_bwd(qc, kv, probs, dctx_p[cu[:-1].long()].contiguous(), dqc, dkv, nseq, L, H, dropout_p=p, seed=78, cu=cu if pk else None)
+        torch.cuda.synchronize()
+        if not pk:
+            ctx, dqkv, dkv = packed(ctx), packed(dqkv), packed(dkv)
+            c16 = packed(c16) if c16 is not None else None
+        res[kind] = dict(ctx=ctx, c16=c16, lse=lse, bits=bits, dqkv=dqkv, cctx=cctx, probs=probs, dqc=dqc, dkv=dkv)
+    a, b = res["padded"], res["packed"]
+    lv = mask.bool()[:, None, :].expand(nseq, H, L)
+    for k in ("ctx", "c16", "dqkv", "cctx", "dqc", "dkv"):
+        if a[k] is None:
+            continue
+        assert not torch.isnan(b[k].float()).any(), k
+        assert torch.equal(a[k], b[k]), f"{k}: the packed rows give other bits than the padded layout"
+    assert torch.equal(a["lse"][lv], b["lse"][lv]) and torch.equal(a["probs"][lv], b["probs"][lv])
+    assert (b["probs"][~lv] == 0).all()
+    if a["bits"] is not None:
+        assert torch.equal(a["bits"], b["bits"])
+
+
 def test_attention_dropout_statistics():
     nseq, L, H = 2, 64, 2
     T, d = nseq * L, H * 64
