@@ -98,6 +98,10 @@ __device__ __forceinline__ uint4 widen_pair(const uint2& g0, const uint2& g1) {
 // layout: Tp = sum of the lengths rows, no padding rows anywhere) instead of rows seq * L .. seq * L + L of the padded layout; keys and queries
 // >= the sequence's length arrive in LDS as zero rows and are masked, exactly what the padded layout holds after cldrd_unpack_rows16 - so the two
 // layouts give the same bits - and are neither read nor written.  LSE, keep bits and probabilities stay [nseq, H, L(, ..)] (small).
+// Blocks of 32 keys / queries that lie entirely beyond a sequence's length are SKIPPED (nb = ceil(len / 32) live blocks): a masked key's
+// probability is exactly 0 and a zero query row's output is never stored, so every skipped MFMA would have added +0.0f - same bits, less work
+// (a packed MS MARCO batch at max_length 256 holds 37 % real tokens: 3 of 8 blocks per side).  The LSE of a skipped (all-zero) query row has the
+// closed form log(len): scores 0, maximum 0, denominator = the number of unmasked keys, exactly what the arithmetic gives.
 struct SeqRows { int row0, len; };
 __device__ __forceinline__ SeqRows seq_rows(const int* __restrict__ cu, int seq, int L) {
     if (cu) { const int c0 = cu[seq]; return {c0, cu[seq + 1] - c0}; }
@@ -145,13 +149,20 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
+    const int nb = (len + 31) >> 5;          // live blocks (see seq_rows)
     for (int qb = wid; qb < NKB; qb += 4) {
+        if (qb >= nb) {       // a query block beyond the sequence: nothing to store but the LSE of its zero rows
+            const int q = qb * 32 + r;
+            if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (0.f + __log2f((float)len)) * LN2;
+            continue;
+        }
         bf16x8 qf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = row_frag(sQ, qb * 32 + r, s, h);
         f32x16 S[NKB];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
+            if (kb >= nb) break;
             S[kb] = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -166,6 +177,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (kb >= nb) break;
                 const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
                 const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -181,6 +193,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
+                if (kb >= nb) break;
                 const cldrd_f32v2 d = (cldrd_f32v2){S[kb][t], S[kb][t + 1]} - splat2(mx);
                 const float e0 = __builtin_amdgcn_exp2f(d.x), e1 = __builtin_amdgcn_exp2f(d.y);
                 S[kb][t] = e0; S[kb][t + 1] = e1;
@@ -196,6 +209,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
         f32x16 O[2] = {(f32x16){0.f}, (f32x16){0.f}};
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
+            if (kb >= nb) break;
             float pv[16];
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
@@ -338,13 +352,16 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
         const uint32_t* sBits = (const uint32_t*)(sBias + Lp);
         const int seq = item / H, hd = item % H;
         const SeqRows sr = seq_rows(cu, seq, L);
-        const int len = sr.len;
+        const int len = sr.len, nb = (len + 31) >> 5;
         const int t_ = opaque(tid);
         const int lane = t_ & 63, r = lane & 31, h = lane >> 5;
         tb = t_ & 255;
         if (loader) {
             if (next < nitems) { issue(next); commit(cur ^ 1); make_bits(cur ^ 1, next); }
-        } else if (rw < NKB) {
+        } else if (rw < NKB && rw >= nb) {      // a query block beyond the sequence: nothing to store but the LSE of its zero rows
+            const int q = rw * 32 + r;
+            if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (0.f + __log2f((float)len)) * LN2;
+        } else if (rw < nb) {
             const int qb = rw;
         bf16x8 qf[4];
 #pragma unroll
@@ -352,6 +369,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
         f32x16 S[NKB];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
+            if (kb >= nb) break;
             S[kb] = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -366,6 +384,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
+                if (kb >= nb) break;
                 const float4 b4 = *(const float4*)(sBias + kb * 32 + 8 * u + 4 * h);
                 const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
@@ -381,6 +400,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
+                if (kb >= nb) break;
                 const cldrd_f32v2 d = (cldrd_f32v2){S[kb][t], S[kb][t + 1]} - splat2(mx);
                 const float e0 = __builtin_amdgcn_exp2f(d.x), e1 = __builtin_amdgcn_exp2f(d.y);
                 S[kb][t] = e0; S[kb][t + 1] = e1;
@@ -396,6 +416,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
         f32x16 O[2] = {(f32x16){0.f}, (f32x16){0.f}};
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
+            if (kb >= nb) break;
             float pv[16];
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
@@ -486,17 +507,23 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const float scale2 = scale * LOG2E;      // scores in the log2 domain (v_exp_f32 is 2^x)
+    const int nb = (len + 31) >> 5;          // live blocks (see seq_rows)
     for (int qb = wid; qb < NKB; qb += NWAVES) {
+        const int q = qb * 32 + r;
+        if (qb >= nb) {       // a query block beyond the sequence: nothing to store but the LSE of its zero rows
+            if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (0.f + __log2f((float)len)) * LN2;
+            continue;
+        }
         bf16x8 qf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = row_frag(sQ, qb * 32 + r, s, h);
-        const int q = qb * 32 + r;
         // dropout mask element (row, col) = ((seq*H + hd)*L + q, key); keys rowmap(t, h), t even / odd, are a column pair
         const uint32_t rk = drop_rowkey(seed, (uint32_t)((seq * H + hd) * L + q));
         float m = NEG_BIG * 4.f, lsum = 0.f;                       // lsum: this half's share of the denominator
         f32x16 O[2] = {(f32x16){0.f}, (f32x16){0.f}};              // O[dt][t] = ctx^T[d = 32 dt + rowmap(t, h)][q]
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
+            if (kb >= nb) break;
             f32x16 S = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
@@ -669,10 +696,13 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
         const float* sBias = (const float*)(sV + TILE);
         const int seq = item / H, hd = item % H;
         const SeqRows sr = seq_rows(cu, seq, L);
-        const int len = sr.len;
+        const int len = sr.len, nb = (len + 31) >> 5;
         const int lane = tid & 63, wid = tid >> 6;
         const int r = lane & 31, h = lane >> 5;
-        if (wid < NKB) {
+        if (wid < NKB && wid >= nb) {          // a query block beyond the sequence: nothing to store but the LSE of its zero rows (see seq_rows)
+            const int q = wid * 32 + r;
+            if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (0.f + __log2f((float)len)) * LN2;
+        } else if (wid < nb) {
             const int qb = wid;
             const int q = qb * 32 + r;
             // dropout mask element (row, col) = ((seq*H + hd)*L + q, key); keys rowmap(t, h), t even / odd, are a column pair
@@ -681,6 +711,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
             f32x16 O[2] = {(f32x16){0.f}, (f32x16){0.f}};              // O[dt][t] = ctx^T[d = 32 dt + rowmap(t, h)][q]
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
+                if (kb >= nb) break;
                 f32x16 S = (f32x16){0.f};
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -824,8 +855,11 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 
     const float scale2 = scale * LOG2E;      // scores, mask bias and LSE live in the log2 domain (v_exp_f32 is 2^x)
 
+    const int nb = (len + 31) >> 5;          // live blocks (see seq_rows): whole waves are skipped; inside a live wave the block loops stay
+                                             // unrolled over all NKB blocks (an early exit from them cost 40-90 VGPRs and spilled from NKB = 5 up)
     // ---------------- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks ----------------
     for (int kb = wid; kb < NKB; kb += NWAVES) {
+        if (kb >= nb) continue;
         bf16x8 kf[4], vf[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { kf[s] = row_frag(sK, kb * 32 + r, s, h); vf[s] = row_frag(sV, kb * 32 + r, s, h); }
@@ -908,6 +942,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 
     // ---------------- sweep B: query on lane; dQ for 32 queries accumulates over all key blocks ----------------
     for (int qb = wid; qb < NKB; qb += NWAVES) {
+        if (qb >= nb) continue;
         bf16x8 qf[4], dof[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) { qf[s] = row_frag(sQ, qb * 32 + r, s, h); dof[s] = row_frag(sdO, qb * 32 + r, s, h); }
@@ -1097,13 +1132,13 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         const uint32_t* sBits = sRk + Lp;
         const int seq = item / H, hd = item % H;
         const SeqRows sr = seq_rows(cu, seq, L);
-        const int len = sr.len;
+        const int len = sr.len, nb = (len + 31) >> 5;
         const int t_ = opaque(tid);
         const int lane = t_ & 63, r = lane & 31, h = lane >> 5;
         tb = t_ & 255;
         if (role_b) {
             if (has_next) issue(next);
-            if (rw < NKB) {       // ---- sweep B: query on lane; dQ for 32 queries accumulates over all key blocks
+            if (rw < nb) {        // ---- sweep B: query on lane; dQ for 32 queries accumulates over all (live) key blocks
                 const int qb = rw;
         bf16x8 qf[4], dof[4];
 #pragma unroll
@@ -1112,7 +1147,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         const float lse_q = sLse[q], delta_q = sDelta[q];
         const uint32_t rk_q = sRk[q];
         f32x16 dQ[2] = {(f32x16){0.f}, (f32x16){0.f}};
-        for (int kb = 0; kb < NKB; ++kb) {
+        for (int kb = 0; kb < nb; ++kb) {
             f32x16 ST = (f32x16){0.f}, dPT = (f32x16){0.f};
             uint32_t wbits = 0;
             if constexpr (BITS) wbits = sBits[kb * Lp + q] >> (4 * h);
@@ -1179,7 +1214,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         }
                 }
             if (has_next) commit(cur ^ 1, next);
-        } else if (rw < NKB) {    // ---- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks
+        } else if (rw < nb) {     // ---- sweep A: key on lane; dK, dV for 32 keys accumulate over all (live) query blocks
             const int kb = rw;
         bf16x8 kf[4], vf[4];
 #pragma unroll
@@ -1187,7 +1222,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         const int key = kb * 32 + r;
         const float bias_k = sBias[key];
         f32x16 dK[2] = {(f32x16){0.f}, (f32x16){0.f}}, dV[2] = {(f32x16){0.f}, (f32x16){0.f}};
-        for (int qb = 0; qb < NKB; ++qb) {
+        for (int qb = 0; qb < nb; ++qb) {
             f32x16 S = (f32x16){0.f}, dP = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
