@@ -654,7 +654,12 @@ class HipEncoder(nn.Module):
         if (lengths is None or not has_mask or (fp16 and not self.amp16) or not self.cls_only_last or self.cfg.n_layers < 1 or L <= 1
                 or _env_flag("CLDRD_PACK", "1") == "0"):
             return False
-        n_tok = int(sum(int(v) for v in (lengths.reshape(-1).tolist() if hasattr(lengths, "reshape") else lengths)))
+        lens = [int(v) for v in (lengths.reshape(-1).tolist() if hasattr(lengths, "reshape") else lengths)]
+        if len(lens) != M or min(lens) < 1 or max(lens) > L:
+            # the packed kernels take every sequence to own 1 .. L rows (cldrd_attention_*_varlen, CLS row = first row): anything else - an empty
+            # row of a partially filled batch, counts that do not belong to this batch - stays on the padded path, which reads the mask
+            return False
+        n_tok = sum(lens)
         if n_tok < 1024 <= M * L:
             # packing would move the Linear layers from the large-M GEMM kernel to the small-M one (split along K: another summation order), and
             # "packed == padded bit for bit" would stop holding (tools/model_fuzz.py, seed 1 case 0); at such sizes packing buys nothing

@@ -180,6 +180,8 @@ def test_would_pack_rules():
     assert not enc.would_pack([10] * M, M, L)         # 640 tokens < 1024 <= 2048 padded rows: stays padded
     assert enc.would_pack([10] * 16, 16, L)           # 160 of 512: both small-M
     assert not enc.would_pack([31] * M, M, L)         # 3 % padding: not worth the row moves
+    assert not enc.would_pack([20] * (M - 1) + [0], M, L)         # an empty row: the packed kernels take 1 .. L rows per sequence
+    assert not enc.would_pack([20] * (M - 1) + [L + 1], M, L) and not enc.would_pack([20] * (M - 1), M, L)      # counts of another batch shape
 
 
 _MAIN = _FakeStream()
