@@ -647,9 +647,9 @@ class HipEncoder(nn.Module):
             seed = self.next_seed()
         return Stepper(self._encode_pair(input_ids, attention_mask, train=train, save=save, seed=seed, fp16=fp16, lengths=lengths, window=window))
 
-    def would_pack(self, lengths, M, L, has_mask=True, fp16=False) -> bool:
-        """Whether encode() packs a batch with these host-side token counts (CLDRD_PACK=0 turns packing off; a batch with less than
-        8 % padding is not worth the row moves around attention).  The trainer asks BEFORE choosing between the replayed graph and the
+    def would_pack(self, lengths, M, L, has_mask=True, fp16=False, train=True) -> bool:
+        """Whether encode() packs a batch with these host-side token counts (CLDRD_PACK=0 turns packing off; thresholds at the
+        end: a training batch with less than 8 % padding keeps its graph replay, an evaluation batch packs from 3 % padding).  The trainer asks BEFORE choosing between the replayed graph and the
         eager step: only a batch that really is packed changes its row count from step to step."""
         if (lengths is None or not has_mask or (fp16 and not self.amp16) or not self.cls_only_last or self.cfg.n_layers < 1 or L <= 1
                 or _env_flag("CLDRD_PACK", "1") == "0"):
@@ -664,7 +664,9 @@ class HipEncoder(nn.Module):
             # packing would move the Linear layers from the large-M GEMM kernel to the small-M one (split along K: another summation order), and
             # "packed == padded bit for bit" would stop holding (tools/model_fuzz.py, seed 1 case 0); at such sizes packing buys nothing
             return False
-        return 0 < n_tok <= int(0.92 * M * L)
+        # a training step that packs cannot replay its HIP graph (the row count changes every step): only with 8 % padding or more.  An
+        # evaluation pass (index encode) launches eagerly anyway and packing moves no rows any more (attention reads packed rows): 3 %
+        return 0 < n_tok <= int((0.92 if train else 0.97) * M * L)
 
     def next_seed(self) -> int:
         """Advance the step counter; the dropout seed of the step (what encode() draws when no seed is given)."""
@@ -706,7 +708,7 @@ class HipEncoder(nn.Module):
         pk = None
         if lengths is not None and len(lengths) != M:
             raise ValueError("lengths: one entry per sequence")
-        if self.would_pack(lengths, M, L, has_mask=mask is not None, fp16=fp16):
+        if self.would_pack(lengths, M, L, has_mask=mask is not None, fp16=fp16, train=save):
             pk = _Pack.build(lengths, L, dev)
             T = pk.Tp
             ids_padded, ids = ids, torch.index_select(ids.view(-1), 0, pk.tok_idx.long())
