@@ -148,6 +148,11 @@ def main():
         raise SystemExit(f"bench.py: rank {rank} wants cuda:{local_rank} but only {torch.cuda.device_count()} device(s) are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # the host side of every leg is kernel launches and a few tiny CPU tensor ops; torch's intra-op pool is sized to the machine (128 threads on
+    # the 256-CPU GPU box: milliseconds to wake per op, profiles/r06_microbench.txt section 8, and N ranks would each own one).  cpu_baseline
+    # sets its own count.
+    from cldrd_amd.retriever.retrieval_utils import cap_host_threads
+    cap_host_threads(8)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
