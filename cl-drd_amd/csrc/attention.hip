@@ -102,6 +102,24 @@ __device__ __forceinline__ uint4 widen_pair(const uint2& g0, const uint2& g1) {
 // probability is exactly 0 and a zero query row's output is never stored, so every skipped MFMA would have added +0.0f - same bits, less work
 // (a packed MS MARCO batch at max_length 256 holds 37 % real tokens: 3 of 8 blocks per side).  The LSE of a skipped (all-zero) query row has the
 // closed form log(len): scores 0, maximum 0, denominator = the number of unmasked keys, exactly what the arithmetic gives.
+// A block loop that can be LEFT EARLY ends in a branch right behind an MFMA, and the code at the branch target reads that MFMA's accumulator.
+// hipcc (ROCm 7.2) counts the wait states between an XDL write and a VALU read of its result along the fall-through path only: in
+// attn_fwd_full_kernel<4> with two live blocks the exit edge reached `v_accvgpr_read a63 / a62` four cycles behind the MFMA that writes
+// a[48:63] - stale scores for keys 58, 59, 62, 63 of every sequence of 59 .. 64 tokens (tools/wgrad_attn_fuzz.py found it; the keys are masked
+// in shorter sequences, which is why nothing else noticed).  mfma_drain() ends every block iteration of such a loop, in front of the next
+// iteration's exit test: 24 wait states (more than the longest XDL result latency) on BOTH ways out of the branch, pinned against the schedulers;
+// they pass under the last MFMA of the block, which occupies the pipe for longer than that.
+__device__ __forceinline__ void mfma_drain() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+#if defined(CLDRD_DEV_BUILD) && defined(CLDRD_NO_BLOCK_SKIP)
+#define CLDRD_LIVE_BLOCKS(len, NKB) (NKB)                 // development build: compute every block (bisecting)
+#else
+#define CLDRD_LIVE_BLOCKS(len, NKB) (((len) + 31) >> 5)
+#endif
 struct SeqRows { int row0, len; };
 __device__ __forceinline__ SeqRows seq_rows(const int* __restrict__ cu, int seq, int L) {
     if (cu) { const int c0 = cu[seq]; return {c0, cu[seq + 1] - c0}; }
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
 
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int nb = (len + 31) >> 5;          // live blocks (see seq_rows)
+    const int nb = CLDRD_LIVE_BLOCKS(len, NKB);          // live blocks (see seq_rows)
     for (int qb = wid; qb < NKB; qb += 4) {
         if (qb >= nb) {       // a query block beyond the sequence: nothing to store but the LSE of its zero rows
             const int q = qb * 32 + r;
@@ -167,6 +185,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 S[kb] = mfma32<F16>(row_frag(sK, kb * 32 + r, s, h), qf[s], S[kb]);
+            mfma_drain();
         }
         // S[kb][t] = <K[key], Q[q]> with key = 32 kb + rowmap(t, h), q = 32 qb + r
         // softmax in the log2 domain (v_exp_f32 is 2^x): scores * scale * log2(e) + bias, bias read 4 keys at a time
@@ -229,6 +248,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
                 for (int dt = 0; dt < 2; ++dt)      // operands swapped: O^T[d][q], so that a lane (= query) holds consecutive head dimensions
                     O[dt] = mfma32<F16>(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pa, O[dt]);
             }
+            mfma_drain();
         }
         // O[dt][t] = ctx^T[d = 32 dt + rowmap(t, h)][q = 32 qb + r]: registers 4u .. 4u+3 are 4 consecutive head dimensions of the lane's query row;
         // one v_permlane32_swap pair makes them 16 contiguous bytes (widen_pair): 4 (+ 4 for the fp16 copy) 16-byte stores per lane instead of
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
         const uint32_t* sBits = (const uint32_t*)(sBias + Lp);
         const int seq = item / H, hd = item % H;
         const SeqRows sr = seq_rows(cu, seq, L);
-        const int len = sr.len, nb = (len + 31) >> 5;
+        const int len = sr.len, nb = CLDRD_LIVE_BLOCKS(len, NKB);
         const int t_ = opaque(tid);
         const int lane = t_ & 63, r = lane & 31, h = lane >> 5;
         tb = t_ & 255;
@@ -374,6 +394,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
 #pragma unroll
             for (int s = 0; s < 4; ++s)
                 S[kb] = mfma32<F16>(row_frag(sK, kb * 32 + r, s, h), qf[s], S[kb]);
+            mfma_drain();
         }
         // S[kb][t] = <K[key], Q[q]> with key = 32 kb + rowmap(t, h), q = 32 qb + r
         // softmax in the log2 domain (v_exp_f32 is 2^x): scores * scale * log2(e) + bias, bias read 4 keys at a time
@@ -436,6 +457,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
                 for (int dt = 0; dt < 2; ++dt)      // operands swapped: O^T[d][q], so that a lane (= query) holds consecutive head dimensions
                     O[dt] = mfma32<F16>(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pa, O[dt]);
             }
+            mfma_drain();
         }
         // O[dt][t] = ctx^T[d = 32 dt + rowmap(t, h)][q = 32 qb + r]: registers 4u .. 4u+3 are 4 consecutive head dimensions of the lane's query row;
         // one v_permlane32_swap pair makes them 16 contiguous bytes (widen_pair): 4 (+ 4 for the fp16 copy) 16-byte stores per lane instead of
@@ -507,7 +529,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const float scale2 = scale * LOG2E;      // scores in the log2 domain (v_exp_f32 is 2^x)
-    const int nb = (len + 31) >> 5;          // live blocks (see seq_rows)
+    const int nb = CLDRD_LIVE_BLOCKS(len, NKB);          // live blocks (see seq_rows)
     for (int qb = wid; qb < NKB; qb += NWAVES) {
         const int q = qb * 32 + r;
         if (qb >= nb) {       // a query block beyond the sequence: nothing to store but the LSE of its zero rows
@@ -574,6 +596,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
                 for (int dt = 0; dt < 2; ++dt)
                     O[dt] = mfma32<F16>(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, O[dt]);
             }
+            mfma_drain();
         }
         const float l = lsum + __shfl_xor(lsum, 32, 64);
         if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (m + __log2f(l)) * LN2;
@@ -696,7 +719,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
         const float* sBias = (const float*)(sV + TILE);
         const int seq = item / H, hd = item % H;
         const SeqRows sr = seq_rows(cu, seq, L);
-        const int len = sr.len, nb = (len + 31) >> 5;
+        const int len = sr.len, nb = CLDRD_LIVE_BLOCKS(len, NKB);
         const int lane = tid & 63, wid = tid >> 6;
         const int r = lane & 31, h = lane >> 5;
         if (wid < NKB && wid >= nb) {          // a query block beyond the sequence: nothing to store but the LSE of its zero rows (see seq_rows)
@@ -761,6 +784,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
                     for (int dt = 0; dt < 2; ++dt)
                         O[dt] = mfma32<F16>(tr_frag(sV, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), pb, O[dt]);
                 }
+                mfma_drain();
             }
             const float l = lsum + __shfl_xor(lsum, 32, 64);
             if (h == 0 && q < L && lse) lse[((size_t)seq * H + hd) * L + q] = (m + __log2f(l)) * LN2;
@@ -855,7 +879,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 
     const float scale2 = scale * LOG2E;      // scores, mask bias and LSE live in the log2 domain (v_exp_f32 is 2^x)
 
-    const int nb = (len + 31) >> 5;          // live blocks (see seq_rows): whole waves are skipped; inside a live wave the block loops stay
+    const int nb = CLDRD_LIVE_BLOCKS(len, NKB);          // live blocks (see seq_rows): whole waves are skipped; inside a live wave the block loops stay
                                              // unrolled over all NKB blocks (an early exit from them cost 40-90 VGPRs and spilled from NKB = 5 up)
     // ---------------- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks ----------------
     for (int kb = wid; kb < NKB; kb += NWAVES) {
@@ -1132,7 +1156,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         const uint32_t* sBits = sRk + Lp;
         const int seq = item / H, hd = item % H;
         const SeqRows sr = seq_rows(cu, seq, L);
-        const int len = sr.len, nb = (len + 31) >> 5;
+        const int len = sr.len, nb = CLDRD_LIVE_BLOCKS(len, NKB);
         const int t_ = opaque(tid);
         const int lane = t_ & 63, r = lane & 31, h = lane >> 5;
         tb = t_ & 255;

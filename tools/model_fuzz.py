@@ -38,7 +38,9 @@ for c in range(cases):
         ref = E.nway_forward(qp, pp, selftest.oracle_cfg(cfg), batch["query"], batch["nway_passages"]).detach().numpy()
         err = np.abs(lp.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3)
         cos = torch.nn.functional.cosine_similarity(gp, gk, dim=0).item() if gp.norm() > 0 else 1.0
-        ok = err <= 2e-2 and torch.equal(lp, lk) and cos >= 0.9999
+        # (Lp = 1: every passage is the same single token, the N logits of a query are equal and the listwise gradients cancel over N: what is left
+        #  of the passage tower's gradient is rounding noise, its direction means nothing - seed 77 case 20 measured 0.989 between two IDENTICAL calls)
+        ok = err <= 2e-2 and torch.equal(lp, lk) and (cos >= 0.9999 or Lp == 1)
         os.environ["CLDRD_GRAPH"] = "1"
         tr2 = NwayTrainer(selftest.build_tiny_model(cfg, share_weights=share, std=0.05).cuda().train(), loss=loss)
         for s in range(6):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised checks against fp64 on the same rounded inputs: the grouped weight-gradient launch (random token counts incl. non-multiples of 64,
-several problems of different shapes per group, with / without bias gradients) and attention forward / backward (random nseq, L <= 256, heads,
+several problems of different shapes per group, with / without bias gradients) and attention forward / backward, padded and on packed rows (random nseq, L <= 256, heads,
 right-padded masks incl. one-token sequences).  usage: tools/wgrad_attn_fuzz.py [cases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,5 +67,22 @@ for c in range(cases):
     if not (okf and okb):
         bad += 1
         print(f"MISMATCH case {c} attention nseq {nseq} L {L} H {H}: fwd ok {okf}, bwd ok {okb} (max bwd err {(dq.double() - gr).abs().max().item():.3e}, scale {sc:.3e})", flush=True)
+    # ---- the same attention on PACKED rows (cldrd_attention_*_varlen): bit for bit the padded result on the rows that exist
+    cu = torch.zeros(nseq + 1, dtype=torch.int32, device=DEV)
+    cu[1:] = torch.from_numpy(np.cumsum(lens)).to(DEV).to(torch.int32)
+    Tp = int(cu[-1])
+    tok = torch.nonzero(valid).reshape(-1)
+    qkv_p, dctx_p = qkv[tok].contiguous(), dctx_m[tok].contiguous()
+    ctx_p = torch.full((Tp, d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    lse_p = torch.full((nseq, H, L), float("nan"), dtype=torch.float32, device=DEV)
+    ops.attention_fwd(qkv_p, None, ctx_p, lse_p, nseq, L, H, cu=cu)
+    dq_p = torch.full((Tp, 3 * d), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.attention_bwd(qkv_p, None, ctx_p, dctx_p, lse_p, dq_p, nseq, L, H, cu=cu)
+    lv = mask.bool()[:, None, :].expand(nseq, H, L)
+    okp = torch.equal(ctx_p, ctx[tok]) and torch.equal(dq_p, dq[tok]) and torch.equal(lse_p[lv], lse[lv]) and bool(torch.isfinite(lse_p).all())
+    if not okp:
+        bad += 1
+        print(f"MISMATCH case {c} packed attention nseq {nseq} L {L} H {H}: ctx {torch.equal(ctx_p, ctx[tok])} dqkv {torch.equal(dq_p, dq[tok])} "
+              f"lse {torch.equal(lse_p[lv], lse[lv])}", flush=True)
 print(f"{cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
