@@ -1133,7 +1133,12 @@ def main(argv=None):
         import yaml
         with open(os.path.join(args.run_folder, "args.yaml"), "w") as fh:
             yaml.dump({k: (str(v) if isinstance(v, torch.device) else v) for k, v in vars(args).items()}, fh)
-    train(args)
+    owns_group = args.local_rank != -1 and dist.is_initialized()
+    try:
+        train(args)
+    finally:
+        if owns_group:                      # the group set_env() created (torchrun / --local_rank): shut RCCL down in order
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

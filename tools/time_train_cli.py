@@ -5,11 +5,16 @@ batch_to_device, train_step, logging every 50 steps - and the wall clock per ste
 The host's share of a step is split three ways: waiting for the loader, batch_to_device, train_step (enqueue only: nothing here waits for the GPU
 except through the queue depth).
 
-    python tools/time_train_cli.py [steps=400] [--fixed] [--workers N] [--profile]
+    python tools/time_train_cli.py [steps=400] [--fixed] [--workers N] [--profile] [--ddp1]
         --fixed: every passage 128 tokens (the bench's headline batch: one shape, replayed as a HIP graph); default: MS MARCO-shaped lengths
+        --ddp1:  the data-parallel code path (bucket hooks, RCCL all-reduces, agreement step) with a process group of ONE rank (CLDRD_FORCE_DDP=1)
 """
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ddp1 = "--ddp1" in sys.argv
+if ddp1:
+    os.environ.update({"CLDRD_FORCE_DDP": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": os.environ.get("MASTER_PORT", "29533"), "RANK": "0",
+                       "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
 import torch
 from cldrd_amd.trainer import nway_listwise as T
 
@@ -19,7 +24,8 @@ workers = int(sys.argv[sys.argv.index("--workers") + 1]) if "--workers" in sys.a
 with tempfile.TemporaryDirectory(dir="/tmp") as td:
     argv = ["--experiment_folder", td, "--run_folder", "run", "--synthetic_steps", str(steps), "--synthetic_model", "distilbert", "--synthetic_nway", "32",
             "--passage_max_len", "128", "--query_max_len", "30", "--train_batch_size", "8", "--logging_steps", "50", "--evaluate_steps", "1000000",
-            "--num_train_epochs", "1", "--loss", "kl_div", "--label_mode", "9", "--loader_workers", str(workers)] + (["--synthetic_fixed"] if fixed else [])
+            "--num_train_epochs", "1", "--loss", "kl_div", "--label_mode", "9", "--loader_workers", str(workers)] + (["--synthetic_fixed"] if fixed else []) \
+        + (["--local_rank", "0"] if ddp1 else [])
     args = T.set_env(T.get_args(argv))
     stamps, spent = [], {"batch_to_device": 0.0, "train_step": 0.0}
     real_step, real_move = T.NwayTrainer.train_step, T.batch_to_device
@@ -54,7 +60,7 @@ with tempfile.TemporaryDirectory(dir="/tmp") as td:
     n = len(stamps) - 1 - warm
     per = (stamps[-1] - stamps[warm]) / n
     mv, st = spent["batch_to_device"] / (n + 1), spent["train_step"] / (n + 1)
-    print(f"trainer CLI loop, {'fixed-length' if fixed else 'MSMARCO-shaped'} cfg2 batches, {workers} loader workers, {torch.get_num_threads()} torch host threads: "
+    print(f"trainer CLI loop{' (data-parallel path, one rank over RCCL)' if ddp1 else ''}, {'fixed-length' if fixed else 'MSMARCO-shaped'} cfg2 batches, {workers} loader workers, {torch.get_num_threads()} torch host threads: "
           f"{steps} steps in {t1 - t0:.1f} s; steady state {1e3 * per:.3f} ms per step = {8 / per:.1f} samples/s (clock between train_step returns, steps "
           f"{warm}..{len(stamps) - 1}); host per step: batch_to_device {1e3 * mv:.2f} ms, train_step enqueue {1e3 * st:.2f} ms, loader wait + logging "
           f"{1e3 * (per - mv - st):.2f} ms; graph replay: {any(e['graph'] is not None for e in getattr(tr, '_graphs', {}).values())}; final global_step {tr.global_step}")
