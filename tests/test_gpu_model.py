@@ -763,10 +763,11 @@ def test_graph_replay_of_the_training_step_equals_the_eager_step(monkeypatch):
     assert tr.global_step == tr.adam_step == 11
 
 
-def _ragged_batch(cfg, seed, B, N, Lq, Lp):
+def _ragged_batch(cfg, seed, B, N, Lq, Lp, force=()):
     batch = syn.nway_batch(seed, B, N, Lq, Lp, vocab=cfg.vocab_size, ragged=True, label_kind="teacher")
     # lengths spread over the whole range (the MSMARCO length model clips at these toy lengths)
     lens = 2 + (syn.randint(seed + 77, 0, Lp - 1, B * N)).astype(np.int64)
+    lens[:len(force)] = np.asarray(force, dtype=np.int64)
     ar = np.arange(Lp)[None, :]
     mask = (ar < lens[:, None]).astype(np.int64)
     ids = batch["nway_passages"]["input_ids"].reshape(B * N, Lp).numpy().copy()
@@ -776,16 +777,20 @@ def _ragged_batch(cfg, seed, B, N, Lq, Lp):
     return batch, lens
 
 
-@pytest.mark.parametrize("arch,layers", [("distilbert", 3), ("bert", 2)])
-def test_packed_batch_equals_padded_batch(arch, layers, monkeypatch):
+@pytest.mark.parametrize("arch,layers,Lp", [("distilbert", 3, 48), ("bert", 2, 48), ("distilbert", 2, 128)])
+def test_packed_batch_equals_padded_batch(arch, layers, Lp, monkeypatch):
     """Variable-length packing (csrc/pack.hip; the reference pads to the longest sequence of the batch, dataset/nway_dataset.py:103-107):
     with the token counts given, Linear / LayerNorm / weight gradients run on the real tokens only.  Same CLS embeddings, logits and
     gradients as the padded run of the same batch (dropout off; rows are computed by the same kernels in the same order, so nearly
-    everything is bit-identical - the bound is bf16 rounding), and against the oracle."""
+    the LOGITS are bit-identical, gradients to rounding: float atomics in the embedding tables), and against the oracle.  Lp = 128 with sequences
+    of 59 .. 64, 1 and 128 tokens: the lengths at which the attention kernels' block skipping once read stale accumulators (attention.hip,
+    mfma_drain)."""
     cfg = small_cfg(arch, layers)
+    if Lp > cfg.max_position_embeddings:
+        cfg.max_position_embeddings = Lp
     model = selftest.build_tiny_model(cfg).cuda().train()
-    B, N, Lq, Lp = 4, 9, 8, 48
-    batch, lens = _ragged_batch(cfg, 321, B, N, Lq, Lp)
+    B, N, Lq = 4, 9, 8
+    batch, lens = _ragged_batch(cfg, 321, B, N, Lq, Lp, force=(59, 60, 61, 62, 63, 64, 1, 128, 33, 96, 97) if Lp == 128 else ())
     dev = lambda b: {k: ({kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v.cuda()) for k, v in b.items()}
     tr = NwayTrainer(model, loss="margin_mse")
     monkeypatch.setenv("CLDRD_GRAPH", "0")
@@ -802,13 +807,14 @@ def test_packed_batch_equals_padded_batch(arch, layers, monkeypatch):
     cos = torch.nn.functional.cosine_similarity(g_pk.double(), g_pad.double(), dim=0).item()
     print(f"packed vs padded ({arch}, fill {fill:.2f}): logits identical {same:.2f}, max rel diff {err:.2e}; gradient cosine {cos:.7f}, "
           f"norm ratio {(g_pk.norm() / g_pad.norm()).item():.6f}")
+    assert same == 1.0, "packed logits are not bit-identical to the padded ones"
     assert err <= 2e-3 and cos >= 0.99995 and abs((g_pk.norm() / g_pad.norm()).item() - 1.0) <= 2e-3
     # and against the oracle (which, like the reference, computes on the padded batch)
     ref_logits = oracle_run(model, cfg, batch, "margin_mse")[0]
     assert np.abs(logits_pk.cpu().numpy() - ref_logits).max() <= 3e-2 * np.abs(ref_logits).max()
     # a training step with dropout on the packed batch runs and stays finite
     cfg2 = small_cfg(arch, layers)
-    cfg2.dropout, cfg2.attention_dropout = 0.1, 0.1
+    cfg2.dropout, cfg2.attention_dropout, cfg2.max_position_embeddings = 0.1, 0.1, cfg.max_position_embeddings
     m2 = selftest.build_tiny_model(cfg2).cuda().train()
     tr2 = NwayTrainer(m2, loss="kl_div")
     out = tr2.train_step(packed)
