@@ -3,8 +3,10 @@
 // LayerNorm of the encoder then runs over the padding too - ~40 % of the rows of an MS MARCO batch).
 //
 // Packed layout: the tokens of sequence m are rows cu[m] .. cu[m] + len[m] of a [Tp, features] matrix, Tp = sum of the lengths.  GEMMs,
-// LayerNorm and the weight gradients work on any row count, so they simply see fewer rows.  Attention keeps its padded [nseq * L, .]
-// layout (one item = one sequence x head, keys >= len masked): these kernels move rows between the two layouts.  CLS rows are rows cu[m].
+// LayerNorm and the weight gradients work on any row count, so they simply see fewer rows.  Attention reads the same packed rows through cu
+// (attention.hip, cldrd_attention_*_varlen; until round 6 it kept a padded [nseq * L, .] layout and unpack_rows16 / gather_rows moved the rows
+// there and back around every call).  What is left for these kernels: gathering token ids and CLS rows (rows cu[m]), putting the CLS rows'
+// gradients back - and unpack_rows16 as the reference layout the tests compare the packed attention with.
 #include "common.h"
 
 namespace {
