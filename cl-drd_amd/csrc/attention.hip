@@ -822,7 +822,10 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
     }
 }
 
-template <int NKB, bool DROP, bool F16 = false>
+// VARLEN (a packed batch, launch_bwd_d): the two block loops are ROLLED and run over the live blocks only - a sequence of 74 tokens at L = 256 does
+// 3 x 3 block pairs instead of 8 x 8 (measured on packed cfg4, BERT-base L = 256, 29 % real tokens: this kernel was 16 % of the step with whole waves
+// skipped only).  Same per-block arithmetic in the same order: the same bits.  The padded instantiation keeps its unrolled loops.
+template <int NKB, bool DROP, bool F16 = false, bool VARLEN = false>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
@@ -879,8 +882,10 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
 
     const float scale2 = scale * LOG2E;      // scores, mask bias and LSE live in the log2 domain (v_exp_f32 is 2^x)
 
-    const int nb = CLDRD_LIVE_BLOCKS(len, NKB);          // live blocks (see seq_rows): whole waves are skipped; inside a live wave the block loops stay
-                                             // unrolled over all NKB blocks (an early exit from them cost 40-90 VGPRs and spilled from NKB = 5 up)
+    const int nb = CLDRD_LIVE_BLOCKS(len, NKB);          // live blocks (see seq_rows): whole waves are skipped; inside a live wave the padded
+                                             // instantiation's block loops stay unrolled over all NKB blocks (an early exit from an unrolled
+                                             // loop cost 40-90 VGPRs and spilled from NKB = 5 up), the VARLEN one's are rolled and stop at nb
+    const int nbl = VARLEN ? nb : NKB;
     // ---------------- sweep A: key on lane; dK, dV for 32 keys accumulate over all query blocks ----------------
     for (int kb = wid; kb < NKB; kb += NWAVES) {
         if (kb >= nb) continue;
@@ -890,8 +895,8 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
         const int key = kb * 32 + r;
         const float bias_k = sBias[key];
         f32x16 dK[2] = {(f32x16){0.f}, (f32x16){0.f}}, dV[2] = {(f32x16){0.f}, (f32x16){0.f}};
-#pragma unroll
-        for (int qb = 0; qb < NKB; ++qb) {
+#pragma unroll (VARLEN ? 1 : NKB)
+        for (int qb = 0; qb < nbl; ++qb) {
             f32x16 S = (f32x16){0.f}, dP = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -936,6 +941,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
                     dK[dt] = mfma32<F16>(tr_frag(sQ, qb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sb, dK[dt]);
                 }
             }
+            if (VARLEN) mfma_drain();
         }
         // dV[dt][t] = dV[key][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
         {
@@ -974,8 +980,8 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
         const float lse_q = sLse[q], delta_q = sDelta[q];
         const uint32_t rk_q = sRk[q];
         f32x16 dQ[2] = {(f32x16){0.f}, (f32x16){0.f}};
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll (VARLEN ? 1 : NKB)
+        for (int kb = 0; kb < nbl; ++kb) {
             f32x16 ST = (f32x16){0.f}, dPT = (f32x16){0.f};
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -1015,6 +1021,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
                     // leaves in 8-byte stores (the other order gave 32 two-byte stores per lane)
                     dQ[dt] = mfma32<F16>(tr_frag(sK, kb * 32 + 16 * s2 + 4 * h, dt * 32, lane), sa, dQ[dt]);
             }
+            if (VARLEN) mfma_drain();
         }
         {                 // dQ[dt][t] = dQ[q][d = 32 dt + rowmap(t, h)]: regs 4u..4u+3 are 4 consecutive d
             bf16_t* oq = dqkv + ((size_t)sr.row0 + q) * ld + hd * 64;
@@ -1432,6 +1439,14 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
         }
     }
     const size_t lds = 4 * 32 * NKB * RSB + 4 * 32 * NKB * sizeof(float);
+    if (cu != nullptr && NKB > 1) {       // a packed batch: the instantiation whose block loops stop at the sequence's last live block
+        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP, F16, true>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv,
+                           (const int64_t*)mask, (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
+                           DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), cu);
+        CLDRD_LAUNCH_CHECK();
+        return 0;
+    }
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                        (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,

@@ -14,7 +14,10 @@ dev = torch.device("cuda", 0)
 ragged = "ragged" in sys.argv
 cfgs = [("cfg1", "distilbert", 4, 8, 30, 128, "margin_mse"), ("cfg2", "distilbert", 8, 32, 30, 128, "kl_div"),
         ("cfg3", "distilbert", 4, 200, 30, 128, "margin_mse"), ("cfg4", "bert", 4, 64, 30, 256, "ranknet")]
+only = [a for a in sys.argv[1:] if a.startswith("cfg")]
 for name, arch, B, N, Lq, L, loss in cfgs:
+    if only and name not in only:
+        continue
     cfg = EncoderConfig(arch=arch, dropout=0.1, attention_dropout=0.1) if arch == "distilbert" else \
         EncoderConfig(arch="bert", n_layers=12, dropout=0.1, attention_dropout=0.1, max_position_embeddings=512, vocab_size=30522)
     torch.manual_seed(0)
