@@ -83,6 +83,7 @@ SIGNATURES = {
     "cldrd_map_ids": (ci, [vp, vp, C.c_longlong, vp, csz, vp]),
     "cldrd_unpack_rows16": (ci, [vp, vp, vp, ci, ci, ci, vp]),
     "cldrd_gather_rows": (ci, [vp, vp, vp, ci, ci, vp]),
+    "cldrd_gather_i64": (ci, [vp, vp, vp, ci, vp]),
     "cldrd_scatter_cls_grad_idx": (ci, [vp, vp, ci, ci, vp, ci, ci, vp]),
     "cldrd_add_rows_idx": (ci, [vp, vp, ci, ci, vp, ci, vp]),
     "cldrd_set_seed_base": (None, [vp]),

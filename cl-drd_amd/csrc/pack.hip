@@ -39,6 +39,11 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const char* __restrict
     }
 }
 
+// dst[p] = src[idx[p]]   (int64 elements: the token ids of the packed rows)
+__global__ __launch_bounds__(256) void gather_i64_kernel(const long long* __restrict__ src, const int* __restrict__ idx, long long* __restrict__ dst, int n) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < n; p += gridDim.x * 256) dst[p] = src[idx[p]];
+}
+
 // g[idx[r], :] = bf16(dcls[r, :])   (g zeroed by the launcher)
 template <int FMT>      // 0 bf16, 1 fp32, 2 fp16
 __global__ void scatter_cls_idx_kernel(const float* __restrict__ dcls, void* __restrict__ g, const int* __restrict__ idx, int d) {
@@ -77,6 +82,14 @@ extern "C" int cldrd_gather_rows(const void* src, const int* idx, void* dst, int
     CLDRD_CHECK(n > 0 && row_bytes > 0 && row_bytes % 16 == 0, "gather_rows: rows must be a multiple of 16 bytes");
     const int nb = (n + 3) / 4 < 4096 ? (n + 3) / 4 : 4096;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const char*)src, idx, (char*)dst, n, row_bytes);
+    CLDRD_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cldrd_gather_i64(const long long* src, const int* idx, long long* dst, int n, void* stream) {
+    CLDRD_CHECK(n > 0, "gather_i64: n must be positive");
+    const int nb = (n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048;
+    hipLaunchKernelGGL(gather_i64_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }

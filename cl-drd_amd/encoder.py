@@ -711,7 +711,7 @@ class HipEncoder(nn.Module):
         if self.would_pack(lengths, M, L, has_mask=mask is not None, fp16=fp16, train=save):
             pk = _Pack.build(lengths, L, dev)
             T = pk.Tp
-            ids_padded, ids = ids, torch.index_select(ids.view(-1), 0, pk.tok_idx.long())
+            ids_padded, ids = ids, ops.gather_i64(ids.reshape(-1), pk.tok_idx, T)
         tape = None
         if save:
             tape = _Tape()

@@ -522,6 +522,18 @@ def gather_rows(src, idx, dst, n=None):
     return dst
 
 
+def gather_i64(src, idx, n=None):
+    """src[idx[:n]] for int64 ``src`` (flattened) and int32 ``idx``: the token ids of a packed batch's rows."""
+    _chk(src, torch.int64, "src"), _chk(idx, torch.int32, "idx", 1)
+    n = idx.numel() if n is None else n
+    if not src.is_contiguous() or idx.numel() < n:
+        raise ValueError("gather_i64: contiguous src, idx with at least n entries")
+    out = torch.empty(n, dtype=torch.int64, device=src.device)
+    if n > 0:
+        call("cldrd_gather_i64", _p(src), _p(idx), _p(out), n, _stream())
+    return out
+
+
 def _stream_fmt(t):
     """row format code of a gradient-stream tensor: 0 bf16, 1 fp32, 2 fp16"""
     if t.dtype not in (BF16, F32, F16):

@@ -317,6 +317,7 @@ int cldrd_map_ids(const int* I, const long long* ids, long long id_offset, long 
  *   (rows of row_bytes bytes: packing, CLS rows);  scatter_cls_grad_idx: g = 0, g[idx[r]] = bf16(dcls[r]);  add_rows_idx: dst[idx[m]] += src[m]. */
 int cldrd_unpack_rows16(const void* src_packed, void* dst_padded, const int* cu, int nseq, int L, int w, void* stream);
 int cldrd_gather_rows(const void* src, const int* idx, void* dst, int n, int row_bytes, void* stream);
+int cldrd_gather_i64(const long long* src, const int* idx, long long* dst, int n, void* stream);      /* dst[p] = src[idx[p]]: token ids of the packed rows */
 int cldrd_scatter_cls_grad_idx(const float* dcls, void* g, int R, int d, const int* idx, int T, int g_f32, void* stream);
 int cldrd_add_rows_idx(void* dst, const void* src, int M, int d, const int* idx, int f32, void* stream);
 

@@ -695,6 +695,18 @@ def test_attention_on_packed_rows_every_length(L, H, f16, p):
     assert torch.equal(out[True][2][lv], out[False][2][lv]) and bool(torch.isfinite(out[True][2]).all())
 
 
+def test_gather_i64_picks_the_token_ids_of_the_packed_rows():
+    """cldrd_gather_i64: out[p] = src[idx[p]] for int64 elements (what torch.index_select + an index cast did for a packed batch's token ids)."""
+    g = torch.Generator(device=DEV).manual_seed(12)
+    src = torch.randint(-2 ** 40, 2 ** 40, (37, 129), device=DEV, generator=g, dtype=torch.int64)
+    for n in (1, 63, 4773, 100000):
+        idx = torch.randint(0, src.numel(), (n,), device=DEV, generator=g).to(torch.int32)
+        assert torch.equal(ops.gather_i64(src.reshape(-1), idx), src.reshape(-1)[idx.long()])
+    assert torch.equal(ops.gather_i64(src.reshape(-1), idx, 10), src.reshape(-1)[idx[:10].long()])
+    with pytest.raises((TypeError, ValueError)):
+        ops.gather_i64(src.reshape(-1).to(torch.int32), idx)
+
+
 def test_attention_dropout_statistics():
     nseq, L, H = 2, 64, 2
     T, d = nseq * L, H * 64
