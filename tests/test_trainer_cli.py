@@ -115,6 +115,79 @@ def test_logit_norm_regulariser_matches_torch():
     assert torch.allclose(grad, base_grad + xr.grad, rtol=1e-5, atol=1e-7)
 
 
+def _dataset_args(tmp_path, extra=()):
+    """Command-line arguments of a run on the committed dataset fixture (12 queries, 90 passages, 10 relT + 20 neg per example) with the
+    toy tokenizer saved as a HuggingFace tokenizer directory."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    import sys
+    sys.path.insert(0, here)
+    from toy_tokenizer import make_tokenizer
+    fix = os.path.join(here, "golden", "nway_dataset_fixture")
+    tokdir = os.path.join(str(tmp_path), "tok")
+    make_tokenizer().save_pretrained(tokdir)
+    return ["--experiment_folder", str(tmp_path), "--run_folder", "run", "--queries_path", os.path.join(fix, "queries.tsv"),
+            "--collection_path", os.path.join(fix, "collection.tsv"), "--training_path", os.path.join(fix, "train_10relT_20neg.jsonl"),
+            "--label_mode", "9", "--tokenizer_name_or_path", tokdir, "--query_max_len", "6", "--passage_max_len", "16",
+            "--train_batch_size", "4", "--logging_steps", "1", "--evaluate_steps", "1000", "--warmup_steps", "1", "--num_train_epochs", "2",
+            "--loss", "lambda_mrr", "--loader_workers", "2"] + list(extra)
+
+
+def test_dataset_loader_runs_its_collate_in_worker_processes(tmp_path):
+    """build_dataloader (reference :173-245 + the DataLoader of :247): files -> NwayDataset -> tokenizer collate in `--loader_workers` processes ->
+    batches with the passages' token counts attached in the worker (attach_lengths), per-rank batch size, drop_last; the same batches with and
+    without the token cache."""
+    a = T.get_args(_dataset_args(tmp_path))
+    a.rank, a.nranks, a.distributed = 0, 1, False
+    ds, loader = T.build_dataloader(a)
+    assert len(ds) == 12 and len(loader) == 3 and loader.num_workers == 2
+    batches = list(loader)
+    assert len(batches) == 3
+    seen = []
+    for b in batches:
+        nw = b["nway_passages"]
+        assert tuple(nw["input_ids"].shape[:2]) == (4, 30) and tuple(b["labels"].shape) == (4, 30) and b["query"]["input_ids"].shape[0] == 4
+        assert nw["lengths"].tolist() == nw["attention_mask"].sum(-1).reshape(-1).tolist()
+        assert nw["input_ids"].shape[-1] == int(nw["lengths"].max()) <= 16                      # padded to the longest of the batch
+        seen += np.asarray(b["qid"]).tolist()
+    assert len(set(seen)) == 12                                                                   # every example once per epoch
+    a2 = T.get_args(_dataset_args(tmp_path, ["--token_cache_dir", os.path.join(str(tmp_path), "cache")]))
+    a2.rank, a2.nranks, a2.distributed = 0, 1, False
+    ds2, _ = T.build_dataloader(a2)
+    for i in (0, 5, 11):
+        x, y = ds.collate_fn([ds[i]]), ds2.collate_fn([ds2[i]])
+        for side in ("query", "nway_passages"):
+            for k in ("input_ids", "attention_mask"):
+                assert torch.equal(torch.as_tensor(x[side][k]), torch.as_tensor(y[side][k]))
+        assert torch.equal(x["nway_passages"]["lengths"], y["nway_passages"]["lengths"])
+
+
+@pytest.mark.gpu
+def test_cli_on_dataset_files_trains_through_the_worker_loader(tmp_path, monkeypatch):
+    """The training command line on REAL files (not --synthetic_steps): tokenizer collate in worker processes, pinned batches, packed passages
+    (the fixture's passages are 5 .. 16 tokens long), two epochs, a log line per step, finite losses, every step applied."""
+    from cldrd_amd.encoder import EncoderConfig
+    from cldrd_amd.models import NwayDualEncoder
+    cfg = EncoderConfig(arch="distilbert", vocab_size=64, dim=128, n_heads=2, hidden_dim=256, n_layers=2, max_position_embeddings=32,
+                        dropout=0.1, attention_dropout=0.1)
+    real = T.NwayDualEncoder
+    monkeypatch.setattr(T, "NwayDualEncoder", lambda name, **kw: real(cfg if name == "tiny-test-model" else name, **kw))
+    args = T.set_env(T.get_args(_dataset_args(tmp_path, ["--model_name_or_path", "tiny-test-model", "--learning_rate", "1e-3"])))
+    steps = []
+    orig = T.NwayTrainer.train_step
+
+    def spy(self, batch):
+        steps.append(("lengths" in batch["nway_passages"], tuple(batch["nway_passages"]["input_ids"].shape), batch["nway_passages"]["input_ids"].is_cuda))
+        return orig(self, batch)
+    monkeypatch.setattr(T.NwayTrainer, "train_step", spy)
+    tr = T.train(args)
+    assert tr.global_step == 6 and len(steps) == 6 and all(s[0] and s[2] and s[1][:2] == (4, 30) for s in steps)
+    assert torch.isfinite(tr.flat_p).all().item() and tr.skipped_steps() == 0
+    log = open(os.path.join(str(tmp_path), "run", "log", "train_logs.log")).read().splitlines()
+    assert len(log) == 6 and [l.split("\t")[1] for l in log[1:]] == ["2", "3", "4", "5", "6"]      # the first call only writes the header
+    losses = [float(l.split("\t")[2]) for l in log[1:]]
+    assert all(np.isfinite(losses)) and all(l > 0 for l in losses)
+
+
 @pytest.mark.gpu
 def test_cli_synthetic_run_checkpoint_and_resume(tmp_path):
     common = ["--experiment_folder", str(tmp_path), "--run_folder", "run", "--synthetic_steps", "6", "--synthetic_model", "tiny",
