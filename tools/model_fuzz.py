@@ -40,7 +40,8 @@ for c in range(cases):
         cos = torch.nn.functional.cosine_similarity(gp, gk, dim=0).item() if gp.norm() > 0 else 1.0
         # (Lp = 1: every passage is the same single token, the N logits of a query are equal and the listwise gradients cancel over N: what is left
         #  of the passage tower's gradient is rounding noise, its direction means nothing - seed 77 case 20 measured 0.989 between two IDENTICAL calls)
-        ok = err <= 2e-2 and torch.equal(lp, lk) and (cos >= 0.9999 or Lp == 1)
+        bar = 2e-2 if os.environ.get("CLDRD_AMP", "fp16") == "fp16" else 4e-2            # bf16 operands: 8-bit significands (seed 3 case 17: 2.8e-2)
+        ok = err <= bar and torch.equal(lp, lk) and (cos >= 0.9999 or Lp == 1)
         os.environ["CLDRD_GRAPH"] = "1"
         tr2 = NwayTrainer(selftest.build_tiny_model(cfg, share_weights=share, std=0.05).cuda().train(), loss=loss)
         for s in range(6):
