@@ -38,6 +38,8 @@ SIGNATURES = {
     "cldrd_attention_cls_bwd_x": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
     "cldrd_attention_fwd_varlen": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp, vp]),
     "cldrd_attention_bwd_varlen": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp, ci, vp]),
+    "cldrd_attention_fwd_varlen_list": (ci, [vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp, vp, ci, ci, vp]),
+    "cldrd_attention_bwd_varlen_list": (ci, [vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, vp, ci, vp, ci, ci, vp]),
     "cldrd_attention_cls_fwd_varlen": (ci, [vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp, vp]),
     "cldrd_attention_cls_bwd_varlen": (ci, [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, cf, cull, ci, vp]),
     "cldrd_add_rows_strided": (ci, [vp, vp, ci, ci, ci, ci, vp]),

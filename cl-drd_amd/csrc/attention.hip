@@ -120,6 +120,11 @@ __device__ __forceinline__ void mfma_drain() {
 #else
 #define CLDRD_LIVE_BLOCKS(len, NKB) (((len) + 31) >> 5)
 #endif
+// A launch may cover a LIST of sequences (seq_list, device int32; null: all of them in order): item i / H is then the list position and
+// seq_list[i / H] the sequence - how a packed batch with L > 128 sends its sequences of at most 128 tokens (most of an MS MARCO batch) to the
+// L <= 128 kernels (persistent, double-buffered) and only the long ones to the streaming / one-item kernels: `L` stays the stride of LSE and of
+// the dropout row keys, the kernel's tile height comes from its NKB.
+__device__ __forceinline__ int seq_of(const int* __restrict__ seq_list, int pos) { return seq_list ? seq_list[pos] : pos; }
 struct SeqRows { int row0, len; };
 __device__ __forceinline__ SeqRows seq_rows(const int* __restrict__ cu, int seq, int L) {
     if (cu) { const int c0 = cu[seq]; return {c0, cu[seq + 1] - c0}; }
@@ -145,7 +150,7 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
-                                                        bf16_t* __restrict__ ctx16, const int* __restrict__ cu) {
+                                                        bf16_t* __restrict__ ctx16, const int* __restrict__ cu, const int* __restrict__ seq_list) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(256) void attn_fwd_full_kernel(const bf16_t* __rest
     char* sK = sQ + Lp * RSB;
     char* sV = sK + Lp * RSB;
     float* sBias = (float*)(sV + Lp * RSB);
-    const int seq = blockIdx.x / H, hd = blockIdx.x % H;
+    const int seq = seq_of(seq_list, blockIdx.x / H), hd = blockIdx.x % H;
     const int dm = H * 64, ld = 3 * dm;
     const SeqRows sr = seq_rows(cu, seq, L);
     const int len = sr.len;
@@ -292,7 +297,7 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                          bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                          float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
-                                                         uint32_t* __restrict__ bits_out, bf16_t* __restrict__ ctx16, const int* __restrict__ cu) {
+                                                         uint32_t* __restrict__ bits_out, bf16_t* __restrict__ ctx16, const int* __restrict__ cu, const int* __restrict__ seq_list) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
     uint4 pq[NCH], pk[NCH], pv[NCH];
     float p_bias = 0.f;
     auto issue = [&](int item) {
-        const int seq = item / H, hd = item % H;
+        const int seq = seq_of(seq_list, item / H), hd = item % H;
         const SeqRows nr = seq_rows(cu, seq, L);
         const bf16_t* base = qkv + (size_t)nr.row0 * ld + hd * 64;
 #pragma unroll
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
     // compute waves (one per SIMD here) dropout cost 23 us of 70 per layer.
     auto make_bits = [&](int b, int item) {
         if constexpr (DROP) {
-            const int seq = item / H, hd = item % H;
+            const int seq = seq_of(seq_list, item / H), hd = item % H;
             uint32_t* sb = (uint32_t*)(smem + b * BUF + 3 * TILE) + Lp;
             for (int idx = tb; idx < NBITS; idx += 256) {
                 const int q = idx % Lp, kb = idx / Lp;
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(512) void attn_fwd2_kernel(const bf16_t* __restrict
         const char* sV = sK + TILE;
         const float* sBias = (const float*)(sV + TILE);
         const uint32_t* sBits = (const uint32_t*)(sBias + Lp);
-        const int seq = item / H, hd = item % H;
+        const int seq = seq_of(seq_list, item / H), hd = item % H;
         const SeqRows sr = seq_rows(cu, seq, L);
         const int len = sr.len, nb = CLDRD_LIVE_BLOCKS(len, NKB);
         const int t_ = opaque(tid);
@@ -505,7 +510,7 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                         bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
-                                                        bf16_t* __restrict__ ctx16, const int* __restrict__ cu) {
+                                                        bf16_t* __restrict__ ctx16, const int* __restrict__ cu, const int* __restrict__ seq_list) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_fwd_kernel(const bf1
     char* sK = sQ + Lp * RSB;
     char* sV = sK + Lp * RSB;
     float* sBias = (float*)(sV + Lp * RSB);
-    const int seq = blockIdx.x / H, hd = blockIdx.x % H;
+    const int seq = seq_of(seq_list, blockIdx.x / H), hd = blockIdx.x % H;
     const int dm = H * 64, ld = 3 * dm;
     const SeqRows sr = seq_rows(cu, seq, L);
     const int len = sr.len;
@@ -643,7 +648,7 @@ template <int NKB, bool DROP, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict__ qkv, const int64_t* __restrict__ mask,
                                                          bf16_t* __restrict__ ctx, float* __restrict__ lse, int L, int H,
                                                          float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
-                                                         bf16_t* __restrict__ ctx16, const int* __restrict__ cu) {
+                                                         bf16_t* __restrict__ ctx16, const int* __restrict__ cu, const int* __restrict__ seq_list) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -663,7 +668,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
     // a V row that meets p = 0, a Q row whose output nobody stores - all finite, results unchanged bit for bit.
     const long long* mask_or_any = mask ? (const long long*)mask : (const long long*)qkv;      // null mask: the value loaded is ignored
     auto issue = [&](int item) {
-        const int seq = item / H, hd = item % H;
+        const int seq = seq_of(seq_list, item / H), hd = item % H;
         const SeqRows nr = seq_rows(cu, seq, L);
         p_len = nr.len;
         const bf16_t* base = qkv + (size_t)nr.row0 * ld + hd * 64;
@@ -717,7 +722,7 @@ __global__ __launch_bounds__(512) void attn_fwd3_kernel(const bf16_t* __restrict
         const char* sK = smem + cur * BUF;
         const char* sV = sK + TILE;
         const float* sBias = (const float*)(sV + TILE);
-        const int seq = item / H, hd = item % H;
+        const int seq = seq_of(seq_list, item / H), hd = item % H;
         const SeqRows sr = seq_rows(cu, seq, L);
         const int len = sr.len, nb = CLDRD_LIVE_BLOCKS(len, NKB);
         const int lane = tid & 63, wid = tid >> 6;
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
                                                         const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                         const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
                                                         float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a,
-                                                        const int* __restrict__ cu) {
+                                                        const int* __restrict__ cu, const int* __restrict__ seq_list) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -843,7 +848,7 @@ __global__ __launch_bounds__(NKB > 4 ? 512 : 256) void attn_bwd_kernel(const bf1
     float* sLse = sBias + Lp;
     float* sDelta = sLse + Lp;
     uint32_t* sRk = (uint32_t*)(sDelta + Lp);          // dropout row key of every query row (common.h)
-    const int seq = blockIdx.x / H, hd = blockIdx.x % H;
+    const int seq = seq_of(seq_list, blockIdx.x / H), hd = blockIdx.x % H;
     const int dm = H * 64, ld = 3 * dm;
     const SeqRows sr = seq_rows(cu, seq, L);
     const int len = sr.len;
@@ -1059,7 +1064,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
                                                          const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                          const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int L, int H,
                                                          float scale, uint32_t drop_thresh, float drop_scale, SeedArg seed_a, int nitems,
-                                                         const uint32_t* __restrict__ drop_bits, const int* __restrict__ cu) {
+                                                         const uint32_t* __restrict__ drop_bits, const int* __restrict__ cu, const int* __restrict__ seq_list) {
     const uint64_t seed = seed_a.get();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = 32 * NKB;
@@ -1086,7 +1091,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
     int p_len = 0;                   // row count of the prefetched item (L, or its length in the packed layout)
     uint32_t pbits[NBW > 0 ? NBW : 1];
     auto issue = [&](int item) {
-        const int seq = item / H, hd = item % H;
+        const int seq = seq_of(seq_list, item / H), hd = item % H;
         const SeqRows nr = seq_rows(cu, seq, L);
         p_len = nr.len;
         const bf16_t* base = qkv + (size_t)nr.row0 * ld + hd * 64;
@@ -1116,7 +1121,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         }
     };
     auto commit = [&](int b, int item) {
-        const int seq = item / H, hd = item % H;
+        const int seq = seq_of(seq_list, item / H), hd = item % H;
         char* base = smem + b * BUF;
         float* fl = (float*)(base + 4 * TILE);
 #pragma unroll
@@ -1161,7 +1166,7 @@ __global__ __launch_bounds__(512) void attn_bwd2_kernel(const bf16_t* __restrict
         const float* sDelta = sLse + Lp;
         const uint32_t* sRk = (const uint32_t*)(sDelta + Lp);
         const uint32_t* sBits = sRk + Lp;
-        const int seq = item / H, hd = item % H;
+        const int seq = seq_of(seq_list, item / H), hd = item % H;
         const SeqRows sr = seq_rows(cu, seq, L);
         const int len = sr.len, nb = CLDRD_LIVE_BLOCKS(len, NKB);
         const int t_ = opaque(tid);
@@ -1340,40 +1345,40 @@ bool attn_fwd2_enabled(int nseq, int L, int H);
 
 template <int NKB, bool DROP>
 int launch_fwd_f16(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-                   unsigned long long seed, hipStream_t st, const int* cu) {      // fp16 in, fp16 out: no second copy
+                   unsigned long long seed, hipStream_t st, const int* cu, const int* seq_list) {      // fp16 in, fp16 out: no second copy
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
     (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP, true>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)nullptr, cu);
+                       (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)nullptr, cu, seq_list);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 template <int NKB>
 int launch_fwd_h(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-                 unsigned long long seed, hipStream_t st, const int* cu) {
-    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_f16<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, st, cu)
-                                              : launch_fwd_f16<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, st, cu);
+                 unsigned long long seed, hipStream_t st, const int* cu, const int* seq_list) {
+    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_f16<NKB, true>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, st, cu, seq_list)
+                                              : launch_fwd_f16<NKB, false>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, st, cu, seq_list);
 }
 
 template <int NKB, bool DROP, bool F16 = false>
 int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-                 unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st, const int* cu) {
+                 unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st, const int* cu, const int* seq_list) {
     const size_t lds = 3 * 32 * NKB * RSB + 32 * NKB * sizeof(float);
     if constexpr (NKB <= 4) {
         // many items: the persistent loader / compute kernel (CLDRD_ATTN_FWD2=0 keeps the one-item-per-workgroup kernel: A/B runs and tests)
         const int nitems = nseq * H, cus = attn_num_cus();
-        if (attn_fwd2_enabled(nseq, L, H)) {
+        if (attn_fwd2_enabled(nseq, 32 * NKB, H)) {       // (the tile height, not L: a listed launch of short sequences has L > 128)
             const size_t lds2 = 2 * (lds + (DROP ? 32 * NKB * NKB * sizeof(uint32_t) : 0));
             (void)hipFuncSetAttribute((const void*)attn_fwd2_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipLaunchKernelGGL((attn_fwd2_kernel<NKB, DROP, F16>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems,
-                               bits_out, (bf16_t*)ctx16, cu);
+                               bits_out, (bf16_t*)ctx16, cu, seq_list);
             CLDRD_LAUNCH_CHECK();
             return 0;
         }
         (void)hipFuncSetAttribute((const void*)attn_fwd_full_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_full_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16, cu);
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16, cu, seq_list);
     } else {
         // many items at 128 < L <= 256: the persistent streaming kernel (K / V double-buffered, Q from global memory); cldrd_set_tuning("attn_fwd2", 0)
         // keeps the one-item-per-workgroup kernel (tests: the two are bit-identical)
@@ -1383,22 +1388,22 @@ int launch_fwd_d(const void* qkv, const long long* mask, void* ctx, float* lse, 
             (void)hipFuncSetAttribute((const void*)attn_fwd3_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
             hipLaunchKernelGGL((attn_fwd3_kernel<NKB, DROP, F16>), dim3(cus), dim3(512), lds3, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems,
-                               (bf16_t*)ctx16, cu);
+                               (bf16_t*)ctx16, cu, seq_list);
             CLDRD_LAUNCH_CHECK();
             return 0;
         }
         (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_fwd_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(512), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
-                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16, cu);
+                           (bf16_t*)ctx, lse, L, H, scale, DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), (bf16_t*)ctx16, cu, seq_list);
     }
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 template <int NKB, bool F16 = false>
 int launch_fwd(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float scale, float p,
-               unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st, const int* cu) {
-    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, bits_out, ctx16, st, cu)
-                                              : launch_fwd_d<NKB, false, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, nullptr, ctx16, st, cu);
+               unsigned long long seed, uint32_t* bits_out, void* ctx16, hipStream_t st, const int* cu, const int* seq_list) {
+    return p > 0.f && dropout_thresh16(p) > 0 ? launch_fwd_d<NKB, true, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, p, seed, bits_out, ctx16, st, cu, seq_list)
+                                              : launch_fwd_d<NKB, false, F16>(qkv, mask, ctx, lse, nseq, L, H, scale, 0.f, seed, nullptr, ctx16, st, cu, seq_list);
 }
 int attn_num_cus() {
     static int n = 0;
@@ -1416,7 +1421,7 @@ bool attn_fwd2_enabled(int nseq, int L, int H) {
 
 template <int NKB, bool DROP, bool F16 = false>
 int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
-                 int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st, const int* cu) {
+                 int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st, const int* cu, const int* seq_list) {
     if constexpr (NKB <= 4) {
         // many items: the persistent two-role kernel (cldrd_set_tuning("attn_bwd2", 0) keeps the one-item-per-workgroup kernel: tests)
         const int nitems = nseq * H, cus = attn_num_cus();
@@ -1427,12 +1432,12 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
                 (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
                 hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, DROP, F16>), dim3(cus), dim3(512), lds2, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                    (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, drop_bits, cu);
+                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, drop_bits, cu, seq_list);
             } else {
                 (void)hipFuncSetAttribute((const void*)attn_bwd2_kernel<NKB, DROP, false, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds1));
                 hipLaunchKernelGGL((attn_bwd2_kernel<NKB, DROP, false, F16>), dim3(cus), dim3(512), 2 * lds1, st, (const bf16_t*)qkv, (const int64_t*)mask,
                                    (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, (const uint32_t*)nullptr, cu);
+                                   DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), nitems, (const uint32_t*)nullptr, cu, seq_list);
             }
             CLDRD_LAUNCH_CHECK();
             return 0;
@@ -1443,23 +1448,23 @@ int launch_bwd_d(const void* qkv, const long long* mask, const void* ctx, const 
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP, F16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP, F16, true>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv,
                            (const int64_t*)mask, (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                           DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), cu);
+                           DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), cu, seq_list);
         CLDRD_LAUNCH_CHECK();
         return 0;
     }
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<NKB, DROP, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((attn_bwd_kernel<NKB, DROP, F16>), dim3(nseq * H), dim3(NKB > 4 ? 512 : 256), lds, st, (const bf16_t*)qkv, (const int64_t*)mask,
                        (const bf16_t*)ctx, (const bf16_t*)dctx, lse, (bf16_t*)dqkv, L, H, scale,
-                       DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), cu);
+                       DROP ? dropout_thresh16(p) : 0u, 1.0f / (1.0f - p), seed_arg(seed), cu, seq_list);
     CLDRD_LAUNCH_CHECK();
     return 0;
 }
 template <int NKB, bool F16 = false>
 int launch_bwd(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
-               int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st, const int* cu) {
+               int L, int H, float scale, float p, unsigned long long seed, const uint32_t* drop_bits, hipStream_t st, const int* cu, const int* seq_list) {
     return p > 0.f && dropout_thresh16(p) > 0
-               ? launch_bwd_d<NKB, true, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, p, seed, drop_bits, st, cu)
-               : launch_bwd_d<NKB, false, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, 0.f, seed, nullptr, st, cu);
+               ? launch_bwd_d<NKB, true, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, p, seed, drop_bits, st, cu, seq_list)
+               : launch_bwd_d<NKB, false, F16>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, 0.f, seed, nullptr, st, cu, seq_list);
 }
 
 }  // namespace
@@ -1485,7 +1490,8 @@ extern "C" int cldrd_attention_fwd(const void* qkv, const long long* mask, void*
 // ctx_f16_copy (optional, bf16 pass only): the same context in fp16 - the operand of an fp16 out-projection GEMM; ctx itself may then be null
 // (an evaluation forward keeps no bf16 tape).
 static int attention_fwd_impl(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float dropout_p,
-                              unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy, const int* cu, void* stream);
+                              unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy, const int* cu, void* stream,
+                              const int* seq_list = nullptr, int n_list = 0, int Ltile = 0);
 extern "C" int cldrd_attention_fwd_bits(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H,
                                         float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy,
                                         void* stream) {
@@ -1501,45 +1507,61 @@ extern "C" int cldrd_attention_fwd_varlen(const void* qkv_packed, const int* cu_
     CLDRD_CHECK(cu_rows != nullptr, "attention_fwd_varlen: cu_rows is required");
     return attention_fwd_impl(qkv_packed, nullptr, ctx_packed, lse, nseq, L, H, dropout_p, seed, io_f16, drop_bits_out, ctx_f16_copy, cu_rows, stream);
 }
-static int attention_fwd_impl(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq, int L, int H, float dropout_p,
-                              unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy, const int* cu, void* stream) {
-    CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_fwd: need 0 < L <= 256");
+// The same for a LIST of the batch's sequences (seq_list: device int32 [n_list], positions in 0 .. nseq - 1, each at most Ltile <= L tokens long):
+// the launch runs the kernels of tile height Ltile - a packed batch at L = 256 sends its sequences of at most 128 tokens through the persistent
+// L <= 128 kernels and the rest through a second call (round 6).  LSE rows and dropout row keys keep the stride L of the whole batch, so the
+// backward of a sequence must be given the same L (any list).  No keep bits are produced for L > 128 (cldrd_attention_bits_words).
+extern "C" int cldrd_attention_fwd_varlen_list(const void* qkv_packed, const int* cu_rows, void* ctx_packed, float* lse, int nseq, int L, int H,
+                                               float dropout_p, unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy,
+                                               const int* seq_list, int n_list, int Ltile, void* stream) {
+    CLDRD_CHECK(cu_rows != nullptr && seq_list != nullptr, "attention_fwd_varlen_list: cu_rows and seq_list are required");
+    return attention_fwd_impl(qkv_packed, nullptr, ctx_packed, lse, nseq, L, H, dropout_p, seed, io_f16, drop_bits_out, ctx_f16_copy, cu_rows, stream,
+                              seq_list, n_list, Ltile);
+}
+static int attention_fwd_impl(const void* qkv, const long long* mask, void* ctx, float* lse, int nseq_all, int L, int H, float dropout_p,
+                              unsigned long long seed, int io_f16, void* drop_bits_out, void* ctx_f16_copy, const int* cu, void* stream,
+                              const int* seq_list, int n_list, int Ltile) {
+    CLDRD_CHECK(nseq_all > 0 && L > 0 && L <= 256 && H > 0, "attention_fwd: need 0 < L <= 256");
+    CLDRD_CHECK(seq_list == nullptr || (cu != nullptr && n_list > 0 && n_list <= nseq_all && Ltile > 0 && Ltile <= L),
+                "attention_fwd: a sequence list goes with a packed batch, 0 < n_list <= nseq, 0 < Ltile <= L");
+    const int nseq = seq_list ? n_list : nseq_all;          // sequences of THIS launch (items = nseq x H)
+    const int Lt = seq_list ? Ltile : L;                    // rows a sequence of this launch can have: the kernels' tile height
     CLDRD_CHECK(ctx != nullptr || ctx_f16_copy != nullptr, "attention_fwd: no output");
     CLDRD_CHECK(!(io_f16 && (ctx_f16_copy != nullptr || ctx == nullptr)), "attention_fwd: the fp16 pass writes ctx only");
     CLDRD_CHECK(io_f16 == 0 || io_f16 == 1 || io_f16 == 5, "attention_fwd: io_f16 is 0 (bf16), 1 (fp16, L <= 128, no keep bits) or 5 (fp16, every kernel of the bf16 path)");
     const float scale = 0.125f;   // 1 / sqrt(64)
-    const int nkb = (L + 31) / 32;
+    const int nkb = (Lt + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (io_f16 == 5) {            // fp16 activations through the whole kernel family (round 4: the all-fp16 training mode)
         switch (nkb) {
-            case 1: return launch_fwd<1, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
-            case 2: return launch_fwd<2, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
-            case 3: return launch_fwd<3, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
-            case 4: return launch_fwd<4, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
-            case 5: return launch_fwd<5, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
-            case 6: return launch_fwd<6, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
-            case 7: return launch_fwd<7, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
-            default: return launch_fwd<8, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu);
+            case 1: return launch_fwd<1, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu, seq_list);
+            case 2: return launch_fwd<2, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu, seq_list);
+            case 3: return launch_fwd<3, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu, seq_list);
+            case 4: return launch_fwd<4, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu, seq_list);
+            case 5: return launch_fwd<5, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu, seq_list);
+            case 6: return launch_fwd<6, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu, seq_list);
+            case 7: return launch_fwd<7, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu, seq_list);
+            default: return launch_fwd<8, true>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, nullptr, st, cu, seq_list);
         }
     }
     if (io_f16) {                 // fp16 activations: the all-scores-in-registers kernel only (L <= 128)
-        CLDRD_CHECK(L <= 128, "attention_fwd: the fp16 forward handles L <= 128");
+        CLDRD_CHECK(Lt <= 128, "attention_fwd: the fp16 forward handles L <= 128");
         switch (nkb) {
-            case 1: return launch_fwd_h<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu);
-            case 2: return launch_fwd_h<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu);
-            case 3: return launch_fwd_h<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu);
-            default: return launch_fwd_h<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu);
+            case 1: return launch_fwd_h<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu, seq_list);
+            case 2: return launch_fwd_h<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu, seq_list);
+            case 3: return launch_fwd_h<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu, seq_list);
+            default: return launch_fwd_h<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, st, cu, seq_list);
         }
     }
     switch (nkb) {
-        case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
-        case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
-        case 3: return launch_fwd<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
-        case 4: return launch_fwd<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
-        case 5: return launch_fwd<5>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
-        case 6: return launch_fwd<6>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
-        case 7: return launch_fwd<7>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
-        default: return launch_fwd<8>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu);
+        case 1: return launch_fwd<1>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu, seq_list);
+        case 2: return launch_fwd<2>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu, seq_list);
+        case 3: return launch_fwd<3>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu, seq_list);
+        case 4: return launch_fwd<4>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu, seq_list);
+        case 5: return launch_fwd<5>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu, seq_list);
+        case 6: return launch_fwd<6>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu, seq_list);
+        case 7: return launch_fwd<7>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu, seq_list);
+        default: return launch_fwd<8>(qkv, mask, ctx, lse, nseq, L, H, scale, dropout_p, seed, (uint32_t*)drop_bits_out, ctx_f16_copy, st, cu, seq_list);
     }
 }
 
@@ -1561,7 +1583,8 @@ extern "C" int cldrd_attention_bwd_bits(const void* qkv, const long long* mask, 
 }
 // io_f16 != 0: q / k / v, ctx, dctx and dqkv are fp16 (the all-fp16 training mode: gradients carry the loss scale)
 static int attention_bwd_impl(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
-                              int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits, int io_f16, const int* cu, void* stream);
+                              int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits, int io_f16, const int* cu, void* stream,
+                              const int* seq_list = nullptr, int n_list = 0, int Ltile = 0);
 extern "C" int cldrd_attention_bwd_x(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse,
                                      void* dqkv, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
                                      int io_f16, void* stream) {
@@ -1575,34 +1598,46 @@ extern "C" int cldrd_attention_bwd_varlen(const void* qkv_packed, const int* cu_
     CLDRD_CHECK(cu_rows != nullptr, "attention_bwd_varlen: cu_rows is required");
     return attention_bwd_impl(qkv_packed, nullptr, ctx_packed, dctx_packed, lse, dqkv_packed, nseq, L, H, dropout_p, seed, drop_bits, io_f16, cu_rows, stream);
 }
-static int attention_bwd_impl(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq,
-                              int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits, int io_f16, const int* cu, void* stream) {
-    CLDRD_CHECK(nseq > 0 && L > 0 && L <= 256 && H > 0, "attention_bwd: need 0 < L <= 256");
+extern "C" int cldrd_attention_bwd_varlen_list(const void* qkv_packed, const int* cu_rows, const void* ctx_packed, const void* dctx_packed,
+                                               const float* lse, void* dqkv_packed, int nseq, int L, int H, float dropout_p, unsigned long long seed,
+                                               const void* drop_bits, int io_f16, const int* seq_list, int n_list, int Ltile, void* stream) {
+    CLDRD_CHECK(cu_rows != nullptr && seq_list != nullptr, "attention_bwd_varlen_list: cu_rows and seq_list are required");
+    return attention_bwd_impl(qkv_packed, nullptr, ctx_packed, dctx_packed, lse, dqkv_packed, nseq, L, H, dropout_p, seed, drop_bits, io_f16, cu_rows,
+                              stream, seq_list, n_list, Ltile);
+}
+static int attention_bwd_impl(const void* qkv, const long long* mask, const void* ctx, const void* dctx, const float* lse, void* dqkv, int nseq_all,
+                              int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits, int io_f16, const int* cu, void* stream,
+                              const int* seq_list, int n_list, int Ltile) {
+    CLDRD_CHECK(nseq_all > 0 && L > 0 && L <= 256 && H > 0, "attention_bwd: need 0 < L <= 256");
+    CLDRD_CHECK(seq_list == nullptr || (cu != nullptr && n_list > 0 && n_list <= nseq_all && Ltile > 0 && Ltile <= L),
+                "attention_bwd: a sequence list goes with a packed batch, 0 < n_list <= nseq, 0 < Ltile <= L");
+    const int nseq = seq_list ? n_list : nseq_all;          // sequences of THIS launch; Lt: the rows one of them can have (tile height)
+    const int Lt = seq_list ? Ltile : L;
     CLDRD_CHECK(lse != nullptr, "attention_bwd: lse is required");
     const float scale = 0.125f;
-    const int nkb = (L + 31) / 32;
+    const int nkb = (Lt + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
     if (io_f16) {
         switch (nkb) {
-            case 1: return launch_bwd<1, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-            case 2: return launch_bwd<2, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-            case 3: return launch_bwd<3, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-            case 4: return launch_bwd<4, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-            case 5: return launch_bwd<5, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-            case 6: return launch_bwd<6, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-            case 7: return launch_bwd<7, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-            default: return launch_bwd<8, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+            case 1: return launch_bwd<1, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+            case 2: return launch_bwd<2, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+            case 3: return launch_bwd<3, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+            case 4: return launch_bwd<4, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+            case 5: return launch_bwd<5, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+            case 6: return launch_bwd<6, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+            case 7: return launch_bwd<7, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+            default: return launch_bwd<8, true>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
         }
     }
     switch (nkb) {
-        case 1: return launch_bwd<1>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-        case 2: return launch_bwd<2>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-        case 3: return launch_bwd<3>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-        case 4: return launch_bwd<4>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-        case 5: return launch_bwd<5>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-        case 6: return launch_bwd<6>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-        case 7: return launch_bwd<7>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
-        default: return launch_bwd<8>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu);
+        case 1: return launch_bwd<1>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+        case 2: return launch_bwd<2>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+        case 3: return launch_bwd<3>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+        case 4: return launch_bwd<4>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+        case 5: return launch_bwd<5>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+        case 6: return launch_bwd<6>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+        case 7: return launch_bwd<7>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
+        default: return launch_bwd<8>(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, scale, dropout_p, seed, (const uint32_t*)drop_bits, st, cu, seq_list);
     }
 }
 

@@ -218,7 +218,7 @@ class _Tape:
 
 class _Pack:
     """Row maps of a packed batch (csrc/pack.hip): sequence m owns rows cu[m] .. cu[m + 1] of the packed matrices."""
-    __slots__ = ("Tp", "cu", "tok_idx", "pos", "cls_idx")
+    __slots__ = ("Tp", "cu", "tok_idx", "pos", "cls_idx", "groups")
 
     @classmethod
     def build(cls, lengths, L, dev):
@@ -234,6 +234,18 @@ class _Pack:
         pk.tok_idx = torch.from_numpy((seq * L + pos).astype(np.int32)).to(dev, non_blocking=True)
         pk.pos = torch.from_numpy(pos.astype(np.int32)).to(dev, non_blocking=True)
         pk.cls_idx = pk.cu[:-1]
+        # attention launches of the batch: [(sequence list or None = all, tile height)].  At L > 128 the sequences of at most 128 tokens - most
+        # of an MS MARCO batch - go through the L <= 128 kernels (persistent, double-buffered; 4 x 4 blocks at most), only the long ones through
+        # the streaming forward / one-item backward of L <= 256 (cldrd_attention_*_varlen_list)
+        pk.groups = [(None, 0)]
+        if L > 128:
+            short = np.nonzero(lens <= 128)[0]
+            if short.shape[0] == lens.shape[0]:
+                pk.groups = [(torch.from_numpy(short.astype(np.int32)).to(dev, non_blocking=True), 128)]
+            elif short.shape[0] > 0:
+                long_ = np.nonzero(lens > 128)[0]
+                pk.groups = [(torch.from_numpy(short.astype(np.int32)).to(dev, non_blocking=True), 128),
+                             (torch.from_numpy(long_.astype(np.int32)).to(dev, non_blocking=True), L)]
         return pk
 
 
@@ -776,8 +788,9 @@ class HipEncoder(nn.Module):
             yield
             if window is not None:
                 window("attn")
-            ops.attention_fwd(qkv, mask if pk is None else None, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16,
-                              full_family=fp16 and self.amp16, cu=cu)
+            for sl, tile in (pk.groups if pk is not None else [(None, 0)]):
+                ops.attention_fwd(qkv, mask if pk is None else None, ctx, lse, M, L, H, p_a, s_l + 1, drop_bits=dbits, ctx16=ctx16,
+                                  full_family=fp16 and self.amp16, cu=cu, seq_list=sl, tile=tile)
             yield
             s1 = self._buf(T, d, dev, sdt)
             ops.gemm_nt(ctx16 if OUT16 else ctx, (W16 if OUT16 else W)["Wo"], s1, T, bias=W["bo"], residual=x32, dropout_p=p_out,
@@ -1113,8 +1126,9 @@ class HipEncoder(nn.Module):
             if window is not None:
                 window("attn")
             dqkv = buf(T, 3 * d, dev)
-            ops.attention_bwd(a["qkv"], tape.mask if pk is None else None, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1,
-                              drop_bits=a.get("dbits"), cu=pk.cu if pk is not None else None)
+            for sl, tile in (pk.groups if pk is not None else [(None, 0)]):
+                ops.attention_bwd(a["qkv"], tape.mask if pk is None else None, a["ctx"], dctx, a["lse"], dqkv, M, L, H, p_a, s_l + 1,
+                                  drop_bits=a.get("dbits"), cu=pk.cu if pk is not None else None, seq_list=sl, tile=tile)
             self._wq.add(dqkv, a["x_in"], G["Wqkv"], T, dbias=G["bqkv"])
             yield
             gb = buf(T, d, dev)

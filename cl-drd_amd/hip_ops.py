@@ -363,15 +363,32 @@ def _cu_rows(cu, nseq, mask, what):
     return cu
 
 
-def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, ctx16=None, full_family=False, cu=None):
+def _seq_list(seq_list, tile, cu, nseq, L, what):
+    """``seq_list`` (int32 on the device) with ``tile``: the launch covers only these sequences of a packed batch, each at most ``tile`` <= L tokens
+    long, with the kernels of that tile height (cldrd_attention_*_varlen_list)."""
+    if cu is None:
+        raise ValueError(f"{what}: a sequence list goes with a packed batch (cu)")
+    _chk(seq_list, torch.int32, "seq_list", 1)
+    if not seq_list.is_contiguous() or not (0 < seq_list.numel() <= nseq) or not (0 < int(tile) <= L):
+        raise ValueError(f"{what}: seq_list must be contiguous int32 with 1 .. nseq entries, 0 < tile <= L")
+    return (_p(seq_list), int(seq_list.numel()), int(tile))
+
+
+def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, ctx16=None, full_family=False, cu=None, seq_list=None, tile=0):
     """``ctx16`` (fp16, bf16 pass only): the same context in fp16, for an fp16-operand out-projection; ``ctx`` may then be None.
-    ``cu``: qkv / ctx / ctx16 are packed [Tp, .] (see _cu_rows); ``lse`` and ``drop_bits`` keep their padded shapes."""
+    ``cu``: qkv / ctx / ctx16 are packed [Tp, .] (see _cu_rows); ``lse`` and ``drop_bits`` keep their padded shapes.  ``seq_list`` / ``tile``:
+    see _seq_list."""
     io_f16 = _fmt16(qkv, "qkv")
     entry = "cldrd_attention_fwd_bits"
+    tail = ()
     if cu is not None:
         entry, mask_arg = "cldrd_attention_fwd_varlen", _p(_cu_rows(cu, nseq, mask, "attention_fwd"))
+        if seq_list is not None:
+            entry, tail = "cldrd_attention_fwd_varlen_list", _seq_list(seq_list, tile, cu, nseq, L, "attention_fwd")
     else:
         mask_arg = _p(mask)
+        if seq_list is not None:
+            raise ValueError("attention_fwd: a sequence list goes with a packed batch (cu)")
     _chk(qkv, F16 if io_f16 else BF16, "qkv", 2)
     if ctx16 is not None:
         if io_f16:
@@ -382,7 +399,7 @@ def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_b
         if ctx is None:
             if mask is not None:
                 _chk(mask, torch.int64, "mask", 2)
-            call(entry, _p(qkv), mask_arg, None, _p(lse), nseq, L, H, dropout_p, seed, 0, _p(drop_bits), _p(ctx16), _stream())
+            call(entry, _p(qkv), mask_arg, None, _p(lse), nseq, L, H, dropout_p, seed, 0, _p(drop_bits), _p(ctx16), *tail, _stream())
             return ctx16
     _chk(ctx, F16 if io_f16 else BF16, "ctx", 2)
     if mask is not None:
@@ -399,12 +416,12 @@ def attention_fwd(qkv, mask, ctx, lse, nseq, L, H, dropout_p=0.0, seed=0, drop_b
             raise ValueError("attention_fwd: drop_bits must come from attention_drop_bits() for the same shape")
     if io_f16 and (drop_bits is not None or L > 128 or full_family):
         io_f16 = 5                    # fp16 through the whole kernel family of the bf16 path (persistent kernel, keep bits, L > 128)
-    call(entry, _p(qkv), mask_arg, _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _p(drop_bits), _p(ctx16), _stream())
+    call(entry, _p(qkv), mask_arg, _p(ctx), _p(lse), nseq, L, H, dropout_p, seed, io_f16, _p(drop_bits), _p(ctx16), *tail, _stream())
     return ctx
 
 
-def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, cu=None):
-    """``cu``: qkv / ctx / dctx / dqkv are packed [Tp, .] (see _cu_rows)."""
+def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, seed=0, drop_bits=None, cu=None, seq_list=None, tile=0):
+    """``cu``: qkv / ctx / dctx / dqkv are packed [Tp, .] (see _cu_rows); ``seq_list`` / ``tile``: see _seq_list."""
     io_f16 = _fmt16(qkv, "qkv")       # fp16 everywhere (the all-fp16 training mode) or bf16 everywhere
     for t, n in ((qkv, "qkv"), (ctx, "ctx"), (dctx, "dctx"), (dqkv, "dqkv")):
         _chk(t, F16 if io_f16 else BF16, n, 2)
@@ -413,6 +430,10 @@ def attention_bwd(qkv, mask, ctx, dctx, lse, dqkv, nseq, L, H, dropout_p=0.0, se
     _chk(lse, F32, "lse")
     if drop_bits is not None:
         _chk(drop_bits, torch.int32, "drop_bits", 1)
+    if seq_list is not None:
+        call("cldrd_attention_bwd_varlen_list", _p(qkv), _p(_cu_rows(cu, nseq, mask, "attention_bwd") if cu is not None else None), _p(ctx), _p(dctx),
+             _p(lse), _p(dqkv), nseq, L, H, dropout_p, seed, _p(drop_bits), io_f16, *_seq_list(seq_list, tile, cu, nseq, L, "attention_bwd"), _stream())
+        return dqkv
     if cu is not None:
         call("cldrd_attention_bwd_varlen", _p(qkv), _p(_cu_rows(cu, nseq, mask, "attention_bwd")), _p(ctx), _p(dctx), _p(lse), _p(dqkv), nseq, L, H,
              dropout_p, seed, _p(drop_bits), io_f16, _stream())

@@ -143,6 +143,16 @@ int cldrd_attention_fwd_varlen(const void* qkv_packed, const int* cu_rows, void*
 int cldrd_attention_bwd_varlen(const void* qkv_packed, const int* cu_rows, const void* ctx_packed, const void* dctx_packed, const float* lse,
                                void* dqkv_packed, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
                                int fmt, void* stream);
+/* ... for a LIST of the batch's sequences (seq_list: device int32 [n_list], positions in 0 .. nseq - 1, each sequence at most Ltile <= L tokens
+ * long): the launch runs the kernels of tile height Ltile.  A packed batch at L = 256 sends its sequences of at most 128 tokens (most of an
+ * MS MARCO batch) through the persistent L <= 128 kernels and the others through a second call; LSE rows and dropout row keys keep the stride L
+ * of the batch, so forward and backward of a sequence must be given the same L (the lists may differ). */
+int cldrd_attention_fwd_varlen_list(const void* qkv_packed, const int* cu_rows, void* ctx_packed, float* lse, int nseq, int L, int H,
+                                    float dropout_p, unsigned long long seed, int fmt, void* drop_bits_out, void* ctx_f16_copy,
+                                    const int* seq_list, int n_list, int Ltile, void* stream);
+int cldrd_attention_bwd_varlen_list(const void* qkv_packed, const int* cu_rows, const void* ctx_packed, const void* dctx_packed, const float* lse,
+                                    void* dqkv_packed, int nseq, int L, int H, float dropout_p, unsigned long long seed, const void* drop_bits,
+                                    int fmt, const int* seq_list, int n_list, int Ltile, void* stream);
 int cldrd_attention_cls_fwd_varlen(const void* qc, const void* kv_packed, const int* cu_rows, void* ctx, float* probs, int nseq, int L, int H,
                                    float dropout_p, unsigned long long seed, int fmt, void* ctx_f16_copy, void* stream);
 int cldrd_attention_cls_bwd_varlen(const void* qc, const void* kv_packed, const int* cu_rows, const float* probs, const void* dctx, void* dqc,

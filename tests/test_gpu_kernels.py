@@ -695,6 +695,106 @@ def test_attention_on_packed_rows_every_length(L, H, f16, p):
     assert torch.equal(out[True][2][lv], out[False][2][lv]) and bool(torch.isfinite(out[True][2]).all())
 
 
+@pytest.mark.parametrize("L,H,f16,p", [(256, 2, False, 0.0), (256, 4, True, 0.0), (200, 1, True, 0.0)])
+def test_attention_sequence_lists_send_short_sequences_through_the_short_kernels(L, H, f16, p):
+    """cldrd_attention_{fwd,bwd}_varlen_list: a packed batch at 128 < L <= 256 in TWO launches - the sequences of at most 128 tokens through the
+    L <= 128 kernels (tile height 128), the longer ones through the L <= 256 kernels - with LSE rows and dropout row keys on the stride L of the
+    whole batch.  One batch holds a sequence of every length 1 .. L.  Without dropout: the long sequences equal the one-launch result bit for bit
+    (same kernels), the short ones equal a launch of the SAME sequences as a batch of their own at L = 128 bit for bit (same kernels, other
+    strides), context, LSE and q / k / v gradients.  (With dropout: test_attention_sequence_lists_with_dropout_against_the_oracle_mask.)"""
+    nseq, d = L, H * 64
+    g = torch.Generator(device=DEV).manual_seed(L * 3 + H)
+    dt = torch.float16 if f16 else torch.bfloat16
+    lens = (torch.randperm(L, device=DEV, generator=g) + 1).to(torch.int64)
+    cu = torch.zeros(nseq + 1, dtype=torch.int32, device=DEV)
+    cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    Tp = int(cu[-1])
+    qkv = torch.randn(Tp, 3 * d, device=DEV, generator=g).to(dt)
+    dctx = torch.randn(Tp, d, device=DEV, generator=g).to(dt)
+    short = torch.nonzero(lens <= 128).reshape(-1).to(torch.int32)
+    long_ = torch.nonzero(lens > 128).reshape(-1).to(torch.int32)
+    assert short.numel() == 128 and long_.numel() == L - 128
+
+    def run(groups, Lr=L, x=qkv, dy=dctx, cur=cu, n=nseq):
+        rows = x.shape[0]
+        ctx = torch.full((rows, d), float("nan"), dtype=dt, device=DEV)
+        lse = torch.full((n, H, Lr), float("nan"), dtype=torch.float32, device=DEV)
+        dq = torch.full((rows, 3 * d), float("nan"), dtype=dt, device=DEV)
+        for sl, tile in groups:
+            ops.attention_fwd(x, None, ctx, lse, n, Lr, H, dropout_p=p, seed=19, full_family=f16, cu=cur, seq_list=sl, tile=tile)
+        for sl, tile in groups:
+            ops.attention_bwd(x, None, ctx, dy, lse, dq, n, Lr, H, dropout_p=p, seed=19, cu=cur, seq_list=sl, tile=tile)
+        torch.cuda.synchronize()
+        return ctx, lse, dq
+    one = run([(None, 0)])
+    two = run([(short, 128), (long_, L)])
+    assert not torch.isnan(two[0].float()).any() and not torch.isnan(two[2].float()).any()
+    seq_of = torch.repeat_interleave(torch.arange(nseq, device=DEV), lens)
+    is_long = (lens > 128)[seq_of]
+    valid = torch.arange(L, device=DEV)[None, :] < lens[:, None]
+    lv = valid[:, None, :].expand(nseq, H, L)
+    if p == 0.0:
+        assert torch.equal(two[0][is_long], one[0][is_long]) and torch.equal(two[2][is_long], one[2][is_long])
+        longv = lv & (lens > 128)[:, None, None]
+        assert torch.equal(two[1][longv], one[1][longv])
+        # the short sequences as a batch of their own at L = 128
+        sl = short.long()
+        rows_s = torch.cat([torch.arange(int(cu[m]), int(cu[m + 1]), device=DEV) for m in sl.tolist()])
+        cu_s = torch.zeros(sl.numel() + 1, dtype=torch.int32, device=DEV)
+        cu_s[1:] = torch.cumsum(lens[sl], 0).to(torch.int32)
+        own = run([(None, 0)], Lr=128, x=qkv[rows_s].contiguous(), dy=dctx[rows_s].contiguous(), cur=cu_s, n=sl.numel())
+        assert torch.equal(two[0][rows_s], own[0]), "short sequences: context differs from the L = 128 launch of the same sequences"
+        assert torch.equal(two[2][rows_s], own[2]), "short sequences: q / k / v gradients differ from the L = 128 launch"
+        vs = (torch.arange(128, device=DEV)[None, :] < lens[sl][:, None])[:, None, :].expand(sl.numel(), H, 128)
+        assert torch.equal(two[1][sl][:, :, :128][vs], own[1][vs])
+    # everything within 16-bit rounding of the one-launch result (the short sequences change kernels: another summation order)
+    tol = 2.0 ** (-9 if f16 else -6)
+    for a, b, name in ((two[0], one[0], "context"), (two[2], one[2], "gradients")):
+        err = (a.float() - b.float()).abs()
+        assert bool((err <= tol * b.float().abs() + tol * b.float().abs().max() * 0.25).all()), (name, float(err.max()))
+    assert torch.allclose(two[1][lv], one[1][lv], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("f16", [False, True])
+def test_attention_sequence_lists_with_dropout_against_the_oracle_mask(f16):
+    """The two-launch form of a packed L = 256 batch WITH dropout against fp64 and the mask of oracle/dropout_ref.py (a function of sequence,
+    head, L, query, key: the short kernels must hash with the batch's L = 256, not with their tile height), forward and backward, same bars as
+    test_attention_dropout_fwd_bwd_against_the_oracle_mask; and the one-launch form against the same reference."""
+    p, seed, L, H = 0.25, 977, 256, 2
+    lens_l = [256, 1, 17, 64, 100, 128, 129, 200, 33, 96, 127, 130, 255, 2, 59, 64, 65, 31, 32, 160, 8, 77, 78, 192]
+    nseq, d = len(lens_l), H * 64
+    dt = torch.float16 if f16 else torch.bfloat16
+    lens = torch.tensor(lens_l, dtype=torch.int64, device=DEV)
+    cu = torch.zeros(nseq + 1, dtype=torch.int32, device=DEV)
+    cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
+    mask = (torch.arange(L, device=DEV)[None, :] < lens[:, None])
+    tok = torch.nonzero(mask.reshape(-1)).reshape(-1)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    qkv = torch.randn(nseq * L, 3 * d, device=DEV, generator=g).to(dt)
+    dctx = (torch.randn(nseq * L, d, device=DEV, generator=g).to(dt) * mask.reshape(-1, 1).to(dt))
+    keep = torch.from_numpy(DR.attention_keep_mask(seed, p, nseq, H, L)).to(DEV)
+    qv = qkv.double().requires_grad_(True)
+    x = qv.view(nseq, L, 3, H, 64)
+    q, k, v = x[:, :, 0].transpose(1, 2), x[:, :, 1].transpose(1, 2), x[:, :, 2].transpose(1, 2)
+    sc = (q @ k.transpose(2, 3) * 0.125).masked_fill(~mask[:, None, None, :], -1e30)
+    ref = ((torch.softmax(sc, -1) * keep / (1 - p)) @ v).transpose(1, 2).reshape(nseq * L, d)
+    ref.backward(dctx.double())
+    gref = qv.grad[tok].float()
+    short = torch.nonzero(lens <= 128).reshape(-1).to(torch.int32)
+    long_ = torch.nonzero(lens > 128).reshape(-1).to(torch.int32)
+    x_p, dy_p, Tp = qkv[tok].contiguous(), dctx[tok].contiguous(), int(cu[-1])
+    for groups in ([(short, 128), (long_, L)], [(None, 0)]):
+        ctx = torch.full((Tp, d), float("nan"), dtype=dt, device=DEV)
+        lse = torch.full((nseq, H, L), float("nan"), dtype=torch.float32, device=DEV)
+        dq = torch.full((Tp, 3 * d), float("nan"), dtype=dt, device=DEV)
+        for sl, tile in groups:
+            ops.attention_fwd(x_p, None, ctx, lse, nseq, L, H, dropout_p=p, seed=seed, full_family=f16, cu=cu, seq_list=sl, tile=tile)
+        for sl, tile in groups:
+            ops.attention_bwd(x_p, None, ctx, dy_p, lse, dq, nseq, L, H, dropout_p=p, seed=seed, cu=cu, seq_list=sl, tile=tile)
+        close(ctx, ref.detach()[tok].float(), 1 / 64, 3e-2, f"packed attention fwd with dropout, {len(groups)} launch(es)")
+        close(dq, gref, 1 / 32, 2e-2 * gref.abs().max().item(), f"packed attention bwd with dropout, {len(groups)} launch(es)")
+
+
 def test_gather_i64_picks_the_token_ids_of_the_packed_rows():
     """cldrd_gather_i64: out[p] = src[idx[p]] for int64 elements (what torch.index_select + an index cast did for a packed batch's token ids)."""
     g = torch.Generator(device=DEV).manual_seed(12)
