@@ -88,6 +88,29 @@ def test_forward_backward_walks_every_mode(stubbed, monkeypatch, arch, layers, p
     assert "cldrd_unpack_rows16" not in kinds                      # round 6: attention reads the packed rows through cu, no row moves
 
 
+@pytest.mark.parametrize("lens,want", [([200, 3, 10, 130, 5, 128], 2), ([100, 3, 10, 128, 5, 64], 1), ([200, 150, 129, 130, 131, 199], 0)])
+def test_packed_batches_above_128_tokens_split_their_attention_launches_by_length(stubbed, monkeypatch, lens, want):
+    """encoder._Pack at L > 128: the sequences of at most 128 tokens go through the L <= 128 kernels (cldrd_attention_*_varlen_list with tile 128),
+    the others through a second launch at tile L; all short: one listed launch; all long: the plain packed launch."""
+    monkeypatch.setenv("CLDRD_AMP", "fp16")
+    cfg = EncoderConfig(arch="distilbert", vocab_size=512, dim=128, n_heads=2, hidden_dim=256, n_layers=2, max_position_embeddings=256,
+                        dropout=0.1, attention_dropout=0.1)
+    enc = HipEncoder(cfg, seed=1)
+    lens = lens * 4                                   # 24 sequences: enough tokens for the encoder to pack (would_pack: >= 1024)
+    M, L = len(lens), 200
+    ids = torch.randint(3, 500, (M, L))
+    mask = (torch.arange(L)[None, :] < torch.tensor(lens)[:, None]).long()
+    n0 = len(stubbed)
+    cls, tape = enc.encode(ids, mask, train=True, save=True, lengths=lens)
+    assert tape.pack is not None and [t for _, t in tape.pack.groups] == ([128, L] if want == 2 else [128] if want == 1 else [0])
+    if want:
+        assert sorted(int(i) for sl, _ in tape.pack.groups for i in sl.tolist()) == list(range(M))
+    enc.backward_from_cls(tape, torch.randn(M, cfg.dim))
+    calls = stubbed[n0:]
+    fwd_l, bwd_l = calls.count("cldrd_attention_fwd_varlen_list"), calls.count("cldrd_attention_bwd_varlen_list")
+    assert fwd_l == bwd_l == want * 1 and calls.count("cldrd_attention_fwd_varlen") == calls.count("cldrd_attention_bwd_varlen") == (0 if want else 1)
+
+
 def test_trainer_step_walks_with_stubbed_kernels(stubbed, monkeypatch):
     """forward_backward + optimizer launches of NwayTrainer (padded and packed batch) with stubbed kernels; `lengths` travel from the
     host-side mask (trainer.batch_to_device) to the passage tower."""
