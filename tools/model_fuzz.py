@@ -41,7 +41,10 @@ for c in range(cases):
         # (Lp = 1: every passage is the same single token, the N logits of a query are equal and the listwise gradients cancel over N: what is left
         #  of the passage tower's gradient is rounding noise, its direction means nothing - seed 77 case 20 measured 0.989 between two IDENTICAL calls)
         bar = 2e-2 if os.environ.get("CLDRD_AMP", "fp16") == "fp16" else 4e-2            # bf16 operands: 8-bit significands (seed 3 case 17: 2.8e-2)
-        ok = err <= bar and torch.equal(lp, lk) and (cos >= 0.9999 or Lp == 1)
+        # packed == padded bit for bit up to L = 128; above, a packed batch sends its sequences of at most 128 tokens through the L <= 128 kernels
+        # (one softmax pass) while the padded batch runs the streaming kernels on all of them: the same values to 16-bit rounding
+        same = torch.equal(lp, lk) if Lp <= 128 else bool(((lp - lk).abs().max() <= 4e-3 * lp.abs().max()).item())
+        ok = err <= bar and same and (cos >= 0.9999 or Lp == 1)
         os.environ["CLDRD_GRAPH"] = "1"
         tr2 = NwayTrainer(selftest.build_tiny_model(cfg, share_weights=share, std=0.05).cuda().train(), loss=loss)
         for s in range(6):
@@ -49,7 +52,7 @@ for c in range(cases):
         ok = ok and bool(torch.isfinite(tr2.flat_p).all())
         if not ok:
             bad += 1
-            print(f"MISMATCH {tag}: logit err {err:.2e}, packed logits equal {torch.equal(lp, lk)}, gradient cosine {cos:.7f}", flush=True)
+            print(f"MISMATCH {tag}: logit err {err:.2e}, packed logits equal {torch.equal(lp, lk)} (max diff {(lp - lk).abs().max().item() / max(lp.abs().max().item(), 1e-9):.1e} of the scale), gradient cosine {cos:.7f}", flush=True)
     except Exception as e:
         bad += 1
         print(f"EXC {tag}: {type(e).__name__} {str(e)[:160]}", flush=True)
